@@ -1,0 +1,71 @@
+"""Synthetic TPC-H-shaped columns.
+
+The reference ships no data, only catalog metadata: value ranges in
+/root/reference/tests/tpch10noorder/bounds.csv:59-79 and storage widths in
+storage.csv:188-208.  Columns are produced by a counter-based hash so that any GPU can
+materialise any row range in place:
+
+    v(row) = add + mul * (lo + splitmix64(seed ^ col_id * PHI ^ row) mod (hi - lo + 1))
+
+``col_id`` is the FNV-1a-64 hash of the column key path ("lineitem.l_shipdate").
+The device generator (csrc/vdl_kernels.hip: k_gen_column) and this numpy one are
+bit-identical (tests/test_datagen.py, tests/test_gpu_parity.py).
+"""
+from collections import namedtuple
+
+import numpy as np
+
+SEED = 0x5EED0006
+PHI = 0x9E3779B97F4A7C15
+_M64 = (1 << 64) - 1
+
+ColumnSpec = namedtuple("ColumnSpec", "name dtype lo hi mul add")
+
+# lineitem row counts: SF0.01 tests/tpchnoorder/bounds.csv:59, SF10 tests/tpch10noorder/bounds.csv:59,
+# SF1/SF100 from the TPC-H specification.
+LINEITEM_ROWS = {"sf0.01": 60175, "sf1": 6001215, "sf10": 59986052, "sf100": 600037902}
+
+LINEITEM = {
+    "lineitem.l_shipdate":      ColumnSpec("lineitem.l_shipdate", np.int32, 727564, 730089, 1, 0),
+    "lineitem.l_discount":      ColumnSpec("lineitem.l_discount", np.int64, 0, 10, 1, 0),
+    "lineitem.l_quantity":      ColumnSpec("lineitem.l_quantity", np.int64, 1, 50, 100, 0),
+    "lineitem.l_extendedprice": ColumnSpec("lineitem.l_extendedprice", np.int64, 90091, 10494950, 1, 0),
+    "lineitem.l_tax":           ColumnSpec("lineitem.l_tax", np.int64, 0, 8, 1, 0),
+    # dictionary codes {16,40,64} / {16,40}: dictionary.csv:80-82, bounds.csv:67-68 (3 trailing zero bits)
+    "lineitem.l_returnflag":    ColumnSpec("lineitem.l_returnflag", np.int32, 0, 2, 24, 16),
+    "lineitem.l_linestatus":    ColumnSpec("lineitem.l_linestatus", np.int32, 0, 1, 24, 16),
+}
+
+Q6_COLUMNS = ["lineitem.l_shipdate", "lineitem.l_discount", "lineitem.l_quantity", "lineitem.l_extendedprice"]
+Q1_COLUMNS = Q6_COLUMNS + ["lineitem.l_tax", "lineitem.l_returnflag", "lineitem.l_linestatus"]
+Q6_BYTES_PER_ROW = 28   # 4 + 8 + 8 + 8, SURVEY.md section 8(d)
+Q1_BYTES_PER_ROW = 44
+
+
+def col_id(name):
+    h = 0xCBF29CE484222325
+    for b in name.encode():
+        h = ((h ^ b) * 0x100000001B3) & _M64
+    return h
+
+
+def _splitmix64(x):
+    x = x + np.uint64(PHI)
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def generate(spec, row0, n, seed=SEED):
+    """Host (numpy) generation of rows [row0, row0+n) of one column."""
+    with np.errstate(over="ignore"):
+        rows = np.arange(row0, row0 + n, dtype=np.uint64)
+        key = np.uint64(seed) ^ np.uint64((col_id(spec.name) * PHI) & _M64)
+        h = _splitmix64(key ^ rows)
+        span = np.uint64(spec.hi - spec.lo + 1)
+        v = (np.uint64(spec.lo & _M64) + h % span) * np.uint64(spec.mul & _M64) + np.uint64(spec.add & _M64)
+    return v.astype(np.int64).astype(spec.dtype)
+
+
+def generate_table(names, row0, n, seed=SEED):
+    return {name: generate(LINEITEM[name], row0, n, seed) for name in names}
