@@ -1,0 +1,136 @@
+/*
+ * vdl.h -- C ABI of libvdl, the MI355X-native execution engine for the textual VDL
+ * (Voodoo vector-operator dataflow) printed by orm011/mplan2vdl.
+ *
+ * What this boundary replaces.  The reference has no in-process executor: its VDL text
+ * leaves the process on stdout (/root/reference/src/MainFuns.hs:157) and is POSTed to
+ * an external Voodoo server, whose JSON reply is decoded by resolve.py
+ * (/root/reference/eval_query.sh:18-26, /root/reference/resolve.py:8-32).  libvdl is
+ * that server's `/voodoo/.../run` hop as a library:
+ *
+ *     request  body  = VDL text (grammar: /root/reference/src/Vdl.hs:410-477;
+ *                      " ;; metadata" suffixes as stripped by eval_query.sh:20 are ignored)
+ *     response body  = {"results": {"tmpN": {".<name>": [ints]}}, "timings": {label: usec}}
+ *                      -> vdl_output() / vdl_timing() below, one entry per MaterializeCompact.
+ *
+ * A Haskell host binds these with `foreign import ccall` (stub in INTEGRATION.md); the
+ * CLI `vdlrun` and the Python package `mplan2vdl_amd` are the callers exercised here.
+ *
+ * Conventions: plain C types only, no callbacks; every call returns VDL_OK (0) or a
+ * VDL_ERR_* code and leaves a message for vdl_last_error(); pointers returned by
+ * vdl_output()/vdl_timing()/vdl_plan_describe() are borrowed and stay valid until the
+ * plan is run again or freed.  One context per process and GPU; calls on one context
+ * are not re-entrant (the reference's model is one query per request, no shared state).
+ * There is NO CPU fallback: every run call needs a HIP device and fails with
+ * VDL_ERR_DEVICE without one.
+ */
+#ifndef VDL_H
+#define VDL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vdl_ctx  vdl_ctx;   /* device, stream, column catalog, memory pool   */
+typedef struct vdl_plan vdl_plan;  /* parsed program + fused execution plan + results */
+
+enum {
+    VDL_OK              = 0,
+    VDL_ERR_PARSE       = 1,  /* malformed VDL text (line number in vdl_last_error)          */
+    VDL_ERR_COLUMN      = 2,  /* Load of a column that is not in the catalog                  */
+    VDL_ERR_UNSUPPORTED = 3,  /* operator / pattern outside the implemented set               */
+    VDL_ERR_DEVICE      = 4,  /* no HIP device, or a HIP call failed                          */
+    VDL_ERR_ARG         = 5,  /* bad argument                                                 */
+    VDL_ERR_SHAPE       = 6,  /* operand lengths / field names do not fit                     */
+    VDL_ERR_NOMEM       = 7
+};
+
+/* partial-state merge operators for sharded execution */
+enum { VDL_REDUCE_NONE = 0, VDL_REDUCE_SUM = 1, VDL_REDUCE_MIN = 2, VDL_REDUCE_MAX = 3 };
+
+/* ---- context ------------------------------------------------------------------ */
+
+/* device >= 0 binds that HIP device and creates the engine stream; device < 0 makes a
+ * host-only context that can parse, plan and describe but not run (used by CPU tests). */
+int  vdl_open(vdl_ctx **out, int device);
+void vdl_close(vdl_ctx *ctx);
+const char *vdl_last_error(const vdl_ctx *ctx);
+const char *vdl_version(void);
+
+/* Run on the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream);
+ * NULL restores the engine's own stream. */
+int  vdl_set_stream(vdl_ctx *ctx, void *hip_stream);
+
+/* ---- column catalog ("Load table.col", /root/reference/src/Vdl.hs:161-168,419-420) --
+ * Columns are contiguous little-endian signed integers of elem_bytes in {1,2,4,8}
+ * (storage widths /root/reference/tests/tpch10noorder/storage.csv:188-208), resident in
+ * HBM.  `name` is the key path as printed after Load, e.g. "lineitem.l_shipdate". */
+int  vdl_register_column(vdl_ctx *ctx, const char *name, const void *dev_ptr,
+                         int elem_bytes, int64_t nrows);               /* borrowed device memory */
+int  vdl_upload_column(vdl_ctx *ctx, const char *name, const void *host_ptr,
+                       int elem_bytes, int64_t nrows);                 /* engine-owned copy, H2D   */
+/* Synthetic column generated in place in HBM by the counter-based generator of
+ * v(row) = add + mul*(lo + splitmix64(seed ^ fnv1a(name)*PHI ^ row) % (hi-lo+1)),
+ * rows [row0, row0+nrows). */
+int  vdl_generate_column(vdl_ctx *ctx, const char *name, int elem_bytes, int64_t row0,
+                         int64_t nrows, uint64_t seed, int64_t lo, int64_t hi,
+                         int64_t mul, int64_t add);
+int  vdl_drop_column(vdl_ctx *ctx, const char *name);
+int  vdl_column_info(const vdl_ctx *ctx, const char *name, int *elem_bytes, int64_t *nrows,
+                     const void **dev_ptr);
+/* Copy a catalog column back to the host (tests, debugging). */
+int  vdl_download_column(vdl_ctx *ctx, const char *name, void *host_ptr, size_t bytes);
+
+/* ---- plans --------------------------------------------------------------------- */
+
+/* Parse the VDL text, check it, and build the execution plan (operator fusion included).
+ * Needs no device. */
+int  vdl_parse(vdl_ctx *ctx, const char *vdl_text, size_t len, vdl_plan **out);
+void vdl_plan_free(vdl_plan *plan);
+
+/* Human-readable plan: one line per execution step ("scan ...", "op 17 Greater ..."). */
+const char *vdl_plan_describe(const vdl_plan *plan);
+/* 1 if every output of the plan comes from fused scan kernels (no per-operator steps). */
+int  vdl_plan_is_fused(const vdl_plan *plan);
+/* Force per-operator execution (no fusion) for this plan: used by parity tests to check
+ * every operator kernel against the oracle on programs that would otherwise fuse. */
+int  vdl_plan_set_fusion(vdl_plan *plan, int enabled);
+
+/* Execute: binds Loads to the catalog, runs all kernels, copies the MaterializeCompact
+ * outputs to the host and synchronises. */
+int  vdl_run(vdl_ctx *ctx, vdl_plan *plan);
+
+int  vdl_n_outputs(const vdl_plan *plan);
+/* k-th output in program order: `name` is the output field (resolve.py:64-78 splits it on
+ * "__"), `tmp` the "tmpN" result key (N = id of the MaterializeCompact line). */
+int  vdl_output(const vdl_plan *plan, int k, const char **name, const char **tmp,
+                const int64_t **vals, size_t *n);
+int  vdl_n_timings(const vdl_plan *plan);
+int  vdl_timing(const vdl_plan *plan, int k, const char **label, double *usec);
+
+/* Per-kernel device time of the last vdl_run()/vdl_run_local(), measured with HIP events
+ * on the stream the kernels were launched on; enabled with vdl_plan_set_profiling(). */
+int  vdl_plan_set_profiling(vdl_plan *plan, int enabled);
+/* Rows scanned and algorithmic bytes read by the dominant (fused scan) kernel of the last
+ * run, and its device time in microseconds (0 if profiling was off). */
+int  vdl_plan_scan_stats(const vdl_plan *plan, int64_t *rows, int64_t *algo_bytes, double *usec);
+
+/* ---- sharded execution: one process per GPU, columns sharded by row range --------
+ * A plan whose outputs are global folds keeps its mergeable state in `n_words` int64
+ * words, each tagged with a VDL_REDUCE_* operator.  Each rank runs the local phase over
+ * its row range, the caller merges the words across ranks (RCCL all-reduce through
+ * torch.distributed, one call per operator class), and every rank finalises. */
+int  vdl_plan_partial_spec(const vdl_plan *plan, int64_t *n_words, const int32_t **reduce_ops);
+/* Local phase, asynchronous on the context stream; dev_partials = caller-owned device
+ * buffer of n_words int64 (fully overwritten). */
+int  vdl_run_local(vdl_ctx *ctx, vdl_plan *plan, void *dev_partials);
+/* After the merge: produce the outputs from the (merged) words; synchronises. */
+int  vdl_finalize(vdl_ctx *ctx, vdl_plan *plan, const void *dev_partials);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VDL_H */

@@ -1,0 +1,805 @@
+// vdl_engine.cpp -- context, column catalog, HBM pool, plan execution and the C ABI (include/vdl.h).
+//
+// Two execution strategies, both HIP-only (there is no CPU fallback anywhere in this library):
+//   * fused   : programs of the "filter -> gather -> global fold" shape run as one read-once scan
+//               per table (vdl_fuse.cpp decides, k_scan executes);
+//   * general : any other program runs statement by statement with one kernel per operator;
+//               RangeV/RangeC, Project, Shuffle and identity Gathers never touch memory.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "vdl.h"
+#include "vdl_fuse.h"
+#include "vdl_ir.h"
+#include "vdl_kernels.h"
+
+using namespace vdl;
+
+namespace {
+
+#define HIP_CHECK(expr)                                                                                         \
+    do {                                                                                                        \
+        hipError_t e_ = (expr);                                                                                 \
+        if (e_ != hipSuccess)                                                                                   \
+            throw Error(VDL_ERR_DEVICE, std::string(#expr) + " failed: " + hipGetErrorString(e_));              \
+    } while (0)
+
+// ---- HBM pool: size-class free lists; everything runs on one stream, so a buffer released on the
+// host can be handed to a later launch without extra synchronisation (stream order protects it).
+struct Pool {
+    std::multimap<size_t, void *> free_list;
+    size_t live_bytes = 0, peak_bytes = 0;
+    static size_t round_up(size_t b) {
+        size_t c = 256;
+        while (c < b) c <<= 1;
+        if (c > (size_t(1) << 26)) c = (b + (size_t(1) << 26) - 1) & ~((size_t(1) << 26) - 1);   // 64 MiB granules above 64 MiB
+        return c;
+    }
+    void *alloc(size_t bytes, size_t *cls) {
+        size_t c = round_up(bytes ? bytes : 1);
+        *cls = c;
+        auto it = free_list.find(c);
+        void *p = nullptr;
+        if (it != free_list.end()) { p = it->second; free_list.erase(it); }
+        else {
+            hipError_t e = hipMalloc(&p, c);
+            if (e != hipSuccess) {
+                trim();
+                e = hipMalloc(&p, c);
+                if (e != hipSuccess) throw Error(VDL_ERR_NOMEM, "hipMalloc of " + std::to_string(c) + " bytes failed");
+            }
+        }
+        live_bytes += c;
+        peak_bytes = std::max(peak_bytes, live_bytes);
+        return p;
+    }
+    void release(void *p, size_t cls) { free_list.emplace(cls, p); live_bytes -= cls; }
+    void trim() { for (auto &kv : free_list) (void)hipFree(kv.second); free_list.clear(); }
+};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cls = 0;
+    Pool *pool = nullptr;
+    ~DevBuf() { if (p && pool) pool->release(p, cls); }
+};
+using BufP = std::shared_ptr<DevBuf>;
+
+struct Column {
+    const void *dev = nullptr;
+    int width = 0;
+    int64_t n = 0;
+    BufP owned;
+};
+
+// device-side vector of the general path
+struct DVec {
+    enum Kind { NONE, DENSE, COLUMN, RANGE, ONEHOT, OHCONST } kind = NONE;
+    int64_t n = 0;
+    BufP data;                  // DENSE: n int64; ONEHOT/OHCONST: {value, slot, count}
+    const void *ptr = nullptr;  // COLUMN: borrowed catalog pointer
+    int width = 8;
+    int64_t from = 0, step = 0; // RANGE; OHCONST: from = the constant
+    BufP valid;                 // bitmap, null = every slot holds a value
+    BufP keep;                  // COLUMN: keeps an engine-owned column alive
+};
+
+struct Output {
+    int node = 0;
+    std::string name, tmp;
+    std::vector<int64_t> vals;
+};
+struct Timing { std::string label; double usec; };
+
+}  // namespace
+
+struct vdl_ctx {
+    int device = -1;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    int num_cus = 256;
+    std::map<std::string, Column> cols;
+    Pool pool;
+    std::string err;
+};
+
+struct vdl_plan {
+    vdl_ctx *ctx = nullptr;
+    Program prog;
+    FusedPlan fused;
+    bool use_fusion = true;
+    bool profiling = false;
+    std::string description;
+    std::vector<Output> outs;
+    std::vector<Timing> timings;
+    // fused state
+    std::vector<ScanArgs> sargs;
+    std::vector<ScanLaunch> scfg;
+    std::vector<BufP> block_partials;
+    std::vector<int32_t> reduce_ops;
+    std::vector<int64_t> word_offset;
+    int64_t n_words = 0;
+    BufP words;
+    bool bound = false;
+    int64_t scan_rows = 0, scan_bytes = 0;
+    double scan_usec = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_pending = false;
+    ~vdl_plan() {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+    }
+};
+
+namespace {
+
+BufP dev_alloc(vdl_ctx *c, size_t bytes) {
+    auto b = std::make_shared<DevBuf>();
+    b->pool = &c->pool;
+    b->p = c->pool.alloc(bytes, &b->cls);
+    return b;
+}
+
+void need_device(vdl_ctx *c) {
+    if (c->device < 0) throw Error(VDL_ERR_DEVICE, "this context has no HIP device (opened with device < 0)");
+    HIP_CHECK(hipSetDevice(c->device));
+}
+
+uint64_t fnv1a(const std::string &s) {
+    uint64_t h = 0xCBF29CE484222325ULL;
+    for (unsigned char ch : s) { h ^= ch; h *= 0x100000001B3ULL; }
+    return h;
+}
+
+const Column &find_col(vdl_ctx *c, const std::string &name) {
+    auto it = c->cols.find(name);
+    if (it == c->cols.end()) throw Error(VDL_ERR_COLUMN, "Load: column '" + name + "' is not in the catalog");
+    return it->second;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused execution
+// ------------------------------------------------------------------------------------------------
+void bind_fused(vdl_ctx *c, vdl_plan *p) {
+    const FusedPlan &F = p->fused;
+    p->sargs.assign(F.scans.size(), ScanArgs{});
+    p->scfg.assign(F.scans.size(), ScanLaunch{});
+    p->block_partials.assign(F.scans.size(), nullptr);
+    p->word_offset.assign(F.scans.size(), 0);
+    p->reduce_ops.clear();
+    int64_t off = 0;
+    p->scan_rows = 0; p->scan_bytes = 0;
+    for (size_t s = 0; s < F.scans.size(); s++) {
+        const ScanPlan &sp = F.scans[s];
+        ScanArgs &a = p->sargs[s];
+        a.ncol = (int)sp.cols.size();
+        a.nagg = (int)sp.aggs.size();
+        a.never = sp.never ? 1 : 0;
+        int64_t n = -1, bytes_per_row = 0;
+        for (int k = 0; k < a.ncol; k++) {
+            const Column &col = find_col(c, sp.cols[(size_t)k].name);
+            if (n >= 0 && col.n != n)
+                throw Error(VDL_ERR_SHAPE, "columns of table '" + sp.table + "' have different lengths in the catalog");
+            n = col.n;
+            a.ptr[k] = col.dev; a.width[k] = col.width;
+            a.lo[k] = sp.cols[(size_t)k].lo; a.hi[k] = sp.cols[(size_t)k].hi;
+            a.filtered[k] = (a.lo[k] != INT64_MIN || a.hi[k] != INT64_MAX) ? 1 : 0;
+            bytes_per_row += col.width;
+        }
+        a.n = n;
+        for (int j = 0; j < a.nagg; j++) {
+            const ScanAgg &ag = sp.aggs[(size_t)j];
+            a.kind[j] = ag.kind;
+            a.constant[j] = ag.constant;
+            for (const ScanFactor &f : ag.fac) {
+                if ((a.used[j] >> f.col) & 1u)
+                    throw Error(VDL_ERR_UNSUPPORTED, "a column appears twice in one aggregate product; run with fusion disabled");
+                a.used[j] |= 1u << f.col;
+                if (f.a == 0 && f.s == 1) a.plain[j] |= 1u << f.col;
+                a.fa[j][f.col] = f.a; a.fs[j][f.col] = f.s;
+            }
+        }
+        p->scfg[s] = scan_launch_config(a, c->num_cus);
+        if (p->scfg[s].variant < 0) throw Error(VDL_ERR_UNSUPPORTED, "no scan kernel variant for this shape");
+        p->block_partials[s] = dev_alloc(c, sizeof(int64_t) * (size_t)p->scfg[s].grid * (size_t)(a.nagg + 1));
+        a.block_partials = (int64_t *)p->block_partials[s]->p;
+        p->word_offset[s] = off;
+        p->reduce_ops.push_back(VDL_REDUCE_SUM);            // selected-row count
+        for (int j = 0; j < a.nagg; j++)
+            p->reduce_ops.push_back(a.kind[j] == AGG_SUM ? VDL_REDUCE_SUM : a.kind[j] == AGG_MIN ? VDL_REDUCE_MIN : VDL_REDUCE_MAX);
+        off += a.nagg + 1;
+        if (!sp.never && n * bytes_per_row > p->scan_bytes) { p->scan_bytes = n * bytes_per_row; p->scan_rows = n; }
+    }
+    p->n_words = off;
+    p->bound = true;
+}
+
+void run_fused_local(vdl_ctx *c, vdl_plan *p, int64_t *dev_words) {
+    bind_fused(c, p);      // cheap; the catalog may have changed since the last run
+    if (p->profiling && !p->ev0) { HIP_CHECK(hipEventCreate(&p->ev0)); HIP_CHECK(hipEventCreate(&p->ev1)); }
+    p->ev_pending = false;
+    // the scan with the most bytes is the one timed
+    size_t dominant = 0; int64_t best = -1;
+    for (size_t s = 0; s < p->sargs.size(); s++) {
+        int64_t b = 0;
+        for (int k = 0; k < p->sargs[s].ncol; k++) b += p->sargs[s].width[k];
+        b *= p->sargs[s].n;
+        if (!p->sargs[s].never && b > best) { best = b; dominant = s; }
+    }
+    for (size_t s = 0; s < p->sargs.size(); s++) {
+        const ScanArgs &a = p->sargs[s];
+        int nblocks = 0;
+        if (!a.never && a.n > 0) {
+            const bool timed = p->profiling && s == dominant;
+            if (timed) HIP_CHECK(hipEventRecord(p->ev0, c->stream));
+            HIP_CHECK(launch_scan(a, p->scfg[s], c->stream));
+            if (timed) { HIP_CHECK(hipEventRecord(p->ev1, c->stream)); p->ev_pending = true; }
+            nblocks = p->scfg[s].grid;
+        }
+        HIP_CHECK(launch_scan_finish(a.block_partials, nblocks, a.nagg, nullptr, a, dev_words + p->word_offset[s], c->stream));
+    }
+}
+
+void finalize_fused(vdl_ctx *c, vdl_plan *p, const int64_t *dev_words) {
+    if (!p->bound) throw Error(VDL_ERR_ARG, "vdl_finalize called before vdl_run_local");
+    std::vector<int64_t> w((size_t)p->n_words);
+    if (p->n_words) HIP_CHECK(hipMemcpyAsync(w.data(), dev_words, sizeof(int64_t) * (size_t)p->n_words, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    p->timings.clear();
+    if (p->ev_pending) {
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+        p->scan_usec = (double)ms * 1e3;
+        p->timings.push_back({"timeInMicrosecondsForFusedScan", p->scan_usec});
+        p->ev_pending = false;
+    }
+    p->outs.clear();
+    for (const FusedOutput &fo : p->fused.outputs) {
+        Output o;
+        o.node = fo.node;
+        o.name = p->prog.at(fo.node).field;
+        o.tmp = "tmp" + std::to_string(fo.node);
+        const int64_t *sw = w.data() + p->word_offset[(size_t)fo.scan];
+        if (sw[0] > 0) o.vals.push_back(eval_scalar(*fo.value, sw + 1));   // no selected row -> the fold slot is EPS
+        p->outs.push_back(std::move(o));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// general (per-operator) execution
+// ------------------------------------------------------------------------------------------------
+struct GenExec {
+    vdl_ctx *c;
+    vdl_plan *p;
+    std::vector<DVec> vec;
+    std::vector<int> last_use;
+    hipStream_t s;
+
+    GenExec(vdl_ctx *ctx, vdl_plan *plan) : c(ctx), p(plan), vec(plan->prog.nodes.size()), last_use(plan->prog.nodes.size(), -1), s(ctx->stream) {}
+
+    static int64_t nwords(int64_t n) { return (n + 63) >> 6; }
+    const uint64_t *vp(const DVec &v) const { return v.valid ? (const uint64_t *)v.valid->p : nullptr; }
+
+    Src src_of(const DVec &v) const {
+        Src r;
+        switch (v.kind) {
+        case DVec::DENSE: r.p = v.data->p; r.kind = SRC_I64; break;
+        case DVec::COLUMN:
+            r.p = v.ptr;
+            r.kind = v.width == 8 ? SRC_I64 : v.width == 4 ? SRC_I32 : v.width == 2 ? SRC_I16 : SRC_I8;
+            break;
+        case DVec::RANGE: r.kind = SRC_RANGE; r.from = v.from; r.step = v.step; break;
+        default: throw Error(VDL_ERR_UNSUPPORTED, "internal: operand form not addressable");
+        }
+        return r;
+    }
+
+    BufP and_valid(const DVec &a, const DVec &b, int64_t n) {
+        if (!a.valid) return b.valid;
+        if (!b.valid || a.valid == b.valid) return a.valid;
+        BufP o = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(n), 1));
+        HIP_CHECK(launch_and_words((const uint64_t *)a.valid->p, (const uint64_t *)b.valid->p, (uint64_t *)o->p, nwords(n), s));
+        return o;
+    }
+
+    DVec densify(const DVec &v) {
+        if (v.kind != DVec::ONEHOT && v.kind != DVec::OHCONST) return v;
+        DVec src = v;
+        if (v.kind == DVec::OHCONST) {   // materialise the constant into a one-hot record first
+            BufP oh = dev_alloc(c, 3 * sizeof(int64_t));
+            HIP_CHECK(launch_onehot_const(B_MUL, (const int64_t *)v.data->p, 0, 0, (int64_t *)oh->p, s));
+            HIP_CHECK(launch_onehot_const(B_ADD, (const int64_t *)oh->p, v.from, 0, (int64_t *)oh->p, s));
+            src.data = oh;
+        }
+        DVec o;
+        o.kind = DVec::DENSE; o.n = v.n;
+        o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(v.n, 1));
+        o.valid = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(v.n), 1));
+        HIP_CHECK(launch_onehot_dense((const int64_t *)src.data->p, (int64_t *)o.data->p, (uint64_t *)o.valid->p, v.n, s));
+        return o;
+    }
+
+    DVec binary(const Node &n, const DVec &a0, const DVec &b0) {
+        DVec a = a0, b = b0;
+        const bool a_oh = a.kind == DVec::ONEHOT || a.kind == DVec::OHCONST;
+        const bool b_oh = b.kind == DVec::ONEHOT || b.kind == DVec::OHCONST;
+        if (a.n != b.n)
+            throw Error(VDL_ERR_SHAPE, std::string(kBinNames[n.bin]) + " (Id " + std::to_string(n.id) + "): operand lengths differ (" +
+                                           std::to_string(a.n) + " vs " + std::to_string(b.n) + ")");
+        if (a_oh && b_oh) {
+            DVec o; o.n = a.n;
+            if (a.kind == DVec::OHCONST && b.kind == DVec::OHCONST) {
+                if (a.data != b.data) { a = densify(a); b = densify(b); }
+                else { o = a; o.from = apply_bin(n.bin, a.from, b.from); return o; }
+            } else {
+                o.kind = DVec::ONEHOT;
+                o.data = dev_alloc(c, 3 * sizeof(int64_t));
+                if (a.kind == DVec::ONEHOT && b.kind == DVec::ONEHOT)
+                    HIP_CHECK(launch_onehot_binary(n.bin, (const int64_t *)a.data->p, (const int64_t *)b.data->p, (int64_t *)o.data->p, s));
+                else if (a.kind == DVec::ONEHOT && a.data == b.data)
+                    HIP_CHECK(launch_onehot_const(n.bin, (const int64_t *)a.data->p, b.from, 0, (int64_t *)o.data->p, s));
+                else if (b.kind == DVec::ONEHOT && a.data == b.data)
+                    HIP_CHECK(launch_onehot_const(n.bin, (const int64_t *)b.data->p, a.from, 1, (int64_t *)o.data->p, s));
+                else { a = densify(a); b = densify(b); o.kind = DVec::NONE; }
+                if (o.kind == DVec::ONEHOT) return o;
+            }
+        } else if (a_oh || b_oh) {
+            a = densify(a); b = densify(b);
+        }
+        DVec o;
+        o.n = a.n;
+        if (a.kind == DVec::RANGE && b.kind == DVec::RANGE && a.step == 0 && b.step == 0) {   // constant folding
+            o.kind = DVec::RANGE; o.from = apply_bin(n.bin, a.from, b.from); o.step = 0;
+            o.valid = and_valid(a, b, o.n);
+            return o;
+        }
+        o.kind = DVec::DENSE;
+        o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(o.n, 1));
+        HIP_CHECK(launch_binary(n.bin, src_of(a), src_of(b), (int64_t *)o.data->p, o.n, s));
+        o.valid = and_valid(a, b, o.n);
+        return o;
+    }
+
+    void materialize(const Node &n, const DVec &v0) {
+        Output o;
+        o.node = n.id;
+        o.name = n.field;
+        o.tmp = "tmp" + std::to_string(n.id);
+        DVec v = v0;
+        if (v.kind == DVec::OHCONST) v = densify(v);
+        if (v.kind == DVec::ONEHOT) {
+            int64_t h[3];
+            HIP_CHECK(hipMemcpyAsync(h, v.data->p, sizeof h, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            if (h[2] > 0) o.vals.push_back(h[0]);
+        } else {
+            const int64_t nb = (v.n + compact_tile() - 1) / compact_tile();
+            if (nb > 0) {
+                BufP counts = dev_alloc(c, sizeof(int64_t) * (size_t)(nb + 1));
+                HIP_CHECK(launch_compact_count(vp(v), v.n, (int64_t *)counts->p, s));
+                HIP_CHECK(launch_compact_scan((int64_t *)counts->p, nb, s));
+                int64_t total = 0;
+                HIP_CHECK(hipMemcpyAsync(&total, (int64_t *)counts->p + nb, sizeof total, hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+                if (total > 0) {
+                    BufP outb = dev_alloc(c, sizeof(int64_t) * (size_t)total);
+                    HIP_CHECK(launch_compact_write(src_of(v), vp(v), v.n, (const int64_t *)counts->p, (int64_t *)outb->p, s));
+                    o.vals.resize((size_t)total);
+                    HIP_CHECK(hipMemcpyAsync(o.vals.data(), outb->p, sizeof(int64_t) * (size_t)total, hipMemcpyDeviceToHost, s));
+                    HIP_CHECK(hipStreamSynchronize(s));
+                }
+            }
+        }
+        p->outs.push_back(std::move(o));
+    }
+
+    DVec exec(const Node &n) {
+        auto V = [&](int id) -> const DVec & { return vec[(size_t)id]; };
+        DVec o;
+        switch (n.op) {
+        case Op::Load: {
+            const Column &col = find_col(c, n.column);
+            o.kind = DVec::COLUMN; o.n = col.n; o.ptr = col.dev; o.width = col.width; o.keep = col.owned;
+            return o;
+        }
+        case Op::Project: case Op::Shuffle:
+            return V(n.a);
+        case Op::RangeV: {
+            const DVec &r = V(n.a);
+            if (r.kind == DVec::ONEHOT || r.kind == DVec::OHCONST) {
+                if (n.imm1 == 0) { o.kind = DVec::OHCONST; o.n = r.n; o.data = r.data; o.from = n.imm0; return o; }
+                DVec d = densify(r);
+                o.kind = DVec::RANGE; o.n = d.n; o.from = n.imm0; o.step = n.imm1; o.valid = d.valid;
+                return o;
+            }
+            o.kind = DVec::RANGE; o.n = r.n; o.from = n.imm0; o.step = n.imm1; o.valid = r.valid;
+            return o;
+        }
+        case Op::RangeC:
+            o.kind = DVec::RANGE; o.n = n.imm1; o.from = n.imm0; o.step = n.imm2;
+            return o;
+        case Op::Binary:
+            return binary(n, V(n.a), V(n.b));
+        case Op::FoldSelect: {
+            DVec ctl = densify(V(n.a)), d = densify(V(n.b));
+            if (ctl.n != d.n) throw Error(VDL_ERR_SHAPE, "FoldSelect (Id " + std::to_string(n.id) + "): operand lengths differ");
+            if (!(ctl.kind == DVec::RANGE && ctl.step != 0))
+                throw Error(VDL_ERR_UNSUPPORTED, "FoldSelect (Id " + std::to_string(n.id) +
+                                                     "): only unit-length runs (control = RangeV with non-zero step) are implemented");
+            o.kind = DVec::RANGE; o.n = d.n; o.from = 0; o.step = 1;
+            o.valid = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(d.n), 1));
+            HIP_CHECK(launch_select_bitmap(src_of(d), vp(d), vp(ctl), (uint64_t *)o.valid->p, d.n, s));
+            return o;
+        }
+        case Op::Gather: {
+            DVec src = densify(V(n.a)), pos = densify(V(n.b));
+            if (pos.kind == DVec::RANGE && pos.from == 0 && pos.step == 1 && pos.n == src.n) {
+                // positions are the slot ids themselves (a filter): a view, no data movement
+                o = src;
+                o.valid = and_valid(src, pos, src.n);
+                return o;
+            }
+            o.kind = DVec::DENSE; o.n = pos.n;
+            o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(o.n, 1));
+            o.valid = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(o.n), 1));
+            HIP_CHECK(launch_gather(src_of(src), vp(src), src.n, src_of(pos), vp(pos), pos.n, (int64_t *)o.data->p, (uint64_t *)o.valid->p, s));
+            return o;
+        }
+        case Op::Scatter: {
+            DVec src = densify(V(n.a)), pos = densify(V(n.c));
+            const DVec &fold = V(n.b);
+            if (src.n != pos.n) throw Error(VDL_ERR_SHAPE, "Scatter (Id " + std::to_string(n.id) + "): source and position lengths differ");
+            o.kind = DVec::DENSE; o.n = fold.n;
+            o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(o.n, 1));
+            o.valid = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(o.n), 1));
+            HIP_CHECK(launch_fill_words((uint64_t *)o.valid->p, 0, nwords(o.n), s));
+            HIP_CHECK(launch_scatter(src_of(src), vp(src), src_of(pos), vp(pos), src.n, o.n, (int64_t *)o.data->p, (uint64_t *)o.valid->p, s));
+            return o;
+        }
+        case Op::FoldSum: case Op::FoldMin: case Op::FoldMax: case Op::FoldCount: case Op::FoldChoose: {
+            DVec ctl = densify(V(n.a)), d = densify(V(n.b));
+            if (ctl.n != d.n) throw Error(VDL_ERR_SHAPE, std::string(op_name(n.op, -1)) + " (Id " + std::to_string(n.id) + "): operand lengths differ");
+            if (!(ctl.kind == DVec::RANGE && ctl.step == 0))
+                throw Error(VDL_ERR_UNSUPPORTED, std::string(op_name(n.op, -1)) + " (Id " + std::to_string(n.id) +
+                                                     "): only a constant control vector (one global run) is implemented");
+            const int kind = n.op == Op::FoldSum ? 0 : n.op == Op::FoldMin ? 1 : n.op == Op::FoldMax ? 2 : n.op == Op::FoldCount ? 3 : 4;
+            BufP scratch = dev_alloc(c, sizeof(int64_t) * 3 * (size_t)fold_scratch_blocks());
+            o.kind = DVec::ONEHOT; o.n = d.n;
+            o.data = dev_alloc(c, 3 * sizeof(int64_t));
+            HIP_CHECK(launch_fold_global(kind, src_of(d), vp(d), vp(ctl), d.n, (int64_t *)scratch->p, (int64_t *)o.data->p, s));
+            return o;
+        }
+        case Op::Partition:
+            throw Error(VDL_ERR_UNSUPPORTED, "Partition (Id " + std::to_string(n.id) + ") is not implemented yet");
+        case Op::Materialize:
+            materialize(n, V(n.a));
+            return V(n.a);
+        }
+        return o;
+    }
+
+    void run() {
+        const Program &P = p->prog;
+        // liveness: only statements an output depends on are executed
+        std::vector<char> needed(P.nodes.size(), 0);
+        for (int id : P.outputs) needed[(size_t)id] = 1;
+        for (auto it = P.order.rbegin(); it != P.order.rend(); ++it) {
+            const Node &n = P.at(*it);
+            if (!needed[(size_t)n.id]) continue;
+            for (int opnd : {n.a, n.b, n.c}) if (opnd > 0) needed[(size_t)opnd] = 1;
+        }
+        for (size_t k = 0; k < P.order.size(); k++) {
+            const Node &n = P.at(P.order[k]);
+            if (!needed[(size_t)n.id]) continue;
+            for (int opnd : {n.a, n.b, n.c}) if (opnd > 0) last_use[(size_t)opnd] = (int)k;
+        }
+        p->outs.clear();
+        p->timings.clear();
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (p->profiling) { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1)); }
+        for (size_t k = 0; k < P.order.size(); k++) {
+            const Node &n = P.at(P.order[k]);
+            if (!needed[(size_t)n.id]) continue;
+            if (p->profiling) HIP_CHECK(hipEventRecord(e0, s));
+            vec[(size_t)n.id] = exec(n);
+            if (p->profiling) {
+                HIP_CHECK(hipEventRecord(e1, s));
+                HIP_CHECK(hipEventSynchronize(e1));
+                float ms = 0;
+                HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+                p->timings.push_back({"timeInMicrosecondsForStatement" + std::to_string(n.id) + "_" + op_name(n.op, n.bin), (double)ms * 1e3});
+            }
+            for (int opnd : {n.a, n.b, n.c})
+                if (opnd > 0 && last_use[(size_t)opnd] == (int)k) vec[(size_t)opnd] = DVec{};
+        }
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
+    }
+};
+
+std::string describe_plan(const vdl_plan *p) {
+    std::ostringstream o;
+    if (p->use_fusion && p->fused.ok) {
+        o << "fused: " << p->fused.scans.size() << " scan(s)\n" << describe_fused(p->fused);
+    } else {
+        if (!p->fused.ok) o << describe_fused(p->fused);
+        else o << "fusion disabled\n";
+        o << "general: " << p->prog.order.size() << " statement(s), one kernel per operator\n";
+        for (int id : p->prog.order) {
+            const Node &n = p->prog.at(id);
+            o << "  op " << n.id << " " << op_name(n.op, n.bin) << "\n";
+        }
+    }
+    return o.str();
+}
+
+template <typename F>
+int guard(vdl_ctx *c, F &&f) {
+    try {
+        f();
+        return VDL_OK;
+    } catch (const Error &e) {
+        if (c) c->err = e.what();
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        if (c) c->err = "out of host memory";
+        return VDL_ERR_NOMEM;
+    } catch (const std::exception &e) {
+        if (c) c->err = e.what();
+        return VDL_ERR_ARG;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *vdl_version(void) { return "vdl-mi355x 0.1 (gfx950)"; }
+
+int vdl_open(vdl_ctx **out, int device) {
+    if (!out) return VDL_ERR_ARG;
+    *out = nullptr;
+    vdl_ctx *c = new vdl_ctx();
+    int rc = guard(c, [&] {
+        c->device = device;
+        if (device >= 0) {
+            int count = 0;
+            if (hipGetDeviceCount(&count) != hipSuccess || device >= count)
+                throw Error(VDL_ERR_DEVICE, "HIP device " + std::to_string(device) + " not available (" + std::to_string(count) + " device(s) visible)");
+            HIP_CHECK(hipSetDevice(device));
+            hipDeviceProp_t prop;
+            HIP_CHECK(hipGetDeviceProperties(&prop, device));
+            c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            HIP_CHECK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+            c->stream = c->own_stream;
+        }
+    });
+    if (rc != VDL_OK) {
+        // keep the context so the caller can read the message
+        c->device = -1;
+    }
+    *out = c;
+    return rc;
+}
+
+void vdl_close(vdl_ctx *c) {
+    if (!c) return;
+    if (c->device >= 0) {
+        (void)hipSetDevice(c->device);
+        (void)hipDeviceSynchronize();
+        c->cols.clear();
+        c->pool.trim();
+        if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    }
+    delete c;
+}
+
+const char *vdl_last_error(const vdl_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int vdl_set_stream(vdl_ctx *c, void *hip_stream) {
+    if (!c) return VDL_ERR_ARG;
+    return guard(c, [&] {
+        need_device(c);
+        c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    });
+}
+
+static void check_width(int w) {
+    if (w != 1 && w != 2 && w != 4 && w != 8) throw Error(VDL_ERR_ARG, "elem_bytes must be 1, 2, 4 or 8");
+}
+
+int vdl_register_column(vdl_ctx *c, const char *name, const void *dev_ptr, int elem_bytes, int64_t nrows) {
+    if (!c || !name) return VDL_ERR_ARG;
+    return guard(c, [&] {
+        check_width(elem_bytes);
+        if (nrows < 0 || (!dev_ptr && nrows > 0)) throw Error(VDL_ERR_ARG, "bad column pointer / length");
+        if (((uintptr_t)dev_ptr) % (uintptr_t)elem_bytes) throw Error(VDL_ERR_ARG, "column pointer is not aligned to its element size");
+        Column col; col.dev = dev_ptr; col.width = elem_bytes; col.n = nrows;
+        c->cols[name] = col;
+    });
+}
+
+int vdl_upload_column(vdl_ctx *c, const char *name, const void *host_ptr, int elem_bytes, int64_t nrows) {
+    if (!c || !name) return VDL_ERR_ARG;
+    return guard(c, [&] {
+        need_device(c);
+        check_width(elem_bytes);
+        if (nrows < 0 || (!host_ptr && nrows > 0)) throw Error(VDL_ERR_ARG, "bad column pointer / length");
+        Column col; col.width = elem_bytes; col.n = nrows;
+        col.owned = dev_alloc(c, (size_t)nrows * (size_t)elem_bytes);
+        col.dev = col.owned->p;
+        if (nrows) HIP_CHECK(hipMemcpyAsync(col.owned->p, host_ptr, (size_t)nrows * (size_t)elem_bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->cols[name] = col;
+    });
+}
+
+int vdl_generate_column(vdl_ctx *c, const char *name, int elem_bytes, int64_t row0, int64_t nrows, uint64_t seed,
+                        int64_t lo, int64_t hi, int64_t mul, int64_t add) {
+    if (!c || !name) return VDL_ERR_ARG;
+    return guard(c, [&] {
+        need_device(c);
+        check_width(elem_bytes);
+        if (nrows < 0 || hi < lo) throw Error(VDL_ERR_ARG, "bad generator arguments");
+        Column col; col.width = elem_bytes; col.n = nrows;
+        col.owned = dev_alloc(c, (size_t)nrows * (size_t)elem_bytes);
+        col.dev = col.owned->p;
+        HIP_CHECK(launch_gen_column(col.owned->p, elem_bytes, row0, nrows, seed, fnv1a(name), lo, hi, mul, add, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->cols[name] = col;
+    });
+}
+
+int vdl_drop_column(vdl_ctx *c, const char *name) {
+    if (!c || !name) return VDL_ERR_ARG;
+    return guard(c, [&] {
+        if (!c->cols.erase(name)) throw Error(VDL_ERR_COLUMN, std::string("no column '") + name + "'");
+    });
+}
+
+int vdl_column_info(const vdl_ctx *c, const char *name, int *elem_bytes, int64_t *nrows, const void **dev_ptr) {
+    if (!c || !name) return VDL_ERR_ARG;
+    auto it = c->cols.find(name);
+    if (it == c->cols.end()) return VDL_ERR_COLUMN;
+    if (elem_bytes) *elem_bytes = it->second.width;
+    if (nrows) *nrows = it->second.n;
+    if (dev_ptr) *dev_ptr = it->second.dev;
+    return VDL_OK;
+}
+
+int vdl_download_column(vdl_ctx *c, const char *name, void *host_ptr, size_t bytes) {
+    if (!c || !name || !host_ptr) return VDL_ERR_ARG;
+    return guard(c, [&] {
+        need_device(c);
+        const Column &col = find_col(c, name);
+        if (bytes != (size_t)col.n * (size_t)col.width) throw Error(VDL_ERR_ARG, "host buffer size does not match the column");
+        if (bytes) HIP_CHECK(hipMemcpyAsync(host_ptr, col.dev, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+    });
+}
+
+int vdl_parse(vdl_ctx *c, const char *text, size_t len, vdl_plan **out) {
+    if (!c || !text || !out) return VDL_ERR_ARG;
+    *out = nullptr;
+    return guard(c, [&] {
+        std::unique_ptr<vdl_plan> p(new vdl_plan());
+        p->ctx = c;
+        p->prog = parse_program(text, len);
+        p->fused = fuse_program(p->prog);
+        p->description = describe_plan(p.get());
+        *out = p.release();
+    });
+}
+
+void vdl_plan_free(vdl_plan *p) {
+    if (!p) return;
+    if (p->ctx && p->ctx->device >= 0) (void)hipSetDevice(p->ctx->device);
+    delete p;
+}
+
+const char *vdl_plan_describe(const vdl_plan *p) { return p ? p->description.c_str() : ""; }
+int vdl_plan_is_fused(const vdl_plan *p) { return p && p->use_fusion && p->fused.ok; }
+int vdl_plan_set_fusion(vdl_plan *p, int enabled) {
+    if (!p) return VDL_ERR_ARG;
+    p->use_fusion = enabled != 0;
+    p->description = describe_plan(p);
+    return VDL_OK;
+}
+int vdl_plan_set_profiling(vdl_plan *p, int enabled) {
+    if (!p) return VDL_ERR_ARG;
+    p->profiling = enabled != 0;
+    return VDL_OK;
+}
+
+int vdl_run(vdl_ctx *c, vdl_plan *p) {
+    if (!c || !p) return VDL_ERR_ARG;
+    return guard(c, [&] {
+        need_device(c);
+        if (p->use_fusion && p->fused.ok) {
+            int64_t nw = 0;
+            for (const ScanPlan &sp : p->fused.scans) nw += (int64_t)sp.aggs.size() + 1;
+            if (!p->words) p->words = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(nw, 1));
+            run_fused_local(c, p, (int64_t *)p->words->p);
+            finalize_fused(c, p, (const int64_t *)p->words->p);
+        } else {
+            GenExec g(c, p);
+            g.run();
+        }
+    });
+}
+
+int vdl_n_outputs(const vdl_plan *p) { return p ? (int)p->outs.size() : 0; }
+int vdl_output(const vdl_plan *p, int k, const char **name, const char **tmp, const int64_t **vals, size_t *n) {
+    if (!p || k < 0 || k >= (int)p->outs.size()) return VDL_ERR_ARG;
+    const Output &o = p->outs[(size_t)k];
+    if (name) *name = o.name.c_str();
+    if (tmp) *tmp = o.tmp.c_str();
+    if (vals) *vals = o.vals.data();
+    if (n) *n = o.vals.size();
+    return VDL_OK;
+}
+int vdl_n_timings(const vdl_plan *p) { return p ? (int)p->timings.size() : 0; }
+int vdl_timing(const vdl_plan *p, int k, const char **label, double *usec) {
+    if (!p || k < 0 || k >= (int)p->timings.size()) return VDL_ERR_ARG;
+    if (label) *label = p->timings[(size_t)k].label.c_str();
+    if (usec) *usec = p->timings[(size_t)k].usec;
+    return VDL_OK;
+}
+int vdl_plan_scan_stats(const vdl_plan *p, int64_t *rows, int64_t *algo_bytes, double *usec) {
+    if (!p) return VDL_ERR_ARG;
+    if (rows) *rows = p->scan_rows;
+    if (algo_bytes) *algo_bytes = p->scan_bytes;
+    if (usec) *usec = p->scan_usec;
+    return VDL_OK;
+}
+
+int vdl_plan_partial_spec(const vdl_plan *p, int64_t *n_words, const int32_t **reduce_ops) {
+    if (!p) return VDL_ERR_ARG;
+    if (!(p->use_fusion && p->fused.ok)) {
+        if (p->ctx) p->ctx->err = "sharded execution needs a plan whose outputs are global folds (fused plan)";
+        return VDL_ERR_UNSUPPORTED;
+    }
+    // word layout depends only on the fused plan: per scan [count, agg0, ...]
+    vdl_plan *q = const_cast<vdl_plan *>(p);
+    q->reduce_ops.clear();
+    int64_t off = 0;
+    for (const ScanPlan &sp : p->fused.scans) {
+        q->reduce_ops.push_back(VDL_REDUCE_SUM);
+        for (const ScanAgg &ag : sp.aggs)
+            q->reduce_ops.push_back(ag.kind == AGG_SUM ? VDL_REDUCE_SUM : ag.kind == AGG_MIN ? VDL_REDUCE_MIN : VDL_REDUCE_MAX);
+        off += (int64_t)sp.aggs.size() + 1;
+    }
+    if (n_words) *n_words = off;
+    if (reduce_ops) *reduce_ops = q->reduce_ops.data();
+    return VDL_OK;
+}
+
+int vdl_run_local(vdl_ctx *c, vdl_plan *p, void *dev_partials) {
+    if (!c || !p || !dev_partials) return VDL_ERR_ARG;
+    return guard(c, [&] {
+        need_device(c);
+        if (!(p->use_fusion && p->fused.ok)) throw Error(VDL_ERR_UNSUPPORTED, "sharded execution needs a fused plan");
+        run_fused_local(c, p, (int64_t *)dev_partials);
+    });
+}
+
+int vdl_finalize(vdl_ctx *c, vdl_plan *p, const void *dev_partials) {
+    if (!c || !p || !dev_partials) return VDL_ERR_ARG;
+    return guard(c, [&] {
+        need_device(c);
+        if (!(p->use_fusion && p->fused.ok)) throw Error(VDL_ERR_UNSUPPORTED, "sharded execution needs a fused plan");
+        finalize_fused(c, p, (const int64_t *)dev_partials);
+    });
+}
+
+}  // extern "C"

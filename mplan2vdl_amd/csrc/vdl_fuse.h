@@ -1,0 +1,75 @@
+// vdl_fuse.h -- pattern fusion: recognises "select -> gather -> global fold" programs
+// (the shape mplan2vdl emits for filter + aggregate queries such as TPC-H Q6:
+// Select -> FoldSelect + Gather, /root/reference/src/Vlite.hs:721-730; ungrouped
+// aggregate -> Fold over an all-zeros key, Vlite.hs:636-639,1048-1060) and turns them
+// into one read-once scan per table: per-column closed-range filters AND-ed together,
+// and per-aggregate products of affine column factors.
+#pragma once
+#include "vdl_ir.h"
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace vdl {
+
+constexpr int kMaxScanCols = 8;
+constexpr int kMaxScanAggs = 8;
+constexpr int kMaxFactors = 4;
+
+enum AggKind : int { AGG_SUM = 0, AGG_MIN = 1, AGG_MAX = 2 };
+
+struct ScanColumn {
+    std::string name;          // catalog key path
+    int64_t lo = INT64_MIN;    // row passes iff lo <= value <= hi for every column
+    int64_t hi = INT64_MAX;
+};
+
+struct ScanFactor {            // (a + s * column[col])
+    int col = -1;
+    int64_t a = 0, s = 1;
+};
+
+struct ScanAgg {
+    int kind = AGG_SUM;
+    int64_t constant = 1;      // used when there are no factors: the datum is this constant
+    std::vector<ScanFactor> fac;
+};
+
+// Scalar expression over the aggregates of one scan, evaluated at finalisation
+// (e.g. avg = Divide(FoldSum, FoldSum), /root/reference/src/Vlite.hs:1038-1041).
+struct Scalar {
+    enum K { AGG, CONST, BIN } k = CONST;
+    int agg = -1;
+    int64_t c = 0;
+    int bin = -1;
+    std::shared_ptr<const Scalar> l, r;
+};
+using ScalarP = std::shared_ptr<const Scalar>;
+
+struct ScanPlan {
+    std::string table;
+    std::vector<ScanColumn> cols;
+    std::vector<ScanAgg> aggs;   // partial words of this scan: [selected-row count, agg 0, agg 1, ...]
+    bool never = false;          // predicate is constant false
+};
+
+struct FusedOutput {
+    int node = 0;                // MaterializeCompact id
+    int scan = 0;                // index into FusedPlan::scans
+    ScalarP value;
+};
+
+struct FusedPlan {
+    bool ok = false;
+    std::string why_not;         // reason the program did not fuse (reported by describe)
+    std::vector<ScanPlan> scans;
+    std::vector<FusedOutput> outputs;
+};
+
+FusedPlan fuse_program(const Program &P);
+std::string describe_fused(const FusedPlan &F);
+int64_t eval_scalar(const Scalar &s, const int64_t *agg_values);
+
+}  // namespace vdl

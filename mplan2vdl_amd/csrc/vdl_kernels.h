@@ -1,0 +1,86 @@
+// vdl_kernels.h -- launch wrappers for the HIP kernels in vdl_kernels.hip (gfx950).
+// All launchers are asynchronous on the given stream and return the hipError_t of the launch.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "vdl_fuse.h"
+
+namespace vdl {
+
+// ---- operand descriptor of the per-operator kernels --------------------------------
+// A vector operand is a column of 1/2/4/8-byte signed integers, or a virtual range
+// (RangeV / RangeC never touch memory: /root/reference/src/Vdl.hs:428-434 notes the
+// backend "only materializes what's needed").
+enum SrcKind : int { SRC_I64 = 0, SRC_I32 = 1, SRC_I16 = 2, SRC_I8 = 3, SRC_RANGE = 4 };
+struct Src {
+    const void *p = nullptr;
+    int kind = SRC_I64;
+    int64_t from = 0, step = 0;
+};
+
+// ---- fused scan ----------------------------------------------------------------------
+struct ScanArgs {
+    int ncol = 0, nagg = 0;
+    int64_t n = 0;
+    const void *ptr[kMaxScanCols] = {};
+    int width[kMaxScanCols] = {};            // bytes: 1, 2, 4, 8
+    int filtered[kMaxScanCols] = {};         // 0: column has no range filter
+    int64_t lo[kMaxScanCols] = {}, hi[kMaxScanCols] = {};
+    int kind[kMaxScanAggs] = {};             // AGG_SUM / AGG_MIN / AGG_MAX
+    uint32_t used[kMaxScanAggs] = {};        // bit c: column c contributes a factor
+    uint32_t plain[kMaxScanAggs] = {};       // bit c: that factor is the bare column (a=0, s=1)
+    int64_t fa[kMaxScanAggs][kMaxScanCols] = {}, fs[kMaxScanAggs][kMaxScanCols] = {};
+    int64_t constant[kMaxScanAggs] = {};     // datum when the aggregate has no column factor
+    int64_t *block_partials = nullptr;       // [grid][1 + nagg]
+    int never = 0;
+};
+
+struct ScanLaunch { int grid = 0, block = 0, variant = 0; };
+// Chooses template instantiation and grid for (ncol, nagg) on this device.
+ScanLaunch scan_launch_config(const ScanArgs &a, int num_cus);
+hipError_t launch_scan(const ScanArgs &a, const ScanLaunch &cfg, hipStream_t s);
+// Reduces the per-block partials into words[0..nagg] = {count, agg0, ...}.
+hipError_t launch_scan_finish(const int64_t *block_partials, int nblocks, int nagg, const int *kinds_dev_or_null,
+                              const ScanArgs &a, int64_t *words, hipStream_t s);
+const char *scan_kernel_name(const ScanLaunch &cfg);
+
+// ---- synthetic data --------------------------------------------------------------------
+hipError_t launch_gen_column(void *out, int elem_bytes, int64_t row0, int64_t n, uint64_t seed, uint64_t col_id,
+                             int64_t lo, int64_t hi, int64_t mul, int64_t add, hipStream_t s);
+
+// ---- per-operator kernels -----------------------------------------------------------------
+// validity bitmaps: bit (i & 63) of word (i >> 6); nullptr = every slot holds a value.
+hipError_t launch_binary(int op, Src a, Src b, int64_t *out, int64_t n, hipStream_t s);
+hipError_t launch_and_words(const uint64_t *a, const uint64_t *b, uint64_t *out, int64_t nwords, hipStream_t s);
+// FoldSelect with unit-length runs: out bitmap = (d != 0) & vd & vc
+hipError_t launch_select_bitmap(Src d, const uint64_t *vd, const uint64_t *vc, uint64_t *out, int64_t n, hipStream_t s);
+// Global (single-run) fold of `d` over slots valid in both bitmaps.
+// result[0] = value, result[1] = first slot whose control is valid (or -1), result[2] = number of data folded.
+// scratch: at least 3 * fold_scratch_blocks() int64.
+int fold_scratch_blocks();
+hipError_t launch_fold_global(int kind /*0 sum,1 min,2 max,3 count,4 choose*/, Src d, const uint64_t *vd, const uint64_t *vc,
+                              int64_t n, int64_t *scratch, int64_t *result, hipStream_t s);
+// element-wise op on two one-hot (fold result) vectors: valid iff both valid and same slot
+hipError_t launch_onehot_binary(int op, const int64_t *a, const int64_t *b, int64_t *out, hipStream_t s);
+// broadcast-constant operand: b_is_const selects (a op k) / (k op a)
+hipError_t launch_onehot_const(int op, const int64_t *a, int64_t k, int const_left, int64_t *out, hipStream_t s);
+// one-hot -> dense n-slot vector (values + bitmap)
+hipError_t launch_onehot_dense(const int64_t *oh, int64_t *out, uint64_t *valid, int64_t n, hipStream_t s);
+
+// MaterializeCompact: out[rank(i)] = v[i] for valid i, slot order kept.
+// block_counts: ceil(n / compact_tile()) int64; returns total in block_counts[nblocks] (device).
+int64_t compact_tile();
+hipError_t launch_compact_count(const uint64_t *valid, int64_t n, int64_t *block_counts, hipStream_t s);
+hipError_t launch_compact_scan(int64_t *block_counts, int64_t nblocks, hipStream_t s);   // exclusive scan in place, total at [nblocks]
+hipError_t launch_compact_write(Src v, const uint64_t *valid, int64_t n, const int64_t *block_offsets, int64_t *out, hipStream_t s);
+
+// Gather / Scatter / Partition / segmented folds
+hipError_t launch_gather(Src src, const uint64_t *vsrc, int64_t nsrc, Src pos, const uint64_t *vpos, int64_t n,
+                         int64_t *out, uint64_t *vout, hipStream_t s);
+hipError_t launch_scatter(Src src, const uint64_t *vsrc, Src pos, const uint64_t *vpos, int64_t n, int64_t nout,
+                          int64_t *out, uint64_t *vout /* pre-zeroed */, hipStream_t s);
+hipError_t launch_fill_words(uint64_t *p, uint64_t v, int64_t nwords, hipStream_t s);
+
+}  // namespace vdl

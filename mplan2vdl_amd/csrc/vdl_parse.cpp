@@ -1,0 +1,209 @@
+// vdl_parse.cpp -- text front door: VDL lines -> Program.
+// One statement per line, "<id>,<Op>,<fields...>", operands print as "Id <n>"
+// (/root/reference/src/Vdl.hs:97-99,410-453,476-477).  Everything from ";;" on is the
+// --metadata suffix (Vdl.hs:463-466) that eval_query.sh:20 strips; it is ignored here.
+#include "vdl_ir.h"
+#include "vdl.h"
+
+#include <cctype>
+#include <cstring>
+
+namespace vdl {
+
+const char *const kBinNames[B_COUNT] = {"LogicalAnd", "LogicalOr", "BitwiseAnd", "BitwiseOr", "BitShift", "Equals",
+                                        "Add", "Subtract", "Greater", "Multiply", "Divide", "Modulo"};
+
+const char *op_name(Op op, int bin) {
+    switch (op) {
+    case Op::Load: return "Load";
+    case Op::Project: return "Project";
+    case Op::RangeV: return "RangeV";
+    case Op::RangeC: return "RangeC";
+    case Op::Binary: return (bin >= 0 && bin < B_COUNT) ? kBinNames[bin] : "Binary";
+    case Op::FoldSelect: return "FoldSelect";
+    case Op::FoldSum: return "FoldSum";
+    case Op::FoldMin: return "FoldMin";
+    case Op::FoldMax: return "FoldMax";
+    case Op::FoldChoose: return "FoldChoose";
+    case Op::FoldCount: return "FoldCount";
+    case Op::Gather: return "Gather";
+    case Op::Scatter: return "Scatter";
+    case Op::Partition: return "Partition";
+    case Op::Shuffle: return "Shuffle";
+    case Op::Materialize: return "MaterializeCompact";
+    }
+    return "?";
+}
+
+namespace {
+
+[[noreturn]] void bad(int code, int line, const std::string &msg) {
+    throw Error(code, "line " + std::to_string(line) + ": " + msg);
+}
+
+std::string trim(const std::string &s) {
+    size_t b = 0, e = s.size();
+    while (b < e && isspace((unsigned char)s[b])) b++;
+    while (e > b && isspace((unsigned char)s[e - 1])) e--;
+    return s.substr(b, e - b);
+}
+
+std::vector<std::string> split(const std::string &s) {
+    std::vector<std::string> out;
+    size_t p = 0;
+    for (;;) {
+        size_t q = s.find(',', p);
+        if (q == std::string::npos) { out.push_back(trim(s.substr(p))); break; }
+        out.push_back(trim(s.substr(p, q - p)));
+        p = q + 1;
+    }
+    return out;
+}
+
+int64_t to_int(const std::string &s, int line) {
+    if (s.empty()) bad(VDL_ERR_PARSE, line, "empty integer field");
+    errno = 0;
+    char *end = nullptr;
+    long long v = strtoll(s.c_str(), &end, 10);
+    if (*end || errno) bad(VDL_ERR_PARSE, line, "bad integer '" + s + "'");
+    return (int64_t)v;
+}
+
+int to_ref(const std::string &s, int line) {
+    if (s.compare(0, 3, "Id ") != 0) bad(VDL_ERR_PARSE, line, "expected 'Id <n>', got '" + s + "'");
+    int64_t v = to_int(trim(s.substr(3)), line);
+    if (v <= 0 || v > (1 << 24)) bad(VDL_ERR_PARSE, line, "operand id out of range");
+    return (int)v;
+}
+
+}  // namespace
+
+Program parse_program(const char *text, size_t len) {
+    Program P;
+    P.nodes.resize(64);
+    int lineno = 0;
+    size_t pos = 0;
+    auto use = [&](int id, int line) -> const Node & {
+        if (id <= 0 || (size_t)id >= P.nodes.size() || P.nodes[(size_t)id].id == 0)
+            bad(VDL_ERR_PARSE, line, "reference to undefined vector Id " + std::to_string(id));
+        return P.nodes[(size_t)id];
+    };
+    auto need_field = [&](const Node &v, const std::string &f, int line, const char *opn) {
+        if (v.field != f)
+            bad(VDL_ERR_SHAPE, line, std::string(opn) + ": operand Id " + std::to_string(v.id) + " has field '" + v.field +
+                                         "', expected '" + f + "'");
+    };
+    while (pos <= len) {
+        size_t eol = pos;
+        while (eol < len && text[eol] != '\n') eol++;
+        std::string raw(text + pos, eol - pos);
+        pos = eol + 1;
+        lineno++;
+        size_t cut = raw.find(";;");
+        if (cut != std::string::npos) raw.resize(cut);
+        std::string s = trim(raw);
+        if (s.empty()) { if (eol >= len) break; continue; }
+        std::vector<std::string> f = split(s);
+        if (f.size() < 2) bad(VDL_ERR_PARSE, lineno, "expected '<id>,<Op>,...'");
+        int64_t id64 = to_int(f[0], lineno);
+        if (id64 <= 0 || id64 > (1 << 24)) bad(VDL_ERR_PARSE, lineno, "statement id out of range");
+        Node n;
+        n.id = (int)id64;
+        n.line = lineno;
+        if ((size_t)n.id >= P.nodes.size()) P.nodes.resize((size_t)n.id + 64);
+        if (P.nodes[(size_t)n.id].id != 0) bad(VDL_ERR_PARSE, lineno, "Id " + std::to_string(n.id) + " defined twice");
+        const std::string &op = f[1];
+        auto arity = [&](size_t k) {
+            if (f.size() != k)
+                bad(VDL_ERR_PARSE, lineno, op + " expects " + std::to_string(k) + " fields, got " + std::to_string(f.size()));
+        };
+        if (op == "Load") {
+            arity(3);
+            n.op = Op::Load;
+            n.column = f[2];
+            if (n.column.empty()) bad(VDL_ERR_PARSE, lineno, "Load: empty column name");
+            // the struct field is the key path minus its first component (Vdl.hs:161-168)
+            size_t dot = n.column.find('.');
+            n.field = dot == std::string::npos ? n.column : n.column.substr(dot + 1);
+        } else if (op == "Project") {           // Project,<out>,Id v,<in>  (Vdl.hs:422-423)
+            arity(5);
+            n.op = Op::Project;
+            n.a = to_ref(f[3], lineno);
+            need_field(use(n.a, lineno), f[4], lineno, "Project");
+            n.field = f[2];
+        } else if (op == "RangeV") {            // RangeV,val,<from>,Id v,<step>  (Vdl.hs:428-431)
+            arity(6);
+            n.op = Op::RangeV;
+            n.imm0 = to_int(f[3], lineno);
+            n.a = to_ref(f[4], lineno);
+            n.imm1 = to_int(f[5], lineno);
+            use(n.a, lineno);
+            n.field = f[2];
+        } else if (op == "RangeC") {            // RangeC,val,<from>,<count>,<step>  (Vdl.hs:433-434)
+            arity(6);
+            n.op = Op::RangeC;
+            n.imm0 = to_int(f[3], lineno);
+            n.imm1 = to_int(f[4], lineno);
+            n.imm2 = to_int(f[5], lineno);
+            if (n.imm1 < 0) bad(VDL_ERR_PARSE, lineno, "RangeC: negative count");
+            n.field = f[2];
+        } else if (op == "Gather") {            // Gather,Id src,Id pos,val  (Vdl.hs:438)
+            arity(5);
+            n.op = Op::Gather;
+            n.a = to_ref(f[2], lineno);
+            n.b = to_ref(f[3], lineno);
+            need_field(use(n.b, lineno), f[4], lineno, "Gather");
+            n.field = use(n.a, lineno).field;
+        } else if (op == "Scatter") {           // Scatter,Id src,Id fold,val,Id pos,val  (Vdl.hs:441-442)
+            arity(7);
+            n.op = Op::Scatter;
+            n.a = to_ref(f[2], lineno);
+            n.b = to_ref(f[3], lineno);
+            n.c = to_ref(f[5], lineno);
+            need_field(use(n.b, lineno), f[4], lineno, "Scatter");
+            need_field(use(n.c, lineno), f[6], lineno, "Scatter");
+            n.field = use(n.a, lineno).field;
+        } else if (op == "Shuffle") {           // Shuffle,Id v  (Vdl.hs:449-450)
+            arity(3);
+            n.op = Op::Shuffle;
+            n.a = to_ref(f[2], lineno);
+            n.field = use(n.a, lineno).field;
+        } else if (op == "MaterializeCompact") {  // MaterializeCompact,Id v  (Vdl.hs:452-453)
+            arity(3);
+            n.op = Op::Materialize;
+            n.a = to_ref(f[2], lineno);
+            n.field = use(n.a, lineno).field;
+        } else if (op == "Like" || op == "CrossProductOuter" || op == "CrossProductInner" || op == "Semisort") {
+            bad(VDL_ERR_UNSUPPORTED, lineno, "operator '" + op + "' is not implemented (SURVEY.md section 8(f))");
+        } else {
+            // <BinOp|Fold|Partition>,val,Id a,val,Id b,val  (Vdl.hs:436-439)
+            n.op = Op::Binary;
+            n.bin = -1;
+            for (int k = 0; k < B_COUNT; k++) if (op == kBinNames[k]) n.bin = k;
+            if (n.bin < 0) {
+                if (op == "FoldSelect") n.op = Op::FoldSelect;
+                else if (op == "FoldSum") n.op = Op::FoldSum;
+                else if (op == "FoldMin") n.op = Op::FoldMin;
+                else if (op == "FoldMax") n.op = Op::FoldMax;
+                else if (op == "FoldChoose") n.op = Op::FoldChoose;
+                else if (op == "FoldCount") n.op = Op::FoldCount;
+                else if (op == "Partition") n.op = Op::Partition;
+                else bad(VDL_ERR_PARSE, lineno, "unknown operator '" + op + "'");
+            }
+            arity(7);
+            n.a = to_ref(f[3], lineno);
+            n.b = to_ref(f[5], lineno);
+            need_field(use(n.a, lineno), f[4], lineno, op.c_str());
+            need_field(use(n.b, lineno), f[6], lineno, op.c_str());
+            n.field = f[2];
+        }
+        P.nodes[(size_t)n.id] = n;
+        P.order.push_back(n.id);
+        if (n.op == Op::Materialize) P.outputs.push_back(n.id);
+        if (eol >= len) break;
+    }
+    if (P.order.empty()) throw Error(VDL_ERR_PARSE, "empty program");
+    return P;
+}
+
+}  // namespace vdl

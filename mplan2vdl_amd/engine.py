@@ -1,0 +1,173 @@
+"""Host-side mirror of the reference's executor interface.
+
+In the reference the executor is reached as text over a pipe: VDL in, JSON out
+(/root/reference/eval_query.sh:18-26; reply shape /root/reference/resolve.py:8-32).
+``Engine.run_vdl(text)`` is that request/response pair as a function call; everything it
+does goes through the C ABI of libvdl.so (include/vdl.h) into hand-written HIP kernels.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from . import datagen
+
+
+class VdlError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("[vdl error %d] %s" % (code, message))
+        self.code = code
+
+
+class Plan:
+    def __init__(self, engine, handle, text):
+        self._e = engine
+        self._h = handle
+        self.text = text
+
+    def close(self):
+        if self._h:
+            self._e._L.vdl_plan_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def describe(self):
+        return self._e._L.vdl_plan_describe(self._h).decode()
+
+    @property
+    def is_fused(self):
+        return bool(self._e._L.vdl_plan_is_fused(self._h))
+
+    def set_fusion(self, enabled):
+        self._e._check(self._e._L.vdl_plan_set_fusion(self._h, int(bool(enabled))))
+
+    def set_profiling(self, enabled):
+        self._e._check(self._e._L.vdl_plan_set_profiling(self._h, int(bool(enabled))))
+
+    def _collect(self):
+        L = self._e._L
+        results = {}
+        for k in range(L.vdl_n_outputs(self._h)):
+            name, tmp = ctypes.c_char_p(), ctypes.c_char_p()
+            vals, n = ctypes.POINTER(ctypes.c_int64)(), ctypes.c_size_t()
+            L.vdl_output(self._h, k, ctypes.byref(name), ctypes.byref(tmp), ctypes.byref(vals), ctypes.byref(n))
+            results[tmp.value.decode()] = {"." + name.value.decode(): [int(vals[i]) for i in range(n.value)]}
+        timings = {}
+        for k in range(L.vdl_n_timings(self._h)):
+            label, us = ctypes.c_char_p(), ctypes.c_double()
+            L.vdl_timing(self._h, k, ctypes.byref(label), ctypes.byref(us))
+            timings[label.value.decode()] = int(round(us.value))
+        return {"results": results, "timings": timings}
+
+    def run(self):
+        """Execute on the GPU; returns {"results": {tmpN: {".name": [ints]}}, "timings": {...}}."""
+        self._e._check(self._e._L.vdl_run(self._e._c, self._h))
+        return self._collect()
+
+    # ---- sharded execution (one process per GPU) ----
+    def partial_spec(self):
+        n, ops = ctypes.c_int64(), ctypes.POINTER(ctypes.c_int32)()
+        self._e._check(self._e._L.vdl_plan_partial_spec(self._h, ctypes.byref(n), ctypes.byref(ops)))
+        return n.value, [int(ops[i]) for i in range(n.value)]
+
+    def run_local(self, dev_ptr):
+        self._e._check(self._e._L.vdl_run_local(self._e._c, self._h, ctypes.c_void_p(dev_ptr)))
+
+    def finalize(self, dev_ptr):
+        self._e._check(self._e._L.vdl_finalize(self._e._c, self._h, ctypes.c_void_p(dev_ptr)))
+        return self._collect()
+
+    def scan_stats(self):
+        rows, nbytes, us = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_double()
+        self._e._check(self._e._L.vdl_plan_scan_stats(self._h, ctypes.byref(rows), ctypes.byref(nbytes), ctypes.byref(us)))
+        return rows.value, nbytes.value, us.value
+
+
+class Engine:
+    """One context = one GPU (``device=None``: host-only, can parse/describe but not run)."""
+
+    def __init__(self, device=0):
+        self._L = _lib.load()
+        c = ctypes.c_void_p()
+        rc = self._L.vdl_open(ctypes.byref(c), -1 if device is None else int(device))
+        self._c = c
+        self._keep = {}
+        if rc:
+            msg = self._L.vdl_last_error(c).decode()
+            self._L.vdl_close(c)
+            self._c = None
+            raise VdlError(rc, msg)
+
+    def close(self):
+        if self._c:
+            self._L.vdl_close(self._c)
+            self._c = None
+            self._keep.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise VdlError(rc, self._L.vdl_last_error(self._c).decode())
+
+    def version(self):
+        return self._L.vdl_version().decode()
+
+    def set_stream(self, hip_stream_handle):
+        self._check(self._L.vdl_set_stream(self._c, ctypes.c_void_p(hip_stream_handle or 0)))
+
+    # ---- catalog ----
+    def register_tensor(self, name, tensor):
+        """Borrow a 1-D integer torch tensor that already lives in HBM."""
+        if not tensor.is_cuda or tensor.dim() != 1 or not tensor.is_contiguous():
+            raise VdlError(_lib.VDL_ERR_ARG, "register_tensor needs a contiguous 1-D device tensor")
+        self._keep[name] = tensor
+        self._check(self._L.vdl_register_column(self._c, name.encode(), ctypes.c_void_p(tensor.data_ptr()),
+                                                tensor.element_size(), tensor.numel()))
+
+    def upload(self, name, array):
+        a = np.ascontiguousarray(array)
+        if a.dtype.kind != "i":
+            raise VdlError(_lib.VDL_ERR_ARG, "columns are signed integers")
+        self._check(self._L.vdl_upload_column(self._c, name.encode(), a.ctypes.data_as(ctypes.c_void_p),
+                                              a.dtype.itemsize, a.shape[0]))
+
+    def generate(self, spec, row0, nrows, seed=datagen.SEED):
+        """Materialise rows [row0, row0+nrows) of a synthetic column directly in HBM."""
+        self._check(self._L.vdl_generate_column(self._c, spec.name.encode(), np.dtype(spec.dtype).itemsize, row0, nrows,
+                                                seed, spec.lo, spec.hi, spec.mul, spec.add))
+
+    def download(self, name):
+        w, n = ctypes.c_int(), ctypes.c_int64()
+        self._check(self._L.vdl_column_info(self._c, name.encode(), ctypes.byref(w), ctypes.byref(n), None))
+        out = np.empty(n.value, dtype={1: np.int8, 2: np.int16, 4: np.int32, 8: np.int64}[w.value])
+        self._check(self._L.vdl_download_column(self._c, name.encode(), out.ctypes.data_as(ctypes.c_void_p), out.nbytes))
+        return out
+
+    def drop(self, name):
+        self._keep.pop(name, None)
+        self._check(self._L.vdl_drop_column(self._c, name.encode()))
+
+    # ---- programs ----
+    def parse(self, vdl_text):
+        data = vdl_text.encode() if isinstance(vdl_text, str) else vdl_text
+        h = ctypes.c_void_p()
+        self._check(self._L.vdl_parse(self._c, data, len(data), ctypes.byref(h)))
+        return Plan(self, h, vdl_text)
+
+    def run_vdl(self, vdl_text, fuse=True):
+        plan = self.parse(vdl_text)
+        try:
+            plan.set_fusion(fuse)
+            return plan.run()
+        finally:
+            plan.close()

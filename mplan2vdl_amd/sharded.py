@@ -1,0 +1,56 @@
+"""Row-range sharded execution: one process per GPU, RCCL all-reduce of the fold partials.
+
+The reference has no distribution at all; this is the MI355X design of
+SURVEY.md section 8(e): rank g owns rows [g*n/G, (g+1)*n/G), runs the fused scan over them,
+and the per-scan partial words {selected-row count, aggregates...} are merged with
+all-reduce (SUM / MIN / MAX) -- 8 to a few hundred bytes, i.e. latency-bound on xGMI --
+before every rank finalises the same answer.
+"""
+from . import _lib
+
+
+def shard_rows(n_rows, rank, world):
+    """Contiguous row range [lo, hi) of `rank`; sizes differ by at most one row."""
+    lo = (n_rows * rank) // world
+    hi = (n_rows * (rank + 1)) // world
+    return lo, hi
+
+
+def merge_partials(buf, ops, dist, group=None):
+    """All-reduce the words of `buf` (1-D int64 tensor) according to their VDL_REDUCE_* tags."""
+    import torch
+
+    classes = sorted(set(ops))
+    table = {_lib.REDUCE_SUM: dist.ReduceOp.SUM, _lib.REDUCE_MIN: dist.ReduceOp.MIN, _lib.REDUCE_MAX: dist.ReduceOp.MAX}
+    if len(classes) == 1:
+        dist.all_reduce(buf, op=table[classes[0]], group=group)
+        return buf
+    for cls in classes:
+        idx = torch.tensor([i for i, o in enumerate(ops) if o == cls], dtype=torch.long, device=buf.device)
+        part = buf.index_select(0, idx)
+        dist.all_reduce(part, op=table[cls], group=group)
+        buf.index_copy_(0, idx, part)
+    return buf
+
+
+class ShardedQuery:
+    """Drives local phase -> merge -> finalise for a plan whose outputs are global folds.
+
+    `runner` provides partial_spec() -> (n_words, ops), run_local(dev_ptr), finalize(dev_ptr)
+    (mplan2vdl_amd.engine.Plan does); `buf` is a 1-D int64 tensor on the runner's device.
+    """
+
+    def __init__(self, runner, buf, dist=None, group=None):
+        self.runner = runner
+        self.buf = buf
+        self.dist = dist
+        self.group = group
+        self.n_words, self.ops = runner.partial_spec()
+        if buf.numel() < self.n_words:
+            raise ValueError("partials buffer too small")
+
+    def step(self):
+        self.runner.run_local(self.buf.data_ptr())
+        if self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size(self.group) > 1:
+            merge_partials(self.buf[: self.n_words], self.ops, self.dist, self.group)
+        return self.runner.finalize(self.buf.data_ptr())
