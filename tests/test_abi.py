@@ -1,0 +1,138 @@
+"""The C-ABI library loads and exports every symbol include/vdl.h declares; host-only contexts can
+parse, plan and describe; anything that needs a device fails loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import mplan2vdl_amd as m
+from mplan2vdl_amd import _lib
+from conftest import ROOT
+from helpers import prog
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "vdl.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vdl_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    names = header_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), n
+    assert sorted(_lib.ABI_SYMBOLS) == names
+
+
+def test_host_only_context_parses_and_describes_q6(q6_text):
+    e = m.Engine(device=None)
+    p = e.parse(q6_text)
+    assert p.is_fused
+    d = p.describe()
+    assert "lineitem.l_shipdate in [728294,728658]" in d        # >= 1994-01-01 and < 1995-01-01
+    assert "lineitem.l_discount in [5,7]" in d                  # between 0.06-0.01 and 0.06+0.01, constants folded
+    assert "lineitem.l_quantity in [-inf,2399]" in d            # < 24.00
+    assert "sum" in d and "lineitem.l_extendedprice" in d
+    assert p.partial_spec() == (2, [_lib.REDUCE_SUM, _lib.REDUCE_SUM])
+    with pytest.raises(m.VdlError) as ei:
+        p.run()
+    assert ei.value.code == _lib.VDL_ERR_DEVICE                 # loud: no CPU fallback
+    p.set_fusion(False)
+    assert not p.is_fused and "general: 42 statement(s)" in p.describe()
+
+
+def test_q1_is_not_fused_yet_and_says_why(q1_text):
+    e = m.Engine(device=None)
+    p = e.parse(q1_text)
+    assert not p.is_fused
+    assert "not fused" in p.describe()
+    with pytest.raises(m.VdlError) as ei:
+        p.partial_spec()
+    assert ei.value.code == _lib.VDL_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("text,code", [
+    ("", _lib.VDL_ERR_PARSE),
+    ("1,Load\n", _lib.VDL_ERR_PARSE),
+    ("x,Load,t.a\n", _lib.VDL_ERR_PARSE),
+    ("1,Load,t.a\n2,Project,val,Id 9,a\n", _lib.VDL_ERR_PARSE),
+    ("1,Load,t.a\n1,Load,t.b\n", _lib.VDL_ERR_PARSE),
+    ("1,Load,t.a\n2,Project,val,Id 1,b\n", _lib.VDL_ERR_SHAPE),
+    ("1,Load,t.a\n2,Greater,val,Id 1,val,Id 1,val\n", _lib.VDL_ERR_SHAPE),
+    ("1,Load,t.a\n2,Frob,val,Id 1,a,Id 1,a\n", _lib.VDL_ERR_PARSE),
+    ("1,Load,t.a\n2,Project,val,Id 1,a\n3,Like,val,Id 2,val,Id 2,val,%x%\n", _lib.VDL_ERR_UNSUPPORTED),
+    ("1,Load,t.a\n2,Semisort,Id 1\n", _lib.VDL_ERR_UNSUPPORTED),
+])
+def test_parse_errors_carry_codes(text, code):
+    e = m.Engine(device=None)
+    with pytest.raises(m.VdlError) as ei:
+        e.parse(text)
+    assert ei.value.code == code
+
+
+def test_metadata_suffix_is_ignored():
+    e = m.Engine(device=None)
+    p = e.parse("1,Load,t.a ;; Metadata {databounds = (0,1), name = Just t.a}\n\n2,Project,val,Id 1,a\n3,MaterializeCompact,Id 2\n")
+    assert "general: 3 statement(s)" in p.describe()
+
+
+def test_opening_a_device_without_gpu_is_an_error_not_a_fallback():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(m.VdlError) as ei:
+        m.Engine(device=0)
+    assert ei.value.code == _lib.VDL_ERR_DEVICE
+
+
+HEAD = ["1,Load,t.a", "2,Project,val,Id 1,a", "3,Load,t.b", "4,Project,val,Id 3,b", "5,Load,t.c", "6,Project,val,Id 5,c"]
+
+
+def plan_of(lines):
+    return m.Engine(device=None).parse(prog(*(HEAD + lines)))
+
+
+def test_fusion_of_range_predicates_and_affine_products():
+    p = plan_of(["7,RangeV,val,10,Id 2,0", "8,Greater,val,Id 2,val,Id 7,val",            # a > 10
+                 "9,RangeV,val,3,Id 2,0", "10,Equals,val,Id 4,val,Id 9,val",               # b == 3
+                 "11,LogicalAnd,val,Id 8,val,Id 10,val",
+                 "12,RangeV,val,0,Id 11,1", "13,FoldSelect,val,Id 12,val,Id 11,val",
+                 "14,Gather,Id 6,Id 13,val", "15,Gather,Id 2,Id 13,val",
+                 "16,RangeV,val,100,Id 14,0", "17,Subtract,val,Id 16,val,Id 14,val",     # 100 - c
+                 "18,RangeV,val,2,Id 14,0", "19,Multiply,val,Id 17,val,Id 18,val",       # * 2
+                 "20,Multiply,val,Id 19,val,Id 15,val",                                  # * a
+                 "21,RangeV,val,0,Id 20,0", "22,FoldSum,val,Id 21,val,Id 20,val",
+                 "23,Project,s,Id 22,val", "24,MaterializeCompact,Id 23"])
+    assert p.is_fused
+    d = p.describe()
+    assert "t.a in [11,+inf]" in d and "t.b in [3,3]" in d
+    assert "(200 + -2*col" in d                                                       # (100 - c) * 2 folded into one factor
+
+
+def test_disjunction_across_columns_is_not_fused():
+    p = plan_of(["7,RangeV,val,10,Id 2,0", "8,Greater,val,Id 2,val,Id 7,val",
+                 "9,Greater,val,Id 4,val,Id 7,val", "10,LogicalOr,val,Id 8,val,Id 9,val",  # a > 10 or b > 10
+                 "11,RangeV,val,0,Id 10,1", "12,FoldSelect,val,Id 11,val,Id 10,val",
+                 "13,Gather,Id 6,Id 12,val", "14,RangeV,val,0,Id 13,0", "15,FoldSum,val,Id 14,val,Id 13,val",
+                 "16,MaterializeCompact,Id 15"])
+    assert not p.is_fused and "not a conjunction of per-column ranges" in p.describe()
+
+
+def test_contradictory_predicate_is_detected():
+    p = plan_of(["7,RangeV,val,10,Id 2,0", "8,Greater,val,Id 2,val,Id 7,val", "9,Greater,val,Id 7,val,Id 2,val",
+                 "10,LogicalAnd,val,Id 8,val,Id 9,val",                                   # a > 10 and a < 10
+                 "11,RangeV,val,0,Id 10,1", "12,FoldSelect,val,Id 11,val,Id 10,val",
+                 "13,Gather,Id 6,Id 12,val", "14,RangeV,val,0,Id 13,0", "15,FoldSum,val,Id 14,val,Id 13,val",
+                 "16,MaterializeCompact,Id 15"])
+    assert p.is_fused and "[never]" in p.describe()
+
+
+def test_unfiltered_aggregate_and_min_max_fuse():
+    p = plan_of(["7,RangeV,val,0,Id 2,0", "8,FoldMax,val,Id 7,val,Id 2,val", "9,MaterializeCompact,Id 8",
+                 "10,FoldMin,val,Id 7,val,Id 4,val", "11,MaterializeCompact,Id 10"])
+    assert p.is_fused
+    assert p.partial_spec() == (3, [_lib.REDUCE_SUM, _lib.REDUCE_MAX, _lib.REDUCE_MIN])

@@ -1,0 +1,153 @@
+"""The CPU oracle against (a) committed golden vectors, (b) independent SQL-semantics evaluators,
+(c) hand-computed operator cases that fix the EPS-slot vector model (DESIGN.md "Semantics")."""
+import json
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import golden
+from mplan2vdl_amd import datagen
+from helpers import lineitem, oracle_run, prog
+
+
+def test_oracle_reproduces_golden_q6(q6_text):
+    g = json.loads(golden("q6_sf001.json"))
+    cols = lineitem(datagen.Q6_COLUMNS, g["rows"], seed=g["seed"])
+    assert oracle_run(q6_text, cols) == g["results"]
+
+
+def test_oracle_reproduces_golden_q1(q1_text):
+    g = json.loads(golden("q1_sf001.json"))
+    cols = lineitem(datagen.Q1_COLUMNS, g["rows"], seed=g["seed"])
+    assert oracle_run(q1_text, cols) == g["results"]
+
+
+@pytest.mark.parametrize("seed", [3, 4, 5])
+def test_interpreter_equals_sql_evaluators(q6_text, q1_text, seed):
+    n = 30011
+    cols = lineitem(datagen.Q1_COLUMNS, n, seed=seed)
+    rev, cnt = oracle.sql_q6(*[cols[c] for c in datagen.Q6_COLUMNS])
+    assert oracle_run(q6_text, cols) == {"tmp42": {".revenue": [rev]}}
+    sd, di, qt, ep = [cols[c] for c in datagen.Q6_COLUMNS]
+    m = (sd >= 728294) & (sd < 728659) & (di >= 5) & (di <= 7) & (qt < 2400)       # third evaluation: numpy
+    assert (int((ep[m] * di[m]).sum()), int(m.sum())) == (rev, cnt)
+    q1 = oracle_run(q1_text, cols)
+    tab = oracle.sql_q1(cols["lineitem.l_shipdate"], cols["lineitem.l_returnflag"], cols["lineitem.l_linestatus"],
+                        cols["lineitem.l_quantity"], cols["lineitem.l_extendedprice"], cols["lineitem.l_discount"],
+                        cols["lineitem.l_tax"])
+    assert q1["tmp101"][".count_order"] == [int(x) for x in tab[:, 9]]
+    assert q1["tmp82"][".sum_charge"] == [int(x) for x in tab[:, 5]]
+    assert q1["tmp40"][".l_returnflag__lineitem__l_returnflag"] == [int(x) for x in tab[:, 0]]
+
+
+def test_generated_q6_equals_materialised_q6():
+    n = 100000
+    cols = lineitem(datagen.Q6_COLUMNS, n)
+    specs = [(datagen.SEED, datagen.col_id(c), datagen.LINEITEM[c].lo, datagen.LINEITEM[c].hi, datagen.LINEITEM[c].mul,
+              datagen.LINEITEM[c].add) for c in datagen.Q6_COLUMNS]
+    want = oracle.sql_q6(*[cols[c] for c in datagen.Q6_COLUMNS])
+    assert oracle.sql_q6_generated(specs, 0, n, 1) == want
+    assert oracle.sql_q6_generated(specs, 0, n, 4) == want
+    a = oracle.sql_q6_generated(specs, 0, 40000, 2)
+    b = oracle.sql_q6_generated(specs, 40000, 60000, 2)
+    assert (a[0] + b[0], a[1] + b[1]) == want
+
+
+A = np.array([5, -3, 0, 7, 7, 2, 9, 9], dtype=np.int64)
+B = np.array([1, 0, 1, 1, 0, 1, 0, 1], dtype=np.int32)
+HEAD = ["1,Load,t.a", "2,Project,val,Id 1,a", "3,Load,t.b", "4,Project,val,Id 3,b"]
+SEL = ["5,RangeV,val,0,Id 4,1", "6,FoldSelect,val,Id 5,val,Id 4,val"]          # b != 0 -> slots 0,2,3,5,7
+
+
+def run(lines, cols=None):
+    return oracle_run(prog(*lines), cols or {"t.a": A, "t.b": B})
+
+
+def out(lines, cols=None):
+    r = run(lines, cols)
+    return [list(v.values())[0] for v in r.values()]
+
+
+def test_foldselect_positions_and_compaction():
+    assert out(HEAD + SEL + ["7,MaterializeCompact,Id 6"]) == [[0, 2, 3, 5, 7]]
+
+
+def test_gather_keeps_holes_until_materialize():
+    assert out(HEAD + SEL + ["7,Gather,Id 2,Id 6,val", "8,MaterializeCompact,Id 7"]) == [[5, 0, 7, 2, 9]]
+
+
+def test_rangev_inherits_eps_so_count_star_counts_selected_rows():
+    # count(*) lowering: FoldSum(zeros_ refv, ones_ refv), Vlite.hs:636-639,1044-1046,982-983
+    lines = HEAD + SEL + ["7,Gather,Id 2,Id 6,val", "8,RangeV,val,0,Id 7,0", "9,RangeV,val,1,Id 7,0",
+                          "10,FoldSum,val,Id 8,val,Id 9,val", "11,MaterializeCompact,Id 10"]
+    assert out(lines) == [[5]]
+
+
+def test_global_fold_result_sits_in_first_slot_and_skips_eps():
+    lines = HEAD + SEL + ["7,Gather,Id 2,Id 6,val", "8,RangeV,val,0,Id 7,0",
+                          "9,FoldSum,val,Id 8,val,Id 7,val", "10,MaterializeCompact,Id 9",
+                          "11,FoldMin,val,Id 8,val,Id 7,val", "12,MaterializeCompact,Id 11",
+                          "13,FoldMax,val,Id 8,val,Id 7,val", "14,MaterializeCompact,Id 13",
+                          "15,FoldChoose,val,Id 8,val,Id 7,val", "16,MaterializeCompact,Id 15"]
+    assert out(lines) == [[23], [0], [9], [5]]
+
+
+def test_fold_runs_follow_control_values():
+    ctl = np.array([1, 1, 2, 2, 2, 1, 3, 3], dtype=np.int64)
+    lines = ["1,Load,t.k", "2,Project,val,Id 1,k", "3,Load,t.a", "4,Project,val,Id 3,a",
+             "5,FoldSum,val,Id 2,val,Id 4,val", "6,MaterializeCompact,Id 5",
+             "7,FoldCount,val,Id 2,val,Id 4,val", "8,MaterializeCompact,Id 7"]
+    assert out(lines, {"t.k": ctl, "t.a": A}) == [[2, 14, 2, 18], [2, 3, 1, 2]]
+
+
+def test_scatter_partition_group_by_pattern():
+    # Partition + Scatter + Fold = group by (Vlite.hs:1056-1060,1082-1098)
+    key = np.array([2, 0, 1, 2, 0, 1, 2, 2], dtype=np.int64)
+    lines = ["1,Load,t.k", "2,Project,val,Id 1,k", "3,Load,t.a", "4,Project,val,Id 3,a",
+             "5,RangeC,val,0,3,1", "6,Partition,val,Id 2,val,Id 5,val", "7,MaterializeCompact,Id 6",
+             "8,RangeV,val,0,Id 2,1", "9,Scatter,Id 2,Id 8,val,Id 6,val", "10,MaterializeCompact,Id 9",
+             "11,RangeV,val,0,Id 4,1", "12,Scatter,Id 4,Id 11,val,Id 6,val",
+             "13,FoldSum,val,Id 9,val,Id 12,val", "14,MaterializeCompact,Id 13"]
+    r = out(lines, {"t.k": key, "t.a": A})
+    assert r[0] == [4, 0, 2, 5, 1, 3, 6, 7]               # stable counting-sort destinations
+    assert r[1] == [0, 0, 1, 1, 2, 2, 2, 2]
+    assert r[2] == [-3 + 7, 0 + 2, 5 + 7 + 9 + 9]
+
+
+def test_partition_skips_eps_rows():
+    key = np.array([1, 0, 1, 0, 1, 0, 1, 0], dtype=np.int64)
+    lines = ["1,Load,t.k", "2,Project,val,Id 1,k", "3,Load,t.b", "4,Project,val,Id 3,b",
+             "5,RangeV,val,0,Id 4,1", "6,FoldSelect,val,Id 5,val,Id 4,val", "7,Gather,Id 2,Id 6,val",
+             "8,RangeC,val,0,2,1", "9,Partition,val,Id 7,val,Id 8,val", "10,MaterializeCompact,Id 9"]
+    assert out(lines, {"t.k": key, "t.b": B}) == [[3, 4, 0, 1, 2]]       # selected rows 0,2,3,5,7 carry keys 1,1,0,0,0
+
+
+def test_arithmetic_edge_cases():
+    a = np.array([7, -7, 7, -2**63, 5, 1, -8, 3], dtype=np.int64)
+    b = np.array([2, 2, 0, -1, -1, -3, 1, 64], dtype=np.int64)
+    def one(op):
+        return out(["1,Load,t.a", "2,Project,val,Id 1,a", "3,Load,t.b", "4,Project,val,Id 3,b",
+                    "5,%s,val,Id 2,val,Id 4,val" % op, "6,MaterializeCompact,Id 5"], {"t.a": a, "t.b": b})[0]
+    assert one("Divide") == [3, -3, 0, -2**63, -5, 0, -8, 0]            # C truncation, x/0 := 0, wrap
+    assert one("Modulo") == [1, -1, 0, 0, 0, 1, 0, 3]
+    assert one("BitShift") == [1, -2, 7, 0, 10, 8, -4, 0]               # b<0 shifts left (Vlite.hs:205-208)
+    assert one("Greater") == [1, 0, 1, 0, 1, 1, 0, 0]
+    assert one("LogicalAnd") == [1, 1, 0, 1, 1, 1, 1, 1]
+
+
+def test_metadata_suffix_and_blank_lines_are_ignored():
+    lines = ["1,Load,t.a ;; Metadata {databounds = (0,1)}", "", "2,Project,val,Id 1,a", "3,MaterializeCompact,Id 2"]
+    assert out(lines) == [list(A)]
+
+
+@pytest.mark.parametrize("bad", [
+    ["1,Load,t.missing", "2,MaterializeCompact,Id 1"],
+    ["1,Load,t.a", "2,Project,val,Id 1,wrongfield"],
+    ["1,Load,t.a", "2,Frobnicate,val,Id 1,val,Id 1,val"],
+    ["1,Load,t.a", "2,Project,val,Id 7,a"],
+    ["1,Load,t.a", "1,Load,t.b"],
+])
+def test_errors(bad):
+    with pytest.raises(oracle.OracleError):
+        run(bad)

@@ -1,0 +1,96 @@
+"""N > 1 path on CPU: two gloo ranks each fold their own row range, the partial words are merged
+with all-reduce exactly as bench.py does with RCCL, and both ranks finalise the full answer."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import mplan2vdl_amd as m
+from mplan2vdl_amd import _lib, datagen
+
+
+def test_shard_rows_cover_everything_once():
+    for n in (0, 1, 7, 600037902):
+        for world in (1, 2, 3, 8):
+            r = [m.shard_rows(n, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
+            assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+
+
+class OracleShardRunner:
+    """Stands in for engine.Plan on a CPU-only box (TEST ONLY): computes the partial words of the
+    Q6 scan {selected rows, sum(ep*disc), max(ep), min(disc)} for one row range with the oracle."""
+
+    def __init__(self, lo, hi):
+        import oracle
+
+        cols = {c: datagen.generate(datagen.LINEITEM[c], lo, hi - lo) for c in datagen.Q6_COLUMNS}
+        sd, di, qt, ep = [cols[c] for c in datagen.Q6_COLUMNS]
+        self.rev, self.cnt = oracle.sql_q6(sd, di, qt, ep)
+        sel = (sd >= 728294) & (sd < 728659) & (di >= 5) & (di <= 7) & (qt < 2400)
+        self.mx = int(ep[sel].max()) if sel.any() else np.iinfo(np.int64).min
+        self.mn = int(di[sel].min()) if sel.any() else np.iinfo(np.int64).max
+        self.buf = None
+
+    def partial_spec(self):
+        return 4, [_lib.REDUCE_SUM, _lib.REDUCE_SUM, _lib.REDUCE_MAX, _lib.REDUCE_MIN]
+
+    def run_local(self, ptr):
+        self.buf[:4] = torch.tensor([self.cnt, self.rev, self.mx, self.mn], dtype=torch.int64)
+
+    def finalize(self, ptr):
+        w = [int(x) for x in self.buf[:4]]
+        return {"results": {"tmp42": {".revenue": [w[1]] if w[0] else []}, "tmpX": {".max": [w[2]]}, "tmpY": {".min": [w[3]]}},
+                "timings": {}, "count": w[0]}
+
+
+def _worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = m.shard_rows(n, rank, world)
+    runner = OracleShardRunner(lo, hi)
+    buf = torch.zeros(4, dtype=torch.int64)
+    runner.buf = buf
+    query = m.ShardedQuery(runner, buf, dist)
+    out = None
+    for _ in range(2):
+        out = query.step()
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_gloo_merge_equals_single_rank():
+    n = 200001
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29000 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=150) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    single = OracleShardRunner(0, n)
+    want = {"tmp42": {".revenue": [single.rev]}, "tmpX": {".max": [single.mx]}, "tmpY": {".min": [single.mn]}}
+    assert outs[0]["results"] == want and outs[1]["results"] == want
+    assert outs[0]["count"] == single.cnt
+
+
+def test_merge_partials_mixed_ops_single_process():
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(31000 + (os.getpid() % 2000))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        buf = torch.tensor([3, 10, 7, 2], dtype=torch.int64)
+        m.merge_partials(buf, [_lib.REDUCE_SUM, _lib.REDUCE_SUM, _lib.REDUCE_MAX, _lib.REDUCE_MIN], dist)
+        assert buf.tolist() == [3, 10, 7, 2]
+    finally:
+        dist.destroy_process_group()
