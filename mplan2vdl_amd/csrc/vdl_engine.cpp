@@ -466,18 +466,52 @@ struct GenExec {
         case Op::FoldSum: case Op::FoldMin: case Op::FoldMax: case Op::FoldCount: case Op::FoldChoose: {
             DVec ctl = densify(V(n.a)), d = densify(V(n.b));
             if (ctl.n != d.n) throw Error(VDL_ERR_SHAPE, std::string(op_name(n.op, -1)) + " (Id " + std::to_string(n.id) + "): operand lengths differ");
-            if (!(ctl.kind == DVec::RANGE && ctl.step == 0))
-                throw Error(VDL_ERR_UNSUPPORTED, std::string(op_name(n.op, -1)) + " (Id " + std::to_string(n.id) +
-                                                     "): only a constant control vector (one global run) is implemented");
             const int kind = n.op == Op::FoldSum ? 0 : n.op == Op::FoldMin ? 1 : n.op == Op::FoldMax ? 2 : n.op == Op::FoldCount ? 3 : 4;
+            if (!(ctl.kind == DVec::RANGE && ctl.step == 0)) {
+                // general control vector (grouped aggregates fold data scattered into key order)
+                const size_t nw = (size_t)std::max<int64_t>(nwords(d.n), 1);
+                BufP heads = dev_alloc(c, sizeof(uint64_t) * nw);
+                BufP wordhd = dev_alloc(c, sizeof(int64_t) * nw);
+                o.kind = DVec::DENSE; o.n = d.n;
+                o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(d.n, 1));
+                o.valid = dev_alloc(c, sizeof(uint64_t) * nw);
+                HIP_CHECK(launch_fill_words((uint64_t *)o.valid->p, 0, nwords(d.n), s));
+                HIP_CHECK(launch_fold_segmented(kind, src_of(ctl), vp(ctl), src_of(d), vp(d), d.n, (uint64_t *)heads->p,
+                                                (int64_t *)wordhd->p, (int64_t *)o.data->p, (uint64_t *)o.valid->p, s));
+                return o;
+            }
             BufP scratch = dev_alloc(c, sizeof(int64_t) * 3 * (size_t)fold_scratch_blocks());
             o.kind = DVec::ONEHOT; o.n = d.n;
             o.data = dev_alloc(c, 3 * sizeof(int64_t));
             HIP_CHECK(launch_fold_global(kind, src_of(d), vp(d), vp(ctl), d.n, (int64_t *)scratch->p, (int64_t *)o.data->p, s));
             return o;
         }
-        case Op::Partition:
-            throw Error(VDL_ERR_UNSUPPORTED, "Partition (Id " + std::to_string(n.id) + ") is not implemented yet");
+        case Op::Partition: {
+            DVec data = densify(V(n.a));
+            const DVec &piv = V(n.b);
+            if (!(piv.kind == DVec::RANGE && piv.step == 1 && !piv.valid))
+                throw Error(VDL_ERR_UNSUPPORTED, "Partition (Id " + std::to_string(n.id) +
+                                                     "): pivots must be a RangeC with step 1 (what mplan2vdl emits, Vlite.hs:1088-1091)");
+            o.kind = DVec::DENSE; o.n = data.n; o.valid = data.valid;
+            o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(o.n, 1));
+            if (o.n > 0) {
+                const int passes = partition_passes(piv.n);
+                const int64_t hn = 256 * partition_tiles(o.n);
+                BufP hist = dev_alloc(c, sizeof(int64_t) * (size_t)(hn + 1));
+                BufP scr = dev_alloc(c, sizeof(int64_t) * (size_t)(prefix_sum_blocks(hn) + 2));
+                BufP nvalid = dev_alloc(c, sizeof(int64_t));
+                BufP ka, sa, kb, sb;
+                if (passes > 1) {
+                    ka = dev_alloc(c, sizeof(int64_t) * (size_t)o.n); sa = dev_alloc(c, sizeof(int64_t) * (size_t)o.n);
+                    kb = dev_alloc(c, sizeof(int64_t) * (size_t)o.n); sb = dev_alloc(c, sizeof(int64_t) * (size_t)o.n);
+                }
+                HIP_CHECK(launch_partition(src_of(data), vp(data), o.n, piv.from, piv.n, (int64_t *)hist->p, (int64_t *)scr->p,
+                                           ka ? (uint64_t *)ka->p : nullptr, sa ? (int64_t *)sa->p : nullptr,
+                                           kb ? (uint64_t *)kb->p : nullptr, sb ? (int64_t *)sb->p : nullptr,
+                                           (int64_t *)nvalid->p, (int64_t *)o.data->p, s));
+            }
+            return o;
+        }
         case Op::Materialize:
             materialize(n, V(n.a));
             return V(n.a);

@@ -83,4 +83,19 @@ hipError_t launch_scatter(Src src, const uint64_t *vsrc, Src pos, const uint64_t
                           int64_t *out, uint64_t *vout /* pre-zeroed */, hipStream_t s);
 hipError_t launch_fill_words(uint64_t *p, uint64_t v, int64_t nwords, hipStream_t s);
 
+// device-wide exclusive prefix sum (in place); sums = prefix_sum_blocks(n) + 1 int64 of scratch
+int64_t prefix_sum_blocks(int64_t n);
+hipError_t launch_prefix_sum(int64_t *x, int64_t n, int64_t *sums, hipStream_t s);
+
+// Partition with pivots RangeC pmin pcount 1 (bucket = clamp(data - pmin, 0, pcount)); see vdl_kernels.hip
+int64_t partition_tiles(int64_t n);
+int partition_passes(int64_t pcount);
+hipError_t launch_partition(Src data, const uint64_t *valid, int64_t n, int64_t pmin, int64_t pcount, int64_t *hist,
+                            int64_t *scan_scratch, uint64_t *keys_a, int64_t *slots_a, uint64_t *keys_b, int64_t *slots_b,
+                            int64_t *n_valid_dev, int64_t *pos_out, hipStream_t s);
+
+// Fold over a general control vector; kind 0 sum, 1 min, 2 max, 3 count, 4 choose
+hipError_t launch_fold_segmented(int kind, Src ctl, const uint64_t *vc, Src d, const uint64_t *vd, int64_t n, uint64_t *heads,
+                                 int64_t *wordhd, int64_t *out, uint64_t *vout, hipStream_t s);
+
 }  // namespace vdl

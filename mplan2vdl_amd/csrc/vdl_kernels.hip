@@ -15,6 +15,11 @@ typedef char i8x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kWave = 64;
 
+// hipGetLastError() is sticky per thread: a failed call made earlier by anybody in this process
+// (e.g. an advisory query) would be reported by the next launch check.  Launchers therefore clear
+// the slot before launching and read it right after (launch_status).
+static inline hipError_t launch_status() { return hipGetLastError(); }
+
 // ------------------------------------------------------------------------------------------
 // reductions
 // ------------------------------------------------------------------------------------------
@@ -60,6 +65,7 @@ __global__ void k_gen_column(T *out, int64_t row0, int64_t n, uint64_t key, int6
 
 hipError_t launch_gen_column(void *out, int elem_bytes, int64_t row0, int64_t n, uint64_t seed, uint64_t col_id,
                              int64_t lo, int64_t hi, int64_t mul, int64_t add, hipStream_t s) {
+    (void)hipGetLastError();   // see launch_status()
     if (n <= 0) return hipSuccess;
     const uint64_t key = seed ^ (col_id * 0x9E3779B97F4A7C15ULL);
     const uint64_t span = (uint64_t)hi - (uint64_t)lo + 1;
@@ -72,7 +78,7 @@ hipError_t launch_gen_column(void *out, int elem_bytes, int64_t row0, int64_t n,
     case 8: k_gen_column<int64_t><<<grid, block, 0, s>>>((int64_t *)out, row0, n, key, lo, span, mul, add); break;
     default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
+    return launch_status();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -299,7 +305,10 @@ ScanLaunch scan_launch_config(const ScanArgs &a, int num_cus) {
     if (cfg.variant < 0) return cfg;
     const ScanVariant &v = kScanVariants[cfg.variant];
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v.fn, kScanBlock, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v.fn, kScanBlock, 0) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();      // the query is advisory: do not leave its error for the next launch check
+        per_cu = 4;
+    }
     if (per_cu > 8) per_cu = 8;
     const int64_t tile = (int64_t)kScanBlock * 2 * v.u;
     const int64_t ntiles = a.n / tile;
@@ -316,15 +325,17 @@ const char *scan_kernel_name(const ScanLaunch &cfg) {
 }
 
 hipError_t launch_scan(const ScanArgs &a, const ScanLaunch &cfg, hipStream_t s) {
+    (void)hipGetLastError();   // see launch_status()
     if (cfg.variant < 0 || cfg.variant >= kNumScanVariants) return hipErrorInvalidValue;
     hipLaunchKernelGGL(kScanVariants[cfg.variant].fn, dim3(cfg.grid), dim3(cfg.block), 0, s, a);
-    return hipGetLastError();
+    return launch_status();
 }
 
 hipError_t launch_scan_finish(const int64_t *block_partials, int nblocks, int, const int *, const ScanArgs &a, int64_t *words,
                               hipStream_t s) {
+    (void)hipGetLastError();   // see launch_status()
     k_scan_finish<<<1, 256, 0, s>>>(block_partials, nblocks, a, words);
-    return hipGetLastError();
+    return launch_status();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -366,6 +377,7 @@ __global__ __launch_bounds__(256) void k_binary(Src a, Src b, int64_t *__restric
 }
 
 hipError_t launch_binary(int op, Src a, Src b, int64_t *out, int64_t n, hipStream_t s) {
+    (void)hipGetLastError();   // see launch_status()
     if (n <= 0) return hipSuccess;
     const int block = 256, grid = grid_for(n, block, 4);
 #define VDL_BIN(OP) case OP: k_binary<OP><<<grid, block, 0, s>>>(a, b, out, n); break;
@@ -375,7 +387,7 @@ hipError_t launch_binary(int op, Src a, Src b, int64_t *out, int64_t n, hipStrea
     default: return hipErrorInvalidValue;
     }
 #undef VDL_BIN
-    return hipGetLastError();
+    return launch_status();
 }
 
 __global__ void k_and_words(const uint64_t *a, const uint64_t *b, uint64_t *out, int64_t nw) {
@@ -383,9 +395,10 @@ __global__ void k_and_words(const uint64_t *a, const uint64_t *b, uint64_t *out,
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += stride) out[i] = a[i] & b[i];
 }
 hipError_t launch_and_words(const uint64_t *a, const uint64_t *b, uint64_t *out, int64_t nw, hipStream_t s) {
+    (void)hipGetLastError();   // see launch_status()
     if (nw <= 0) return hipSuccess;
     k_and_words<<<grid_for(nw, 256, 1), 256, 0, s>>>(a, b, out, nw);
-    return hipGetLastError();
+    return launch_status();
 }
 
 __global__ void k_fill_words(uint64_t *p, uint64_t v, int64_t nw) {
@@ -393,9 +406,10 @@ __global__ void k_fill_words(uint64_t *p, uint64_t v, int64_t nw) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += stride) p[i] = v;
 }
 hipError_t launch_fill_words(uint64_t *p, uint64_t v, int64_t nw, hipStream_t s) {
+    (void)hipGetLastError();   // see launch_status()
     if (nw <= 0) return hipSuccess;
     k_fill_words<<<grid_for(nw, 256, 1), 256, 0, s>>>(p, v, nw);
-    return hipGetLastError();
+    return launch_status();
 }
 
 // FoldSelect with unit runs (/root/reference/src/Vlite.hs:725-727): the output values are the
@@ -415,9 +429,10 @@ __global__ __launch_bounds__(256) void k_select_bitmap(Src d, const uint64_t *vd
     }
 }
 hipError_t launch_select_bitmap(Src d, const uint64_t *vd, const uint64_t *vc, uint64_t *out, int64_t n, hipStream_t s) {
+    (void)hipGetLastError();   // see launch_status()
     if (n <= 0) return hipSuccess;
     k_select_bitmap<<<grid_for(n, 256, 4), 256, 0, s>>>(d, vd, vc, out, n);
-    return hipGetLastError();
+    return launch_status();
 }
 
 // Global (single-run) fold (/root/reference/src/Vlite.hs:337-356 with an all-equal control
@@ -484,11 +499,12 @@ __global__ __launch_bounds__(256) void k_fold_global_finish(int kind, Src d, con
 
 hipError_t launch_fold_global(int kind, Src d, const uint64_t *vd, const uint64_t *vc, int64_t n, int64_t *scratch,
                               int64_t *result, hipStream_t s) {
+    (void)hipGetLastError();   // see launch_status()
     int grid = grid_for(n, 256, 8);
     if (grid > kFoldBlocks) grid = kFoldBlocks;
     k_fold_global<<<grid, 256, 0, s>>>(kind, d, vd, vc, n, scratch);
     k_fold_global_finish<<<1, 256, 0, s>>>(kind, d, scratch, grid, result);
-    return hipGetLastError();
+    return launch_status();
 }
 
 // one-hot vectors {value, slot, count}: element-wise ops between fold results
@@ -499,8 +515,9 @@ __global__ void k_onehot_binary(int op, const int64_t *a, const int64_t *b, int6
     out[2] = ok ? 1 : 0;
 }
 hipError_t launch_onehot_binary(int op, const int64_t *a, const int64_t *b, int64_t *out, hipStream_t s) {
+    (void)hipGetLastError();   // see launch_status()
     k_onehot_binary<<<1, 1, 0, s>>>(op, a, b, out);
-    return hipGetLastError();
+    return launch_status();
 }
 __global__ void k_onehot_const(int op, const int64_t *a, int64_t k, int const_left, int64_t *out) {
     const bool ok = a[2] > 0;
@@ -509,8 +526,9 @@ __global__ void k_onehot_const(int op, const int64_t *a, int64_t k, int const_le
     out[2] = a[2];
 }
 hipError_t launch_onehot_const(int op, const int64_t *a, int64_t k, int const_left, int64_t *out, hipStream_t s) {
+    (void)hipGetLastError();   // see launch_status()
     k_onehot_const<<<1, 1, 0, s>>>(op, a, k, const_left, out);
-    return hipGetLastError();
+    return launch_status();
 }
 __global__ void k_onehot_dense(const int64_t *oh, int64_t *out, uint64_t *valid, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -521,9 +539,10 @@ __global__ void k_onehot_dense(const int64_t *oh, int64_t *out, uint64_t *valid,
         valid[w] = (slot >= 0 && (slot >> 6) == w) ? (1ull << (slot & 63)) : 0ull;
 }
 hipError_t launch_onehot_dense(const int64_t *oh, int64_t *out, uint64_t *valid, int64_t n, hipStream_t s) {
+    (void)hipGetLastError();   // see launch_status()
     if (n <= 0) return hipSuccess;
     k_onehot_dense<<<grid_for(n, 256, 4), 256, 0, s>>>(oh, out, valid, n);
-    return hipGetLastError();
+    return launch_status();
 }
 
 // MaterializeCompact (/root/reference/src/Vdl.hs:452-453): stream compaction with the order kept.
@@ -545,10 +564,11 @@ __global__ __launch_bounds__(64) void k_compact_count(const uint64_t *valid, int
     if (threadIdx.x == 0) counts[blockIdx.x] = c;
 }
 hipError_t launch_compact_count(const uint64_t *valid, int64_t n, int64_t *counts, hipStream_t s) {
+    (void)hipGetLastError();   // see launch_status()
     const int64_t nb = (n + compact_tile() - 1) / compact_tile();
     if (nb <= 0) return hipSuccess;
     k_compact_count<<<(int)nb, 64, 0, s>>>(valid, n, counts);
-    return hipGetLastError();
+    return launch_status();
 }
 
 // single-block exclusive scan (in place); total written at [nblocks]
@@ -580,8 +600,9 @@ __global__ __launch_bounds__(1024) void k_scan_counts(int64_t *c, int64_t nb) {
     if (tid == 0) c[nb] = carry;
 }
 hipError_t launch_compact_scan(int64_t *counts, int64_t nb, hipStream_t s) {
+    (void)hipGetLastError();   // see launch_status()
     k_scan_counts<<<1, 1024, 0, s>>>(counts, nb);
-    return hipGetLastError();
+    return launch_status();
 }
 
 __global__ __launch_bounds__(256) void k_compact_write(Src v, const uint64_t *valid, int64_t n, const int64_t *offsets, int64_t *out) {
@@ -616,10 +637,11 @@ __global__ __launch_bounds__(256) void k_compact_write(Src v, const uint64_t *va
     }
 }
 hipError_t launch_compact_write(Src v, const uint64_t *valid, int64_t n, const int64_t *offsets, int64_t *out, hipStream_t s) {
+    (void)hipGetLastError();   // see launch_status()
     const int64_t nb = (n + compact_tile() - 1) / compact_tile();
     if (nb <= 0) return hipSuccess;
     k_compact_write<<<(int)nb, 256, 0, s>>>(v, valid, n, offsets, out);
-    return hipGetLastError();
+    return launch_status();
 }
 
 // Gather (/root/reference/src/Vdl.hs:438): out_i = src[pos_i]; EPS if pos_i is EPS / out of range /
@@ -641,9 +663,10 @@ __global__ __launch_bounds__(256) void k_gather(Src src, const uint64_t *vsrc, i
 }
 hipError_t launch_gather(Src src, const uint64_t *vsrc, int64_t nsrc, Src pos, const uint64_t *vpos, int64_t n, int64_t *out,
                          uint64_t *vout, hipStream_t s) {
+    (void)hipGetLastError();   // see launch_status()
     if (n <= 0) return hipSuccess;
     k_gather<<<grid_for(n, 256, 4), 256, 0, s>>>(src, vsrc, nsrc, pos, vpos, n, out, vout);
-    return hipGetLastError();
+    return launch_status();
 }
 
 // Scatter (/root/reference/src/Vdl.hs:441-442): out[pos_i] = src_i; positions are unique at every
@@ -662,9 +685,337 @@ __global__ __launch_bounds__(256) void k_scatter(Src src, const uint64_t *vsrc, 
 }
 hipError_t launch_scatter(Src src, const uint64_t *vsrc, Src pos, const uint64_t *vpos, int64_t n, int64_t nout, int64_t *out,
                           uint64_t *vout, hipStream_t s) {
+    (void)hipGetLastError();   // see launch_status()
     if (n <= 0) return hipSuccess;
     k_scatter<<<grid_for(n, 256, 4), 256, 0, s>>>(src, vsrc, pos, vpos, n, nout, out, vout);
-    return hipGetLastError();
+    return launch_status();
+}
+
+
+// ------------------------------------------------------------------------------------------
+// device-wide exclusive prefix sum over int64 (in place): block sums -> one-block scan of the
+// sums -> per-block scan with carry.  Tile = 1024 threads x 4 consecutive items.
+// ------------------------------------------------------------------------------------------
+constexpr int kPsBlock = 1024, kPsItems = 4, kPsTile = kPsBlock * kPsItems;
+int64_t prefix_sum_blocks(int64_t n) { return (n + kPsTile - 1) / kPsTile; }
+
+__global__ __launch_bounds__(kPsBlock) void k_ps_block_sums(const int64_t *x, int64_t n, int64_t *sums) {
+    __shared__ int64_t red[kPsBlock / kWave];
+    const int64_t base = (int64_t)blockIdx.x * kPsTile + (int64_t)threadIdx.x * kPsItems;
+    int64_t t = 0;
+#pragma unroll
+    for (int k = 0; k < kPsItems; k++) if (base + k < n) t += x[base + k];
+    t = wave_reduce(t, R_SUM);
+    if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) { int64_t a = 0; for (int w = 0; w < kPsBlock / kWave; w++) a += red[w]; sums[blockIdx.x] = a; }
+}
+
+__global__ __launch_bounds__(kPsBlock) void k_ps_apply(int64_t *x, int64_t n, const int64_t *block_excl) {
+    __shared__ int64_t wsum[kPsBlock / kWave];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const int64_t base = (int64_t)blockIdx.x * kPsTile + (int64_t)tid * kPsItems;
+    int64_t v[kPsItems], t = 0;
+#pragma unroll
+    for (int k = 0; k < kPsItems; k++) { v[k] = (base + k < n) ? x[base + k] : 0; t += v[k]; }
+    int64_t incl = t;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) { int64_t y = __shfl_up(incl, off, kWave); if (lane >= off) incl += y; }
+    if (lane == kWave - 1) wsum[wave] = incl;
+    __syncthreads();
+    int64_t run = block_excl[blockIdx.x] + incl - t;
+    for (int w = 0; w < wave; w++) run += wsum[w];
+#pragma unroll
+    for (int k = 0; k < kPsItems; k++) { if (base + k < n) x[base + k] = run; run += v[k]; }
+}
+
+// sums: prefix_sum_blocks(n) + 1 int64 of scratch; the grand total is left in sums[nblocks]
+hipError_t launch_prefix_sum(int64_t *x, int64_t n, int64_t *sums, hipStream_t s) {
+    (void)hipGetLastError();   // see launch_status()
+    const int64_t nb = prefix_sum_blocks(n);
+    if (nb <= 0) return hipSuccess;
+    k_ps_block_sums<<<(int)nb, kPsBlock, 0, s>>>(x, n, sums);
+    k_scan_counts<<<1, 1024, 0, s>>>(sums, nb);
+    k_ps_apply<<<(int)nb, kPsBlock, 0, s>>>(x, n, sums);
+    return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
+// Partition (/root/reference/src/Vdl.hs:130,266-269; Vlite.hs:358-366,508,1082-1098): positions
+// that stably group `data` by pivot bucket.  Pivots are the emitted RangeC min cnt 1, so
+// bucket = clamp(data - min, 0, cnt).  Implemented as an LSD radix sort of (bucket, slot) over the
+// non-EPS slots, 8 bits per pass; each pass = tile histogram (LDS atomics) -> device-wide prefix
+// sum in digit-major order -> stable scatter (per-wave peer masks from 8 ballots, cross-wave
+// order through LDS).  The last pass writes out[slot] = rank instead of the sorted pair.
+// Dense group-by domains (Q1: 32 buckets) need one pass, Q3's 2^38 domain five.
+// ------------------------------------------------------------------------------------------
+constexpr int kPartBlock = 256, kPartSteps = 16, kPartTile = kPartBlock * kPartSteps, kRadix = 256;
+int64_t partition_tiles(int64_t n) { return (n + kPartTile - 1) / kPartTile; }
+
+struct PartIn {
+    Src data;                    // first pass: raw data column
+    const uint64_t *valid;       // first pass: validity of data
+    int64_t pmin, pcount;        // pivots = RangeC pmin pcount 1
+    const uint64_t *keys;        // later passes: bucket values of the previous pass
+    const int64_t *slots;        // later passes: originating slot
+    const int64_t *n_dev;        // later passes: number of elements (device scalar)
+    int64_t n;                   // first pass: number of slots; later: upper bound for the grid
+    int shift;
+};
+
+template <bool FIRST>
+__device__ __forceinline__ bool part_fetch(const PartIn &in, int64_t i, int64_t n, uint64_t &key, int64_t &slot) {
+    if (i >= n) return false;
+    if (FIRST) {
+        if (!bit(in.valid, i)) return false;
+        const int64_t x = ld(in.data, i);
+        int64_t b = 0;
+        if (x > in.pmin) { b = (int64_t)((uint64_t)x - (uint64_t)in.pmin); if (b < 0 || b > in.pcount) b = in.pcount; }
+        key = (uint64_t)b; slot = i;
+    } else {
+        key = in.keys[i]; slot = in.slots[i];
+    }
+    return true;
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(kPartBlock) void k_part_hist(PartIn in, int64_t ntiles, int64_t *hist /*[256][ntiles]*/) {
+    __shared__ unsigned int h[kRadix];
+    const int64_t n = FIRST ? in.n : *in.n_dev;
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kPartTile;
+    for (int st = 0; st < kPartSteps; st++) {
+        uint64_t key; int64_t slot;
+        if (part_fetch<FIRST>(in, base + st * kPartBlock + threadIdx.x, n, key, slot))
+            atomicAdd(&h[(key >> in.shift) & (kRadix - 1)], 1u);
+    }
+    __syncthreads();
+    hist[(int64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
+template <bool FIRST, bool LAST>
+__global__ __launch_bounds__(kPartBlock) void k_part_scatter(PartIn in, int64_t ntiles, const int64_t *offsets,
+                                                              uint64_t *keys_out, int64_t *slots_out, int64_t *pos_out) {
+    __shared__ int64_t running[kRadix];
+    __shared__ unsigned int whist[kPartBlock / kWave][kRadix];
+    const int64_t n = FIRST ? in.n : *in.n_dev;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    running[tid] = offsets[(int64_t)tid * ntiles + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < kPartBlock / kWave; w++) whist[w][tid] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kPartTile;
+    for (int st = 0; st < kPartSteps; st++) {
+        uint64_t key = 0; int64_t slot = 0;
+        const bool ok = part_fetch<FIRST>(in, base + st * kPartBlock + tid, n, key, slot);
+        const unsigned d = (unsigned)((key >> in.shift) & (kRadix - 1));
+        // peers = lanes of this wave holding the same digit (and a value)
+        uint64_t peers = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const uint64_t m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const int rank = __popcll(peers & ((1ull << lane) - 1));
+        if (ok && rank == 0) whist[wave][d] = (unsigned)__popcll(peers);    // one leader per digit
+        __syncthreads();
+        if (ok) {
+            int64_t dest = running[d] + rank;
+            for (int w = 0; w < wave; w++) dest += whist[w][d];
+            if (LAST) pos_out[slot] = dest;
+            else { keys_out[dest] = key; slots_out[dest] = slot; }
+        }
+        __syncthreads();
+        unsigned add = 0;
+#pragma unroll
+        for (int w = 0; w < kPartBlock / kWave; w++) { add += whist[w][tid]; whist[w][tid] = 0; }
+        running[tid] += add;
+        __syncthreads();
+    }
+}
+
+// scratch layout is owned by the caller (vdl_engine.cpp); see launch_partition's arguments.
+hipError_t launch_partition(Src data, const uint64_t *valid, int64_t n, int64_t pmin, int64_t pcount,
+                            int64_t *hist /* 256*ntiles + 1 */, int64_t *scan_scratch /* prefix_sum_blocks(256*ntiles)+1 */,
+                            uint64_t *keys_a, int64_t *slots_a, uint64_t *keys_b, int64_t *slots_b /* n each, or null if one pass */,
+                            int64_t *n_valid_dev /* 1 word */, int64_t *pos_out, hipStream_t s) {
+    (void)hipGetLastError();   // see launch_status()
+    if (n <= 0) return hipSuccess;
+    int bits = 0;
+    while (bits < 63 && ((uint64_t)pcount >> bits) != 0) bits++;       // buckets 0..pcount
+    const int passes = bits <= 8 ? 1 : (bits + 7) / 8;
+    const int64_t ntiles = partition_tiles(n);
+    const int64_t hn = (int64_t)kRadix * ntiles;
+    PartIn in{};
+    in.data = data; in.valid = valid; in.pmin = pmin; in.pcount = pcount; in.n = n; in.n_dev = n_valid_dev;
+    uint64_t *kin = nullptr, *kout = keys_a; int64_t *sin = nullptr, *sout = slots_a;
+    for (int p = 0; p < passes; p++) {
+        in.shift = 8 * p; in.keys = kin; in.slots = sin;
+        const bool first = p == 0, last = p == passes - 1;
+        if (first) k_part_hist<true><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist);
+        else k_part_hist<false><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist);
+        hipError_t e = launch_prefix_sum(hist, hn, scan_scratch, s);
+        if (e != hipSuccess) return e;
+        if (first) {   // number of non-EPS slots = grand total of the first histogram
+            e = hipMemcpyAsync(n_valid_dev, scan_scratch + prefix_sum_blocks(hn), sizeof(int64_t), hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) return e;
+        }
+        if (first && last) k_part_scatter<true, true><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist, nullptr, nullptr, pos_out);
+        else if (first) k_part_scatter<true, false><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist, kout, sout, nullptr);
+        else if (last) k_part_scatter<false, true><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist, nullptr, nullptr, pos_out);
+        else k_part_scatter<false, false><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist, kout, sout, nullptr);
+        kin = kout; sin = sout;
+        kout = (kout == keys_a) ? keys_b : keys_a;
+        sout = (sout == slots_a) ? slots_b : slots_a;
+    }
+    return launch_status();
+}
+int partition_passes(int64_t pcount) {
+    int bits = 0;
+    while (bits < 63 && ((uint64_t)pcount >> bits) != 0) bits++;
+    return bits <= 8 ? 1 : (bits + 7) / 8;
+}
+
+// ------------------------------------------------------------------------------------------
+// Folds over a general control vector (/root/reference/src/Vlite.hs:337-356; grouped aggregates
+// fold data scattered into key order, Vlite.hs:1056-1060).  Run = maximal stretch of equal control
+// values, EPS control slots skipped; the result lands in the run's first slot.
+//   k_seg_heads  : bitmap of run-first slots (previous non-EPS control slot found with clz on the
+//                  validity words -- O(1) for the dense / prefix-valid vectors group-by produces)
+//   k_seg_wordhd : per bitmap word, the last head slot at or before the word's end
+//   (device-wide max-scan of that array on one block: n/64 entries)
+//   k_seg_fold   : per-lane head slot, 64-lane segmented shuffle scan, one 64-bit atomic per
+//                  (wave, run) onto out[head].
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t prev_valid_slot(const uint64_t *v, int64_t i) {   // nearest valid slot < i, or -1
+    if (!v) return i - 1;
+    int64_t w = i >> 6;
+    uint64_t m = v[w] & ((1ull << (i & 63)) - 1);
+    while (true) {
+        if (m) return (w << 6) + 63 - __clzll((long long)m);
+        if (--w < 0) return -1;
+        m = v[w];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_seg_heads(Src ctl, const uint64_t *vc, int64_t n, uint64_t *heads) {
+    const int64_t nw = (n + 63) >> 6;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave);
+    for (int64_t w = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; w < nw; w += wstride) {
+        const int64_t i = (w << 6) + lane;
+        bool head = false;
+        if (i < n && bit(vc, i)) {
+            const int64_t p = prev_valid_slot(vc, i);
+            head = p < 0 || ld(ctl, p) != ld(ctl, i);
+        }
+        const uint64_t m = __ballot(head);
+        if (lane == 0) heads[w] = m;
+    }
+}
+
+__global__ void k_seg_wordhd(const uint64_t *heads, int64_t nw, int64_t *wordhd) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nw; w += stride) {
+        const uint64_t m = heads[w];
+        wordhd[w] = m ? (w << 6) + 63 - __clzll((long long)m) : -1;
+    }
+}
+
+// in-place inclusive max-scan, single block (n/64 entries; 9.4 M for SF100 -> ~9 K iterations)
+__global__ __launch_bounds__(1024) void k_maxscan(int64_t *x, int64_t n) {
+    __shared__ int64_t wmax[1024 / kWave];
+    __shared__ int64_t carry;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    if (tid == 0) carry = -1;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 1024) {
+        const int64_t i = base + tid;
+        int64_t v = i < n ? x[i] : -1;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) { int64_t y = __shfl_up(v, off, kWave); if (lane >= off && y > v) v = y; }
+        if (lane == kWave - 1) wmax[wave] = v;
+        __syncthreads();
+        int64_t pre = carry;
+        for (int w = 0; w < wave; w++) pre = wmax[w] > pre ? wmax[w] : pre;
+        v = pre > v ? pre : v;
+        __syncthreads();
+        if (i < n) x[i] = v;
+        if (tid == 1023) carry = v;
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void atomic_combine(int rk, int64_t *addr, int64_t v) {
+    if (rk == R_SUM) atomicAdd((unsigned long long *)addr, (unsigned long long)v);
+    else if (rk == R_MIN) atomicMin((long long *)addr, (long long)v);
+    else atomicMax((long long *)addr, (long long)v);
+}
+
+// kind: 0 sum, 1 min, 2 max, 3 count, 4 choose-pass (min over slot index of the data)
+__global__ __launch_bounds__(256) void k_seg_fold(int kind, Src d, const uint64_t *vd, const uint64_t *vc, const uint64_t *heads,
+                                                  const int64_t *wordhd, int64_t n, int64_t *out, uint64_t *vout) {
+    const int rk = (kind == 1 || kind == 4) ? R_MIN : kind == 2 ? R_MAX : R_SUM;
+    const int64_t nw = (n + 63) >> 6;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave);
+    for (int64_t w = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; w < nw; w += wstride) {
+        const int64_t i = (w << 6) + lane;
+        const uint64_t hm = heads[w] & (lane == 63 ? ~0ull : ((2ull << lane) - 1));   // heads at or before this lane
+        int64_t h = hm ? (w << 6) + 63 - __clzll((long long)hm) : (w > 0 ? wordhd[w - 1] : -1);
+        const bool ok = i < n && bit(vc, i) && bit(vd, i) && h >= 0;
+        int64_t x = r_identity(rk);
+        if (ok) x = kind == 3 ? 1 : kind == 4 ? i : ld(d, i);
+        // lane segments = maximal stretches of consecutive active lanes with one head; an EPS slot
+        // inside a run splits it into several segments, each adds its part to the same out[h]
+        const int64_t hp = __shfl_up(h, 1, kWave);
+        const bool okp = __shfl_up((int)ok, 1, kWave) != 0;
+        const bool starts = lane == 0 || !ok || !okp || hp != h;
+        const uint64_t sm = __ballot(starts) & (lane == 63 ? ~0ull : ((2ull << lane) - 1));
+        const int seg0 = 63 - __clzll((long long)sm);   // first lane of my segment (bit 0 is always set)
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const int64_t y = __shfl_up(x, off, kWave);
+            if (lane - off >= seg0) x = r_combine(rk, x, y);
+        }
+        const int64_t hn = __shfl_down(h, 1, kWave);
+        const bool okn = __shfl_down((int)ok, 1, kWave) != 0;
+        const bool tail = ok && (lane == kWave - 1 || !okn || hn != h);
+        // EPS slots inside a run split it into several lane segments with the same head: each adds its part
+        if (tail) {
+            atomic_combine(rk, &out[h], x);
+            atomicOr((unsigned long long *)&vout[h >> 6], 1ull << (h & 63));
+        }
+    }
+}
+
+__global__ void k_seg_fill(int64_t *out, int64_t v, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = v;
+}
+
+// FoldChoose second pass: out[h] currently holds the smallest data slot of the run -> its value
+__global__ void k_seg_choose_fix(Src d, const uint64_t *vout, int64_t n, int64_t *out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        if (bit(vout, i)) out[i] = ld(d, out[i]);
+}
+
+// scratch: heads bitmap (nwords) and wordhd (nwords int64) supplied by the caller
+hipError_t launch_fold_segmented(int kind, Src ctl, const uint64_t *vc, Src d, const uint64_t *vd, int64_t n,
+                                 uint64_t *heads, int64_t *wordhd, int64_t *out, uint64_t *vout /* pre-zeroed */, hipStream_t s) {
+    (void)hipGetLastError();   // see launch_status()
+    if (n <= 0) return hipSuccess;
+    const int64_t nw = (n + 63) >> 6;
+    const int rk = (kind == 1 || kind == 4) ? R_MIN : kind == 2 ? R_MAX : R_SUM;
+    k_seg_heads<<<grid_for(n, 256, 4), 256, 0, s>>>(ctl, vc, n, heads);
+    k_seg_wordhd<<<grid_for(nw, 256, 1), 256, 0, s>>>(heads, nw, wordhd);
+    k_maxscan<<<1, 1024, 0, s>>>(wordhd, nw);
+    k_seg_fill<<<grid_for(n, 256, 4), 256, 0, s>>>(out, rk == R_SUM ? 0 : rk == R_MIN ? INT64_MAX : INT64_MIN, n);
+    k_seg_fold<<<grid_for(n, 256, 4), 256, 0, s>>>(kind, d, vd, vc, heads, wordhd, n, out, vout);
+    if (kind == 4) k_seg_choose_fix<<<grid_for(n, 256, 4), 256, 0, s>>>(d, vout, n, out);
+    return launch_status();
 }
 
 }  // namespace vdl

@@ -285,7 +285,7 @@ static int op_fold(orc_ctx *c, ovec *out, int kind, const ovec *ctl, const ovec 
         if (!slot_ok(ctl, i)) continue;
         int64_t k = slot_val(ctl, i);
         if (!have_run || k != run_key) {
-            if (have_run && kind != F_SEL && (acc_ok || kind == F_COUNT)) { out->val[run_first] = acc; out->ok[run_first] = 1; }
+            if (have_run && kind != F_SEL && acc_ok) { out->val[run_first] = acc; out->ok[run_first] = 1; }
             have_run = 1; run_key = k; run_first = i; acc = 0; acc_ok = 0; sel_write = i;
         }
         if (!slot_ok(d, i)) continue;
@@ -306,7 +306,7 @@ static int op_fold(orc_ctx *c, ovec *out, int kind, const ovec *ctl, const ovec 
         default:       acc = w_add(acc, 1); acc_ok = 1; break;
         }
     }
-    if (have_run && kind != F_SEL && (acc_ok || kind == F_COUNT)) { out->val[run_first] = acc; out->ok[run_first] = 1; }
+    if (have_run && kind != F_SEL && acc_ok) { out->val[run_first] = acc; out->ok[run_first] = 1; }
     return 0;
 }
 

@@ -223,3 +223,60 @@ def test_errors_are_loud(q6_text):
         e.run_vdl(q6_text)                                  # nothing in the catalog
     assert ei.value.code == 2
     e.close()
+
+
+@pytest.mark.parametrize("n", [1, 100, 4097, 60175, 300007])
+def test_q1_general_path_matches_oracle(q1_text, n):
+    """Q1 = Partition + Scatter + folds over the sorted key (group-by lowering,
+    /root/reference/src/Vlite.hs:1056-1060,1082-1098), one kernel per operator."""
+    cols = lineitem(datagen.Q1_COLUMNS, n)
+    want = oracle_run(q1_text, cols)
+    e = engine_with(cols)
+    assert e.run_vdl(q1_text)["results"] == want
+    e.close()
+
+
+@pytest.mark.parametrize("domain", [3, 32, 300, 70000])
+def test_partition_scatter_grouped_folds_match_oracle(domain):
+    rng = np.random.default_rng(domain)
+    n = 50021
+    cols = rand_cols(rng, n, {"t.k": (np.int32, 5, 5 + domain - 1), "t.a": (np.int64, -10**6, 10**6), "t.b": (np.int8, 0, 4)})
+    lines = ["1,Load,t.k", "2,Project,val,Id 1,k", "3,Load,t.a", "4,Project,val,Id 3,a", "5,Load,t.b", "6,Project,val,Id 5,b",
+             "7,RangeV,val,0,Id 6,1", "8,FoldSelect,val,Id 7,val,Id 6,val",            # b != 0: EPS rows
+             "9,Gather,Id 2,Id 8,val", "10,Gather,Id 4,Id 8,val",
+             "11,RangeC,val,5,%d,1" % domain, "12,Partition,val,Id 9,val,Id 11,val",
+             "13,Project,pos,Id 12,val", "14,MaterializeCompact,Id 13",
+             "15,RangeV,val,0,Id 9,1", "16,Scatter,Id 9,Id 15,val,Id 12,val",
+             "17,RangeV,val,0,Id 10,1", "18,Scatter,Id 10,Id 17,val,Id 12,val"]
+    k = 19
+    for fold in ("FoldSum", "FoldMin", "FoldMax", "FoldCount", "FoldChoose"):
+        lines += ["%d,%s,val,Id 16,val,Id 18,val" % (k, fold), "%d,Project,%s,Id %d,val" % (k + 1, fold.lower(), k),
+                  "%d,MaterializeCompact,Id %d" % (k + 2, k + 1)]
+        k += 3
+    text = prog(*lines)
+    want = oracle_run(text, cols)
+    e = engine_with(cols)
+    assert e.run_vdl(text)["results"] == want
+    e.close()
+
+
+def test_fold_over_unsorted_control_with_holes_matches_oracle():
+    """Runs follow the control values in slot order; EPS control slots are skipped, EPS data ignored."""
+    rng = np.random.default_rng(99)
+    n = 33333
+    ctl = np.repeat(rng.integers(0, 5, size=n // 7 + 1), 7)[:n].astype(np.int64)     # runs of length 7 (some merge)
+    cols = {"t.c": ctl, "t.a": rng.integers(-1000, 1000, size=n).astype(np.int64),
+            "t.b": rng.integers(0, 3, size=n).astype(np.int8), "t.d": rng.integers(0, 4, size=n).astype(np.int8)}
+    lines = ["1,Load,t.c", "2,Project,val,Id 1,c", "3,Load,t.a", "4,Project,val,Id 3,a", "5,Load,t.b", "6,Project,val,Id 5,b",
+             "7,Load,t.d", "8,Project,val,Id 7,d",
+             "9,RangeV,val,0,Id 6,1", "10,FoldSelect,val,Id 9,val,Id 6,val", "11,Gather,Id 2,Id 10,val",      # control with holes
+             "12,RangeV,val,0,Id 8,1", "13,FoldSelect,val,Id 12,val,Id 8,val", "14,Gather,Id 4,Id 13,val"]    # data with other holes
+    k = 15
+    for fold in ("FoldSum", "FoldMin", "FoldMax", "FoldCount", "FoldChoose"):
+        lines += ["%d,%s,val,Id 11,val,Id 14,val" % (k, fold), "%d,MaterializeCompact,Id %d" % (k + 1, k)]
+        k += 2
+    text = prog(*lines)
+    want = oracle_run(text, cols)
+    e = engine_with(cols)
+    assert e.run_vdl(text)["results"] == want
+    e.close()
