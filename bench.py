@@ -94,6 +94,7 @@ def main():
         elapsed = float(t.item())
 
     revenue = result["results"]["tmp42"][".revenue"]
+    kernel_label = next((k.replace("timeInMicrosecondsForFusedScan_", "") for k in result["timings"] if "FusedScan" in k), "k_scan")
     ms_per_step = elapsed / args.steps * 1e3
     rows_per_s = total_rows / (elapsed / args.steps)
     kern_us = sum(scan_us) / len(scan_us)
@@ -153,7 +154,7 @@ def main():
                        "finalise": "RCCL all-reduce of 2 int64 words" if world > 1 else "local"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "k_scan<4,1,4,vec>", "kernel_us": kern_us,
+                         "kernel": kernel_label, "kernel_us": kern_us,
                          "algorithmic_bytes_per_launch": my_rows * datagen.Q6_BYTES_PER_ROW},
             "cpu_baseline": cpu_baseline,
             "revenue": revenue[0] if revenue else None, "verified_bit_exact_vs_cpu": verified,

@@ -257,7 +257,7 @@ void finalize_fused(vdl_ctx *c, vdl_plan *p, const int64_t *dev_words) {
         float ms = 0;
         HIP_CHECK(hipEventElapsedTime(&ms, p->ev0, p->ev1));
         p->scan_usec = (double)ms * 1e3;
-        p->timings.push_back({"timeInMicrosecondsForFusedScan", p->scan_usec});
+        p->timings.push_back({std::string("timeInMicrosecondsForFusedScan_") + scan_kernel_name(p->scfg.empty() ? ScanLaunch{0, 0, -1} : p->scfg[0]) + "_grid" + std::to_string(p->scfg.empty() ? 0 : p->scfg[0].grid), p->scan_usec});
         p->ev_pending = false;
     }
     p->outs.clear();

@@ -35,11 +35,12 @@ struct ScanArgs {
     int64_t constant[kMaxScanAggs] = {};     // datum when the aggregate has no column factor
     int64_t *block_partials = nullptr;       // [grid][1 + nagg]
     int never = 0;
+    int chunked = 0;                         // tile->block mapping: 0 grid-stride, 1 contiguous chunks
 };
 
 struct ScanLaunch { int grid = 0, block = 0, variant = 0; };
 // Chooses template instantiation and grid for (ncol, nagg) on this device.
-ScanLaunch scan_launch_config(const ScanArgs &a, int num_cus);
+ScanLaunch scan_launch_config(ScanArgs &a, int num_cus);
 hipError_t launch_scan(const ScanArgs &a, const ScanLaunch &cfg, hipStream_t s);
 // Reduces the per-block partials into words[0..nagg] = {count, agg0, ...}.
 hipError_t launch_scan_finish(const int64_t *block_partials, int nblocks, int nagg, const int *kinds_dev_or_null,

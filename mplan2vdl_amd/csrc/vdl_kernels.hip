@@ -6,6 +6,9 @@
 // LDS only for the cross-wave step, and one pass over every byte.
 #include "vdl_kernels.h"
 
+#include <cstdlib>
+#include <cstring>
+
 namespace vdl {
 
 typedef long long ll2 __attribute__((ext_vector_type(2)));
@@ -161,9 +164,15 @@ __device__ __forceinline__ int64_t load_scalar(const void *p, int width, int64_t
     }
 }
 
-template <int NC, int NA, int U, bool VEC>
-__global__ __launch_bounds__(kScanBlock) void k_scan(const ScanArgs A) {
-    constexpr int TILE = kScanBlock * 2 * U;
+template <bool NT, typename V>
+__device__ __forceinline__ V stream_load(const char *p) {
+    if (NT) return __builtin_nontemporal_load((const V *)p);
+    return *(const V *)p;
+}
+
+template <int NC, int NA, int U, bool VEC, bool NT, int BS>
+__global__ __launch_bounds__(BS) void k_scan(const ScanArgs A) {
+    constexpr int TILE = BS * 2 * U;
     constexpr int ROWS = 2 * U;
     const int tid = threadIdx.x;
     int64_t acc[NA];
@@ -172,7 +181,15 @@ __global__ __launch_bounds__(kScanBlock) void k_scan(const ScanArgs A) {
     for (int j = 0; j < NA; j++) acc[j] = (j < A.nagg) ? r_identity(A.kind[j]) : 0;
 
     const int64_t ntiles = A.n / TILE;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // tile -> block mapping: grid-stride (neighbouring blocks read neighbouring tiles) or one
+    // contiguous chunk of tiles per block (A.chunked)
+    int64_t tile = blockIdx.x, tile_end = ntiles, tile_step = gridDim.x;
+    if (A.chunked) {
+        tile = ntiles * blockIdx.x / gridDim.x;
+        tile_end = ntiles * (blockIdx.x + 1) / gridDim.x;
+        tile_step = 1;
+    }
+    for (; tile < tile_end; tile += tile_step) {
         int64_t v[NC][ROWS];
         const int64_t base = tile * TILE + (int64_t)tid * 2;
 #pragma unroll
@@ -183,31 +200,31 @@ __global__ __launch_bounds__(kScanBlock) void k_scan(const ScanArgs A) {
                 if (!VEC) {
 #pragma unroll
                     for (int u = 0; u < U; u++) {
-                        v[c][2 * u] = load_scalar(p, w, base + (int64_t)u * (kScanBlock * 2));
-                        v[c][2 * u + 1] = load_scalar(p, w, base + (int64_t)u * (kScanBlock * 2) + 1);
+                        v[c][2 * u] = load_scalar(p, w, base + (int64_t)u * (BS * 2));
+                        v[c][2 * u + 1] = load_scalar(p, w, base + (int64_t)u * (BS * 2) + 1);
                     }
                 } else if (w == 8) {
 #pragma unroll
                     for (int u = 0; u < U; u++) {
-                        ll2 x = *(const ll2 *)(p + (base + (int64_t)u * (kScanBlock * 2)) * 8);
+                        ll2 x = stream_load<NT, ll2>(p + (base + (int64_t)u * (BS * 2)) * 8);
                         v[c][2 * u] = x.x; v[c][2 * u + 1] = x.y;
                     }
                 } else if (w == 4) {
 #pragma unroll
                     for (int u = 0; u < U; u++) {
-                        i32x2 x = *(const i32x2 *)(p + (base + (int64_t)u * (kScanBlock * 2)) * 4);
+                        i32x2 x = stream_load<NT, i32x2>(p + (base + (int64_t)u * (BS * 2)) * 4);
                         v[c][2 * u] = x.x; v[c][2 * u + 1] = x.y;
                     }
                 } else if (w == 2) {
 #pragma unroll
                     for (int u = 0; u < U; u++) {
-                        i16x2 x = *(const i16x2 *)(p + (base + (int64_t)u * (kScanBlock * 2)) * 2);
+                        i16x2 x = stream_load<NT, i16x2>(p + (base + (int64_t)u * (BS * 2)) * 2);
                         v[c][2 * u] = x.x; v[c][2 * u + 1] = x.y;
                     }
                 } else {
 #pragma unroll
                     for (int u = 0; u < U; u++) {
-                        i8x2 x = *(const i8x2 *)(p + (base + (int64_t)u * (kScanBlock * 2)));
+                        i8x2 x = stream_load<NT, i8x2>(p + (base + (int64_t)u * (BS * 2)));
                         v[c][2 * u] = x.x; v[c][2 * u + 1] = x.y;
                     }
                 }
@@ -217,7 +234,7 @@ __global__ __launch_bounds__(kScanBlock) void k_scan(const ScanArgs A) {
     }
     // tail rows (fewer than one tile) go to the last block, one row per lane
     if (blockIdx.x == gridDim.x - 1) {
-        for (int64_t i = ntiles * TILE + tid; i < A.n; i += kScanBlock) {
+        for (int64_t i = ntiles * TILE + tid; i < A.n; i += BS) {
             int64_t v1[NC][1];
 #pragma unroll
             for (int c = 0; c < NC; c++)
@@ -225,8 +242,8 @@ __global__ __launch_bounds__(kScanBlock) void k_scan(const ScanArgs A) {
             scan_accumulate<NC, NA, 1>(A, v1, acc, cnt);
         }
     }
-    // block reduction: shuffles inside each wave, LDS across the 4 waves
-    __shared__ int64_t red[kScanBlock / kWave][NA + 1];
+    // block reduction: shuffles inside each wave, LDS across the waves
+    __shared__ int64_t red[BS / kWave][NA + 1];
     const int lane = tid & (kWave - 1), wave = tid / kWave;
     int64_t c = wave_reduce(cnt, R_SUM);
     if (lane == 0) red[wave][0] = c;
@@ -242,14 +259,14 @@ __global__ __launch_bounds__(kScanBlock) void k_scan(const ScanArgs A) {
         int64_t *dst = A.block_partials + (int64_t)blockIdx.x * (A.nagg + 1);
         int64_t x = red[0][0];
 #pragma unroll
-        for (int w = 1; w < kScanBlock / kWave; w++) x += red[w][0];
+        for (int w = 1; w < BS / kWave; w++) x += red[w][0];
         dst[0] = x;
 #pragma unroll
         for (int j = 0; j < NA; j++) {
             if (j < A.nagg) {
                 int64_t y = red[0][j + 1];
 #pragma unroll
-                for (int w = 1; w < kScanBlock / kWave; w++) y = r_combine(A.kind[j], y, red[w][j + 1]);
+                for (int w = 1; w < BS / kWave; w++) y = r_combine(A.kind[j], y, red[w][j + 1]);
                 dst[j + 1] = y;
             }
         }
@@ -279,44 +296,84 @@ __global__ __launch_bounds__(256) void k_scan_finish(const int64_t *partials, in
 
 namespace {
 typedef void (*scan_fn)(const ScanArgs);
-struct ScanVariant { int nc, na, u; bool vec; scan_fn fn; const char *name; };
+struct ScanVariant { int nc, na, u; bool vec, nt; int bs; scan_fn fn; const char *name; };
+#define VDL_SV(NC, NA, U, VEC, NT, BS) {NC, NA, U, VEC, NT, BS, k_scan<NC, NA, U, VEC, NT, BS>, "k_scan<" #NC "," #NA "," #U "," #VEC "," #NT "," #BS ">"}
+// The first entry that fits (ncol, nagg, alignment) is the production kernel; the rest of the
+// (4,1) family exists for tuning sweeps (VDL_SCAN_TUNE, see scan_launch_config).
 const ScanVariant kScanVariants[] = {
-    {4, 1, 4, true, k_scan<4, 1, 4, true>, "k_scan<4,1,4,vec>"},
-    {4, 4, 4, true, k_scan<4, 4, 4, true>, "k_scan<4,4,4,vec>"},
-    {8, 8, 2, true, k_scan<8, 8, 2, true>, "k_scan<8,8,2,vec>"},
-    {4, 1, 4, false, k_scan<4, 1, 4, false>, "k_scan<4,1,4,scalar>"},
-    {4, 4, 4, false, k_scan<4, 4, 4, false>, "k_scan<4,4,4,scalar>"},
-    {8, 8, 2, false, k_scan<8, 8, 2, false>, "k_scan<8,8,2,scalar>"},
+    // production kernels (tuned on Q6 SF100, profiles/r01/tune_scan.md): non-temporal loads, one
+    // wave per SIMD with 12 sub-iterations = 48 loads (42 KiB) in flight per wave
+    VDL_SV(4, 1, 12, true, true, 256),
+    VDL_SV(4, 4, 8, true, true, 256),
+    VDL_SV(8, 8, 6, true, true, 256),
+    VDL_SV(4, 1, 4, false, false, 256),
+    VDL_SV(4, 4, 4, false, false, 256),
+    VDL_SV(8, 8, 2, false, false, 256),
+    // small inputs: smaller tiles so that every CU gets work
+    VDL_SV(4, 1, 4, true, true, 256), VDL_SV(4, 4, 4, true, true, 256), VDL_SV(8, 8, 2, true, true, 256),
+    // tuning family for sweeps (VDL_SCAN_TUNE)
+    VDL_SV(4, 1, 2, true, false, 256), VDL_SV(4, 1, 4, true, false, 256), VDL_SV(4, 1, 8, true, false, 256),
+    VDL_SV(4, 1, 2, true, true, 256),  VDL_SV(4, 1, 8, true, true, 256),
+    VDL_SV(4, 1, 2, true, false, 512), VDL_SV(4, 1, 4, true, false, 512), VDL_SV(4, 1, 8, true, false, 512),
+    VDL_SV(4, 1, 2, true, true, 512),  VDL_SV(4, 1, 4, true, true, 512),  VDL_SV(4, 1, 8, true, true, 512),
+    VDL_SV(4, 1, 10, true, true, 256), VDL_SV(4, 1, 14, true, true, 256), VDL_SV(4, 1, 12, true, false, 256), VDL_SV(4, 1, 6, true, true, 512),
+    VDL_SV(4, 1, 2, true, false, 1024), VDL_SV(4, 1, 2, true, true, 1024),
 };
+#undef VDL_SV
 constexpr int kNumScanVariants = sizeof(kScanVariants) / sizeof(kScanVariants[0]);
+
+int tune_value(const char *spec, const char *key, int dflt) {
+    if (!spec) return dflt;
+    const char *p = strstr(spec, key);
+    if (!p) return dflt;
+    p += strlen(key);
+    if (*p != '=') return dflt;
+    return atoi(p + 1);
+}
 }  // namespace
 
-ScanLaunch scan_launch_config(const ScanArgs &a, int num_cus) {
+ScanLaunch scan_launch_config(ScanArgs &a, int num_cus) {
     // vector loads need every column base aligned to its two-row access
     bool vec = true;
     for (int c = 0; c < a.ncol; c++)
         if (((uintptr_t)a.ptr[c]) % (uintptr_t)(2 * a.width[c]) != 0) vec = false;
+    // Tuning knob for sweeps (tools/tune_scan.py): VDL_SCAN_TUNE="u=8,nt=1,bs=512,gridmul=2,percu=4,chunk=1"
+    const char *tune = getenv("VDL_SCAN_TUNE");
+    const int want_u = tune_value(tune, "u", -1), want_nt = tune_value(tune, "nt", -1), want_bs = tune_value(tune, "bs", -1);
     ScanLaunch cfg;
     cfg.variant = -1;
     for (int i = 0; i < kNumScanVariants; i++) {
         const ScanVariant &v = kScanVariants[i];
-        if (v.vec == vec && a.ncol <= v.nc && a.nagg <= v.na) { cfg.variant = i; break; }
+        if (v.vec != vec || a.ncol > v.nc || a.nagg > v.na) continue;
+        if (tune && vec && ((want_u >= 0 && v.u != want_u) || (want_nt >= 0 && (int)v.nt != want_nt) || (want_bs >= 0 && v.bs != want_bs))) continue;
+        // a big-tile kernel needs a few tiles per CU to balance; smaller inputs take the next fitting variant
+        if (!tune && vec && v.u > 4 && a.n / ((int64_t)v.bs * 2 * v.u) < 4 * (int64_t)num_cus) continue;
+        cfg.variant = i;
+        break;
+    }
+    if (cfg.variant < 0 && tune) {     // no tuning variant of this shape: fall back to production
+        for (int i = 0; i < kNumScanVariants; i++) {
+            const ScanVariant &v = kScanVariants[i];
+            if (v.vec == vec && a.ncol <= v.nc && a.nagg <= v.na) { cfg.variant = i; break; }
+        }
     }
     if (cfg.variant < 0) return cfg;
     const ScanVariant &v = kScanVariants[cfg.variant];
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v.fn, kScanBlock, 0) != hipSuccess || per_cu < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v.fn, v.bs, 0) != hipSuccess || per_cu < 1) {
         (void)hipGetLastError();      // the query is advisory: do not leave its error for the next launch check
         per_cu = 4;
     }
     if (per_cu > 8) per_cu = 8;
-    const int64_t tile = (int64_t)kScanBlock * 2 * v.u;
+    per_cu = tune_value(tune, "percu", per_cu);
+    const int64_t tile = (int64_t)v.bs * 2 * v.u;
     const int64_t ntiles = a.n / tile;
-    int64_t grid = (int64_t)num_cus * per_cu;
+    int64_t grid = (int64_t)num_cus * per_cu * tune_value(tune, "gridmul", 1);
     if (grid > ntiles) grid = ntiles;
     if (grid < 1) grid = 1;
     cfg.grid = (int)grid;
-    cfg.block = kScanBlock;
+    cfg.block = v.bs;
+    a.chunked = tune_value(tune, "chunk", 0);
     return cfg;
 }
 
