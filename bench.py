@@ -49,10 +49,18 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+    # Rehearsal switches (one-GPU boxes): VDL_BENCH_SHARE_DEVICE=1 puts every rank on device 0 and
+    # VDL_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device).  Not for reported numbers.
+    backend = os.environ.get("VDL_BENCH_BACKEND", "nccl")
+    if os.environ.get("VDL_BENCH_SHARE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     total_rows = args.rows or datagen.LINEITEM_ROWS[args.sf]
     lo, hi = m.shard_rows(total_rows, rank, world)
@@ -151,7 +159,7 @@ def main():
             "config": {"workload": "tpch_q6_%s" % (args.sf if not args.rows else "rows%d" % args.rows),
                        "rows_total": total_rows, "rows_per_gpu": my_rows, "bytes_per_row": datagen.Q6_BYTES_PER_ROW,
                        "sharding": "row-range, one process per GPU" if world > 1 else "single GPU",
-                       "finalise": "RCCL all-reduce of 2 int64 words" if world > 1 else "local"},
+                       "finalise": ("%s all-reduce of %d int64 words" % ("RCCL" if backend == "nccl" else backend, nw)) if world > 1 else "local"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": kernel_label, "kernel_us": kern_us,

@@ -125,8 +125,16 @@ struct vdl_plan {
     std::vector<BufP> block_partials;
     std::vector<int32_t> reduce_ops;
     std::vector<int64_t> word_offset;
+    std::vector<GroupArgs> gargs;
+    std::vector<ScanLaunch> gcfg;
+    std::vector<BufP> gparts, gdev;
+    std::vector<int64_t> gword_offset;
+    int dominant = -1;
+    std::string dominant_kernel;
     int64_t n_words = 0;
     BufP words;
+    int64_t words_cap = 0;
+    std::string fallback_note;
     bool bound = false;
     int64_t scan_rows = 0, scan_bytes = 0;
     double scan_usec = 0;
@@ -167,83 +175,146 @@ const Column &find_col(vdl_ctx *c, const std::string &name) {
 // ------------------------------------------------------------------------------------------------
 // fused execution
 // ------------------------------------------------------------------------------------------------
+struct NeedGeneralPath : Error {          // a fused assumption did not hold for this data: rerun unfused
+    explicit NeedGeneralPath(const std::string &m) : Error(VDL_ERR_UNSUPPORTED, m) {}
+};
+
+int64_t plan_words(const vdl_plan *p, std::vector<int32_t> *ops, bool *shardable) {
+    int64_t off = 0;
+    if (shardable) *shardable = true;
+    for (const ScanPlan &sp : p->fused.scans) {
+        if (ops) {
+            ops->push_back(VDL_REDUCE_SUM);
+            for (const ScanAgg &ag : sp.aggs) ops->push_back(ag.kind == AGG_SUM ? VDL_REDUCE_SUM : ag.kind == AGG_MIN ? VDL_REDUCE_MIN : VDL_REDUCE_MAX);
+        }
+        off += (int64_t)sp.aggs.size() + 1;
+    }
+    for (const GroupScanPlan &gp : p->fused.gscans) {
+        for (int64_t b = 0; b < gp.pcount; b++) {
+            if (ops) ops->push_back(VDL_REDUCE_SUM);
+            for (const ScanAgg &ag : gp.aggs) {
+                if (ag.kind == AGG_FIRST && shardable) *shardable = false;   // needs the owning rank's column value
+                if (ops) ops->push_back(ag.kind == AGG_SUM ? VDL_REDUCE_SUM : ag.kind == AGG_MAX ? VDL_REDUCE_MAX : VDL_REDUCE_MIN);
+            }
+        }
+        if (ops) ops->push_back(VDL_REDUCE_SUM);                              // out-of-domain key count
+        off += gp.pcount * ((int64_t)gp.aggs.size() + 1) + 1;
+    }
+    return off;
+}
+
+template <typename Args, typename PlanT>
+int64_t bind_columns(vdl_ctx *c, const PlanT &sp, Args &a, int64_t *bytes_per_row) {
+    a.ncol = (int)sp.cols.size();
+    a.nagg = (int)sp.aggs.size();
+    a.never = sp.never ? 1 : 0;
+    int64_t n = -1;
+    *bytes_per_row = 0;
+    for (int k = 0; k < a.ncol; k++) {
+        const Column &col = find_col(c, sp.cols[(size_t)k].name);
+        if (n >= 0 && col.n != n)
+            throw Error(VDL_ERR_SHAPE, "columns of table '" + sp.table + "' have different lengths in the catalog");
+        n = col.n;
+        a.ptr[k] = col.dev; a.width[k] = col.width;
+        a.lo[k] = sp.cols[(size_t)k].lo; a.hi[k] = sp.cols[(size_t)k].hi;
+        a.filtered[k] = (a.lo[k] != INT64_MIN || a.hi[k] != INT64_MAX) ? 1 : 0;
+        *bytes_per_row += col.width;
+    }
+    a.n = n;
+    for (int j = 0; j < a.nagg; j++) {
+        const ScanAgg &ag = sp.aggs[(size_t)j];
+        a.kind[j] = ag.kind;
+        a.constant[j] = ag.constant;
+        for (const ScanFactor &f : ag.fac) {
+            a.used[j] |= 1u << f.col;
+            if (f.a == 0 && f.s == 1) a.plain[j] |= 1u << f.col;
+            a.fa[j][f.col] = f.a; a.fs[j][f.col] = f.s;
+        }
+    }
+    return n;
+}
+
 void bind_fused(vdl_ctx *c, vdl_plan *p) {
     const FusedPlan &F = p->fused;
     p->sargs.assign(F.scans.size(), ScanArgs{});
     p->scfg.assign(F.scans.size(), ScanLaunch{});
     p->block_partials.assign(F.scans.size(), nullptr);
     p->word_offset.assign(F.scans.size(), 0);
+    p->gargs.assign(F.gscans.size(), GroupArgs{});
+    p->gcfg.assign(F.gscans.size(), ScanLaunch{});
+    p->gparts.assign(F.gscans.size(), nullptr);
+    p->gdev.resize(F.gscans.size());
+    p->gword_offset.assign(F.gscans.size(), 0);
     p->reduce_ops.clear();
+    bool shardable = true;
+    p->n_words = plan_words(p, &p->reduce_ops, &shardable);
     int64_t off = 0;
     p->scan_rows = 0; p->scan_bytes = 0;
+    p->dominant_kernel = "none";
     for (size_t s = 0; s < F.scans.size(); s++) {
         const ScanPlan &sp = F.scans[s];
         ScanArgs &a = p->sargs[s];
-        a.ncol = (int)sp.cols.size();
-        a.nagg = (int)sp.aggs.size();
-        a.never = sp.never ? 1 : 0;
-        int64_t n = -1, bytes_per_row = 0;
-        for (int k = 0; k < a.ncol; k++) {
-            const Column &col = find_col(c, sp.cols[(size_t)k].name);
-            if (n >= 0 && col.n != n)
-                throw Error(VDL_ERR_SHAPE, "columns of table '" + sp.table + "' have different lengths in the catalog");
-            n = col.n;
-            a.ptr[k] = col.dev; a.width[k] = col.width;
-            a.lo[k] = sp.cols[(size_t)k].lo; a.hi[k] = sp.cols[(size_t)k].hi;
-            a.filtered[k] = (a.lo[k] != INT64_MIN || a.hi[k] != INT64_MAX) ? 1 : 0;
-            bytes_per_row += col.width;
-        }
-        a.n = n;
-        for (int j = 0; j < a.nagg; j++) {
-            const ScanAgg &ag = sp.aggs[(size_t)j];
-            a.kind[j] = ag.kind;
-            a.constant[j] = ag.constant;
-            for (const ScanFactor &f : ag.fac) {
-                if ((a.used[j] >> f.col) & 1u)
-                    throw Error(VDL_ERR_UNSUPPORTED, "a column appears twice in one aggregate product; run with fusion disabled");
-                a.used[j] |= 1u << f.col;
-                if (f.a == 0 && f.s == 1) a.plain[j] |= 1u << f.col;
-                a.fa[j][f.col] = f.a; a.fs[j][f.col] = f.s;
-            }
-        }
+        int64_t bpr = 0;
+        const int64_t n = bind_columns(c, sp, a, &bpr);
         p->scfg[s] = scan_launch_config(a, c->num_cus);
         if (p->scfg[s].variant < 0) throw Error(VDL_ERR_UNSUPPORTED, "no scan kernel variant for this shape");
         p->block_partials[s] = dev_alloc(c, sizeof(int64_t) * (size_t)p->scfg[s].grid * (size_t)(a.nagg + 1));
         a.block_partials = (int64_t *)p->block_partials[s]->p;
         p->word_offset[s] = off;
-        p->reduce_ops.push_back(VDL_REDUCE_SUM);            // selected-row count
-        for (int j = 0; j < a.nagg; j++)
-            p->reduce_ops.push_back(a.kind[j] == AGG_SUM ? VDL_REDUCE_SUM : a.kind[j] == AGG_MIN ? VDL_REDUCE_MIN : VDL_REDUCE_MAX);
         off += a.nagg + 1;
-        if (!sp.never && n * bytes_per_row > p->scan_bytes) { p->scan_bytes = n * bytes_per_row; p->scan_rows = n; }
+        if (!sp.never && n * bpr > p->scan_bytes) {
+            p->scan_bytes = n * bpr; p->scan_rows = n; p->dominant = (int)s;
+            p->dominant_kernel = std::string(scan_kernel_name(p->scfg[s])) + "_grid" + std::to_string(p->scfg[s].grid);
+        }
     }
-    p->n_words = off;
+    for (size_t g = 0; g < F.gscans.size(); g++) {
+        const GroupScanPlan &gp = F.gscans[g];
+        GroupArgs &a = p->gargs[g];
+        int64_t bpr = 0;
+        const int64_t n = bind_columns(c, gp, a, &bpr);
+        a.nkey = (int)gp.key.size();
+        for (int k = 0; k < a.nkey; k++) a.key[k] = gp.key[(size_t)k];
+        a.pmin = gp.pmin; a.pcount = gp.pcount; a.row0 = 0;
+        p->gcfg[g] = group_launch_config(a, c->num_cus);
+        if (p->gcfg[g].variant < 0) throw Error(VDL_ERR_UNSUPPORTED, "no grouped-scan kernel variant for this shape");
+        const int64_t words = a.pcount * (a.nagg + 1) + 1;
+        p->gparts[g] = dev_alloc(c, sizeof(int64_t) * (size_t)p->gcfg[g].grid * (size_t)words);
+        a.block_partials = (int64_t *)p->gparts[g]->p;
+        if (!p->gdev[g]) p->gdev[g] = dev_alloc(c, sizeof(GroupArgs));
+        p->gword_offset[g] = off;
+        off += words;
+        if (!gp.never && n * bpr > p->scan_bytes) {
+            p->scan_bytes = n * bpr; p->scan_rows = n; p->dominant = (int)(F.scans.size() + g);
+            p->dominant_kernel = std::string(group_kernel_name(p->gcfg[g])) + "_grid" + std::to_string(p->gcfg[g].grid) + "_rep" + std::to_string(a.replicas);
+        }
+    }
     p->bound = true;
 }
 
-void run_fused_local(vdl_ctx *c, vdl_plan *p, int64_t *dev_words) {
+void run_fused_local(vdl_ctx *c, vdl_plan *p, int64_t *dev_words, bool single_rank) {
     bind_fused(c, p);      // cheap; the catalog may have changed since the last run
     if (p->profiling && !p->ev0) { HIP_CHECK(hipEventCreate(&p->ev0)); HIP_CHECK(hipEventCreate(&p->ev1)); }
     p->ev_pending = false;
-    // the scan with the most bytes is the one timed
-    size_t dominant = 0; int64_t best = -1;
-    for (size_t s = 0; s < p->sargs.size(); s++) {
-        int64_t b = 0;
-        for (int k = 0; k < p->sargs[s].ncol; k++) b += p->sargs[s].width[k];
-        b *= p->sargs[s].n;
-        if (!p->sargs[s].never && b > best) { best = b; dominant = s; }
-    }
     for (size_t s = 0; s < p->sargs.size(); s++) {
         const ScanArgs &a = p->sargs[s];
         int nblocks = 0;
         if (!a.never && a.n > 0) {
-            const bool timed = p->profiling && s == dominant;
+            const bool timed = p->profiling && (int)s == p->dominant;
             if (timed) HIP_CHECK(hipEventRecord(p->ev0, c->stream));
             HIP_CHECK(launch_scan(a, p->scfg[s], c->stream));
             if (timed) { HIP_CHECK(hipEventRecord(p->ev1, c->stream)); p->ev_pending = true; }
             nblocks = p->scfg[s].grid;
         }
         HIP_CHECK(launch_scan_finish(a.block_partials, nblocks, a.nagg, nullptr, a, dev_words + p->word_offset[s], c->stream));
+    }
+    for (size_t g = 0; g < p->gargs.size(); g++) {
+        const GroupArgs &a = p->gargs[g];
+        HIP_CHECK(hipMemcpyAsync(p->gdev[g]->p, &a, sizeof(GroupArgs), hipMemcpyHostToDevice, c->stream));
+        const bool timed = p->profiling && (int)(p->sargs.size() + g) == p->dominant && !a.never && a.n > 0;
+        // events bracket the grouped scan together with its small finish kernels
+        if (timed) HIP_CHECK(hipEventRecord(p->ev0, c->stream));
+        HIP_CHECK(launch_group_scan(a, (const GroupArgs *)p->gdev[g]->p, p->gcfg[g], dev_words + p->gword_offset[g], single_rank, c->stream));
+        if (timed) { HIP_CHECK(hipEventRecord(p->ev1, c->stream)); p->ev_pending = true; }
     }
 }
 
@@ -257,8 +328,15 @@ void finalize_fused(vdl_ctx *c, vdl_plan *p, const int64_t *dev_words) {
         float ms = 0;
         HIP_CHECK(hipEventElapsedTime(&ms, p->ev0, p->ev1));
         p->scan_usec = (double)ms * 1e3;
-        p->timings.push_back({std::string("timeInMicrosecondsForFusedScan_") + scan_kernel_name(p->scfg.empty() ? ScanLaunch{0, 0, -1} : p->scfg[0]) + "_grid" + std::to_string(p->scfg.empty() ? 0 : p->scfg[0].grid), p->scan_usec});
+        p->timings.push_back({"timeInMicrosecondsForFusedScan_" + p->dominant_kernel, p->scan_usec});
         p->ev_pending = false;
+    }
+    for (size_t g = 0; g < p->gargs.size(); g++) {
+        const GroupArgs &a = p->gargs[g];
+        const int64_t oob = w[(size_t)(p->gword_offset[g] + a.pcount * (a.nagg + 1))];
+        if (oob > 0)
+            throw NeedGeneralPath(std::to_string(oob) + " row(s) carry a group key outside the Partition pivots [" + std::to_string(a.pmin) + "," +
+                                  std::to_string(a.pmin + a.pcount - 1) + "]");
     }
     p->outs.clear();
     for (const FusedOutput &fo : p->fused.outputs) {
@@ -266,8 +344,17 @@ void finalize_fused(vdl_ctx *c, vdl_plan *p, const int64_t *dev_words) {
         o.node = fo.node;
         o.name = p->prog.at(fo.node).field;
         o.tmp = "tmp" + std::to_string(fo.node);
-        const int64_t *sw = w.data() + p->word_offset[(size_t)fo.scan];
-        if (sw[0] > 0) o.vals.push_back(eval_scalar(*fo.value, sw + 1));   // no selected row -> the fold slot is EPS
+        if (fo.gscan < 0) {
+            const int64_t *sw = w.data() + p->word_offset[(size_t)fo.scan];
+            if (sw[0] > 0) o.vals.push_back(eval_scalar(*fo.value, sw + 1));   // no selected row -> the fold slot is EPS
+        } else {
+            // one value per non-empty bucket, ascending = the order of the runs of the sorted key
+            const GroupArgs &a = p->gargs[(size_t)fo.gscan];
+            const int W = a.nagg + 1;
+            const int64_t *tab = w.data() + p->gword_offset[(size_t)fo.gscan];
+            for (int64_t b = 0; b < a.pcount; b++)
+                if (tab[b * W] > 0) o.vals.push_back(eval_scalar(*fo.value, tab + b * W + 1));
+        }
         p->outs.push_back(std::move(o));
     }
 }
@@ -760,15 +847,19 @@ int vdl_run(vdl_ctx *c, vdl_plan *p) {
     return guard(c, [&] {
         need_device(c);
         if (p->use_fusion && p->fused.ok) {
-            int64_t nw = 0;
-            for (const ScanPlan &sp : p->fused.scans) nw += (int64_t)sp.aggs.size() + 1;
-            if (!p->words) p->words = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(nw, 1));
-            run_fused_local(c, p, (int64_t *)p->words->p);
-            finalize_fused(c, p, (const int64_t *)p->words->p);
-        } else {
-            GenExec g(c, p);
-            g.run();
+            const int64_t nw = plan_words(p, nullptr, nullptr);
+            if (!p->words || p->words_cap < nw) { p->words = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(nw, 1)); p->words_cap = nw; }
+            try {
+                run_fused_local(c, p, (int64_t *)p->words->p, true);
+                finalize_fused(c, p, (const int64_t *)p->words->p);
+                return;
+            } catch (const NeedGeneralPath &e) {
+                p->fallback_note = e.what();          // exact for any data: rerun statement by statement
+            }
         }
+        GenExec g(c, p);
+        g.run();
+        if (!p->fallback_note.empty()) { p->timings.push_back({"fusedPlanAbandoned: " + p->fallback_note, 0.0}); p->fallback_note.clear(); }
     });
 }
 
@@ -803,15 +894,13 @@ int vdl_plan_partial_spec(const vdl_plan *p, int64_t *n_words, const int32_t **r
         if (p->ctx) p->ctx->err = "sharded execution needs a plan whose outputs are global folds (fused plan)";
         return VDL_ERR_UNSUPPORTED;
     }
-    // word layout depends only on the fused plan: per scan [count, agg0, ...]
     vdl_plan *q = const_cast<vdl_plan *>(p);
     q->reduce_ops.clear();
-    int64_t off = 0;
-    for (const ScanPlan &sp : p->fused.scans) {
-        q->reduce_ops.push_back(VDL_REDUCE_SUM);
-        for (const ScanAgg &ag : sp.aggs)
-            q->reduce_ops.push_back(ag.kind == AGG_SUM ? VDL_REDUCE_SUM : ag.kind == AGG_MIN ? VDL_REDUCE_MIN : VDL_REDUCE_MAX);
-        off += (int64_t)sp.aggs.size() + 1;
+    bool shardable = true;
+    const int64_t off = plan_words(p, &q->reduce_ops, &shardable);
+    if (!shardable) {
+        if (p->ctx) p->ctx->err = "sharded execution of grouped plans with FoldChoose outputs is not implemented";
+        return VDL_ERR_UNSUPPORTED;
     }
     if (n_words) *n_words = off;
     if (reduce_ops) *reduce_ops = q->reduce_ops.data();
@@ -823,7 +912,10 @@ int vdl_run_local(vdl_ctx *c, vdl_plan *p, void *dev_partials) {
     return guard(c, [&] {
         need_device(c);
         if (!(p->use_fusion && p->fused.ok)) throw Error(VDL_ERR_UNSUPPORTED, "sharded execution needs a fused plan");
-        run_fused_local(c, p, (int64_t *)dev_partials);
+        bool shardable = true;
+        plan_words(p, nullptr, &shardable);
+        if (!shardable) throw Error(VDL_ERR_UNSUPPORTED, "sharded execution of grouped plans with FoldChoose outputs is not implemented");
+        run_fused_local(c, p, (int64_t *)dev_partials, false);
     });
 }
 

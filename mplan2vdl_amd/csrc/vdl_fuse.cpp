@@ -35,13 +35,30 @@ RowP mk_bin(int op, RowP l, RowP r) {
 }
 
 struct Sym {
-    enum Kind { NONE, ROW, FOLD } kind = NONE;
+    //  RANGEC : RangeC from count step (pivots)
+    //  PART   : Partition(ROW key, RangeC min cnt 1) -- positions that sort the selected rows by key
+    //  SORTED : Scatter(ROW x, _, PART) -- x in key order
+    //  GFOLD  : Fold(SORTED key, SORTED x) -- one value per distinct key = per group
+    enum Kind { NONE, ROW, FOLD, RANGEC, PART, SORTED, GFOLD } kind = NONE;
     std::string table;
-    int sel = 0;       // ROW: selection index (0 = every row); FOLD: selection of the control vector
-    RowP e;            // ROW
-    int scan = -1;     // FOLD
-    ScalarP sc;        // FOLD
+    int sel = 0;       // ROW/SORTED/PART: selection index (0 = every row); FOLD: selection of the control vector
+    RowP e;            // ROW, SORTED (source expression), PART (key expression)
+    int scan = -1;     // FOLD: scan index; GFOLD: group-scan index
+    ScalarP sc;        // FOLD, GFOLD
+    int part = -1;     // PART/SORTED: node id of the Partition
+    int64_t r_from = 0, r_count = 0, r_step = 0;   // RANGEC; PART: pivots
 };
+
+bool row_equal(const RowP &a, const RowP &b) {
+    if (a == b) return true;
+    if (!a || !b || a->k != b->k) return false;
+    switch (a->k) {
+    case Row::COL: return a->col == b->col;
+    case Row::CONST: return a->c0 == b->c0;
+    case Row::IOTA: return a->c0 == b->c0 && a->c1 == b->c1;
+    default: return a->bin == b->bin && row_equal(a->l, b->l) && row_equal(a->r, b->r);
+    }
+}
 
 struct Selection { std::string table; RowP pred; };   // pred == nullptr: all rows
 
@@ -174,6 +191,8 @@ struct Builder {
     std::map<std::pair<int, int>, int> conj_memo;
     struct PendingScan { std::string table; int sel; std::vector<RowP> data; std::vector<int> kind; };
     std::vector<PendingScan> scans;
+    struct PendingGroup { int part; std::string table; int sel; RowP key; int64_t pmin, pcount; std::vector<RowP> data; std::vector<int> kind; };
+    std::vector<PendingGroup> groups;
     std::string why;
 
     explicit Builder(const Program &p) : P(p), sym(p.nodes.size()) {}
@@ -211,12 +230,32 @@ struct Builder {
         }
         case Op::Project: case Op::Shuffle: case Op::Materialize:
             return S(n.a);
+        case Op::RangeC:
+            out.kind = Sym::RANGEC; out.r_from = n.imm0; out.r_count = n.imm1; out.r_step = n.imm2;
+            return out;
+        case Op::Partition: {
+            // group-by scatter mask, /root/reference/src/Vlite.hs:1082-1098
+            const Sym &d = S(n.a), &pv = S(n.b);
+            if (d.kind != Sym::ROW || pv.kind != Sym::RANGEC || pv.r_step != 1 || pv.r_count <= 0) return out;
+            out.kind = Sym::PART; out.table = d.table; out.sel = d.sel; out.e = d.e; out.part = n.id;
+            out.r_from = pv.r_from; out.r_count = pv.r_count;
+            return out;
+        }
+        case Op::Scatter: {
+            // sorted keys / sorted aggregate inputs, Vlite.hs:1058-1059
+            const Sym &src = S(n.a), &fold = S(n.b), &pos = S(n.c);
+            if (src.kind != Sym::ROW || pos.kind != Sym::PART || fold.kind != Sym::ROW) return out;
+            if (src.table != pos.table || fold.table != pos.table) return out;
+            out.kind = Sym::SORTED; out.table = src.table; out.e = src.e; out.part = pos.part;
+            out.sel = combine_sel(src.table, src.sel, pos.sel);
+            return out;
+        }
         case Op::RangeV: {
             const Sym &r = S(n.a);
             if (r.kind == Sym::ROW) {
                 out.kind = Sym::ROW; out.table = r.table; out.sel = r.sel;
                 out.e = n.imm1 == 0 ? mk_const(n.imm0) : mk_iota(n.imm0, n.imm1);
-            } else if (r.kind == Sym::FOLD && n.imm1 == 0) {
+            } else if ((r.kind == Sym::FOLD || r.kind == Sym::GFOLD) && n.imm1 == 0) {
                 out = r;
                 auto s = std::make_shared<Scalar>(); s->k = Scalar::CONST; s->c = n.imm0; out.sc = s;
             }
@@ -228,7 +267,7 @@ struct Builder {
                 out.kind = Sym::ROW; out.table = a.table;
                 out.sel = combine_sel(a.table, a.sel, b.sel);
                 out.e = mk_bin(n.bin, a.e, b.e);
-            } else if (a.kind == Sym::FOLD && b.kind == Sym::FOLD && a.scan == b.scan && a.sel == b.sel) {
+            } else if ((a.kind == Sym::FOLD || a.kind == Sym::GFOLD) && a.kind == b.kind && a.scan == b.scan && a.sel == b.sel) {
                 out = a;
                 auto s = std::make_shared<Scalar>(); s->k = Scalar::BIN; s->bin = n.bin; s->l = a.sc; s->r = b.sc; out.sc = s;
             }
@@ -252,8 +291,28 @@ struct Builder {
             out.sel = combine_sel(src.table, src.sel, pos.sel);
             return out;
         }
-        case Op::FoldSum: case Op::FoldMin: case Op::FoldMax: case Op::FoldCount: {
+        case Op::FoldSum: case Op::FoldMin: case Op::FoldMax: case Op::FoldCount: case Op::FoldChoose: {
             const Sym &ctl = S(n.a), &d = S(n.b);
+            if (ctl.kind == Sym::SORTED && d.kind == Sym::SORTED && ctl.part == d.part) {
+                // grouped aggregate: fold of data scattered into key order over the sorted key
+                // (Vlite.hs:1056-1060).  Exact only if control and data cover the same rows.
+                const Sym &pt = sym[(size_t)ctl.part];
+                if (!row_equal(ctl.e, pt.e) || ctl.sel != pt.sel || d.sel != pt.sel) return out;
+                int g = -1;
+                for (size_t i = 0; i < groups.size(); i++) if (groups[i].part == ctl.part) g = (int)i;
+                if (g < 0) { groups.push_back({ctl.part, pt.table, pt.sel, pt.e, pt.r_from, pt.r_count, {}, {}}); g = (int)groups.size() - 1; }
+                PendingGroup &pg = groups[(size_t)g];
+                int kind = n.op == Op::FoldMin ? AGG_MIN : n.op == Op::FoldMax ? AGG_MAX : n.op == Op::FoldChoose ? AGG_FIRST : AGG_SUM;
+                if (kind == AGG_FIRST && d.e->k != Row::COL) return out;
+                RowP data = n.op == Op::FoldCount ? mk_const(1) : d.e;
+                int idx = -1;      // the emitter repeats folds (CSE keyed on metadata, Vdl.hs:302,314-320): share them
+                for (size_t i = 0; i < pg.data.size(); i++) if (pg.kind[i] == kind && row_equal(pg.data[i], data)) idx = (int)i;
+                if (idx < 0) { pg.data.push_back(data); pg.kind.push_back(kind); idx = (int)pg.data.size() - 1; }
+                out.kind = Sym::GFOLD; out.table = pt.table; out.sel = pt.sel; out.scan = g;
+                auto s = std::make_shared<Scalar>(); s->k = Scalar::AGG; s->agg = idx; out.sc = s;
+                return out;
+            }
+            if (n.op == Op::FoldChoose) return out;
             if (ctl.kind != Sym::ROW || d.kind != Sym::ROW || ctl.table != d.table) return out;
             if (ctl.e->k != Row::CONST) return out;                       // single run = global fold
             int eff = combine_sel(d.table, ctl.sel, d.sel);
@@ -261,13 +320,15 @@ struct Builder {
             PendingScan &ps = scans[(size_t)sc];
             int kind = n.op == Op::FoldMin ? AGG_MIN : n.op == Op::FoldMax ? AGG_MAX : AGG_SUM;
             RowP data = n.op == Op::FoldCount ? mk_const(1) : d.e;
-            ps.data.push_back(data); ps.kind.push_back(kind);
+            int idx = -1;
+            for (size_t i = 0; i < ps.data.size(); i++) if (ps.kind[i] == kind && row_equal(ps.data[i], data)) idx = (int)i;
+            if (idx < 0) { ps.data.push_back(data); ps.kind.push_back(kind); idx = (int)ps.data.size() - 1; }
             out.kind = Sym::FOLD; out.table = d.table; out.sel = ctl.sel; out.scan = sc;
-            auto s = std::make_shared<Scalar>(); s->k = Scalar::AGG; s->agg = (int)ps.data.size() - 1; out.sc = s;
+            auto s = std::make_shared<Scalar>(); s->k = Scalar::AGG; s->agg = idx; out.sc = s;
             return out;
         }
         default:
-            return out;   // RangeC, FoldChoose, Scatter, Partition: operator-by-operator path
+            return out;
         }
     }
 };
@@ -279,6 +340,98 @@ void show_row(const RowP &e, std::ostringstream &o) {
     case Row::IOTA: o << "iota(" << e->c0 << "," << e->c1 << ")"; break;
     case Row::BIN: o << kBinNames[e->bin] << "("; show_row(e->l, o); o << ","; show_row(e->r, o); o << ")"; break;
     }
+}
+
+
+// key expression -> two-accumulator program (vdl_fuse.h KeyStep); false if the tree is not
+// left/right-deep with single-column leaves
+bool single_column_chain(const RowP &e) {
+    if (e->k == Row::COL) return true;
+    if (e->k != Row::BIN) return false;
+    if (e->r->k == Row::CONST) return single_column_chain(e->l);
+    if (e->l->k == Row::CONST) return single_column_chain(e->r);
+    return false;
+}
+
+template <typename ColIndex>
+bool emit_key(const RowP &e, int target, std::vector<KeyStep> &prog, ColIndex &col_index) {
+    KeyStep st;
+    if (e->k == Row::COL) { st.kind = KeyStep::LOAD; st.target = target; st.col = col_index(e->col); prog.push_back(st); return true; }
+    if (e->k != Row::BIN) return false;
+    if (e->r->k == Row::CONST || e->l->k == Row::CONST) {
+        const bool left = e->r->k != Row::CONST;
+        if (!emit_key(left ? e->r : e->l, target, prog, col_index)) return false;
+        st.kind = KeyStep::OPK; st.target = target; st.bin = e->bin; st.const_left = left ? 1 : 0; st.k = left ? e->l->c0 : e->r->c0;
+        prog.push_back(st);
+        return true;
+    }
+    if (target != 0) return false;
+    if (single_column_chain(e->r)) {
+        if (!emit_key(e->l, 0, prog, col_index) || !emit_key(e->r, 1, prog, col_index)) return false;
+        st.kind = KeyStep::COMBINE; st.bin = e->bin; st.const_left = 0; prog.push_back(st);
+        return true;
+    }
+    if (single_column_chain(e->l)) {
+        if (!emit_key(e->r, 0, prog, col_index) || !emit_key(e->l, 1, prog, col_index)) return false;
+        st.kind = KeyStep::COMBINE; st.bin = e->bin; st.const_left = 1; prog.push_back(st);
+        return true;
+    }
+    return false;
+}
+
+// predicate + aggregate inputs -> ScanColumn filters and ScanAgg products; shared by scans and group scans
+template <typename Plan>
+bool lower_common(const RowP &pred, const std::vector<RowP> &data, const std::vector<int> &kind, Plan &sp, std::string &why) {
+    Clause cl;
+    if (!to_clause(pred, cl)) {
+        std::ostringstream o; o << "predicate is not a conjunction of per-column ranges: ";
+        show_row(pred, o);
+        why = o.str();
+        return false;
+    }
+    sp.never = cl.never;
+    auto col_index = [&](const std::string &name) -> int {
+        for (size_t i = 0; i < sp.cols.size(); i++) if (sp.cols[i].name == name) return (int)i;
+        sp.cols.push_back(ScanColumn{name, INT64_MIN, INT64_MAX});
+        return (int)sp.cols.size() - 1;
+    };
+    for (auto &kv : cl.cols) {
+        if (kv.second.empty()) { sp.never = true; col_index(kv.first); continue; }
+        if (kv.second.size() != 1) { why = "filter on " + kv.first + " is not a single range"; return false; }
+        int c = col_index(kv.first);
+        sp.cols[(size_t)c].lo = kv.second[0].first;
+        sp.cols[(size_t)c].hi = kv.second[0].second;
+    }
+    for (size_t j = 0; j < data.size(); j++) {
+        ScanAgg ag;
+        ag.kind = kind[j];
+        if (ag.kind == AGG_FIRST) {
+            ag.fac.push_back(ScanFactor{col_index(data[j]->col), 0, 1});
+            sp.aggs.push_back(ag);
+            continue;
+        }
+        std::vector<Affine> fac;
+        if (!to_product(data[j], fac)) {
+            std::ostringstream o; o << "aggregate input is not a product of affine column factors: ";
+            show_row(data[j], o);
+            why = o.str();
+            return false;
+        }
+        int64_t mult = 1;
+        bool repeated = false;
+        for (auto &f : fac) {
+            if (!f.has_col || f.s == 0) { mult = apply_bin(B_MUL, mult, f.a); continue; }
+            const int ci = col_index(f.col);
+            for (auto &g : ag.fac) repeated |= g.col == ci;
+            ag.fac.push_back(ScanFactor{ci, f.a, f.s});
+        }
+        if (repeated) { why = "a column appears twice in one aggregate product"; return false; }
+        if (ag.fac.empty()) ag.constant = mult;
+        else { ag.fac[0].a = apply_bin(B_MUL, ag.fac[0].a, mult); ag.fac[0].s = apply_bin(B_MUL, ag.fac[0].s, mult); }
+        if ((int)ag.fac.size() > kMaxFactors) { why = "aggregate has more than 4 column factors"; return false; }
+        sp.aggs.push_back(ag);
+    }
+    return true;
 }
 
 }  // namespace
@@ -298,8 +451,8 @@ FusedPlan fuse_program(const Program &P) {
     if (P.outputs.empty()) { F.why_not = "program has no MaterializeCompact output"; return F; }
     for (int id : P.outputs) {
         const Sym &s = B.sym[(size_t)id];
-        if (s.kind != Sym::FOLD) {
-            F.why_not = "output Id " + std::to_string(id) + " is not a global fold over filtered table columns";
+        if (s.kind != Sym::FOLD && s.kind != Sym::GFOLD) {
+            F.why_not = "output Id " + std::to_string(id) + " is neither a global fold nor a dense-domain grouped fold over filtered table columns";
             return F;
         }
     }
@@ -307,58 +460,39 @@ FusedPlan fuse_program(const Program &P) {
     for (auto &ps : B.scans) {
         ScanPlan sp;
         sp.table = ps.table;
-        Clause cl;
-        if (!to_clause(B.pred_of(ps.sel), cl)) {
-            std::ostringstream o; o << "predicate is not a conjunction of per-column ranges: ";
-            show_row(B.pred_of(ps.sel), o);
-            F.why_not = o.str();
-            return F;
-        }
-        sp.never = cl.never;
-        auto col_index = [&](const std::string &name) -> int {
-            for (size_t i = 0; i < sp.cols.size(); i++) if (sp.cols[i].name == name) return (int)i;
-            sp.cols.push_back(ScanColumn{name, INT64_MIN, INT64_MAX});
-            return (int)sp.cols.size() - 1;
-        };
-        for (auto &kv : cl.cols) {
-            if (kv.second.empty()) { sp.never = true; col_index(kv.first); continue; }
-            if (kv.second.size() != 1) { F.why_not = "filter on " + kv.first + " is not a single range"; return F; }
-            int c = col_index(kv.first);
-            sp.cols[(size_t)c].lo = kv.second[0].first;
-            sp.cols[(size_t)c].hi = kv.second[0].second;
-        }
-        for (size_t j = 0; j < ps.data.size(); j++) {
-            std::vector<Affine> fac;
-            if (!to_product(ps.data[j], fac)) {
-                std::ostringstream o; o << "aggregate input is not a product of affine column factors: ";
-                show_row(ps.data[j], o);
-                F.why_not = o.str();
-                return F;
-            }
-            ScanAgg ag;
-            ag.kind = ps.kind[j];
-            int64_t mult = 1;
-            bool repeated = false;
-            for (auto &f : fac) {
-                if (!f.has_col || f.s == 0) { mult = apply_bin(B_MUL, mult, f.a); continue; }
-                const int ci = col_index(f.col);
-                for (auto &g : ag.fac) repeated |= g.col == ci;
-                ag.fac.push_back(ScanFactor{ci, f.a, f.s});
-            }
-            if (repeated) { F.why_not = "a column appears twice in one aggregate product"; return F; }
-            if (ag.fac.empty()) ag.constant = mult;
-            else { ag.fac[0].a = apply_bin(B_MUL, ag.fac[0].a, mult); ag.fac[0].s = apply_bin(B_MUL, ag.fac[0].s, mult); }
-            if ((int)ag.fac.size() > kMaxFactors) { F.why_not = "aggregate has more than 4 column factors"; return F; }
-            sp.aggs.push_back(ag);
-        }
+        if (!lower_common(B.pred_of(ps.sel), ps.data, ps.kind, sp, F.why_not)) return F;
         if (sp.cols.empty()) { F.why_not = "scan touches no column (row count unknown)"; return F; }
         if ((int)sp.cols.size() > kMaxScanCols) { F.why_not = "scan touches more than 8 columns"; return F; }
         if ((int)sp.aggs.size() > kMaxScanAggs) { F.why_not = "scan has more than 8 aggregates"; return F; }
         F.scans.push_back(sp);
     }
+    for (auto &pg : B.groups) {
+        GroupScanPlan gp;
+        gp.table = pg.table; gp.pmin = pg.pmin; gp.pcount = pg.pcount;
+        if (!lower_common(B.pred_of(pg.sel), pg.data, pg.kind, gp, F.why_not)) return F;
+        auto col_index = [&](const std::string &name) -> int {
+            for (size_t i = 0; i < gp.cols.size(); i++) if (gp.cols[i].name == name) return (int)i;
+            gp.cols.push_back(ScanColumn{name, INT64_MIN, INT64_MAX});
+            return (int)gp.cols.size() - 1;
+        };
+        if (!emit_key(pg.key, 0, gp.key, col_index)) {
+            std::ostringstream o; o << "group key is not a chain of single-column terms: ";
+            show_row(pg.key, o);
+            F.why_not = o.str();
+            return F;
+        }
+        if ((int)gp.key.size() > kMaxKeySteps) { F.why_not = "group key program too long"; return F; }
+        if ((int)gp.cols.size() > kMaxScanCols) { F.why_not = "grouped scan touches more than 8 columns"; return F; }
+        if ((int)gp.aggs.size() > 2 * kMaxScanAggs) { F.why_not = "grouped scan has more than 16 aggregates"; return F; }
+        if (gp.pcount * (int64_t)(gp.aggs.size() + 1) > 8192) { F.why_not = "group domain too large for the LDS-resident grouped scan"; return F; }
+        F.gscans.push_back(gp);
+    }
     for (int id : P.outputs) {
         const Sym &s = B.sym[(size_t)id];
-        F.outputs.push_back(FusedOutput{id, s.scan, s.sc});
+        FusedOutput fo;
+        fo.node = id; fo.value = s.sc;
+        if (s.kind == Sym::FOLD) fo.scan = s.scan; else fo.gscan = s.scan;
+        F.outputs.push_back(fo);
     }
     F.ok = true;
     return F;
@@ -400,8 +534,43 @@ std::string describe_fused(const FusedPlan &F) {
             o << "\n";
         }
     }
+    for (size_t i = 0; i < F.gscans.size(); i++) {
+        const GroupScanPlan &gp = F.gscans[i];
+        o << "group-scan " << i << " table=" << gp.table << " buckets=[" << gp.pmin << "," << gp.pmin + gp.pcount - 1 << "]"
+          << (gp.never ? " [never]" : "") << "\n";
+        for (size_t c = 0; c < gp.cols.size(); c++) {
+            o << "  col " << c << " " << gp.cols[c].name;
+            if (gp.cols[c].lo != INT64_MIN || gp.cols[c].hi != INT64_MAX) {
+                o << " in [";
+                if (gp.cols[c].lo == INT64_MIN) o << "-inf"; else o << gp.cols[c].lo;
+                o << ",";
+                if (gp.cols[c].hi == INT64_MAX) o << "+inf"; else o << gp.cols[c].hi;
+                o << "]";
+            }
+            o << "\n";
+        }
+        o << "  key:";
+        for (const KeyStep &k : gp.key) {
+            const char *t = k.target ? "tmp" : "acc";
+            if (k.kind == KeyStep::LOAD) o << " " << t << "=col" << k.col << ";";
+            else if (k.kind == KeyStep::OPK) { if (k.const_left) o << " " << t << "=" << kBinNames[k.bin] << "(" << k.k << "," << t << ");"; else o << " " << t << "=" << kBinNames[k.bin] << "(" << t << "," << k.k << ");"; }
+            else o << (k.const_left ? " acc=" : " acc=") << kBinNames[k.bin] << (k.const_left ? "(tmp,acc);" : "(acc,tmp);");
+        }
+        o << "\n";
+        for (size_t a = 0; a < gp.aggs.size(); a++) {
+            const ScanAgg &ag = gp.aggs[a];
+            o << "  agg" << a << " " << (ag.kind == AGG_SUM ? "sum" : ag.kind == AGG_MIN ? "min" : ag.kind == AGG_MAX ? "max" : "first") << " ";
+            if (ag.fac.empty()) o << ag.constant;
+            for (size_t f = 0; f < ag.fac.size(); f++) {
+                if (f) o << " * ";
+                o << "(" << ag.fac[f].a << " + " << ag.fac[f].s << "*col" << ag.fac[f].col << ")";
+            }
+            o << "\n";
+        }
+    }
     for (auto &out : F.outputs) {
-        o << "output Id " << out.node << " = scan " << out.scan << " ";
+        if (out.gscan >= 0) o << "output Id " << out.node << " = group-scan " << out.gscan << " ";
+        else o << "output Id " << out.node << " = scan " << out.scan << " ";
         show_scalar(*out.value, o);
         o << "\n";
     }

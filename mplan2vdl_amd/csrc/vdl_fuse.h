@@ -18,7 +18,7 @@ constexpr int kMaxScanCols = 8;
 constexpr int kMaxScanAggs = 8;
 constexpr int kMaxFactors = 4;
 
-enum AggKind : int { AGG_SUM = 0, AGG_MIN = 1, AGG_MAX = 2 };
+enum AggKind : int { AGG_SUM = 0, AGG_MIN = 1, AGG_MAX = 2, AGG_FIRST = 3 };   // FIRST: value of a column at the group's first row
 
 struct ScanColumn {
     std::string name;          // catalog key path
@@ -55,9 +55,34 @@ struct ScanPlan {
     bool never = false;          // predicate is constant false
 };
 
+// ---- grouped scan (dense-domain GROUP BY) -------------------------------------------------
+// The group key is evaluated per row by a two-accumulator straight-line program:
+//   acc / tmp <- column, then (op constant) steps on either, and `acc = acc op tmp` combines.
+// This is exactly the shape makeCompositeKey emits (/root/reference/src/Vlite.hs:1123-1170):
+// ((c0 >> tz0) - min0) << bits | ((c1 >> tz1) - min1) ... & mask.
+constexpr int kMaxKeySteps = 24;
+struct KeyStep {
+    enum Kind : int { LOAD = 0, OPK = 1, COMBINE = 2 } kind = LOAD;
+    int target = 0;          // 0 = acc, 1 = tmp (LOAD / OPK)
+    int col = -1;            // LOAD: scan column index
+    int bin = -1;            // OPK / COMBINE: BinOp
+    int const_left = 0;      // OPK: result = k op x instead of x op k; COMBINE: acc = tmp op acc
+    int64_t k = 0;
+};
+
+struct GroupScanPlan {
+    std::string table;
+    std::vector<ScanColumn> cols;
+    std::vector<KeyStep> key;
+    int64_t pmin = 0, pcount = 0;    // bucket = key - pmin, must lie in [0, pcount)
+    std::vector<ScanAgg> aggs;       // AGG_FIRST: fac[0].col = the column whose first-row value is taken
+    bool never = false;
+};
+
 struct FusedOutput {
     int node = 0;                // MaterializeCompact id
-    int scan = 0;                // index into FusedPlan::scans
+    int scan = -1;               // index into FusedPlan::scans (global fold), or
+    int gscan = -1;              // index into FusedPlan::gscans (one value per non-empty group)
     ScalarP value;
 };
 
@@ -65,6 +90,7 @@ struct FusedPlan {
     bool ok = false;
     std::string why_not;         // reason the program did not fuse (reported by describe)
     std::vector<ScanPlan> scans;
+    std::vector<GroupScanPlan> gscans;
     std::vector<FusedOutput> outputs;
 };
 

@@ -44,11 +44,26 @@ def test_host_only_context_parses_and_describes_q6(q6_text):
     assert not p.is_fused and "general: 42 statement(s)" in p.describe()
 
 
-def test_q1_is_not_fused_yet_and_says_why(q1_text):
+def test_q1_fuses_into_one_grouped_scan(q1_text):
     e = m.Engine(device=None)
     p = e.parse(q1_text)
-    assert not p.is_fused
-    assert "not fused" in p.describe()
+    assert p.is_fused
+    d = p.describe()
+    assert "group-scan 0 table=lineitem buckets=[0,31]" in d                 # RangeC 0 32 1 pivots
+    assert "lineitem.l_shipdate in [-inf,729999]" in d
+    assert "acc=BitwiseAnd(acc,31)" in d                                     # size hint evaluated, Vlite.hs:1111-1115
+    assert d.count(" sum ") == 6 and d.count(" first ") == 2                 # duplicate FoldSums shared
+    assert "Divide(agg2,agg6)" in d                                          # avg = sum / count, Vlite.hs:1038-1041
+    with pytest.raises(m.VdlError) as ei:                                    # FoldChoose outputs: not shardable yet
+        p.partial_spec()
+    assert ei.value.code == _lib.VDL_ERR_UNSUPPORTED
+
+
+def test_unsupported_shapes_stay_on_the_general_path():
+    e = m.Engine(device=None)
+    p = e.parse(prog("1,Load,t.a", "2,Project,val,Id 1,a", "3,RangeV,val,0,Id 2,1", "4,Gather,Id 2,Id 3,val",
+                     "5,MaterializeCompact,Id 4"))
+    assert not p.is_fused and "not fused" in p.describe()
     with pytest.raises(m.VdlError) as ei:
         p.partial_spec()
     assert ei.value.code == _lib.VDL_ERR_UNSUPPORTED

@@ -226,13 +226,84 @@ def test_errors_are_loud(q6_text):
 
 
 @pytest.mark.parametrize("n", [1, 100, 4097, 60175, 300007])
-def test_q1_general_path_matches_oracle(q1_text, n):
+@pytest.mark.parametrize("fuse", [True, False])
+def test_q1_matches_oracle(q1_text, n, fuse):
     """Q1 = Partition + Scatter + folds over the sorted key (group-by lowering,
-    /root/reference/src/Vlite.hs:1056-1060,1082-1098), one kernel per operator."""
+    /root/reference/src/Vlite.hs:1056-1060,1082-1098): as one grouped fused scan, and
+    statement by statement with one kernel per operator."""
     cols = lineitem(datagen.Q1_COLUMNS, n)
     want = oracle_run(q1_text, cols)
     e = engine_with(cols)
-    assert e.run_vdl(q1_text)["results"] == want
+    plan = e.parse(q1_text)
+    plan.set_fusion(fuse)
+    assert plan.is_fused == fuse
+    assert plan.run()["results"] == want
+    e.close()
+
+
+def test_q1_golden_vectors(q1_text):
+    import json
+    from conftest import golden
+
+    g = json.loads(golden("q1_sf001.json"))
+    cols = lineitem(datagen.Q1_COLUMNS, g["rows"], seed=g["seed"])
+    e = engine_with(cols)
+    assert e.run_vdl(q1_text)["results"] == g["results"]
+    g6 = json.loads(golden("q6_sf001.json"))
+    assert e.run_vdl(golden("q6.vdl"))["results"] == g6["results"]
+    e.close()
+
+
+def group_program(domain, folds):
+    lines = ["1,Load,t.k", "2,Project,val,Id 1,k", "3,Load,t.a", "4,Project,val,Id 3,a", "5,Load,t.b", "6,Project,val,Id 5,b",
+             "40,RangeV,val,0,Id 6,0", "41,Greater,val,Id 6,val,Id 40,val",                    # b > 0
+             "7,RangeV,val,0,Id 41,1", "8,FoldSelect,val,Id 7,val,Id 41,val",
+             "9,Gather,Id 2,Id 8,val", "10,Gather,Id 4,Id 8,val",
+             "11,RangeV,val,5,Id 9,0", "12,Subtract,val,Id 9,val,Id 11,val",                 # key - 5
+             "13,RangeC,val,0,%d,1" % domain, "14,Partition,val,Id 12,val,Id 13,val",
+             "15,RangeV,val,0,Id 12,1", "16,Scatter,Id 12,Id 15,val,Id 14,val",
+             "17,RangeV,val,0,Id 10,1", "18,Scatter,Id 10,Id 17,val,Id 14,val"]
+    k = 19
+    for fold in folds:
+        lines += ["%d,%s,val,Id 16,val,Id 18,val" % (k, fold), "%d,Project,%s,Id %d,val" % (k + 1, fold.lower(), k),
+                  "%d,MaterializeCompact,Id %d" % (k + 2, k + 1)]
+        k += 3
+    lines += ["%d,RangeV,val,0,Id 9,1" % k, "%d,Scatter,Id 9,Id %d,val,Id 14,val" % (k + 1, k),      # raw key column in key order
+              "%d,FoldChoose,val,Id 16,val,Id %d,val" % (k + 2, k + 1), "%d,Project,key,Id %d,val" % (k + 3, k + 2),
+              "%d,MaterializeCompact,Id %d" % (k + 4, k + 3)]
+    return prog(*lines)
+
+
+@pytest.mark.parametrize("domain", [2, 32, 700])
+def test_grouped_fused_scan_sum_min_max_count(domain):
+    rng = np.random.default_rng(domain)
+    n = 150001
+    cols = rand_cols(rng, n, {"t.k": (np.int16, 5, 5 + domain - 1), "t.a": (np.int64, -10**9, 10**9), "t.b": (np.int8, 0, 4)})
+    text = group_program(domain, ["FoldSum", "FoldMin", "FoldMax", "FoldCount"])
+    want = oracle_run(text, cols)
+    e = engine_with(cols)
+    plan = e.parse(text)
+    assert plan.is_fused, plan.describe()
+    assert plan.run()["results"] == want
+    plan.set_fusion(False)
+    assert plan.run()["results"] == want
+    e.close()
+
+
+def test_grouped_scan_with_keys_outside_the_pivots_falls_back_and_stays_exact():
+    """Partition clamps out-of-range keys into the edge buckets, where runs then follow key VALUES;
+    the grouped kernel detects such rows and the engine reruns the program on the general path."""
+    rng = np.random.default_rng(5)
+    n = 20011
+    cols = rand_cols(rng, n, {"t.k": (np.int16, 0, 20), "t.a": (np.int64, -100, 100), "t.b": (np.int8, 0, 4)})
+    text = group_program(8, ["FoldSum", "FoldCount"])          # declared domain 5..12, data 0..20
+    want = oracle_run(text, cols)
+    e = engine_with(cols)
+    plan = e.parse(text)
+    assert plan.is_fused
+    out = plan.run()
+    assert out["results"] == want
+    assert any("fusedPlanAbandoned" in k for k in out["timings"])
     e.close()
 
 
