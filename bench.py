@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=59986052, help="rows of the CPU-baseline sample (default SF10)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--query", default="q6", choices=["q6", "q1"],
+                    help="q6 (default, BASELINE.json's metric) or q1 (grouped fused scan; single GPU, secondary measurement)")
     args = ap.parse_args()
 
     import torch
@@ -68,16 +70,28 @@ def main():
 
     eng = m.Engine(device=local_rank)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
-    for name in datagen.Q6_COLUMNS:
+    q_cols = datagen.Q6_COLUMNS if args.query == "q6" else datagen.Q1_COLUMNS
+    q_bytes = datagen.Q6_BYTES_PER_ROW if args.query == "q6" else datagen.Q1_BYTES_PER_ROW
+    for name in q_cols:
         eng.generate(datagen.LINEITEM[name], lo, my_rows)
-    text = open(os.path.join(ROOT, "tests", "golden", "q6.vdl")).read()
+    text = open(os.path.join(ROOT, "tests", "golden", args.query + ".vdl")).read()
     plan = eng.parse(text)
     if not plan.is_fused:
-        raise SystemExit("Q6 did not fuse:\n" + plan.describe())
+        raise SystemExit("%s did not fuse:\n%s" % (args.query, plan.describe()))
     plan.set_profiling(True)
-    nw, ops = plan.partial_spec()
-    buf = torch.zeros(max(nw, 1), dtype=torch.int64, device="cuda")
-    query = m.ShardedQuery(plan, buf, dist if world > 1 else None)
+    if args.query == "q6":
+        nw, ops = plan.partial_spec()
+        buf = torch.zeros(max(nw, 1), dtype=torch.int64, device="cuda")
+        query = m.ShardedQuery(plan, buf, dist if world > 1 else None)
+    else:
+        if world > 1:
+            raise SystemExit("--query q1 is a single-GPU measurement (FoldChoose outputs are not shardable yet)")
+        nw = 0
+
+        class _Direct:
+            def step(self):
+                return plan.run()
+        query = _Direct()
 
     def sync_all():
         torch.cuda.synchronize()
@@ -101,12 +115,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    revenue = result["results"]["tmp42"][".revenue"]
+    revenue = result["results"]["tmp42"][".revenue"] if args.query == "q6" else None
     kernel_label = next((k.replace("timeInMicrosecondsForFusedScan_", "") for k in result["timings"] if "FusedScan" in k), "k_scan")
     ms_per_step = elapsed / args.steps * 1e3
     rows_per_s = total_rows / (elapsed / args.steps)
     kern_us = sum(scan_us) / len(scan_us)
-    achieved = my_rows * datagen.Q6_BYTES_PER_ROW / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
+    achieved = my_rows * q_bytes / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
 
     out = None
     if rank == 0:
@@ -114,7 +128,19 @@ def main():
         cpu_baseline = None
         if not args.no_verify or not args.no_cpu_baseline:
             import oracle
-        if not args.no_verify:
+        if not args.no_verify and args.query == "q1":
+            order = ["lineitem.l_shipdate", "lineitem.l_returnflag", "lineitem.l_linestatus", "lineitem.l_quantity",
+                     "lineitem.l_extendedprice", "lineitem.l_discount", "lineitem.l_tax"]
+            specs = [(datagen.SEED, datagen.col_id(c), datagen.LINEITEM[c].lo, datagen.LINEITEM[c].hi,
+                      datagen.LINEITEM[c].mul, datagen.LINEITEM[c].add) for c in order]
+            tab = oracle.sql_q1_generated(specs, 0, total_rows, threads=oracle.max_threads())
+            names = ["l_returnflag__lineitem__l_returnflag", "l_linestatus__lineitem__l_linestatus", "sum_qty", "sum_base_price",
+                     "sum_disc_price", "sum_charge", "avg_qty", "avg_price", "avg_disc", "count_order"]
+            flat = {list(v.keys())[0][1:]: list(v.values())[0] for v in result["results"].values()}
+            verified = all(flat[nm] == [int(x) for x in tab[:, j]] for j, nm in enumerate(names))
+            if not verified:
+                print("VERIFICATION FAILED (q1)", file=sys.stderr)
+        if not args.no_verify and args.query == "q6":
             # bit-exact check of the full-size answer: the SQL-semantics loop over regenerated rows
             # on all host cores (test infrastructure; outside the timed region)
             specs = [(datagen.SEED, datagen.col_id(c), datagen.LINEITEM[c].lo, datagen.LINEITEM[c].hi,
@@ -123,7 +149,7 @@ def main():
             verified = (revenue == ([rev] if cnt else []))
             if not verified:
                 print("VERIFICATION FAILED: gpu %r vs cpu %r" % (revenue, rev), file=sys.stderr)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.query == "q6":
             # CPU baseline = the scalar op-at-a-time oracle interpreter on a bounded sample of the
             # same workload (first SF10 rows), one host core
             n_s = min(args.cpu_sample_rows, total_rows)
@@ -147,25 +173,25 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("rows") == my_rows:
+                if tj.get("rows") == my_rows and args.query == "q6":
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
-            "metric": "rows/s, TPC-H Q6 SF100 (fused VDL scan), + achieved HBM GB/s in roofline",
+            "metric": "rows/s, TPC-H %s %s (fused VDL scan), + achieved HBM GB/s in roofline" % (args.query.upper(), args.sf.upper()),
             "value": rows_per_s, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int64", "data": "synthetic",
-            "config": {"workload": "tpch_q6_%s" % (args.sf if not args.rows else "rows%d" % args.rows),
-                       "rows_total": total_rows, "rows_per_gpu": my_rows, "bytes_per_row": datagen.Q6_BYTES_PER_ROW,
+            "config": {"workload": "tpch_%s_%s" % (args.query, args.sf if not args.rows else "rows%d" % args.rows),
+                       "rows_total": total_rows, "rows_per_gpu": my_rows, "bytes_per_row": q_bytes,
                        "sharding": "row-range, one process per GPU" if world > 1 else "single GPU",
                        "finalise": ("%s all-reduce of %d int64 words" % ("RCCL" if backend == "nccl" else backend, nw)) if world > 1 else "local"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": kernel_label, "kernel_us": kern_us,
-                         "algorithmic_bytes_per_launch": my_rows * datagen.Q6_BYTES_PER_ROW},
+                         "algorithmic_bytes_per_launch": my_rows * q_bytes},
             "cpu_baseline": cpu_baseline,
-            "revenue": revenue[0] if revenue else None, "verified_bit_exact_vs_cpu": verified,
+            "revenue": (revenue[0] if revenue else None), "verified_bit_exact_vs_cpu": verified,
         }
     eng.close()
     if world > 1:

@@ -125,9 +125,10 @@ struct vdl_plan {
     std::vector<BufP> block_partials;
     std::vector<int32_t> reduce_ops;
     std::vector<int64_t> word_offset;
-    std::vector<GroupArgs> gargs;
-    std::vector<ScanLaunch> gcfg;
-    std::vector<BufP> gparts, gdev;
+    std::vector<MScanCols> mcols;            // [scans..., gscans...] entries that run on k_mscan
+    std::vector<MScanDesc> mdesc;
+    std::vector<ScanLaunch> mcfg;
+    std::vector<BufP> mparts, mdev;
     std::vector<int64_t> gword_offset;
     int dominant = -1;
     std::string dominant_kernel;
@@ -203,32 +204,37 @@ int64_t plan_words(const vdl_plan *p, std::vector<int32_t> *ops, bool *shardable
     return off;
 }
 
-template <typename Args, typename PlanT>
-int64_t bind_columns(vdl_ctx *c, const PlanT &sp, Args &a, int64_t *bytes_per_row) {
-    a.ncol = (int)sp.cols.size();
-    a.nagg = (int)sp.aggs.size();
-    a.never = sp.never ? 1 : 0;
+// single-aggregate scans over <= 4 columns take the tuned k_scan; everything else k_mscan
+static bool use_kscan(const ScanPlan &sp) { return sp.aggs.size() == 1 && sp.cols.size() <= 4; }
+
+template <typename PlanT>
+int64_t bind_mscan(vdl_ctx *c, const PlanT &sp, MScanCols &cols, MScanDesc &d, int64_t *bytes_per_row) {
+    cols = MScanCols{};
+    d = MScanDesc{};
+    cols.ncol = (int)sp.cols.size();
+    d.nagg = (int)sp.aggs.size();
     int64_t n = -1;
     *bytes_per_row = 0;
-    for (int k = 0; k < a.ncol; k++) {
+    for (int k = 0; k < cols.ncol; k++) {
         const Column &col = find_col(c, sp.cols[(size_t)k].name);
         if (n >= 0 && col.n != n)
             throw Error(VDL_ERR_SHAPE, "columns of table '" + sp.table + "' have different lengths in the catalog");
         n = col.n;
-        a.ptr[k] = col.dev; a.width[k] = col.width;
-        a.lo[k] = sp.cols[(size_t)k].lo; a.hi[k] = sp.cols[(size_t)k].hi;
-        a.filtered[k] = (a.lo[k] != INT64_MIN || a.hi[k] != INT64_MAX) ? 1 : 0;
+        cols.ptr[k] = col.dev; cols.width[k] = col.width;
+        cols.lo[k] = sp.cols[(size_t)k].lo; cols.hi[k] = sp.cols[(size_t)k].hi;
+        cols.filtered[k] = (cols.lo[k] != INT64_MIN || cols.hi[k] != INT64_MAX) ? 1 : 0;
         *bytes_per_row += col.width;
     }
-    a.n = n;
-    for (int j = 0; j < a.nagg; j++) {
+    cols.n = n;
+    for (int j = 0; j < d.nagg; j++) {
         const ScanAgg &ag = sp.aggs[(size_t)j];
-        a.kind[j] = ag.kind;
-        a.constant[j] = ag.constant;
+        MAggDesc &m = d.agg[j];
+        m.kind = ag.kind;
+        m.constant = ag.constant;
         for (const ScanFactor &f : ag.fac) {
-            a.used[j] |= 1u << f.col;
-            if (f.a == 0 && f.s == 1) a.plain[j] |= 1u << f.col;
-            a.fa[j][f.col] = f.a; a.fs[j][f.col] = f.s;
+            m.used |= 1u << f.col;
+            if (f.a == 0 && f.s == 1) m.plain |= 1u << f.col;
+            m.fa[f.col] = f.a; m.fs[f.col] = f.s;
         }
     }
     return n;
@@ -236,56 +242,87 @@ int64_t bind_columns(vdl_ctx *c, const PlanT &sp, Args &a, int64_t *bytes_per_ro
 
 void bind_fused(vdl_ctx *c, vdl_plan *p) {
     const FusedPlan &F = p->fused;
-    p->sargs.assign(F.scans.size(), ScanArgs{});
-    p->scfg.assign(F.scans.size(), ScanLaunch{});
-    p->block_partials.assign(F.scans.size(), nullptr);
-    p->word_offset.assign(F.scans.size(), 0);
-    p->gargs.assign(F.gscans.size(), GroupArgs{});
-    p->gcfg.assign(F.gscans.size(), ScanLaunch{});
-    p->gparts.assign(F.gscans.size(), nullptr);
-    p->gdev.resize(F.gscans.size());
-    p->gword_offset.assign(F.gscans.size(), 0);
+    const size_t ns = F.scans.size(), ng = F.gscans.size();
+    p->sargs.assign(ns, ScanArgs{});
+    p->scfg.assign(ns, ScanLaunch{});
+    p->block_partials.assign(ns, nullptr);
+    p->word_offset.assign(ns, 0);
+    p->mcols.assign(ns + ng, MScanCols{});
+    p->mdesc.assign(ns + ng, MScanDesc{});
+    p->mcfg.assign(ns + ng, ScanLaunch{});
+    p->mparts.assign(ns + ng, nullptr);
+    p->mdev.resize(ns + ng);
+    p->gword_offset.assign(ng, 0);
     p->reduce_ops.clear();
     bool shardable = true;
     p->n_words = plan_words(p, &p->reduce_ops, &shardable);
     int64_t off = 0;
-    p->scan_rows = 0; p->scan_bytes = 0;
+    p->scan_rows = 0; p->scan_bytes = 0; p->dominant = -1;
     p->dominant_kernel = "none";
-    for (size_t s = 0; s < F.scans.size(); s++) {
+    for (size_t s = 0; s < ns; s++) {
         const ScanPlan &sp = F.scans[s];
-        ScanArgs &a = p->sargs[s];
-        int64_t bpr = 0;
-        const int64_t n = bind_columns(c, sp, a, &bpr);
-        p->scfg[s] = scan_launch_config(a, c->num_cus);
-        if (p->scfg[s].variant < 0) throw Error(VDL_ERR_UNSUPPORTED, "no scan kernel variant for this shape");
-        p->block_partials[s] = dev_alloc(c, sizeof(int64_t) * (size_t)p->scfg[s].grid * (size_t)(a.nagg + 1));
-        a.block_partials = (int64_t *)p->block_partials[s]->p;
-        p->word_offset[s] = off;
-        off += a.nagg + 1;
-        if (!sp.never && n * bpr > p->scan_bytes) {
-            p->scan_bytes = n * bpr; p->scan_rows = n; p->dominant = (int)s;
-            p->dominant_kernel = std::string(scan_kernel_name(p->scfg[s])) + "_grid" + std::to_string(p->scfg[s].grid);
+        int64_t bpr = 0, n = 0;
+        std::string kname;
+        if (use_kscan(sp)) {
+            ScanArgs &a = p->sargs[s];
+            a.ncol = (int)sp.cols.size(); a.nagg = 1; a.never = sp.never ? 1 : 0;
+            n = -1;
+            for (int k = 0; k < a.ncol; k++) {
+                const Column &col = find_col(c, sp.cols[(size_t)k].name);
+                if (n >= 0 && col.n != n)
+                    throw Error(VDL_ERR_SHAPE, "columns of table '" + sp.table + "' have different lengths in the catalog");
+                n = col.n;
+                a.ptr[k] = col.dev; a.width[k] = col.width;
+                a.lo[k] = sp.cols[(size_t)k].lo; a.hi[k] = sp.cols[(size_t)k].hi;
+                a.filtered[k] = (a.lo[k] != INT64_MIN || a.hi[k] != INT64_MAX) ? 1 : 0;
+                bpr += col.width;
+            }
+            a.n = n;
+            const ScanAgg &ag = sp.aggs[0];
+            a.kind[0] = ag.kind; a.constant[0] = ag.constant;
+            for (const ScanFactor &f : ag.fac) {
+                a.used[0] |= 1u << f.col;
+                if (f.a == 0 && f.s == 1) a.plain[0] |= 1u << f.col;
+                a.fa[0][f.col] = f.a; a.fs[0][f.col] = f.s;
+            }
+            p->scfg[s] = scan_launch_config(a, c->num_cus);
+            if (p->scfg[s].variant < 0) throw Error(VDL_ERR_UNSUPPORTED, "no scan kernel variant for this shape");
+            p->block_partials[s] = dev_alloc(c, sizeof(int64_t) * (size_t)p->scfg[s].grid * 2);
+            a.block_partials = (int64_t *)p->block_partials[s]->p;
+            kname = std::string(scan_kernel_name(p->scfg[s])) + "_grid" + std::to_string(p->scfg[s].grid);
+        } else {
+            n = bind_mscan(c, sp, p->mcols[s], p->mdesc[s], &bpr);
+            p->mcfg[s] = mscan_launch_config(p->mcols[s], p->mdesc[s], false, c->num_cus);
+            if (p->mcfg[s].variant < 0) throw Error(VDL_ERR_UNSUPPORTED, "no multi-aggregate scan kernel variant for this shape");
+            p->mparts[s] = dev_alloc(c, sizeof(int64_t) * (size_t)p->mcfg[s].grid * (size_t)(p->mdesc[s].nagg + 1));
+            p->mdesc[s].block_partials = (int64_t *)p->mparts[s]->p;
+            if (!p->mdev[s]) p->mdev[s] = dev_alloc(c, sizeof(MScanDesc));
+            kname = std::string(mscan_kernel_name(p->mcfg[s])) + "_grid" + std::to_string(p->mcfg[s].grid);
         }
+        p->word_offset[s] = off;
+        off += (int64_t)sp.aggs.size() + 1;
+        if (!sp.never && n * bpr > p->scan_bytes) { p->scan_bytes = n * bpr; p->scan_rows = n; p->dominant = (int)s; p->dominant_kernel = kname; }
     }
-    for (size_t g = 0; g < F.gscans.size(); g++) {
+    for (size_t g = 0; g < ng; g++) {
         const GroupScanPlan &gp = F.gscans[g];
-        GroupArgs &a = p->gargs[g];
+        const size_t m = ns + g;
         int64_t bpr = 0;
-        const int64_t n = bind_columns(c, gp, a, &bpr);
-        a.nkey = (int)gp.key.size();
-        for (int k = 0; k < a.nkey; k++) a.key[k] = gp.key[(size_t)k];
-        a.pmin = gp.pmin; a.pcount = gp.pcount; a.row0 = 0;
-        p->gcfg[g] = group_launch_config(a, c->num_cus);
-        if (p->gcfg[g].variant < 0) throw Error(VDL_ERR_UNSUPPORTED, "no grouped-scan kernel variant for this shape");
-        const int64_t words = a.pcount * (a.nagg + 1) + 1;
-        p->gparts[g] = dev_alloc(c, sizeof(int64_t) * (size_t)p->gcfg[g].grid * (size_t)words);
-        a.block_partials = (int64_t *)p->gparts[g]->p;
-        if (!p->gdev[g]) p->gdev[g] = dev_alloc(c, sizeof(GroupArgs));
+        const int64_t n = bind_mscan(c, gp, p->mcols[m], p->mdesc[m], &bpr);
+        MScanDesc &d = p->mdesc[m];
+        d.nkey = (int)gp.key.size();
+        for (int k = 0; k < d.nkey; k++) d.key[k] = gp.key[(size_t)k];
+        d.pmin = gp.pmin; d.pcount = gp.pcount;
+        p->mcfg[m] = mscan_launch_config(p->mcols[m], d, true, c->num_cus);
+        if (p->mcfg[m].variant < 0) throw Error(VDL_ERR_UNSUPPORTED, "no grouped-scan kernel variant for this shape");
+        const int64_t words = d.pcount * (d.nagg + 1) + 1;
+        p->mparts[m] = dev_alloc(c, sizeof(int64_t) * (size_t)p->mcfg[m].grid * (size_t)words);
+        d.block_partials = (int64_t *)p->mparts[m]->p;
+        if (!p->mdev[m]) p->mdev[m] = dev_alloc(c, sizeof(MScanDesc));
         p->gword_offset[g] = off;
         off += words;
         if (!gp.never && n * bpr > p->scan_bytes) {
-            p->scan_bytes = n * bpr; p->scan_rows = n; p->dominant = (int)(F.scans.size() + g);
-            p->dominant_kernel = std::string(group_kernel_name(p->gcfg[g])) + "_grid" + std::to_string(p->gcfg[g].grid) + "_rep" + std::to_string(a.replicas);
+            p->scan_bytes = n * bpr; p->scan_rows = n; p->dominant = (int)m;
+            p->dominant_kernel = std::string(mscan_kernel_name(p->mcfg[m])) + "_grid" + std::to_string(p->mcfg[m].grid) + "_rep" + std::to_string(d.replicas);
         }
     }
     p->bound = true;
@@ -295,26 +332,32 @@ void run_fused_local(vdl_ctx *c, vdl_plan *p, int64_t *dev_words, bool single_ra
     bind_fused(c, p);      // cheap; the catalog may have changed since the last run
     if (p->profiling && !p->ev0) { HIP_CHECK(hipEventCreate(&p->ev0)); HIP_CHECK(hipEventCreate(&p->ev1)); }
     p->ev_pending = false;
-    for (size_t s = 0; s < p->sargs.size(); s++) {
-        const ScanArgs &a = p->sargs[s];
-        int nblocks = 0;
-        if (!a.never && a.n > 0) {
-            const bool timed = p->profiling && (int)s == p->dominant;
+    const size_t ns = p->fused.scans.size(), ng = p->fused.gscans.size();
+    for (size_t s = 0; s < ns + ng; s++) {
+        const bool grouped = s >= ns;
+        const bool never = grouped ? p->fused.gscans[s - ns].never : p->fused.scans[s].never;
+        int64_t *out = dev_words + (grouped ? p->gword_offset[s - ns] : p->word_offset[s]);
+        const bool kscan = !grouped && use_kscan(p->fused.scans[s]);
+        const int64_t n = kscan ? p->sargs[s].n : p->mcols[s].n;
+        const bool timed = p->profiling && (int)s == p->dominant && !never && n > 0;
+        if (kscan) {
+            const ScanArgs &a = p->sargs[s];
+            int nblocks = 0;
+            if (!never && n > 0) {
+                if (timed) HIP_CHECK(hipEventRecord(p->ev0, c->stream));
+                HIP_CHECK(launch_scan(a, p->scfg[s], c->stream));
+                if (timed) { HIP_CHECK(hipEventRecord(p->ev1, c->stream)); p->ev_pending = true; }
+                nblocks = p->scfg[s].grid;
+            }
+            HIP_CHECK(launch_scan_finish(a.block_partials, nblocks, a.nagg, nullptr, a, out, c->stream));
+        } else {
+            HIP_CHECK(hipMemcpyAsync(p->mdev[s]->p, &p->mdesc[s], sizeof(MScanDesc), hipMemcpyHostToDevice, c->stream));
+            // events bracket the scan together with its tiny finish kernel(s)
             if (timed) HIP_CHECK(hipEventRecord(p->ev0, c->stream));
-            HIP_CHECK(launch_scan(a, p->scfg[s], c->stream));
+            HIP_CHECK(launch_mscan(p->mcols[s], p->mdesc[s], (const MScanDesc *)p->mdev[s]->p, p->mcfg[s], grouped, never, out,
+                                   grouped && single_rank, c->stream));
             if (timed) { HIP_CHECK(hipEventRecord(p->ev1, c->stream)); p->ev_pending = true; }
-            nblocks = p->scfg[s].grid;
         }
-        HIP_CHECK(launch_scan_finish(a.block_partials, nblocks, a.nagg, nullptr, a, dev_words + p->word_offset[s], c->stream));
-    }
-    for (size_t g = 0; g < p->gargs.size(); g++) {
-        const GroupArgs &a = p->gargs[g];
-        HIP_CHECK(hipMemcpyAsync(p->gdev[g]->p, &a, sizeof(GroupArgs), hipMemcpyHostToDevice, c->stream));
-        const bool timed = p->profiling && (int)(p->sargs.size() + g) == p->dominant && !a.never && a.n > 0;
-        // events bracket the grouped scan together with its small finish kernels
-        if (timed) HIP_CHECK(hipEventRecord(p->ev0, c->stream));
-        HIP_CHECK(launch_group_scan(a, (const GroupArgs *)p->gdev[g]->p, p->gcfg[g], dev_words + p->gword_offset[g], single_rank, c->stream));
-        if (timed) { HIP_CHECK(hipEventRecord(p->ev1, c->stream)); p->ev_pending = true; }
     }
 }
 
@@ -331,8 +374,9 @@ void finalize_fused(vdl_ctx *c, vdl_plan *p, const int64_t *dev_words) {
         p->timings.push_back({"timeInMicrosecondsForFusedScan_" + p->dominant_kernel, p->scan_usec});
         p->ev_pending = false;
     }
-    for (size_t g = 0; g < p->gargs.size(); g++) {
-        const GroupArgs &a = p->gargs[g];
+    const size_t ns = p->fused.scans.size();
+    for (size_t g = 0; g < p->fused.gscans.size(); g++) {
+        const MScanDesc &a = p->mdesc[ns + g];
         const int64_t oob = w[(size_t)(p->gword_offset[g] + a.pcount * (a.nagg + 1))];
         if (oob > 0)
             throw NeedGeneralPath(std::to_string(oob) + " row(s) carry a group key outside the Partition pivots [" + std::to_string(a.pmin) + "," +
@@ -349,7 +393,7 @@ void finalize_fused(vdl_ctx *c, vdl_plan *p, const int64_t *dev_words) {
             if (sw[0] > 0) o.vals.push_back(eval_scalar(*fo.value, sw + 1));   // no selected row -> the fold slot is EPS
         } else {
             // one value per non-empty bucket, ascending = the order of the runs of the sorted key
-            const GroupArgs &a = p->gargs[(size_t)fo.gscan];
+            const MScanDesc &a = p->mdesc[ns + (size_t)fo.gscan];
             const int W = a.nagg + 1;
             const int64_t *tab = w.data() + p->gword_offset[(size_t)fo.gscan];
             for (int64_t b = 0; b < a.pcount; b++)

@@ -361,11 +361,12 @@ bool emit_key(const RowP &e, int target, std::vector<KeyStep> &prog, ColIndex &c
     if (e->r->k == Row::CONST || e->l->k == Row::CONST) {
         const bool left = e->r->k != Row::CONST;
         if (!emit_key(left ? e->r : e->l, target, prog, col_index)) return false;
+        if (e->bin == B_DIV || e->bin == B_MOD) return false;      // kept off the in-kernel key evaluator
         st.kind = KeyStep::OPK; st.target = target; st.bin = e->bin; st.const_left = left ? 1 : 0; st.k = left ? e->l->c0 : e->r->c0;
         prog.push_back(st);
         return true;
     }
-    if (target != 0) return false;
+    if (target != 0 || e->bin == B_DIV || e->bin == B_MOD) return false;
     if (single_column_chain(e->r)) {
         if (!emit_key(e->l, 0, prog, col_index) || !emit_key(e->r, 1, prog, col_index)) return false;
         st.kind = KeyStep::COMBINE; st.bin = e->bin; st.const_left = 0; prog.push_back(st);

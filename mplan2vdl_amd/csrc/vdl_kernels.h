@@ -47,29 +47,37 @@ hipError_t launch_scan_finish(const int64_t *block_partials, int nblocks, int na
                               const ScanArgs &a, int64_t *words, hipStream_t s);
 const char *scan_kernel_name(const ScanLaunch &cfg);
 
-// ---- grouped fused scan (dense-domain GROUP BY) ---------------------------------------------
+// ---- multi-aggregate fused scans (vdl_mscan.hip): global and grouped (dense-domain GROUP BY) ----
 constexpr int kMaxGroupAggs = 16;
-struct GroupArgs {                           // lives in device memory (too large for a by-value argument)
-    int ncol = 0, nagg = 0, nkey = 0, replicas = 1;
-    int64_t n = 0, row0 = 0, pmin = 0, pcount = 0;
+struct MScanCols {                           // by-value kernel argument: keeps column loads in the global address space
+    int ncol = 0;
+    int64_t n = 0, row0 = 0;
     const void *ptr[kMaxScanCols] = {};
     int width[kMaxScanCols] = {};
     int filtered[kMaxScanCols] = {};
     int64_t lo[kMaxScanCols] = {}, hi[kMaxScanCols] = {};
-    int kind[kMaxGroupAggs] = {};            // AGG_SUM / AGG_MIN / AGG_MAX / AGG_FIRST
-    uint32_t used[kMaxGroupAggs] = {}, plain[kMaxGroupAggs] = {};
-    int64_t fa[kMaxGroupAggs][kMaxScanCols] = {}, fs[kMaxGroupAggs][kMaxScanCols] = {};
-    int64_t constant[kMaxGroupAggs] = {};
-    KeyStep key[kMaxKeySteps] = {};
-    int64_t *block_partials = nullptr;       // [grid][pcount * (1 + nagg) + 1]
-    int never = 0;
 };
-ScanLaunch group_launch_config(GroupArgs &a, int num_cus);
-const char *group_kernel_name(const ScanLaunch &cfg);
-// table: pcount * (nagg + 1) + 1 int64: per bucket {row count, aggregates...}, last word = rows whose key
-// fell outside [pmin, pmin + pcount).  resolve_first: turn AGG_FIRST row ids into column values (single rank).
-hipError_t launch_group_scan(const GroupArgs &a, const GroupArgs *dev_args, const ScanLaunch &cfg, int64_t *table,
-                             bool resolve_first, hipStream_t s);
+struct MAggDesc {
+    int kind = 0;                            // AGG_SUM / AGG_MIN / AGG_MAX / AGG_FIRST
+    uint32_t used = 0, plain = 0;            // bit c: column c contributes a factor / the factor is the bare column
+    int pad = 0;
+    int64_t constant = 0;                    // datum when there is no column factor
+    int64_t fa[kMaxScanCols] = {}, fs[kMaxScanCols] = {};
+};
+struct MScanDesc {                           // lives in device memory, read with scalar loads
+    int nagg = 0, nkey = 0, replicas = 1, pad = 0;
+    int64_t pmin = 0, pcount = 0;            // grouped: bucket = key - pmin in [0, pcount)
+    int64_t *block_partials = nullptr;       // global: [grid][1 + nagg]; grouped: [grid][pcount * (1 + nagg) + 1]
+    MAggDesc agg[kMaxGroupAggs];
+    KeyStep key[kMaxKeySteps];
+};
+ScanLaunch mscan_launch_config(const MScanCols &cols, MScanDesc &d, bool grouped, int num_cus);
+const char *mscan_kernel_name(const ScanLaunch &cfg);
+// out: global form 1 + nagg words {row count, aggregates}; grouped form pcount * (nagg + 1) + 1 words: per
+// bucket {row count, aggregates...}, last word = rows whose key fell outside [pmin, pmin + pcount).
+// resolve_first: turn AGG_FIRST row ids into column values (single rank only).
+hipError_t launch_mscan(const MScanCols &cols, const MScanDesc &d, const MScanDesc *dev_desc, const ScanLaunch &cfg, bool grouped,
+                        bool never, int64_t *out, bool resolve_first, hipStream_t s);
 
 // ---- synthetic data --------------------------------------------------------------------
 hipError_t launch_gen_column(void *out, int elem_bytes, int64_t row0, int64_t n, uint64_t seed, uint64_t col_id,

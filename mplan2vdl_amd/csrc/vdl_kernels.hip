@@ -304,14 +304,11 @@ struct ScanVariant { int nc, na, u; bool vec, nt; int bs; scan_fn fn; const char
 const ScanVariant kScanVariants[] = {
     // production kernels (tuned on Q6 SF100, profiles/r01/tune_scan.md): non-temporal loads, one
     // wave per SIMD with 12 sub-iterations = 48 loads (42 KiB) in flight per wave
+    // (several aggregates or more than 4 columns: k_mscan, vdl_mscan.hip)
     VDL_SV(4, 1, 12, true, true, 256),
-    VDL_SV(4, 4, 8, true, true, 256),
-    VDL_SV(8, 8, 6, true, true, 256),
     VDL_SV(4, 1, 4, false, false, 256),
-    VDL_SV(4, 4, 4, false, false, 256),
-    VDL_SV(8, 8, 2, false, false, 256),
     // small inputs: smaller tiles so that every CU gets work
-    VDL_SV(4, 1, 4, true, true, 256), VDL_SV(4, 4, 4, true, true, 256), VDL_SV(8, 8, 2, true, true, 256),
+    VDL_SV(4, 1, 4, true, true, 256),
     // tuning family for sweeps (VDL_SCAN_TUNE)
     VDL_SV(4, 1, 2, true, false, 256), VDL_SV(4, 1, 4, true, false, 256), VDL_SV(4, 1, 8, true, false, 256),
     VDL_SV(4, 1, 2, true, true, 256),  VDL_SV(4, 1, 8, true, true, 256),
@@ -1073,287 +1070,6 @@ hipError_t launch_fold_segmented(int kind, Src ctl, const uint64_t *vc, Src d, c
     k_seg_fill<<<grid_for(n, 256, 4), 256, 0, s>>>(out, rk == R_SUM ? 0 : rk == R_MIN ? INT64_MAX : INT64_MIN, n);
     k_seg_fold<<<grid_for(n, 256, 4), 256, 0, s>>>(kind, d, vd, vc, heads, wordhd, n, out, vout);
     if (kind == 4) k_seg_choose_fix<<<grid_for(n, 256, 4), 256, 0, s>>>(d, vout, n, out);
-    return launch_status();
-}
-
-
-// ------------------------------------------------------------------------------------------
-// Grouped fused scan: filter + dense-domain GROUP BY + aggregates in one pass.
-//
-// Replaces, for programs of the Q1 shape, Partition + one Scatter per aggregate input + one Fold
-// per aggregate (/root/reference/src/Vlite.hs:1048-1060,1082-1098): the sorted order is never
-// materialised.  Per row: range filters, the group key by a two-accumulator program (KeyStep),
-// bucket = key - pmin, then one LDS atomic per aggregate into tab[replica][bucket][1 + nagg].
-// Replicas (lane % R picks one) keep same-address conflicts low when few groups are hot (Q1: 4
-// groups take all rows).  Block end: replicas folded, one partial table per block;
-// k_group_finish folds the blocks.  A key outside [pmin, pmin + pcount) is counted in the last
-// word; the engine then reruns the program on the general path (exactness for any data).
-// Column loads are the same 2-rows-per-lane vector loads as k_scan.
-// ------------------------------------------------------------------------------------------
-constexpr int kGroupBlock = 256;
-
-template <int NC, int U, bool VEC, bool NT>
-__global__ __launch_bounds__(kGroupBlock) void k_group_scan(const GroupArgs *__restrict__ Ap) {
-    extern __shared__ int64_t g_tab[];
-    const GroupArgs &A = *Ap;
-    constexpr int BS = kGroupBlock, TILE = BS * 2 * U, ROWS = 2 * U;
-    const int tid = threadIdx.x;
-    const int W = A.nagg + 1;
-    const int64_t G = A.pcount;
-    const int R = A.replicas;
-    const int64_t words = G * W;
-    // identities
-    for (int64_t i = tid; i < words * R; i += BS) {
-        const int w = (int)(i % W);
-        const int kind = w == 0 ? AGG_SUM : A.kind[w - 1];
-        g_tab[i] = kind == AGG_SUM ? 0 : (kind == AGG_MAX ? INT64_MIN : INT64_MAX);
-    }
-    __syncthreads();
-    int64_t *mytab = g_tab + (int64_t)(tid % R) * words;
-    int64_t oob = 0;
-
-    auto process = [&](auto rows_tag, const int64_t (&v)[NC][decltype(rows_tag)::value], const int64_t (&rowid)[decltype(rows_tag)::value]) {
-        constexpr int RW = decltype(rows_tag)::value;
-        bool pass[RW];
-#pragma unroll
-        for (int r = 0; r < RW; r++) pass[r] = true;
-#pragma unroll
-        for (int c = 0; c < NC; c++) {
-            if (c < A.ncol && A.filtered[c]) {
-                const int64_t lo = A.lo[c], hi = A.hi[c];
-#pragma unroll
-                for (int r = 0; r < RW; r++) pass[r] = pass[r] & (v[c][r] >= lo) & (v[c][r] <= hi);
-            }
-        }
-        // group key
-        int64_t acc[RW], tmp[RW];
-#pragma unroll
-        for (int r = 0; r < RW; r++) { acc[r] = 0; tmp[r] = 0; }
-        for (int s = 0; s < A.nkey; s++) {
-            const KeyStep st = A.key[s];                       // wave-uniform
-            if (st.kind == KeyStep::LOAD) {
-#pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    if (c == st.col) {
-#pragma unroll
-                        for (int r = 0; r < RW; r++) { if (st.target) tmp[r] = v[c][r]; else acc[r] = v[c][r]; }
-                    }
-                }
-            } else if (st.kind == KeyStep::OPK) {
-#pragma unroll
-                for (int r = 0; r < RW; r++) {
-                    const int64_t x = st.target ? tmp[r] : acc[r];
-                    const int64_t y = st.const_left ? apply_bin(st.bin, st.k, x) : apply_bin(st.bin, x, st.k);
-                    if (st.target) tmp[r] = y; else acc[r] = y;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < RW; r++) acc[r] = st.const_left ? apply_bin(st.bin, tmp[r], acc[r]) : apply_bin(st.bin, acc[r], tmp[r]);
-            }
-        }
-        int64_t off[RW];
-#pragma unroll
-        for (int r = 0; r < RW; r++) {
-            const int64_t b = (int64_t)((uint64_t)acc[r] - (uint64_t)A.pmin);
-            const bool in = b >= 0 && b < G;
-            if (pass[r] && !in) oob++;
-            pass[r] = pass[r] && in;
-            off[r] = in ? b * W : 0;
-            if (pass[r]) atomicAdd((unsigned long long *)&mytab[off[r]], 1ull);
-        }
-        for (int j = 0; j < A.nagg; j++) {                     // wave-uniform
-            const int kind = A.kind[j];
-            int64_t t[RW];
-            if (kind == AGG_FIRST) {
-#pragma unroll
-                for (int r = 0; r < RW; r++) t[r] = rowid[r];
-            } else {
-                bool first = true;
-#pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    if (c < A.ncol && ((A.used[j] >> c) & 1u)) {
-                        const bool plain = (A.plain[j] >> c) & 1u;
-                        const int64_t a = A.fa[j][c], sc = A.fs[j][c];
-#pragma unroll
-                        for (int r = 0; r < RW; r++) {
-                            const int64_t x = plain ? v[c][r] : (int64_t)((uint64_t)a + (uint64_t)sc * (uint64_t)v[c][r]);
-                            t[r] = first ? x : (int64_t)((uint64_t)t[r] * (uint64_t)x);
-                        }
-                        first = false;
-                    }
-                }
-                if (first) {
-#pragma unroll
-                    for (int r = 0; r < RW; r++) t[r] = A.constant[j];
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < RW; r++) {
-                if (pass[r]) {
-                    int64_t *p = &mytab[off[r] + 1 + j];
-                    if (kind == AGG_SUM) atomicAdd((unsigned long long *)p, (unsigned long long)t[r]);
-                    else if (kind == AGG_MAX) atomicMax((long long *)p, (long long)t[r]);
-                    else atomicMin((long long *)p, (long long)t[r]);
-                }
-            }
-        }
-    };
-
-    const int64_t ntiles = A.n / TILE;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        int64_t v[NC][ROWS], rowid[ROWS];
-        const int64_t base = tile * TILE + (int64_t)tid * 2;
-#pragma unroll
-        for (int u = 0; u < U; u++) { rowid[2 * u] = A.row0 + base + (int64_t)u * (BS * 2); rowid[2 * u + 1] = rowid[2 * u] + 1; }
-#pragma unroll
-        for (int c = 0; c < NC; c++) {
-            if (c < A.ncol) {
-                const char *p = (const char *)A.ptr[c];
-                const int w = A.width[c];
-                if (!VEC) {
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        v[c][2 * u] = load_scalar(p, w, base + (int64_t)u * (BS * 2));
-                        v[c][2 * u + 1] = load_scalar(p, w, base + (int64_t)u * (BS * 2) + 1);
-                    }
-                } else if (w == 8) {
-#pragma unroll
-                    for (int u = 0; u < U; u++) { ll2 x = stream_load<NT, ll2>(p + (base + (int64_t)u * (BS * 2)) * 8); v[c][2 * u] = x.x; v[c][2 * u + 1] = x.y; }
-                } else if (w == 4) {
-#pragma unroll
-                    for (int u = 0; u < U; u++) { i32x2 x = stream_load<NT, i32x2>(p + (base + (int64_t)u * (BS * 2)) * 4); v[c][2 * u] = x.x; v[c][2 * u + 1] = x.y; }
-                } else if (w == 2) {
-#pragma unroll
-                    for (int u = 0; u < U; u++) { i16x2 x = stream_load<NT, i16x2>(p + (base + (int64_t)u * (BS * 2)) * 2); v[c][2 * u] = x.x; v[c][2 * u + 1] = x.y; }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < U; u++) { i8x2 x = stream_load<NT, i8x2>(p + (base + (int64_t)u * (BS * 2))); v[c][2 * u] = x.x; v[c][2 * u + 1] = x.y; }
-                }
-            }
-        }
-        process(std::integral_constant<int, ROWS>{}, v, rowid);
-    }
-    if (blockIdx.x == gridDim.x - 1) {
-        for (int64_t i = ntiles * TILE + tid; i < A.n; i += BS) {
-            int64_t v1[NC][1], rid[1];
-            rid[0] = A.row0 + i;
-#pragma unroll
-            for (int c = 0; c < NC; c++)
-                if (c < A.ncol) v1[c][0] = load_scalar(A.ptr[c], A.width[c], i);
-            process(std::integral_constant<int, 1>{}, v1, rid);
-        }
-    }
-    __syncthreads();
-    int64_t *dst = A.block_partials + (int64_t)blockIdx.x * (words + 1);
-    for (int64_t i = tid; i < words; i += BS) {
-        const int w = (int)(i % W);
-        const int kind = w == 0 ? AGG_SUM : A.kind[w - 1];
-        const int rk = kind == AGG_SUM ? R_SUM : kind == AGG_MAX ? R_MAX : R_MIN;
-        int64_t x = g_tab[i];
-        for (int r = 1; r < R; r++) x = r_combine(rk, x, g_tab[(int64_t)r * words + i]);
-        dst[i] = x;
-    }
-    __shared__ int64_t oob_red[kGroupBlock / kWave];
-    oob = wave_reduce(oob, R_SUM);
-    if ((tid & (kWave - 1)) == 0) oob_red[tid / kWave] = oob;
-    __syncthreads();
-    if (tid == 0) { int64_t x = 0; for (int w = 0; w < kGroupBlock / kWave; w++) x += oob_red[w]; dst[words] = x; }
-}
-
-// table[w] = fold over blocks of partials[b][w]; one thread per word (coalesced across words)
-__global__ __launch_bounds__(256) void k_group_finish(const GroupArgs *__restrict__ Ap, int nblocks, int64_t *table) {
-    const GroupArgs &A = *Ap;
-    const int W = A.nagg + 1;
-    const int64_t words = A.pcount * W;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > words) return;
-    int rk = R_SUM;
-    if (i < words) {
-        const int w = (int)(i % W);
-        const int kind = w == 0 ? AGG_SUM : A.kind[w - 1];
-        rk = kind == AGG_SUM ? R_SUM : kind == AGG_MAX ? R_MAX : R_MIN;
-    }
-    int64_t x = r_identity(rk);
-    for (int b = 0; b < nblocks; b++) x = r_combine(rk, x, A.block_partials[(int64_t)b * (words + 1) + i]);
-    table[i] = x;
-}
-
-// FoldChoose per group: replace the group's smallest row id by that row's column value
-__global__ void k_group_first(const GroupArgs *__restrict__ Ap, int64_t *table) {
-    const GroupArgs &A = *Ap;
-    const int W = A.nagg + 1;
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= A.pcount || table[b * W] <= 0) return;
-    for (int j = 0; j < A.nagg; j++) {
-        if (A.kind[j] != AGG_FIRST) continue;
-        int c = 0;
-        for (int k = 0; k < kMaxScanCols; k++) if ((A.used[j] >> k) & 1u) c = k;
-        table[b * W + 1 + j] = load_scalar(A.ptr[c], A.width[c], table[b * W + 1 + j] - A.row0);
-    }
-}
-
-namespace {
-typedef void (*group_fn)(const GroupArgs *);
-struct GroupVariant { int nc, u; bool vec; group_fn fn; const char *name; };
-const GroupVariant kGroupVariants[] = {
-    {4, 4, true, k_group_scan<4, 4, true, true>, "k_group_scan<4,4,vec,nt>"},
-    {8, 4, true, k_group_scan<8, 4, true, true>, "k_group_scan<8,4,vec,nt>"},
-    {4, 4, false, k_group_scan<4, 4, false, false>, "k_group_scan<4,4,scalar>"},
-    {8, 4, false, k_group_scan<8, 4, false, false>, "k_group_scan<8,4,scalar>"},
-};
-constexpr int kNumGroupVariants = sizeof(kGroupVariants) / sizeof(kGroupVariants[0]);
-}  // namespace
-
-ScanLaunch group_launch_config(GroupArgs &a, int num_cus) {
-    bool vec = true;
-    for (int c = 0; c < a.ncol; c++)
-        if (((uintptr_t)a.ptr[c]) % (uintptr_t)(2 * a.width[c]) != 0) vec = false;
-    ScanLaunch cfg;
-    cfg.variant = -1;
-    for (int i = 0; i < kNumGroupVariants; i++)
-        if (kGroupVariants[i].vec == vec && a.ncol <= kGroupVariants[i].nc) { cfg.variant = i; break; }
-    if (cfg.variant < 0) return cfg;
-    const int64_t words = a.pcount * (a.nagg + 1);
-    int r = 16;
-    while (r > 1 && words * r > 6144) r >>= 1;           // <= 48 KiB of LDS per block
-    const char *tune = getenv("VDL_GROUP_TUNE");
-    if (tune) { int v = atoi(tune); if (v >= 1 && v <= 64 && words * v <= 8192) r = v; }
-    a.replicas = r;
-    const GroupVariant &v = kGroupVariants[cfg.variant];
-    const size_t lds = (size_t)words * r * sizeof(int64_t);
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v.fn, kGroupBlock, lds) != hipSuccess || per_cu < 1) {
-        (void)hipGetLastError();
-        per_cu = 2;
-    }
-    if (per_cu > 8) per_cu = 8;
-    const int64_t tile = (int64_t)kGroupBlock * 2 * v.u;
-    int64_t grid = (int64_t)num_cus * per_cu;
-    if (grid > a.n / tile) grid = a.n / tile;
-    if (grid < 1) grid = 1;
-    cfg.grid = (int)grid;
-    cfg.block = kGroupBlock;
-    return cfg;
-}
-
-const char *group_kernel_name(const ScanLaunch &cfg) {
-    return (cfg.variant >= 0 && cfg.variant < kNumGroupVariants) ? kGroupVariants[cfg.variant].name : "none";
-}
-
-// dev_args: device copy of `a` (its block_partials already set); table: pcount*(nagg+1)+1 int64
-hipError_t launch_group_scan(const GroupArgs &a, const GroupArgs *dev_args, const ScanLaunch &cfg, int64_t *table, bool resolve_first,
-                             hipStream_t s) {
-    (void)hipGetLastError();
-    if (cfg.variant < 0 || cfg.variant >= kNumGroupVariants) return hipErrorInvalidValue;
-    const int64_t words = a.pcount * (a.nagg + 1);
-    int nblocks = 0;
-    if (!a.never && a.n > 0) {
-        const size_t lds = (size_t)words * a.replicas * sizeof(int64_t);
-        hipLaunchKernelGGL(kGroupVariants[cfg.variant].fn, dim3(cfg.grid), dim3(cfg.block), lds, s, dev_args);
-        nblocks = cfg.grid;
-    }
-    k_group_finish<<<(int)((words + 1 + 255) / 256), 256, 0, s>>>(dev_args, nblocks, table);
-    if (resolve_first) k_group_first<<<(int)((a.pcount + 255) / 256), 256, 0, s>>>(dev_args, table);
     return launch_status();
 }
 

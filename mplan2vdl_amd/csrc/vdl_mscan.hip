@@ -1,0 +1,490 @@
+// vdl_mscan.hip -- multi-aggregate fused scans for gfx950: the global form (several Fold* over one
+// filtered table: ungrouped Q1, `select sum(..), min(..), count(*) from t where ..`) and the
+// grouped form (dense-domain GROUP BY: TPC-H Q1).
+//
+// Structure (one kernel template, GROUPED = false / true):
+//   * columns: by-value descriptors, loads fully unrolled over (column, sub-iteration) exactly as in
+//     k_scan -- lane l owns rows base + 512u + 2l, +1; 16-byte non-temporal loads for int64 columns;
+//   * aggregates: a RUNTIME loop over descriptors in device memory (scalar loads, wave-uniform).
+//     Unrolling the aggregate loop as well (the first version of this kernel) exploded into 70 K
+//     instructions with thousands of SGPR spills and ran at 20 % of the HBM roofline;
+//   * per aggregate the term is a product of affine column factors, evaluated for the lane's rows;
+//     global form: the lane's rows are folded in registers and added to the lane's own LDS slot once
+//     per tile (no atomics); grouped form: one LDS atomic per row into tab[replica][bucket][1+j];
+//   * block end: 64-lane shuffle reduction + cross-wave LDS step (global) or replica fold (grouped),
+//     one partial row / table per block; a second tiny kernel folds the blocks (deterministic).
+// Lowering this replaces: /root/reference/src/Vlite.hs:1033-1098 (aggregates, Partition + Scatter
+// + Fold per aggregate) and :721-730 (Select -> FoldSelect + Gather).
+#include "vdl_kernels.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
+namespace vdl {
+
+typedef long long ll2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+typedef char i8x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kMsBlock = 256;
+enum { R_SUM = 0, R_MIN = 1, R_MAX = 2 };
+
+__device__ __forceinline__ int rk_of(int kind) { return kind == AGG_SUM ? R_SUM : kind == AGG_MAX ? R_MAX : R_MIN; }
+__device__ __forceinline__ int64_t r_identity(int rk) { return rk == R_SUM ? 0 : rk == R_MIN ? INT64_MAX : INT64_MIN; }
+__device__ __forceinline__ int64_t r_combine(int rk, int64_t a, int64_t b) {
+    if (rk == R_SUM) return (int64_t)((uint64_t)a + (uint64_t)b);
+    if (rk == R_MIN) return a < b ? a : b;
+    return a > b ? a : b;
+}
+__device__ __forceinline__ int64_t wave_reduce(int64_t x, int rk) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) x = r_combine(rk, x, __shfl_down(x, off, kWave));
+    return x;
+}
+__device__ __forceinline__ int64_t load_scalar(const void *p, int width, int64_t i) {
+    switch (width) {
+    case 8: return ((const int64_t *)p)[i];
+    case 4: return ((const int32_t *)p)[i];
+    case 2: return ((const int16_t *)p)[i];
+    default: return ((const int8_t *)p)[i];
+    }
+}
+template <bool NT, typename V>
+__device__ __forceinline__ V stream_load(const char *p) {
+    if (NT) return __builtin_nontemporal_load((const V *)p);
+    return *(const V *)p;
+}
+
+// key-program operators: apply_bin minus Divide / Modulo (the planner keeps those off this path)
+__device__ __forceinline__ int64_t key_bin(int op, int64_t a, int64_t b) {
+    switch (op) {
+    case B_LAND: return (a != 0) && (b != 0);
+    case B_LOR:  return (a != 0) || (b != 0);
+    case B_BAND: return a & b;
+    case B_BOR:  return a | b;
+    case B_SHIFT:
+        if (b >= 0) return a >> (b > 63 ? 63 : b);
+        if (b <= -64) return 0;
+        return (int64_t)((uint64_t)a << (unsigned)(-b));
+    case B_EQ:  return a == b;
+    case B_ADD: return (int64_t)((uint64_t)a + (uint64_t)b);
+    case B_SUB: return (int64_t)((uint64_t)a - (uint64_t)b);
+    case B_GT:  return a > b;
+    default:    return (int64_t)((uint64_t)a * (uint64_t)b);
+    }
+}
+
+// x[r] = x[r] op k (or k op x[r]) for all rows; the operator switch is wave-uniform and sits OUTSIDE
+// the row loop (a per-row switch made the kernel scalar-issue bound)
+#define VDL_ROWS(EXPR) { _Pragma("unroll") for (int r = 0; r < RW; r++) { const int64_t a = x[r]; x[r] = (EXPR); } }
+template <int RW>
+__device__ __forceinline__ void key_rows(int op, int const_left, int64_t (&x)[RW], int64_t k) {
+    switch (op) {
+    case B_BAND: VDL_ROWS(a & k) break;
+    case B_BOR:  VDL_ROWS(a | k) break;
+    case B_ADD:  VDL_ROWS((int64_t)((uint64_t)a + (uint64_t)k)) break;
+    case B_MUL:  VDL_ROWS((int64_t)((uint64_t)a * (uint64_t)k)) break;
+    case B_SUB:  if (const_left) VDL_ROWS((int64_t)((uint64_t)k - (uint64_t)a)) else VDL_ROWS((int64_t)((uint64_t)a - (uint64_t)k)) break;
+    case B_SHIFT:
+        if (const_left) VDL_ROWS(key_bin(B_SHIFT, k, a))
+        else if (k >= 0) { const int sh = k > 63 ? 63 : (int)k; VDL_ROWS(a >> sh) }
+        else if (k <= -64) VDL_ROWS(0 * a)
+        else { const int sh = (int)(-k); VDL_ROWS((int64_t)((uint64_t)a << sh)) }
+        break;
+    default:
+        if (const_left) VDL_ROWS(key_bin(op, k, a)) else VDL_ROWS(key_bin(op, a, k))
+        break;
+    }
+}
+#undef VDL_ROWS
+template <int RW>
+__device__ __forceinline__ void key_combine(int op, int swap, int64_t (&acc)[RW], const int64_t (&tmp)[RW]) {
+    switch (op) {
+    case B_BOR:
+#pragma unroll
+        for (int r = 0; r < RW; r++) acc[r] |= tmp[r];
+        break;
+    case B_BAND:
+#pragma unroll
+        for (int r = 0; r < RW; r++) acc[r] &= tmp[r];
+        break;
+    case B_ADD:
+#pragma unroll
+        for (int r = 0; r < RW; r++) acc[r] = (int64_t)((uint64_t)acc[r] + (uint64_t)tmp[r]);
+        break;
+    default:
+#pragma unroll
+        for (int r = 0; r < RW; r++) acc[r] = swap ? key_bin(op, tmp[r], acc[r]) : key_bin(op, acc[r], tmp[r]);
+        break;
+    }
+}
+
+template <int NC, int U, bool VEC, bool NT>
+__device__ __forceinline__ void load_tile(const MScanCols &C, int64_t base, int64_t (&v)[NC][2 * U]) {
+    constexpr int BS = kMsBlock;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        if (c < C.ncol) {                                  // wave-uniform
+            const char *p = (const char *)C.ptr[c];
+            const int w = C.width[c];
+            if (!VEC) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    v[c][2 * u] = load_scalar(p, w, base + (int64_t)u * (BS * 2));
+                    v[c][2 * u + 1] = load_scalar(p, w, base + (int64_t)u * (BS * 2) + 1);
+                }
+            } else if (w == 8) {
+#pragma unroll
+                for (int u = 0; u < U; u++) { ll2 x = stream_load<NT, ll2>(p + (base + (int64_t)u * (BS * 2)) * 8); v[c][2 * u] = x.x; v[c][2 * u + 1] = x.y; }
+            } else if (w == 4) {
+#pragma unroll
+                for (int u = 0; u < U; u++) { i32x2 x = stream_load<NT, i32x2>(p + (base + (int64_t)u * (BS * 2)) * 4); v[c][2 * u] = x.x; v[c][2 * u + 1] = x.y; }
+            } else if (w == 2) {
+#pragma unroll
+                for (int u = 0; u < U; u++) { i16x2 x = stream_load<NT, i16x2>(p + (base + (int64_t)u * (BS * 2)) * 2); v[c][2 * u] = x.x; v[c][2 * u + 1] = x.y; }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; u++) { i8x2 x = stream_load<NT, i8x2>(p + (base + (int64_t)u * (BS * 2))); v[c][2 * u] = x.x; v[c][2 * u + 1] = x.y; }
+            }
+        }
+    }
+}
+
+template <int NC, int RW>
+__device__ __forceinline__ void eval_pass(const MScanCols &C, const int64_t (&v)[NC][RW], bool (&pass)[RW]) {
+#pragma unroll
+    for (int r = 0; r < RW; r++) pass[r] = true;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        if (c < C.ncol && C.filtered[c]) {
+            const int64_t lo = C.lo[c], hi = C.hi[c];
+#pragma unroll
+            for (int r = 0; r < RW; r++) pass[r] = pass[r] & (v[c][r] >= lo) & (v[c][r] <= hi);
+        }
+    }
+}
+
+// term of one aggregate for the lane's rows: product of affine column factors (a + s*col), a constant,
+// or the row id (AGG_FIRST).  Everything read from `d` is wave-uniform (scalar loads).
+template <int NC, int RW>
+__device__ __forceinline__ void eval_term(const MAggDesc &d, const int64_t (&v)[NC][RW], const int64_t (&rowid)[RW], int64_t (&t)[RW]) {
+    if (d.kind == AGG_FIRST) {
+#pragma unroll
+        for (int r = 0; r < RW; r++) t[r] = rowid[r];
+        return;
+    }
+    const uint32_t used = d.used, plain = d.plain;
+    bool first = true;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        if ((used >> c) & 1u) {                            // wave-uniform
+            int64_t x[RW];
+            if ((plain >> c) & 1u) {
+#pragma unroll
+                for (int r = 0; r < RW; r++) x[r] = v[c][r];
+            } else {
+                const int64_t a = d.fa[c], s = d.fs[c];
+                if (s == 1) {
+#pragma unroll
+                    for (int r = 0; r < RW; r++) x[r] = (int64_t)((uint64_t)a + (uint64_t)v[c][r]);
+                } else if (s == -1) {
+#pragma unroll
+                    for (int r = 0; r < RW; r++) x[r] = (int64_t)((uint64_t)a - (uint64_t)v[c][r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < RW; r++) x[r] = (int64_t)((uint64_t)a + (uint64_t)s * (uint64_t)v[c][r]);
+                }
+            }
+            if (first) {
+#pragma unroll
+                for (int r = 0; r < RW; r++) t[r] = x[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < RW; r++) t[r] = (int64_t)((uint64_t)t[r] * (uint64_t)x[r]);
+            }
+            first = false;
+        }
+    }
+    if (first) {
+        const int64_t k = d.constant;
+#pragma unroll
+        for (int r = 0; r < RW; r++) t[r] = k;
+    }
+}
+
+// LDS use: global form (1 + nagg) * 256 lane slots; grouped form replicas * (pcount * (1 + nagg) | 1)
+template <int NC, int U, bool VEC, bool NT, bool GROUPED>
+__global__ __launch_bounds__(kMsBlock) void k_mscan(const MScanCols C, const MScanDesc *__restrict__ Dp) {
+    extern __shared__ int64_t lds[];
+    const MScanDesc &D = *Dp;
+    constexpr int BS = kMsBlock, TILE = BS * 2 * U, ROWS = 2 * U;
+    const int tid = threadIdx.x;
+    const int nagg = D.nagg;
+    const int W = nagg + 1;
+    const int64_t G = D.pcount;
+    const int64_t words = G * W;
+    const int64_t rstride = words | 1;                     // odd int64 stride: replicas start on different banks
+    const int R = D.replicas;
+
+    int64_t cnt = 0, oob = 0;
+    int64_t *mytab = lds;
+    int trash = 0;
+    if (GROUPED) {
+        for (int r = 0; r < R; r++)
+            for (int64_t i = tid; i < words; i += BS) {
+                const int w = (int)(i % W);
+                lds[(int64_t)r * rstride + i] = r_identity(w == 0 ? R_SUM : rk_of(D.agg[w - 1].kind));
+            }
+        mytab = lds + (int64_t)(tid % R) * rstride;
+        // per-lane trash rows (W words each) live behind the replicas; offset relative to mytab
+        trash = (int)((int64_t)R * rstride + (int64_t)tid * W - (int64_t)(tid % R) * rstride);
+        for (int w = 0; w < W; w++) lds[(int64_t)R * rstride + (int64_t)tid * W + w] = 0;
+    } else {
+        for (int j = 0; j < nagg; j++) lds[(int64_t)j * BS + tid] = r_identity(rk_of(D.agg[j].kind));
+    }
+    __syncthreads();
+
+    auto process = [&](auto rows_tag, const int64_t (&v)[NC][decltype(rows_tag)::value], const int64_t (&rowid)[decltype(rows_tag)::value]) {
+        constexpr int RW = decltype(rows_tag)::value;
+        bool pass[RW];
+        eval_pass<NC, RW>(C, v, pass);
+        int off[RW];
+        if (GROUPED) {
+            // group key: two-accumulator program (vdl_fuse.h KeyStep)
+            int64_t acc[RW], tmp[RW];
+#pragma unroll
+            for (int r = 0; r < RW; r++) { acc[r] = 0; tmp[r] = 0; }
+            for (int s = 0; s < D.nkey; s++) {
+                const KeyStep st = D.key[s];               // wave-uniform
+                if (st.kind == KeyStep::LOAD) {
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        if (c == st.col) {
+                            if (st.target) {
+#pragma unroll
+                                for (int r = 0; r < RW; r++) tmp[r] = v[c][r];
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < RW; r++) acc[r] = v[c][r];
+                            }
+                        }
+                    }
+                } else if (st.kind == KeyStep::OPK) {
+                    if (st.target) key_rows<RW>(st.bin, st.const_left, tmp, st.k);
+                    else key_rows<RW>(st.bin, st.const_left, acc, st.k);
+                } else {
+                    key_combine<RW>(st.bin, st.const_left, acc, tmp);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RW; r++) {
+                const int64_t b = (int64_t)((uint64_t)acc[r] - (uint64_t)D.pmin);
+                const bool in = b >= 0 && b < G;
+                oob += (pass[r] && !in) ? 1 : 0;
+                pass[r] = pass[r] && in;
+                // rows that do not count go to this lane's own trash slot with the identity: no branches
+                off[r] = pass[r] ? (int)b * W : trash;
+                atomicAdd((unsigned long long *)&mytab[off[r]], pass[r] ? 1ull : 0ull);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RW; r++) cnt += pass[r] ? 1 : 0;
+        }
+        for (int j = 0; j < nagg; j++) {                   // runtime loop: descriptors by scalar loads
+            const MAggDesc d = D.agg[j];                   // whole descriptor into SGPRs: one scalar-load wait per aggregate
+            const int rk = rk_of(d.kind);
+            int64_t t[RW];
+            eval_term<NC, RW>(d, v, rowid, t);
+            if (GROUPED) {
+                if (rk == R_SUM) {
+#pragma unroll
+                    for (int r = 0; r < RW; r++) atomicAdd((unsigned long long *)&mytab[off[r] + 1 + j], (unsigned long long)(pass[r] ? t[r] : 0));
+                } else if (rk == R_MAX) {
+#pragma unroll
+                    for (int r = 0; r < RW; r++) atomicMax((long long *)&mytab[off[r] + 1 + j], (long long)(pass[r] ? t[r] : INT64_MIN));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < RW; r++) atomicMin((long long *)&mytab[off[r] + 1 + j], (long long)(pass[r] ? t[r] : INT64_MAX));
+                }
+            } else {
+                int64_t s = r_identity(rk);
+                if (rk == R_SUM) {
+#pragma unroll
+                    for (int r = 0; r < RW; r++) s = (int64_t)((uint64_t)s + (uint64_t)(pass[r] ? t[r] : 0));
+                } else if (rk == R_MIN) {
+#pragma unroll
+                    for (int r = 0; r < RW; r++) s = (pass[r] && t[r] < s) ? t[r] : s;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < RW; r++) s = (pass[r] && t[r] > s) ? t[r] : s;
+                }
+                int64_t *slot = &lds[(int64_t)j * BS + tid];      // this lane's own slot: no atomics, no conflicts
+                *slot = r_combine(rk, *slot, s);
+            }
+        }
+    };
+
+    const int64_t ntiles = C.n / TILE;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int64_t v[NC][ROWS], rowid[ROWS];
+        const int64_t base = tile * TILE + (int64_t)tid * 2;
+#pragma unroll
+        for (int u = 0; u < U; u++) { rowid[2 * u] = C.row0 + base + (int64_t)u * (BS * 2); rowid[2 * u + 1] = rowid[2 * u] + 1; }
+        load_tile<NC, U, VEC, NT>(C, base, v);
+        process(std::integral_constant<int, ROWS>{}, v, rowid);
+    }
+    if (blockIdx.x == gridDim.x - 1) {                     // tail rows, one per lane
+        for (int64_t i = ntiles * TILE + tid; i < C.n; i += BS) {
+            int64_t v1[NC][1], rid[1];
+            rid[0] = C.row0 + i;
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+                if (c < C.ncol) v1[c][0] = load_scalar(C.ptr[c], C.width[c], i);
+            process(std::integral_constant<int, 1>{}, v1, rid);
+        }
+    }
+    __syncthreads();
+    __shared__ int64_t red[kMsBlock / kWave];
+    const int lane = tid & (kWave - 1), wave = tid / kWave;
+    if (GROUPED) {
+        int64_t *dst = D.block_partials + (int64_t)blockIdx.x * (words + 1);
+        for (int64_t i = tid; i < words; i += BS) {
+            const int w = (int)(i % W);
+            const int rk = w == 0 ? R_SUM : rk_of(D.agg[w - 1].kind);
+            int64_t x = lds[i];
+            for (int r = 1; r < R; r++) x = r_combine(rk, x, lds[(int64_t)r * rstride + i]);
+            dst[i] = x;
+        }
+        oob = wave_reduce(oob, R_SUM);
+        if (lane == 0) red[wave] = oob;
+        __syncthreads();
+        if (tid == 0) { int64_t x = 0; for (int w = 0; w < kMsBlock / kWave; w++) x += red[w]; dst[words] = x; }
+    } else {
+        int64_t *dst = D.block_partials + (int64_t)blockIdx.x * W;
+        for (int j = -1; j < nagg; j++) {
+            const int rk = j < 0 ? R_SUM : rk_of(D.agg[j].kind);
+            int64_t x = j < 0 ? cnt : lds[(int64_t)j * BS + tid];
+            x = wave_reduce(x, rk);
+            if (lane == 0) red[wave] = x;
+            __syncthreads();
+            if (tid == 0) {
+                int64_t y = red[0];
+                for (int w = 1; w < kMsBlock / kWave; w++) y = r_combine(rk, y, red[w]);
+                dst[j + 1] = y;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// out[w] = fold over blocks of partials[b][w]: one wave per word, lanes stride over the blocks
+__global__ __launch_bounds__(256) void k_mscan_finish(const MScanDesc *__restrict__ Dp, int nblocks, int grouped, int64_t *out) {
+    const MScanDesc &D = *Dp;
+    const int W = D.nagg + 1;
+    const int64_t words = grouped ? D.pcount * W + 1 : W;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    if (i >= words) return;
+    int rk = R_SUM;
+    if (!(grouped && i == words - 1)) {
+        const int w = (int)(i % W);
+        rk = w == 0 ? R_SUM : rk_of(D.agg[w - 1].kind);
+    }
+    int64_t x = r_identity(rk);
+    for (int b = lane; b < nblocks; b += kWave) x = r_combine(rk, x, D.block_partials[(int64_t)b * words + i]);
+    x = wave_reduce(x, rk);
+    if (lane == 0) out[i] = x;
+}
+
+// FoldChoose per group (single rank): replace the group's smallest row id by that row's column value
+__global__ void k_mscan_first(const MScanCols C, const MScanDesc *__restrict__ Dp, int64_t *table) {
+    const MScanDesc &D = *Dp;
+    const int W = D.nagg + 1;
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= D.pcount || table[b * W] <= 0) return;
+    for (int j = 0; j < D.nagg; j++) {
+        if (D.agg[j].kind != AGG_FIRST) continue;
+        int c = 0;
+        for (int k = 0; k < kMaxScanCols; k++) if ((D.agg[j].used >> k) & 1u) c = k;
+        table[b * W + 1 + j] = load_scalar(C.ptr[c], C.width[c], table[b * W + 1 + j] - C.row0);
+    }
+}
+
+typedef void (*mscan_fn)(const MScanCols, const MScanDesc *);
+struct MsVariant { int nc, u; bool vec, grouped; mscan_fn fn; const char *name; };
+#define VDL_MS(NC, U, VEC, NT, GR) {NC, U, VEC, GR, k_mscan<NC, U, VEC, NT, GR>, "k_mscan<" #NC "," #U "," #VEC "," #NT "," #GR ">"}
+const MsVariant kMsVariants[] = {
+    VDL_MS(4, 6, true, true, false),  VDL_MS(8, 4, true, true, false),
+    VDL_MS(4, 4, false, false, false), VDL_MS(8, 4, false, false, false),
+    VDL_MS(4, 6, true, true, true),   VDL_MS(8, 4, true, true, true),
+    VDL_MS(4, 4, false, false, true),  VDL_MS(8, 4, false, false, true),
+};
+#undef VDL_MS
+constexpr int kNumMsVariants = sizeof(kMsVariants) / sizeof(kMsVariants[0]);
+
+size_t ms_lds_bytes(const MScanDesc &d, bool grouped) {
+    if (grouped) return ((size_t)((d.pcount * (d.nagg + 1)) | 1) * (size_t)d.replicas + (size_t)kMsBlock * (size_t)(d.nagg + 1)) * sizeof(int64_t);
+    return (size_t)(d.nagg > 0 ? d.nagg : 1) * kMsBlock * sizeof(int64_t);
+}
+
+}  // namespace
+
+ScanLaunch mscan_launch_config(const MScanCols &cols, MScanDesc &d, bool grouped, int num_cus) {
+    bool vec = true;
+    for (int c = 0; c < cols.ncol; c++)
+        if (((uintptr_t)cols.ptr[c]) % (uintptr_t)(2 * cols.width[c]) != 0) vec = false;
+    ScanLaunch cfg;
+    cfg.variant = -1;
+    for (int i = 0; i < kNumMsVariants; i++)
+        if (kMsVariants[i].vec == vec && kMsVariants[i].grouped == grouped && cols.ncol <= kMsVariants[i].nc) { cfg.variant = i; break; }
+    if (cfg.variant < 0) return cfg;
+    d.replicas = 1;
+    if (grouped) {
+        const int64_t words = d.pcount * (d.nagg + 1);
+        int r = 16;
+        while (r > 1 && words * r > 4096) r >>= 1;         // replicas <= 32 KiB, + 256 trash rows; <= 64 KiB per block
+        const char *tune = getenv("VDL_GROUP_TUNE");
+        if (tune) { int v = atoi(tune); if (v >= 1 && v <= 64 && words * v <= 8192) r = v; }
+        d.replicas = r;
+    }
+    const MsVariant &v = kMsVariants[cfg.variant];
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v.fn, kMsBlock, ms_lds_bytes(d, grouped)) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 2;
+    }
+    if (per_cu > 8) per_cu = 8;
+    const int64_t tile = (int64_t)kMsBlock * 2 * v.u;
+    int64_t grid = (int64_t)num_cus * per_cu;
+    if (grid > cols.n / tile) grid = cols.n / tile;
+    if (grid < 1) grid = 1;
+    cfg.grid = (int)grid;
+    cfg.block = kMsBlock;
+    return cfg;
+}
+
+const char *mscan_kernel_name(const ScanLaunch &cfg) {
+    return (cfg.variant >= 0 && cfg.variant < kNumMsVariants) ? kMsVariants[cfg.variant].name : "none";
+}
+
+hipError_t launch_mscan(const MScanCols &cols, const MScanDesc &d, const MScanDesc *dev_desc, const ScanLaunch &cfg, bool grouped,
+                        bool never, int64_t *out, bool resolve_first, hipStream_t s) {
+    (void)hipGetLastError();
+    if (cfg.variant < 0 || cfg.variant >= kNumMsVariants) return hipErrorInvalidValue;
+    int nblocks = 0;
+    if (!never && cols.n > 0) {
+        hipLaunchKernelGGL(kMsVariants[cfg.variant].fn, dim3(cfg.grid), dim3(cfg.block), ms_lds_bytes(d, grouped), s, cols, dev_desc);
+        nblocks = cfg.grid;
+    }
+    const int64_t words = grouped ? d.pcount * (d.nagg + 1) + 1 : d.nagg + 1;
+    k_mscan_finish<<<(int)((words + 3) / 4), 256, 0, s>>>(dev_desc, nblocks, grouped ? 1 : 0, out);
+    if (grouped && resolve_first) k_mscan_first<<<(int)((d.pcount + 255) / 256), 256, 0, s>>>(cols, dev_desc, out);
+    return hipGetLastError();
+}
+
+}  // namespace vdl

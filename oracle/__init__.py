@@ -60,6 +60,8 @@ def lib():
                                            ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
         L.orc_sql_q1.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
                                                          ctypes.POINTER(ctypes.c_int)]
+        L.orc_sql_q1_generated.argtypes = [ctypes.POINTER(ColSpec), ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
+                                           ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
         L.orc_max_threads.restype = ctypes.c_int
         _lib = L
     return _lib
@@ -168,6 +170,18 @@ def sql_q1(shipdate, returnflag, linestatus, quantity, extprice, discount, tax):
                           out.ctypes.data_as(ctypes.c_void_p), 64, ctypes.byref(ng))
     if rc:
         raise OracleError("orc_sql_q1 failed")
+    return out[:ng.value].copy()
+
+
+def sql_q1_generated(specs, row0, n, threads=1):
+    """Q1 over generated rows; specs = 7 (seed, col_id, lo, hi, mul, add) tuples in the order shipdate,
+    returnflag, linestatus, quantity, extendedprice, discount, tax.  Same layout as sql_q1."""
+    arr = (ColSpec * 7)(*[ColSpec(*s) for s in specs])
+    out = np.zeros((64, 10), np.int64)
+    ng = ctypes.c_int()
+    rc = lib().orc_sql_q1_generated(arr, row0, n, threads, out.ctypes.data_as(ctypes.c_void_p), 64, ctypes.byref(ng))
+    if rc:
+        raise OracleError("orc_sql_q1_generated failed")
     return out[:ng.value].copy()
 
 

@@ -705,6 +705,60 @@ int orc_sql_q1(const int32_t *shipdate, const int32_t *returnflag, const int32_t
     return 0;
 }
 
+
+/* Q1 over generated rows (no column storage), OpenMP over row chunks; same output layout as
+ * orc_sql_q1.  specs order: shipdate, returnflag, linestatus, quantity, extendedprice, discount, tax. */
+int orc_sql_q1_generated(const orc_colspec *specs, int64_t row0, int64_t n, int threads,
+                         int64_t *out /* [max_groups][10] */, int max_groups, int *ngroups) {
+    enum { NB = 32 };                       /* returnflag code / 8 in 2..8, linestatus code / 8 in 2..5 */
+    uint64_t span[7];
+    for (int k = 0; k < 7; k++) span[k] = (uint64_t)specs[k].hi - (uint64_t)specs[k].lo + 1;
+    uint64_t acc[16][16][6];
+    memset(acc, 0, sizeof acc);
+#ifdef _OPENMP
+    if (threads > 1) omp_set_num_threads(threads);
+    #pragma omp parallel if (threads > 1)
+#endif
+    {
+        uint64_t loc[16][16][6];
+        memset(loc, 0, sizeof loc);
+#ifdef _OPENMP
+        #pragma omp for schedule(static)
+#endif
+        for (int64_t i = 0; i < n; i++) {
+            uint64_t row = (uint64_t)(row0 + i);
+            int64_t sd = gen_value(specs[0].seed, specs[0].col_id, row, specs[0].lo, span[0], specs[0].mul, specs[0].add);
+            if (sd > 729999) continue;
+            int64_t rf = gen_value(specs[1].seed, specs[1].col_id, row, specs[1].lo, span[1], specs[1].mul, specs[1].add);
+            int64_t ls = gen_value(specs[2].seed, specs[2].col_id, row, specs[2].lo, span[2], specs[2].mul, specs[2].add);
+            int64_t qt = gen_value(specs[3].seed, specs[3].col_id, row, specs[3].lo, span[3], specs[3].mul, specs[3].add);
+            int64_t ep = gen_value(specs[4].seed, specs[4].col_id, row, specs[4].lo, span[4], specs[4].mul, specs[4].add);
+            int64_t di = gen_value(specs[5].seed, specs[5].col_id, row, specs[5].lo, span[5], specs[5].mul, specs[5].add);
+            int64_t tx = gen_value(specs[6].seed, specs[6].col_id, row, specs[6].lo, span[6], specs[6].mul, specs[6].add);
+            uint64_t *a = loc[(rf >> 3) & 15][(ls >> 3) & 15];
+            uint64_t dp = (uint64_t)ep * (uint64_t)(100 - di);
+            a[0] += (uint64_t)qt; a[1] += (uint64_t)ep; a[2] += dp; a[3] += dp * (uint64_t)(100 + tx); a[4] += (uint64_t)di; a[5] += 1;
+        }
+#ifdef _OPENMP
+        #pragma omp critical
+#endif
+        for (int x = 0; x < 16; x++) for (int y = 0; y < 16; y++) for (int k = 0; k < 6; k++) acc[x][y][k] += loc[x][y][k];
+    }
+    int ng = 0;
+    for (int x = 0; x < 16; x++) for (int y = 0; y < 16; y++) {
+        if (!acc[x][y][5]) continue;
+        if (ng == max_groups) return -1;
+        int64_t *o = out + (int64_t)ng * 10; int64_t cnt = (int64_t)acc[x][y][5];
+        o[0] = x * 8; o[1] = y * 8;
+        o[2] = (int64_t)acc[x][y][0]; o[3] = (int64_t)acc[x][y][1]; o[4] = (int64_t)acc[x][y][2]; o[5] = (int64_t)acc[x][y][3];
+        o[6] = w_div((int64_t)acc[x][y][0], cnt); o[7] = w_div((int64_t)acc[x][y][1], cnt); o[8] = w_div((int64_t)acc[x][y][4], cnt);
+        o[9] = cnt; ng++;
+    }
+    *ngroups = ng;
+    (void)threads; (void)NB;
+    return 0;
+}
+
 int orc_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
