@@ -81,17 +81,30 @@ def main():
     plan.set_profiling(True)
     if args.query == "q6":
         nw, ops = plan.partial_spec()
-        buf = torch.zeros(max(nw, 1), dtype=torch.int64, device="cuda")
-        query = m.ShardedQuery(plan, buf, dist if world > 1 else None)
+        bufs = [torch.zeros(max(nw, 1), dtype=torch.int64, device="cuda") for _ in range(2)]
+        query = m.ShardedQuery(plan, bufs[0], dist if world > 1 else None)
     else:
         if world > 1:
             raise SystemExit("--query q1 is a single-GPU measurement (FoldChoose outputs are not shardable yet)")
         nw = 0
+        bufs = None
+        query = None
 
-        class _Direct:
-            def step(self):
-                return plan.run()
-        query = _Direct()
+    scan_us = []
+
+    def run_steps(k, record):
+        """k full queries.  Q6: pipelined (host side of query i overlaps the kernels of query i+1; every
+        query runs completely and every result is produced).  Q1: plain vdl_run per query."""
+        def on_result(out):
+            if record:
+                scan_us.append(plan.scan_stats()[2])
+        if query is not None:
+            return query.run_pipelined(k, bufs, on_result)
+        out = None
+        for _ in range(k):
+            out = plan.run()
+            on_result(out)
+        return out
 
     def sync_all():
         torch.cuda.synchronize()
@@ -99,15 +112,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    result = None
-    for _ in range(args.warmup):
-        result = query.step()
+    result = run_steps(args.warmup, False) if args.warmup > 0 else None
     sync_all()
-    scan_us = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        result = query.step()
-        scan_us.append(plan.scan_stats()[2])
+    result = run_steps(args.steps, True)
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:

@@ -129,6 +129,12 @@ int  vdl_plan_partial_spec(const vdl_plan *plan, int64_t *n_words, const int32_t
 int  vdl_run_local(vdl_ctx *ctx, vdl_plan *plan, void *dev_partials);
 /* After the merge: produce the outputs from the (merged) words; synchronises. */
 int  vdl_finalize(vdl_ctx *ctx, vdl_plan *plan, const void *dev_partials);
+/* Pipelined form (two slots, 0 and 1): `begin` enqueues the copy of the merged words to a pinned host
+ * slot and returns at once; `end` waits for that copy only -- younger launches on the stream keep
+ * running -- and produces the outputs.  Lets a driver overlap the host side of query k with the
+ * kernels of query k+1. */
+int  vdl_finalize_begin(vdl_ctx *ctx, vdl_plan *plan, const void *dev_partials, int slot);
+int  vdl_finalize_end(vdl_ctx *ctx, vdl_plan *plan, int slot);
 
 #ifdef __cplusplus
 }

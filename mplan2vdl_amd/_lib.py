@@ -56,6 +56,8 @@ def load():
         "vdl_plan_partial_spec": (i32, [vp, P(i64), P(P(ctypes.c_int32))]),
         "vdl_run_local": (i32, [vp, vp, vp]),
         "vdl_finalize": (i32, [vp, vp, vp]),
+        "vdl_finalize_begin": (i32, [vp, vp, vp, i32]),
+        "vdl_finalize_end": (i32, [vp, vp, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError here = the library does not export the ABI
@@ -70,5 +72,5 @@ ABI_SYMBOLS = [
     "vdl_upload_column", "vdl_generate_column", "vdl_drop_column", "vdl_column_info", "vdl_download_column",
     "vdl_parse", "vdl_plan_free", "vdl_plan_describe", "vdl_plan_is_fused", "vdl_plan_set_fusion",
     "vdl_plan_set_profiling", "vdl_run", "vdl_n_outputs", "vdl_output", "vdl_n_timings", "vdl_timing",
-    "vdl_plan_scan_stats", "vdl_plan_partial_spec", "vdl_run_local", "vdl_finalize",
+    "vdl_plan_scan_stats", "vdl_plan_partial_spec", "vdl_run_local", "vdl_finalize", "vdl_finalize_begin", "vdl_finalize_end",
 ]

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -106,6 +107,7 @@ struct vdl_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     int num_cus = 256;
     std::map<std::string, Column> cols;
+    uint64_t catalog_version = 1;      // bumped on every catalog change: plans re-bind only when it moved
     Pool pool;
     std::string err;
 };
@@ -137,13 +139,26 @@ struct vdl_plan {
     int64_t words_cap = 0;
     std::string fallback_note;
     bool bound = false;
+    uint64_t bound_version = 0;
+    // pipelined finalisation: two pinned host slots, one event each
+    int64_t *host_words[2] = {nullptr, nullptr};
+    int64_t host_cap = 0;
+    hipEvent_t slot_ev[2] = {nullptr, nullptr};
+    bool slot_pending[2] = {false, false};
     int64_t scan_rows = 0, scan_bytes = 0;
     double scan_usec = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool ev_pending = false;
+    hipEvent_t ev0[2] = {nullptr, nullptr}, ev1[2] = {nullptr, nullptr};   // profiling events, alternating per run
+    bool ev_pending[2] = {false, false};
+    unsigned run_seq = 0;
+    int last_ev = 0;
+    int slot_ev_idx[2] = {-1, -1};
     ~vdl_plan() {
-        if (ev0) (void)hipEventDestroy(ev0);
-        if (ev1) (void)hipEventDestroy(ev1);
+        for (int k = 0; k < 2; k++) {
+            if (ev0[k]) (void)hipEventDestroy(ev0[k]);
+            if (ev1[k]) (void)hipEventDestroy(ev1[k]);
+            if (slot_ev[k]) (void)hipEventDestroy(slot_ev[k]);
+            if (host_words[k]) (void)hipHostFree(host_words[k]);
+        }
     }
 };
 
@@ -329,9 +344,15 @@ void bind_fused(vdl_ctx *c, vdl_plan *p) {
 }
 
 void run_fused_local(vdl_ctx *c, vdl_plan *p, int64_t *dev_words, bool single_rank) {
-    bind_fused(c, p);      // cheap; the catalog may have changed since the last run
-    if (p->profiling && !p->ev0) { HIP_CHECK(hipEventCreate(&p->ev0)); HIP_CHECK(hipEventCreate(&p->ev1)); }
-    p->ev_pending = false;
+    const char *tune_a = getenv("VDL_SCAN_TUNE"), *tune_b = getenv("VDL_GROUP_TUNE");
+    if (!p->bound || p->bound_version != c->catalog_version || tune_a || tune_b) {   // tuning sweeps re-bind every run
+        bind_fused(c, p);
+        p->bound_version = c->catalog_version;
+    }
+    const int ei = (int)(p->run_seq++ & 1u);
+    if (p->profiling && !p->ev0[ei]) { HIP_CHECK(hipEventCreate(&p->ev0[ei])); HIP_CHECK(hipEventCreate(&p->ev1[ei])); }
+    p->ev_pending[ei] = false;
+    p->last_ev = ei;
     const size_t ns = p->fused.scans.size(), ng = p->fused.gscans.size();
     for (size_t s = 0; s < ns + ng; s++) {
         const bool grouped = s >= ns;
@@ -344,35 +365,59 @@ void run_fused_local(vdl_ctx *c, vdl_plan *p, int64_t *dev_words, bool single_ra
             const ScanArgs &a = p->sargs[s];
             int nblocks = 0;
             if (!never && n > 0) {
-                if (timed) HIP_CHECK(hipEventRecord(p->ev0, c->stream));
+                if (timed) HIP_CHECK(hipEventRecord(p->ev0[ei], c->stream));
                 HIP_CHECK(launch_scan(a, p->scfg[s], c->stream));
-                if (timed) { HIP_CHECK(hipEventRecord(p->ev1, c->stream)); p->ev_pending = true; }
+                if (timed) { HIP_CHECK(hipEventRecord(p->ev1[ei], c->stream)); p->ev_pending[ei] = true; }
                 nblocks = p->scfg[s].grid;
             }
             HIP_CHECK(launch_scan_finish(a.block_partials, nblocks, a.nagg, nullptr, a, out, c->stream));
         } else {
             HIP_CHECK(hipMemcpyAsync(p->mdev[s]->p, &p->mdesc[s], sizeof(MScanDesc), hipMemcpyHostToDevice, c->stream));
             // events bracket the scan together with its tiny finish kernel(s)
-            if (timed) HIP_CHECK(hipEventRecord(p->ev0, c->stream));
+            if (timed) HIP_CHECK(hipEventRecord(p->ev0[ei], c->stream));
             HIP_CHECK(launch_mscan(p->mcols[s], p->mdesc[s], (const MScanDesc *)p->mdev[s]->p, p->mcfg[s], grouped, never, out,
                                    grouped && single_rank, c->stream));
-            if (timed) { HIP_CHECK(hipEventRecord(p->ev1, c->stream)); p->ev_pending = true; }
+            if (timed) { HIP_CHECK(hipEventRecord(p->ev1[ei], c->stream)); p->ev_pending[ei] = true; }
         }
     }
 }
 
-void finalize_fused(vdl_ctx *c, vdl_plan *p, const int64_t *dev_words) {
+// Finalisation is split so that callers can pipeline queries: `begin` enqueues the copy of the
+// (merged) partial words into a pinned host slot and records an event; `end` waits for that event
+// only (not for younger work on the stream) and builds the outputs.
+void finalize_begin(vdl_ctx *c, vdl_plan *p, const int64_t *dev_words, int slot) {
     if (!p->bound) throw Error(VDL_ERR_ARG, "vdl_finalize called before vdl_run_local");
-    std::vector<int64_t> w((size_t)p->n_words);
-    if (p->n_words) HIP_CHECK(hipMemcpyAsync(w.data(), dev_words, sizeof(int64_t) * (size_t)p->n_words, hipMemcpyDeviceToHost, c->stream));
-    HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (slot < 0 || slot > 1) throw Error(VDL_ERR_ARG, "finalisation slot must be 0 or 1");
+    if (p->host_cap < p->n_words) {
+        for (int k = 0; k < 2; k++) {
+            if (p->host_words[k]) HIP_CHECK(hipHostFree(p->host_words[k]));
+            HIP_CHECK(hipHostMalloc((void **)&p->host_words[k], sizeof(int64_t) * (size_t)std::max<int64_t>(p->n_words, 1), hipHostMallocDefault));
+        }
+        p->host_cap = p->n_words;
+    }
+    if (!p->slot_ev[slot]) HIP_CHECK(hipEventCreateWithFlags(&p->slot_ev[slot], hipEventDisableTiming));
+    if (p->n_words) HIP_CHECK(hipMemcpyAsync(p->host_words[slot], dev_words, sizeof(int64_t) * (size_t)p->n_words, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipEventRecord(p->slot_ev[slot], c->stream));
+    p->slot_pending[slot] = true;
+    p->slot_ev_idx[slot] = p->ev_pending[p->last_ev] ? p->last_ev : -1;
+}
+
+void finalize_end(vdl_ctx *c, vdl_plan *p, int slot) {
+    if (slot < 0 || slot > 1 || !p->slot_pending[slot]) throw Error(VDL_ERR_ARG, "no finalisation pending in this slot");
+    HIP_CHECK(hipEventSynchronize(p->slot_ev[slot]));
+    p->slot_pending[slot] = false;
+    const int64_t *wp = p->host_words[slot];
+    std::vector<int64_t> w(wp, wp + p->n_words);
+    (void)c;
     p->timings.clear();
-    if (p->ev_pending) {
+    if (p->slot_ev_idx[slot] >= 0) {
+        const int ei = p->slot_ev_idx[slot];
         float ms = 0;
-        HIP_CHECK(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+        HIP_CHECK(hipEventElapsedTime(&ms, p->ev0[ei], p->ev1[ei]));
         p->scan_usec = (double)ms * 1e3;
         p->timings.push_back({"timeInMicrosecondsForFusedScan_" + p->dominant_kernel, p->scan_usec});
-        p->ev_pending = false;
+        p->ev_pending[ei] = false;
+        p->slot_ev_idx[slot] = -1;
     }
     const size_t ns = p->fused.scans.size();
     for (size_t g = 0; g < p->fused.gscans.size(); g++) {
@@ -791,6 +836,7 @@ int vdl_register_column(vdl_ctx *c, const char *name, const void *dev_ptr, int e
         if (((uintptr_t)dev_ptr) % (uintptr_t)elem_bytes) throw Error(VDL_ERR_ARG, "column pointer is not aligned to its element size");
         Column col; col.dev = dev_ptr; col.width = elem_bytes; col.n = nrows;
         c->cols[name] = col;
+        c->catalog_version++;
     });
 }
 
@@ -806,6 +852,7 @@ int vdl_upload_column(vdl_ctx *c, const char *name, const void *host_ptr, int el
         if (nrows) HIP_CHECK(hipMemcpyAsync(col.owned->p, host_ptr, (size_t)nrows * (size_t)elem_bytes, hipMemcpyHostToDevice, c->stream));
         HIP_CHECK(hipStreamSynchronize(c->stream));
         c->cols[name] = col;
+        c->catalog_version++;
     });
 }
 
@@ -822,6 +869,7 @@ int vdl_generate_column(vdl_ctx *c, const char *name, int elem_bytes, int64_t ro
         HIP_CHECK(launch_gen_column(col.owned->p, elem_bytes, row0, nrows, seed, fnv1a(name), lo, hi, mul, add, c->stream));
         HIP_CHECK(hipStreamSynchronize(c->stream));
         c->cols[name] = col;
+        c->catalog_version++;
     });
 }
 
@@ -829,6 +877,7 @@ int vdl_drop_column(vdl_ctx *c, const char *name) {
     if (!c || !name) return VDL_ERR_ARG;
     return guard(c, [&] {
         if (!c->cols.erase(name)) throw Error(VDL_ERR_COLUMN, std::string("no column '") + name + "'");
+        c->catalog_version++;
     });
 }
 
@@ -895,7 +944,8 @@ int vdl_run(vdl_ctx *c, vdl_plan *p) {
             if (!p->words || p->words_cap < nw) { p->words = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(nw, 1)); p->words_cap = nw; }
             try {
                 run_fused_local(c, p, (int64_t *)p->words->p, true);
-                finalize_fused(c, p, (const int64_t *)p->words->p);
+                finalize_begin(c, p, (const int64_t *)p->words->p, 0);
+                finalize_end(c, p, 0);
                 return;
             } catch (const NeedGeneralPath &e) {
                 p->fallback_note = e.what();          // exact for any data: rerun statement by statement
@@ -968,7 +1018,25 @@ int vdl_finalize(vdl_ctx *c, vdl_plan *p, const void *dev_partials) {
     return guard(c, [&] {
         need_device(c);
         if (!(p->use_fusion && p->fused.ok)) throw Error(VDL_ERR_UNSUPPORTED, "sharded execution needs a fused plan");
-        finalize_fused(c, p, (const int64_t *)dev_partials);
+        finalize_begin(c, p, (const int64_t *)dev_partials, 0);
+        finalize_end(c, p, 0);
+    });
+}
+
+int vdl_finalize_begin(vdl_ctx *c, vdl_plan *p, const void *dev_partials, int slot) {
+    if (!c || !p || !dev_partials) return VDL_ERR_ARG;
+    return guard(c, [&] {
+        need_device(c);
+        if (!(p->use_fusion && p->fused.ok)) throw Error(VDL_ERR_UNSUPPORTED, "sharded execution needs a fused plan");
+        finalize_begin(c, p, (const int64_t *)dev_partials, slot);
+    });
+}
+
+int vdl_finalize_end(vdl_ctx *c, vdl_plan *p, int slot) {
+    if (!c || !p) return VDL_ERR_ARG;
+    return guard(c, [&] {
+        need_device(c);
+        finalize_end(c, p, slot);
     });
 }
 

@@ -82,6 +82,13 @@ class Plan:
         self._e._check(self._e._L.vdl_finalize(self._e._c, self._h, ctypes.c_void_p(dev_ptr)))
         return self._collect()
 
+    def finalize_begin(self, dev_ptr, slot):
+        self._e._check(self._e._L.vdl_finalize_begin(self._e._c, self._h, ctypes.c_void_p(dev_ptr), int(slot)))
+
+    def finalize_end(self, slot):
+        self._e._check(self._e._L.vdl_finalize_end(self._e._c, self._h, int(slot)))
+        return self._collect()
+
     def scan_stats(self):
         rows, nbytes, us = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_double()
         self._e._check(self._e._L.vdl_plan_scan_stats(self._h, ctypes.byref(rows), ctypes.byref(nbytes), ctypes.byref(us)))

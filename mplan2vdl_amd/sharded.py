@@ -49,8 +49,33 @@ class ShardedQuery:
         if buf.numel() < self.n_words:
             raise ValueError("partials buffer too small")
 
+    def _merge(self, buf):
+        if self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size(self.group) > 1:
+            merge_partials(buf[: self.n_words], self.ops, self.dist, self.group)
+
     def step(self):
         self.runner.run_local(self.buf.data_ptr())
-        if self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size(self.group) > 1:
-            merge_partials(self.buf[: self.n_words], self.ops, self.dist, self.group)
+        self._merge(self.buf)
         return self.runner.finalize(self.buf.data_ptr())
+
+    def run_pipelined(self, steps, bufs, on_result=None):
+        """`steps` queries back to back with the host side of query k overlapped with the kernels of
+        query k+1 (two partial buffers / finalisation slots).  Every query still runs in full and
+        every result is produced; returns the last one."""
+        if len(bufs) != 2:
+            raise ValueError("run_pipelined needs two partial buffers")
+        out = None
+        for k in range(steps):
+            s = k & 1
+            self.runner.run_local(bufs[s].data_ptr())
+            self._merge(bufs[s])
+            self.runner.finalize_begin(bufs[s].data_ptr(), s)
+            if k > 0:
+                out = self.runner.finalize_end(1 - s)
+                if on_result is not None:
+                    on_result(out)
+        if steps > 0:
+            out = self.runner.finalize_end((steps - 1) & 1)
+            if on_result is not None:
+                on_result(out)
+        return out
