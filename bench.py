@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--cpu-sample-rows", type=int, default=59986052, help="rows of the CPU-baseline sample (default SF10)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--query", default="q6", choices=["q6", "q1"],
-                    help="q6 (default, BASELINE.json's metric) or q1 (grouped fused scan; single GPU, secondary measurement)")
+                    help="q6 (default, BASELINE.json's metric) or q1 (grouped fused scan; secondary measurement)")
     args = ap.parse_args()
 
     import torch
@@ -69,7 +69,11 @@ def main():
     my_rows = hi - lo
 
     eng = m.Engine(device=local_rank)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    # one dedicated stream for everything: engine kernels, torch tensor ops and the RCCL all-reduce
+    # (torch orders its collective against the current stream) -- no implicit default-stream syncs
+    side = torch.cuda.Stream()
+    torch.cuda.set_stream(side)
+    eng.use_torch_stream()
     q_cols = datagen.Q6_COLUMNS if args.query == "q6" else datagen.Q1_COLUMNS
     q_bytes = datagen.Q6_BYTES_PER_ROW if args.query == "q6" else datagen.Q1_BYTES_PER_ROW
     for name in q_cols:
@@ -79,16 +83,10 @@ def main():
     if not plan.is_fused:
         raise SystemExit("%s did not fuse:\n%s" % (args.query, plan.describe()))
     plan.set_profiling(True)
-    if args.query == "q6":
-        nw, ops = plan.partial_spec()
-        bufs = [torch.zeros(max(nw, 1), dtype=torch.int64, device="cuda") for _ in range(2)]
-        query = m.ShardedQuery(plan, bufs[0], dist if world > 1 else None)
-    else:
-        if world > 1:
-            raise SystemExit("--query q1 is a single-GPU measurement (FoldChoose outputs are not shardable yet)")
-        nw = 0
-        bufs = None
-        query = None
+    plan.set_row_offset(lo)
+    nw, ops = plan.partial_spec()
+    bufs = [torch.zeros(max(nw, 1), dtype=torch.int64, device="cuda") for _ in range(2)]
+    query = m.ShardedQuery(plan, bufs[0], dist if world > 1 else None)
 
     scan_us = []
 
@@ -98,13 +96,7 @@ def main():
         def on_result(out):
             if record:
                 scan_us.append(plan.scan_stats()[2])
-        if query is not None:
-            return query.run_pipelined(k, bufs, on_result)
-        out = None
-        for _ in range(k):
-            out = plan.run()
-            on_result(out)
-        return out
+        return query.run_pipelined(k, bufs, on_result)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -148,6 +140,9 @@ def main():
             verified = all(flat[nm] == [int(x) for x in tab[:, j]] for j, nm in enumerate(names))
             if not verified:
                 print("VERIFICATION FAILED (q1)", file=sys.stderr)
+                for j, nm in enumerate(names):
+                    if flat[nm] != [int(x) for x in tab[:, j]]:
+                        print("  %s: gpu %r\n  %s: cpu %r" % (nm, flat[nm], nm, [int(x) for x in tab[:, j]]), file=sys.stderr)
         if not args.no_verify and args.query == "q6":
             # bit-exact check of the full-size answer: the SQL-semantics loop over regenerated rows
             # on all host cores (test infrastructure; outside the timed region)

@@ -49,7 +49,13 @@ enum {
 };
 
 /* partial-state merge operators for sharded execution */
-enum { VDL_REDUCE_NONE = 0, VDL_REDUCE_SUM = 1, VDL_REDUCE_MIN = 2, VDL_REDUCE_MAX = 3 };
+enum {
+    VDL_REDUCE_NONE = 0, VDL_REDUCE_SUM = 1, VDL_REDUCE_MIN = 2, VDL_REDUCE_MAX = 3,
+    /* FoldChoose of a grouped plan: the word holds the group's smallest GLOBAL row id after the local
+     * phase.  Merge = all-reduce MIN, then vdl_resolve_first() (the rank owning that row substitutes the
+     * column value, every other rank 0), then all-reduce SUM of the same words. */
+    VDL_REDUCE_FIRST = 4
+};
 
 /* ---- context ------------------------------------------------------------------ */
 
@@ -60,9 +66,12 @@ void vdl_close(vdl_ctx *ctx);
 const char *vdl_last_error(const vdl_ctx *ctx);
 const char *vdl_version(void);
 
-/* Run on the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream);
- * NULL restores the engine's own stream. */
+/* Run on the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream).  The handle is
+ * used as given: 0 / NULL means the legacy default stream (what torch uses unless told otherwise),
+ * so that collectives and tensor ops issued by the caller order against the engine's kernels.
+ * vdl_use_own_stream() goes back to the engine's private non-blocking stream. */
 int  vdl_set_stream(vdl_ctx *ctx, void *hip_stream);
+int  vdl_use_own_stream(vdl_ctx *ctx);
 
 /* ---- column catalog ("Load table.col", /root/reference/src/Vdl.hs:161-168,419-420) --
  * Columns are contiguous little-endian signed integers of elem_bytes in {1,2,4,8}
@@ -129,6 +138,10 @@ int  vdl_plan_partial_spec(const vdl_plan *plan, int64_t *n_words, const int32_t
 int  vdl_run_local(vdl_ctx *ctx, vdl_plan *plan, void *dev_partials);
 /* After the merge: produce the outputs from the (merged) words; synchronises. */
 int  vdl_finalize(vdl_ctx *ctx, vdl_plan *plan, const void *dev_partials);
+/* Global index of this rank's first row (default 0); row ids in VDL_REDUCE_FIRST words are global. */
+int  vdl_plan_set_row_offset(vdl_plan *plan, int64_t row0);
+/* Second merge phase of VDL_REDUCE_FIRST words (see the enum); asynchronous on the context stream. */
+int  vdl_resolve_first(vdl_ctx *ctx, vdl_plan *plan, void *dev_partials);
 /* Pipelined form (two slots, 0 and 1): `begin` enqueues the copy of the merged words to a pinned host
  * slot and returns at once; `end` waits for that copy only -- younger launches on the stream keep
  * running -- and produces the outputs.  Lets a driver overlap the host side of query k with the

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvdl.so")
 
 VDL_OK, VDL_ERR_PARSE, VDL_ERR_COLUMN, VDL_ERR_UNSUPPORTED, VDL_ERR_DEVICE, VDL_ERR_ARG, VDL_ERR_SHAPE, VDL_ERR_NOMEM = range(8)
-REDUCE_NONE, REDUCE_SUM, REDUCE_MIN, REDUCE_MAX = range(4)
+REDUCE_NONE, REDUCE_SUM, REDUCE_MIN, REDUCE_MAX, REDUCE_FIRST = range(5)
 
 _lib = None
 
@@ -35,6 +35,7 @@ def load():
         "vdl_last_error": (cp, [vp]),
         "vdl_version": (cp, []),
         "vdl_set_stream": (i32, [vp, vp]),
+        "vdl_use_own_stream": (i32, [vp]),
         "vdl_register_column": (i32, [vp, cp, vp, i32, i64]),
         "vdl_upload_column": (i32, [vp, cp, vp, i32, i64]),
         "vdl_generate_column": (i32, [vp, cp, i32, i64, i64, ctypes.c_uint64, i64, i64, i64, i64]),
@@ -56,6 +57,8 @@ def load():
         "vdl_plan_partial_spec": (i32, [vp, P(i64), P(P(ctypes.c_int32))]),
         "vdl_run_local": (i32, [vp, vp, vp]),
         "vdl_finalize": (i32, [vp, vp, vp]),
+        "vdl_plan_set_row_offset": (i32, [vp, i64]),
+        "vdl_resolve_first": (i32, [vp, vp, vp]),
         "vdl_finalize_begin": (i32, [vp, vp, vp, i32]),
         "vdl_finalize_end": (i32, [vp, vp, i32]),
     }
@@ -68,9 +71,9 @@ def load():
 
 
 ABI_SYMBOLS = [
-    "vdl_open", "vdl_close", "vdl_last_error", "vdl_version", "vdl_set_stream", "vdl_register_column",
+    "vdl_open", "vdl_close", "vdl_last_error", "vdl_version", "vdl_set_stream", "vdl_use_own_stream", "vdl_register_column",
     "vdl_upload_column", "vdl_generate_column", "vdl_drop_column", "vdl_column_info", "vdl_download_column",
     "vdl_parse", "vdl_plan_free", "vdl_plan_describe", "vdl_plan_is_fused", "vdl_plan_set_fusion",
     "vdl_plan_set_profiling", "vdl_run", "vdl_n_outputs", "vdl_output", "vdl_n_timings", "vdl_timing",
-    "vdl_plan_scan_stats", "vdl_plan_partial_spec", "vdl_run_local", "vdl_finalize", "vdl_finalize_begin", "vdl_finalize_end",
+    "vdl_plan_scan_stats", "vdl_plan_partial_spec", "vdl_run_local", "vdl_finalize", "vdl_finalize_begin", "vdl_finalize_end", "vdl_plan_set_row_offset", "vdl_resolve_first",
 ]

@@ -113,7 +113,8 @@ struct vdl_ctx {
 };
 
 struct vdl_plan {
-    vdl_ctx *ctx = nullptr;
+    vdl_ctx *ctx = nullptr;          // only dereferenced inside calls that receive the live context
+    int device = -1;                 // copied at parse time: the plan may outlive its context
     Program prog;
     FusedPlan fused;
     bool use_fusion = true;
@@ -135,6 +136,7 @@ struct vdl_plan {
     int dominant = -1;
     std::string dominant_kernel;
     int64_t n_words = 0;
+    int64_t row_offset = 0;                  // global index of this rank's first row (sharded FoldChoose)
     BufP words;
     int64_t words_cap = 0;
     std::string fallback_note;
@@ -209,8 +211,8 @@ int64_t plan_words(const vdl_plan *p, std::vector<int32_t> *ops, bool *shardable
         for (int64_t b = 0; b < gp.pcount; b++) {
             if (ops) ops->push_back(VDL_REDUCE_SUM);
             for (const ScanAgg &ag : gp.aggs) {
-                if (ag.kind == AGG_FIRST && shardable) *shardable = false;   // needs the owning rank's column value
-                if (ops) ops->push_back(ag.kind == AGG_SUM ? VDL_REDUCE_SUM : ag.kind == AGG_MAX ? VDL_REDUCE_MAX : VDL_REDUCE_MIN);
+                if (ops) ops->push_back(ag.kind == AGG_SUM ? VDL_REDUCE_SUM : ag.kind == AGG_MAX ? VDL_REDUCE_MAX
+                                        : ag.kind == AGG_FIRST ? VDL_REDUCE_FIRST : VDL_REDUCE_MIN);
             }
         }
         if (ops) ops->push_back(VDL_REDUCE_SUM);                              // out-of-domain key count
@@ -223,7 +225,7 @@ int64_t plan_words(const vdl_plan *p, std::vector<int32_t> *ops, bool *shardable
 static bool use_kscan(const ScanPlan &sp) { return sp.aggs.size() == 1 && sp.cols.size() <= 4; }
 
 template <typename PlanT>
-int64_t bind_mscan(vdl_ctx *c, const PlanT &sp, MScanCols &cols, MScanDesc &d, int64_t *bytes_per_row) {
+int64_t bind_mscan(vdl_ctx *c, const PlanT &sp, MScanCols &cols, MScanDesc &d, int64_t *bytes_per_row, int64_t row0) {
     cols = MScanCols{};
     d = MScanDesc{};
     cols.ncol = (int)sp.cols.size();
@@ -241,6 +243,7 @@ int64_t bind_mscan(vdl_ctx *c, const PlanT &sp, MScanCols &cols, MScanDesc &d, i
         *bytes_per_row += col.width;
     }
     cols.n = n;
+    cols.row0 = row0;
     for (int j = 0; j < d.nagg; j++) {
         const ScanAgg &ag = sp.aggs[(size_t)j];
         MAggDesc &m = d.agg[j];
@@ -306,7 +309,7 @@ void bind_fused(vdl_ctx *c, vdl_plan *p) {
             a.block_partials = (int64_t *)p->block_partials[s]->p;
             kname = std::string(scan_kernel_name(p->scfg[s])) + "_grid" + std::to_string(p->scfg[s].grid);
         } else {
-            n = bind_mscan(c, sp, p->mcols[s], p->mdesc[s], &bpr);
+            n = bind_mscan(c, sp, p->mcols[s], p->mdesc[s], &bpr, p->row_offset);
             p->mcfg[s] = mscan_launch_config(p->mcols[s], p->mdesc[s], false, c->num_cus);
             if (p->mcfg[s].variant < 0) throw Error(VDL_ERR_UNSUPPORTED, "no multi-aggregate scan kernel variant for this shape");
             p->mparts[s] = dev_alloc(c, sizeof(int64_t) * (size_t)p->mcfg[s].grid * (size_t)(p->mdesc[s].nagg + 1));
@@ -322,7 +325,7 @@ void bind_fused(vdl_ctx *c, vdl_plan *p) {
         const GroupScanPlan &gp = F.gscans[g];
         const size_t m = ns + g;
         int64_t bpr = 0;
-        const int64_t n = bind_mscan(c, gp, p->mcols[m], p->mdesc[m], &bpr);
+        const int64_t n = bind_mscan(c, gp, p->mcols[m], p->mdesc[m], &bpr, p->row_offset);
         MScanDesc &d = p->mdesc[m];
         d.nkey = (int)gp.key.size();
         for (int k = 0; k < d.nkey; k++) d.key[k] = gp.key[(size_t)k];
@@ -820,7 +823,15 @@ int vdl_set_stream(vdl_ctx *c, void *hip_stream) {
     if (!c) return VDL_ERR_ARG;
     return guard(c, [&] {
         need_device(c);
-        c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+        c->stream = (hipStream_t)hip_stream;      // 0 is a real choice: the legacy default stream
+    });
+}
+
+int vdl_use_own_stream(vdl_ctx *c) {
+    if (!c) return VDL_ERR_ARG;
+    return guard(c, [&] {
+        need_device(c);
+        c->stream = c->own_stream;
     });
 }
 
@@ -908,6 +919,7 @@ int vdl_parse(vdl_ctx *c, const char *text, size_t len, vdl_plan **out) {
     return guard(c, [&] {
         std::unique_ptr<vdl_plan> p(new vdl_plan());
         p->ctx = c;
+        p->device = c->device;
         p->prog = parse_program(text, len);
         p->fused = fuse_program(p->prog);
         p->description = describe_plan(p.get());
@@ -917,8 +929,9 @@ int vdl_parse(vdl_ctx *c, const char *text, size_t len, vdl_plan **out) {
 
 void vdl_plan_free(vdl_plan *p) {
     if (!p) return;
-    if (p->ctx && p->ctx->device >= 0) (void)hipSetDevice(p->ctx->device);
+    if (p->device >= 0) (void)hipSetDevice(p->device);
     delete p;
+    (void)hipGetLastError();
 }
 
 const char *vdl_plan_describe(const vdl_plan *p) { return p ? p->description.c_str() : ""; }
@@ -985,17 +998,13 @@ int vdl_plan_scan_stats(const vdl_plan *p, int64_t *rows, int64_t *algo_bytes, d
 int vdl_plan_partial_spec(const vdl_plan *p, int64_t *n_words, const int32_t **reduce_ops) {
     if (!p) return VDL_ERR_ARG;
     if (!(p->use_fusion && p->fused.ok)) {
-        if (p->ctx) p->ctx->err = "sharded execution needs a plan whose outputs are global folds (fused plan)";
+        if (p->ctx) p->ctx->err = "sharded execution needs a fused plan (outputs = global or dense-domain grouped folds)";
         return VDL_ERR_UNSUPPORTED;
     }
     vdl_plan *q = const_cast<vdl_plan *>(p);
     q->reduce_ops.clear();
     bool shardable = true;
     const int64_t off = plan_words(p, &q->reduce_ops, &shardable);
-    if (!shardable) {
-        if (p->ctx) p->ctx->err = "sharded execution of grouped plans with FoldChoose outputs is not implemented";
-        return VDL_ERR_UNSUPPORTED;
-    }
     if (n_words) *n_words = off;
     if (reduce_ops) *reduce_ops = q->reduce_ops.data();
     return VDL_OK;
@@ -1006,9 +1015,6 @@ int vdl_run_local(vdl_ctx *c, vdl_plan *p, void *dev_partials) {
     return guard(c, [&] {
         need_device(c);
         if (!(p->use_fusion && p->fused.ok)) throw Error(VDL_ERR_UNSUPPORTED, "sharded execution needs a fused plan");
-        bool shardable = true;
-        plan_words(p, nullptr, &shardable);
-        if (!shardable) throw Error(VDL_ERR_UNSUPPORTED, "sharded execution of grouped plans with FoldChoose outputs is not implemented");
         run_fused_local(c, p, (int64_t *)dev_partials, false);
     });
 }
@@ -1020,6 +1026,29 @@ int vdl_finalize(vdl_ctx *c, vdl_plan *p, const void *dev_partials) {
         if (!(p->use_fusion && p->fused.ok)) throw Error(VDL_ERR_UNSUPPORTED, "sharded execution needs a fused plan");
         finalize_begin(c, p, (const int64_t *)dev_partials, 0);
         finalize_end(c, p, 0);
+    });
+}
+
+int vdl_plan_set_row_offset(vdl_plan *p, int64_t row0) {
+    if (!p) return VDL_ERR_ARG;
+    p->row_offset = row0;
+    p->bound = false;
+    return VDL_OK;
+}
+
+int vdl_resolve_first(vdl_ctx *c, vdl_plan *p, void *dev_partials) {
+    if (!c || !p || !dev_partials) return VDL_ERR_ARG;
+    return guard(c, [&] {
+        need_device(c);
+        if (!(p->use_fusion && p->fused.ok) || !p->bound) throw Error(VDL_ERR_ARG, "vdl_resolve_first needs a fused plan after vdl_run_local");
+        const size_t ns = p->fused.scans.size();
+        for (size_t g = 0; g < p->fused.gscans.size(); g++) {
+            bool any = false;
+            for (const ScanAgg &ag : p->fused.gscans[g].aggs) any |= ag.kind == AGG_FIRST;
+            if (!any) continue;
+            HIP_CHECK(launch_mscan_resolve_first(p->mcols[ns + g], p->mdesc[ns + g], (const MScanDesc *)p->mdev[ns + g]->p,
+                                                 (int64_t *)dev_partials + p->gword_offset[g], c->stream));
+        }
     });
 }
 

@@ -78,6 +78,8 @@ const char *mscan_kernel_name(const ScanLaunch &cfg);
 // resolve_first: turn AGG_FIRST row ids into column values (single rank only).
 hipError_t launch_mscan(const MScanCols &cols, const MScanDesc &d, const MScanDesc *dev_desc, const ScanLaunch &cfg, bool grouped,
                         bool never, int64_t *out, bool resolve_first, hipStream_t s);
+// sharded FoldChoose: after the MIN all-reduce of the row-id words, the owning rank substitutes the value, others 0
+hipError_t launch_mscan_resolve_first(const MScanCols &cols, const MScanDesc &d, const MScanDesc *dev_desc, int64_t *table, hipStream_t s);
 
 // ---- synthetic data --------------------------------------------------------------------
 hipError_t launch_gen_column(void *out, int elem_bytes, int64_t row0, int64_t n, uint64_t seed, uint64_t col_id,

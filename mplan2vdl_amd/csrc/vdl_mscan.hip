@@ -401,17 +401,23 @@ __global__ __launch_bounds__(256) void k_mscan_finish(const MScanDesc *__restric
     if (lane == 0) out[i] = x;
 }
 
-// FoldChoose per group (single rank): replace the group's smallest row id by that row's column value
-__global__ void k_mscan_first(const MScanCols C, const MScanDesc *__restrict__ Dp, int64_t *table) {
+// FoldChoose per group: replace the group's smallest (global) row id by that row's column value.
+// owned_only (sharded execution, after the MIN all-reduce of the row ids): only the rank that holds the
+// row writes the value, every other rank writes 0, and a SUM all-reduce then spreads it.
+__global__ void k_mscan_first(const MScanCols C, const MScanDesc *__restrict__ Dp, int owned_only, int64_t *table) {
     const MScanDesc &D = *Dp;
     const int W = D.nagg + 1;
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= D.pcount || table[b * W] <= 0) return;
+    if (b >= D.pcount) return;
+    const bool live = table[b * W] > 0;
     for (int j = 0; j < D.nagg; j++) {
         if (D.agg[j].kind != AGG_FIRST) continue;
         int c = 0;
         for (int k = 0; k < kMaxScanCols; k++) if ((D.agg[j].used >> k) & 1u) c = k;
-        table[b * W + 1 + j] = load_scalar(C.ptr[c], C.width[c], table[b * W + 1 + j] - C.row0);
+        const int64_t r = table[b * W + 1 + j] - C.row0;
+        const bool mine = live && r >= 0 && r < C.n;
+        if (mine) table[b * W + 1 + j] = load_scalar(C.ptr[c], C.width[c], r);
+        else if (owned_only || !live) table[b * W + 1 + j] = 0;
     }
 }
 
@@ -483,7 +489,13 @@ hipError_t launch_mscan(const MScanCols &cols, const MScanDesc &d, const MScanDe
     }
     const int64_t words = grouped ? d.pcount * (d.nagg + 1) + 1 : d.nagg + 1;
     k_mscan_finish<<<(int)((words + 3) / 4), 256, 0, s>>>(dev_desc, nblocks, grouped ? 1 : 0, out);
-    if (grouped && resolve_first) k_mscan_first<<<(int)((d.pcount + 255) / 256), 256, 0, s>>>(cols, dev_desc, out);
+    if (grouped && resolve_first) k_mscan_first<<<(int)((d.pcount + 255) / 256), 256, 0, s>>>(cols, dev_desc, 0, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_mscan_resolve_first(const MScanCols &cols, const MScanDesc &d, const MScanDesc *dev_desc, int64_t *table, hipStream_t s) {
+    (void)hipGetLastError();
+    k_mscan_first<<<(int)((d.pcount + 255) / 256), 256, 0, s>>>(cols, dev_desc, 1, table);
     return hipGetLastError();
 }
 

@@ -6,6 +6,7 @@ In the reference the executor is reached as text over a pipe: VDL in, JSON out
 does goes through the C ABI of libvdl.so (include/vdl.h) into hand-written HIP kernels.
 """
 import ctypes
+import weakref
 
 import numpy as np
 
@@ -82,6 +83,12 @@ class Plan:
         self._e._check(self._e._L.vdl_finalize(self._e._c, self._h, ctypes.c_void_p(dev_ptr)))
         return self._collect()
 
+    def set_row_offset(self, row0):
+        self._e._check(self._e._L.vdl_plan_set_row_offset(self._h, int(row0)))
+
+    def resolve_first(self, dev_ptr):
+        self._e._check(self._e._L.vdl_resolve_first(self._e._c, self._h, ctypes.c_void_p(dev_ptr)))
+
     def finalize_begin(self, dev_ptr, slot):
         self._e._check(self._e._L.vdl_finalize_begin(self._e._c, self._h, ctypes.c_void_p(dev_ptr), int(slot)))
 
@@ -104,6 +111,7 @@ class Engine:
         rc = self._L.vdl_open(ctypes.byref(c), -1 if device is None else int(device))
         self._c = c
         self._keep = {}
+        self._plans = weakref.WeakSet()
         if rc:
             msg = self._L.vdl_last_error(c).decode()
             self._L.vdl_close(c)
@@ -112,6 +120,8 @@ class Engine:
 
     def close(self):
         if self._c:
+            for p in list(self._plans):     # plans hold device events / pinned buffers of this context
+                p.close()
             self._L.vdl_close(self._c)
             self._c = None
             self._keep.clear()
@@ -130,7 +140,17 @@ class Engine:
         return self._L.vdl_version().decode()
 
     def set_stream(self, hip_stream_handle):
+        """Launch on this HIP stream handle (0 = the legacy default stream torch uses by default)."""
         self._check(self._L.vdl_set_stream(self._c, ctypes.c_void_p(hip_stream_handle or 0)))
+
+    def use_torch_stream(self):
+        """Launch on torch's current stream, so torch ops / collectives order against the engine."""
+        import torch
+
+        self.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def use_own_stream(self):
+        self._check(self._L.vdl_use_own_stream(self._c))
 
     # ---- catalog ----
     def register_tensor(self, name, tensor):
@@ -169,7 +189,9 @@ class Engine:
         data = vdl_text.encode() if isinstance(vdl_text, str) else vdl_text
         h = ctypes.c_void_p()
         self._check(self._L.vdl_parse(self._c, data, len(data), ctypes.byref(h)))
-        return Plan(self, h, vdl_text)
+        plan = Plan(self, h, vdl_text)
+        self._plans.add(plan)
+        return plan
 
     def run_vdl(self, vdl_text, fuse=True):
         plan = self.parse(vdl_text)

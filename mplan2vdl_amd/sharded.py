@@ -16,19 +16,33 @@ def shard_rows(n_rows, rank, world):
     return lo, hi
 
 
-def merge_partials(buf, ops, dist, group=None):
-    """All-reduce the words of `buf` (1-D int64 tensor) according to their VDL_REDUCE_* tags."""
+def merge_partials(buf, ops, dist, group=None, resolve_first=None):
+    """All-reduce the words of `buf` (1-D int64 tensor) according to their VDL_REDUCE_* tags.
+
+    FIRST words (FoldChoose of a grouped plan) take two rounds: MIN over the global row ids,
+    `resolve_first()` (owner substitutes the value, others 0), then SUM."""
     import torch
 
+    table = {_lib.REDUCE_SUM: dist.ReduceOp.SUM, _lib.REDUCE_MIN: dist.ReduceOp.MIN, _lib.REDUCE_MAX: dist.ReduceOp.MAX,
+             _lib.REDUCE_FIRST: dist.ReduceOp.MIN}
     classes = sorted(set(ops))
-    table = {_lib.REDUCE_SUM: dist.ReduceOp.SUM, _lib.REDUCE_MIN: dist.ReduceOp.MIN, _lib.REDUCE_MAX: dist.ReduceOp.MAX}
-    if len(classes) == 1:
+    if len(classes) == 1 and classes[0] != _lib.REDUCE_FIRST:
         dist.all_reduce(buf, op=table[classes[0]], group=group)
         return buf
+    index = {}
     for cls in classes:
         idx = torch.tensor([i for i, o in enumerate(ops) if o == cls], dtype=torch.long, device=buf.device)
+        index[cls] = idx
         part = buf.index_select(0, idx)
         dist.all_reduce(part, op=table[cls], group=group)
+        buf.index_copy_(0, idx, part)
+    if _lib.REDUCE_FIRST in index:
+        if resolve_first is None:
+            raise ValueError("plan has FoldChoose words: pass resolve_first")
+        resolve_first()
+        idx = index[_lib.REDUCE_FIRST]
+        part = buf.index_select(0, idx)
+        dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group)
         buf.index_copy_(0, idx, part)
     return buf
 
@@ -50,8 +64,12 @@ class ShardedQuery:
             raise ValueError("partials buffer too small")
 
     def _merge(self, buf):
+        has_first = _lib.REDUCE_FIRST in self.ops
         if self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size(self.group) > 1:
-            merge_partials(buf[: self.n_words], self.ops, self.dist, self.group)
+            merge_partials(buf[: self.n_words], self.ops, self.dist, self.group,
+                           (lambda: self.runner.resolve_first(buf.data_ptr())) if has_first else None)
+        elif has_first:
+            self.runner.resolve_first(buf.data_ptr())
 
     def step(self):
         self.runner.run_local(self.buf.data_ptr())

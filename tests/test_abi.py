@@ -54,9 +54,8 @@ def test_q1_fuses_into_one_grouped_scan(q1_text):
     assert "acc=BitwiseAnd(acc,31)" in d                                     # size hint evaluated, Vlite.hs:1111-1115
     assert d.count(" sum ") == 6 and d.count(" first ") == 2                 # duplicate FoldSums shared
     assert "Divide(agg2,agg6)" in d                                          # avg = sum / count, Vlite.hs:1038-1041
-    with pytest.raises(m.VdlError) as ei:                                    # FoldChoose outputs: not shardable yet
-        p.partial_spec()
-    assert ei.value.code == _lib.VDL_ERR_UNSUPPORTED
+    nw, ops = p.partial_spec()                                               # 32 buckets x (count + 8 aggregates) + out-of-domain count
+    assert nw == 32 * 9 + 1 and ops[:9] == [_lib.REDUCE_SUM, _lib.REDUCE_FIRST, _lib.REDUCE_FIRST] + [_lib.REDUCE_SUM] * 6
 
 
 def test_unsupported_shapes_stay_on_the_general_path():

@@ -205,7 +205,7 @@ def test_sharded_query_single_rank_path(q6_text):
     cols = lineitem(datagen.Q6_COLUMNS, n)
     want = oracle_run(q6_text, cols)
     e = engine_with(cols)
-    e.set_stream(torch.cuda.current_stream().cuda_stream)
+    e.use_torch_stream()
     plan = e.parse(q6_text)
     nw, ops = plan.partial_spec()
     buf = torch.zeros(nw, dtype=torch.int64, device="cuda")
@@ -223,7 +223,7 @@ def test_pipelined_queries_produce_every_result(q6_text):
     import mplan2vdl_amd as m
 
     e = m.Engine(device=0)
-    e.set_stream(torch.cuda.current_stream().cuda_stream)
+    e.use_torch_stream()
     plan = e.parse(q6_text)
     plan.set_profiling(True)
     nw, _ = plan.partial_spec()
@@ -238,6 +238,62 @@ def test_pipelined_queries_produce_every_result(q6_text):
         last = q.run_pipelined(7, bufs, lambda out: got.append(out["results"]))
         assert len(got) == 7 and all(g == want for g in got) and last["results"] == want
         assert any("FusedScan" in k for k in last["timings"])
+    e.close()
+
+
+def test_q1_sharded_two_ranks_emulated_in_one_process(q1_text):
+    """Row-range sharding of the grouped plan: two contexts hold the two halves of lineitem; the
+    partial tables are merged exactly as merge_partials does over RCCL (SUM words added; FoldChoose
+    words: MIN of global row ids -> vdl_resolve_first on each rank -> SUM) and both finalise Q1."""
+    import torch
+    import mplan2vdl_amd as m
+    from mplan2vdl_amd import _lib
+
+    n = 200003
+    cols = lineitem(datagen.Q1_COLUMNS, n)
+    want = oracle_run(q1_text, cols)
+    ranks = []
+    for r in range(2):
+        lo, hi = m.shard_rows(n, r, 2)
+        e = engine_with({k: v[lo:hi] for k, v in cols.items()})
+        e.use_torch_stream()
+        p = e.parse(q1_text)
+        p.set_row_offset(lo)
+        nw, ops = p.partial_spec()
+        buf = torch.zeros(nw, dtype=torch.int64, device="cuda")
+        p.run_local(buf.data_ptr())
+        ranks.append((e, p, buf))
+    torch.cuda.synchronize()
+    ops_t = torch.tensor(ops, device="cuda")
+    a, b = ranks[0][2], ranks[1][2]
+    merged = torch.where(ops_t == _lib.REDUCE_SUM, a + b, torch.minimum(a, b))     # SUM words / MIN of row ids
+    for _, p, buf in ranks:
+        buf.copy_(merged)
+        p.resolve_first(buf.data_ptr())
+    torch.cuda.synchronize()
+    first = ops_t == _lib.REDUCE_FIRST
+    total = torch.where(first, ranks[0][2] + ranks[1][2], merged)
+    for e, p, buf in ranks:
+        buf.copy_(total)
+        assert p.finalize(buf.data_ptr())["results"] == want
+        e.close()
+
+
+def test_q1_sharded_query_single_rank_resolves_foldchoose(q1_text):
+    import torch
+    import mplan2vdl_amd as m
+
+    n = 77777
+    cols = lineitem(datagen.Q1_COLUMNS, n)
+    want = oracle_run(q1_text, cols)
+    e = engine_with(cols)
+    e.use_torch_stream()
+    plan = e.parse(q1_text)
+    nw, _ = plan.partial_spec()
+    bufs = [torch.zeros(nw, dtype=torch.int64, device="cuda") for _ in range(2)]
+    q = m.ShardedQuery(plan, bufs[0])
+    assert q.step()["results"] == want
+    assert q.run_pipelined(3, bufs)["results"] == want
     e.close()
 
 

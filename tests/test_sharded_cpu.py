@@ -94,3 +94,73 @@ def test_merge_partials_mixed_ops_single_process():
         assert buf.tolist() == [3, 10, 7, 2]
     finally:
         dist.destroy_process_group()
+
+
+class GroupedShardRunner:
+    """CPU stand-in (TEST ONLY) for a grouped plan: per bucket {count, FIRST(col a), SUM(col a)}."""
+
+    G = 5
+
+    def __init__(self, lo, hi, n):
+        rng = np.random.default_rng(123)
+        self.key = rng.integers(0, self.G, size=n)[lo:hi]
+        self.a = rng.integers(-50, 50, size=n)[lo:hi].astype(np.int64)
+        self.lo, self.hi = lo, hi
+        self.buf = None
+
+    def partial_spec(self):
+        ops = []
+        for _ in range(self.G):
+            ops += [_lib.REDUCE_SUM, _lib.REDUCE_FIRST, _lib.REDUCE_SUM]
+        return 3 * self.G, ops
+
+    def run_local(self, ptr):
+        w = []
+        for g in range(self.G):
+            m_ = self.key == g
+            rows = np.nonzero(m_)[0]
+            w += [int(m_.sum()), int(self.lo + rows[0]) if rows.size else np.iinfo(np.int64).max, int(self.a[m_].sum())]
+        self.buf[: len(w)] = torch.tensor(w, dtype=torch.int64)
+
+    def resolve_first(self, ptr):
+        for g in range(self.G):
+            r = int(self.buf[3 * g + 1])
+            live = int(self.buf[3 * g]) > 0
+            self.buf[3 * g + 1] = int(self.a[r - self.lo]) if (live and self.lo <= r < self.hi) else 0
+
+    def finalize(self, ptr):
+        return [int(x) for x in self.buf[: 3 * self.G]]
+
+
+def _grouped_worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = m.shard_rows(n, rank, world)
+    runner = GroupedShardRunner(lo, hi, n)
+    buf = torch.zeros(3 * runner.G, dtype=torch.int64)
+    runner.buf = buf
+    out = m.ShardedQuery(runner, buf, dist).step()
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_merge_of_foldchoose_words():
+    n = 1001
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33000 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_grouped_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=150) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    single = GroupedShardRunner(0, n, n)
+    single.buf = torch.zeros(3 * single.G, dtype=torch.int64)
+    single.run_local(0)
+    single.resolve_first(0)
+    assert outs[0] == outs[1] == single.finalize(0)
