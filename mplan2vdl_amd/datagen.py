@@ -69,3 +69,46 @@ def generate(spec, row0, n, seed=SEED):
 
 def generate_table(names, row0, n, seed=SEED):
     return {name: generate(LINEITEM[name], row0, n, seed) for name in names}
+
+
+# ---- TPC-H Q3 shape: customer / orders / lineitem with FK join-index columns -----------------------
+# (value ranges /root/reference/tests/tpch10noorder/bounds.csv:38-79).  Join indices are row numbers of
+# the referenced table ("oid = row number in dim table"); every order has
+# exactly 4 lineitems here, so lineitem_orders = row // 4 is non-decreasing and any row range of
+# lineitem can be produced independently.  Order keys follow the TPC-H pattern (8 of every 32 used).
+CUSTOMER = {
+    "customer.c_mktsegment": ColumnSpec("customer.c_mktsegment", np.int32, 1, 5, 16, 0),     # 'BUILDING' = 16 (dictionary.csv:74)
+}
+ORDERS = {
+    "orders.o_orderdate": ColumnSpec("orders.o_orderdate", np.int32, 727563, 729968, 1, 0),
+    "orders.o_shippriority": ColumnSpec("orders.o_shippriority", np.int32, 0, 0, 1, 0),
+}
+Q3_COLUMNS = ["lineitem.l_orderkey", "lineitem.l_shipdate", "lineitem.l_extendedprice", "lineitem.l_discount",
+              "lineitem.lineitem_orders", "lineitem.lineitem_l_orderkey_l_linenumber_pkey",
+              "orders.orders_o_orderkey_pkey", "orders.o_orderdate", "orders.o_shippriority", "orders.orders_customer",
+              "customer.customer_c_custkey_pkey", "customer.c_mktsegment"]
+
+
+def orderkey_of_row(j):
+    j = np.asarray(j, dtype=np.int64)
+    return 1 + (j // 8) * 32 + (j % 8)
+
+
+def q3_tables(n_orders, seed=SEED):
+    """Host (numpy) Q3 catalog: n_orders orders, 4 lineitems each, n_orders // 10 customers."""
+    n_cust = max(n_orders // 10, 1)
+    n_li = 4 * n_orders
+    t = {}
+    t["customer.customer_c_custkey_pkey"] = np.zeros(n_cust, np.int64)                     # ref vector: length only
+    t["customer.c_mktsegment"] = generate(CUSTOMER["customer.c_mktsegment"], 0, n_cust, seed)
+    t["orders.orders_o_orderkey_pkey"] = np.zeros(n_orders, np.int64)
+    for name in ORDERS:
+        t[name] = generate(ORDERS[name], 0, n_orders, seed)
+    t["orders.orders_customer"] = generate(ColumnSpec("orders.orders_customer", np.int64, 0, n_cust - 1, 1, 0), 0, n_orders, seed)
+    li_orders = np.arange(n_li, dtype=np.int64) // 4
+    t["lineitem.lineitem_orders"] = li_orders
+    t["lineitem.lineitem_l_orderkey_l_linenumber_pkey"] = np.zeros(n_li, np.int64)
+    t["lineitem.l_orderkey"] = orderkey_of_row(li_orders).astype(np.int32)
+    for name in ("lineitem.l_shipdate", "lineitem.l_extendedprice", "lineitem.l_discount"):
+        t[name] = generate(LINEITEM[name], 0, n_li, seed)
+    return t

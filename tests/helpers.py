@@ -36,3 +36,24 @@ def prog(*lines):
 def rand_cols(rng, n, spec):
     """spec: {name: (dtype, lo, hi)} -> uniform random integer columns."""
     return {k: rng.integers(lo, hi + 1, size=n, dtype=np.int64).astype(dt) for k, (dt, lo, hi) in spec.items()}
+
+
+def sql_q3(t):
+    """TPC-H Q3 evaluated from its SQL text (/root/reference/tests/tpch10noorder/03.sql.mplan:1-19) with numpy,
+    over the join-index catalog of datagen.q3_tables.  Returns the four output columns in the order the
+    VDL program produces them: ascending composite key (l_orderkey, o_orderdate, o_shippriority)."""
+    seg = t["customer.c_mktsegment"]
+    o_date, o_prio, o_cust = t["orders.o_orderdate"], t["orders.o_shippriority"], t["orders.orders_customer"]
+    l_ord, l_key = t["lineitem.lineitem_orders"], t["lineitem.l_orderkey"].astype(np.int64)
+    l_ship, l_ep, l_disc = t["lineitem.l_shipdate"], t["lineitem.l_extendedprice"], t["lineitem.l_discount"]
+    order_ok = (o_date < 728732) & (seg[o_cust] == 16)            # date '1995-03-15', 'BUILDING'
+    li_ok = (l_ship > 728732) & order_ok[l_ord]
+    rows = np.nonzero(li_ok)[0]
+    key = ((l_key[rows] - 1) << 12) | (o_date[l_ord[rows]].astype(np.int64) - 727563)
+    uniq, first, inv = np.unique(key, return_index=True, return_inverse=True)
+    rev = np.zeros(len(uniq), np.int64)
+    np.add.at(rev, inv, l_ep[rows] * (100 - l_disc[rows]))
+    fr = rows[first]
+    return {"l_orderkey__lineitem__l_orderkey": [int(x) for x in l_key[fr]], "revenue": [int(x) for x in rev],
+            "o_orderdate__orders__o_orderdate": [int(x) for x in o_date[l_ord[fr]]],
+            "o_shippriority__orders__o_shippriority": [int(x) for x in o_prio[l_ord[fr]]]}

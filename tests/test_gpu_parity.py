@@ -433,3 +433,17 @@ def test_fold_over_unsorted_control_with_holes_matches_oracle():
     e = engine_with(cols)
     assert e.run_vdl(text)["results"] == want
     e.close()
+
+
+@pytest.mark.parametrize("n_orders", [1, 100, 15000, 150000])
+def test_q3_matches_oracle(n_orders):
+    """TPC-H Q3: FK joins lowered to Gather/Scatter over join-index columns, GROUP BY over a 2^38 key
+    domain -> five 8-bit radix passes in Partition; statement by statement on the GPU."""
+    from conftest import golden
+
+    text = golden("q3.vdl")
+    t = datagen.q3_tables(n_orders)
+    want = oracle_run(text, t)
+    e = engine_with(t)
+    assert e.run_vdl(text)["results"] == want
+    e.close()

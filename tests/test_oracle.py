@@ -151,3 +151,15 @@ def test_metadata_suffix_and_blank_lines_are_ignored():
 def test_errors(bad):
     with pytest.raises(oracle.OracleError):
         run(bad)
+
+
+@pytest.mark.parametrize("n_orders", [10, 1500, 20000])
+def test_q3_interpreter_equals_sql_evaluation(n_orders):
+    """Joins through join-index Gather/Scatter + sparse Partition (2^38 domain): the machine-generated
+    Q3 program under the oracle equals Q3 evaluated from its SQL text with numpy."""
+    from helpers import sql_q3
+
+    t = datagen.q3_tables(n_orders)
+    got = oracle_run(golden("q3.vdl"), t)
+    flat = {list(v.keys())[0][1:]: list(v.values())[0] for v in got.values()}
+    assert flat == sql_q3(t)
