@@ -128,12 +128,14 @@ def main():
         cpu_baseline = None
         if not args.no_verify or not args.no_cpu_baseline:
             import oracle
+        # torchrun exports OMP_NUM_THREADS=1; the checker may use the host's cores (capped)
+        host_threads = max(1, min(os.cpu_count() or 1, 64))
         if not args.no_verify and args.query == "q1":
             order = ["lineitem.l_shipdate", "lineitem.l_returnflag", "lineitem.l_linestatus", "lineitem.l_quantity",
                      "lineitem.l_extendedprice", "lineitem.l_discount", "lineitem.l_tax"]
             specs = [(datagen.SEED, datagen.col_id(c), datagen.LINEITEM[c].lo, datagen.LINEITEM[c].hi,
                       datagen.LINEITEM[c].mul, datagen.LINEITEM[c].add) for c in order]
-            tab = oracle.sql_q1_generated(specs, 0, total_rows, threads=oracle.max_threads())
+            tab = oracle.sql_q1_generated(specs, 0, total_rows, threads=host_threads)
             names = ["l_returnflag__lineitem__l_returnflag", "l_linestatus__lineitem__l_linestatus", "sum_qty", "sum_base_price",
                      "sum_disc_price", "sum_charge", "avg_qty", "avg_price", "avg_disc", "count_order"]
             flat = {list(v.keys())[0][1:]: list(v.values())[0] for v in result["results"].values()}
@@ -148,7 +150,7 @@ def main():
             # on all host cores (test infrastructure; outside the timed region)
             specs = [(datagen.SEED, datagen.col_id(c), datagen.LINEITEM[c].lo, datagen.LINEITEM[c].hi,
                       datagen.LINEITEM[c].mul, datagen.LINEITEM[c].add) for c in datagen.Q6_COLUMNS]
-            rev, cnt = oracle.sql_q6_generated(specs, 0, total_rows, threads=oracle.max_threads())
+            rev, cnt = oracle.sql_q6_generated(specs, 0, total_rows, threads=host_threads)
             verified = (revenue == ([rev] if cnt else []))
             if not verified:
                 print("VERIFICATION FAILED: gpu %r vs cpu %r" % (revenue, rev), file=sys.stderr)
@@ -163,7 +165,7 @@ def main():
             secs = orc.last_seconds
             cols = [datagen.generate(datagen.LINEITEM[c], 0, n_s) for c in datagen.Q6_COLUMNS]
             t1 = time.perf_counter(); rev1, cnt1 = oracle.sql_q6(*cols, threads=1); f1 = time.perf_counter() - t1
-            nt = oracle.max_threads()
+            nt = host_threads
             t1 = time.perf_counter(); oracle.sql_q6(*cols, threads=nt); fn = time.perf_counter() - t1
             ok = r["results"]["tmp42"][".revenue"] == ([rev1] if cnt1 else [])
             cpu_baseline = {"value": n_s / secs, "unit": "rows/s", "cores": 1, "kind": "port",

@@ -57,7 +57,8 @@ class Plan:
             name, tmp = ctypes.c_char_p(), ctypes.c_char_p()
             vals, n = ctypes.POINTER(ctypes.c_int64)(), ctypes.c_size_t()
             L.vdl_output(self._h, k, ctypes.byref(name), ctypes.byref(tmp), ctypes.byref(vals), ctypes.byref(n))
-            results[tmp.value.decode()] = {"." + name.value.decode(): [int(vals[i]) for i in range(n.value)]}
+            arr = np.ctypeslib.as_array(vals, shape=(n.value,)).tolist() if n.value else []
+            results[tmp.value.decode()] = {"." + name.value.decode(): arr}
         timings = {}
         for k in range(L.vdl_n_timings(self._h)):
             label, us = ctypes.c_char_p(), ctypes.c_double()

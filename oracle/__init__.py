@@ -116,7 +116,7 @@ class Oracle:
             vals, n = ctypes.POINTER(ctypes.c_int64)(), ctypes.c_int64()
             self._L.orc_output(self._c, k, ctypes.byref(name), ctypes.byref(tmp), ctypes.byref(vals), ctypes.byref(n))
             arr = np.ctypeslib.as_array(vals, shape=(n.value,)).copy() if n.value else np.zeros(0, np.int64)
-            results[tmp.value.decode()] = {"." + name.value.decode(): [int(x) for x in arr]}
+            results[tmp.value.decode()] = {"." + name.value.decode(): arr.tolist()}
         secs = self._L.orc_last_run_seconds(self._c)
         return {"results": results,
                 "timings": {"timeInMicrosecondsForCpuOracle": int(secs * 1e6)}}
