@@ -104,6 +104,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:
+        # communicator set-up (seconds on the first collective) must not land in the timed region even with --warmup 0
+        dist.all_reduce(torch.zeros(1, dtype=torch.int64, device="cuda"))
+        torch.cuda.synchronize()
     result = run_steps(args.warmup, False) if args.warmup > 0 else None
     sync_all()
     t0 = time.perf_counter()

@@ -62,14 +62,20 @@ struct Pool {
         peak_bytes = std::max(peak_bytes, live_bytes);
         return p;
     }
-    void release(void *p, size_t cls) { free_list.emplace(cls, p); live_bytes -= cls; }
+    void release(void *p, size_t cls) {
+        if (closed) { (void)hipFree(p); return; }        // the context is gone: give the memory back at once
+        free_list.emplace(cls, p);
+        live_bytes -= cls;
+    }
     void trim() { for (auto &kv : free_list) (void)hipFree(kv.second); free_list.clear(); }
+    bool closed = false;
+    ~Pool() { trim(); }
 };
 
 struct DevBuf {
     void *p = nullptr;
     size_t cls = 0;
-    Pool *pool = nullptr;
+    std::shared_ptr<Pool> pool;       // buffers (held by plans) may outlive their context
     ~DevBuf() { if (p && pool) pool->release(p, cls); }
 };
 using BufP = std::shared_ptr<DevBuf>;
@@ -108,7 +114,7 @@ struct vdl_ctx {
     int num_cus = 256;
     std::map<std::string, Column> cols;
     uint64_t catalog_version = 1;      // bumped on every catalog change: plans re-bind only when it moved
-    Pool pool;
+    std::shared_ptr<Pool> pool = std::make_shared<Pool>();
     std::string err;
 };
 
@@ -168,8 +174,8 @@ namespace {
 
 BufP dev_alloc(vdl_ctx *c, size_t bytes) {
     auto b = std::make_shared<DevBuf>();
-    b->pool = &c->pool;
-    b->p = c->pool.alloc(bytes, &b->cls);
+    b->pool = c->pool;
+    b->p = c->pool->alloc(bytes, &b->cls);
     return b;
 }
 
@@ -811,7 +817,8 @@ void vdl_close(vdl_ctx *c) {
         (void)hipSetDevice(c->device);
         (void)hipDeviceSynchronize();
         c->cols.clear();
-        c->pool.trim();
+        c->pool->trim();
+        c->pool->closed = true;
         if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     }
     delete c;

@@ -34,8 +34,10 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        L = ctypes.CDLL(_SO)
+        so = os.environ.get("VDL_ORACLE_SO")          # e.g. the ASan build of tools/sanitize/run.sh
+        if not so:
+            so = build()
+        L = ctypes.CDLL(so)
         L.orc_open.restype = ctypes.c_void_p
         L.orc_close.argtypes = [ctypes.c_void_p]
         L.orc_last_error.restype = ctypes.c_char_p
