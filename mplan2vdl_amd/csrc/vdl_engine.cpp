@@ -656,7 +656,7 @@ struct GenExec {
                 // general control vector (grouped aggregates fold data scattered into key order)
                 const size_t nw = (size_t)std::max<int64_t>(nwords(d.n), 1);
                 BufP heads = dev_alloc(c, sizeof(uint64_t) * nw);
-                BufP wordhd = dev_alloc(c, sizeof(int64_t) * nw);
+                BufP wordhd = dev_alloc(c, sizeof(int64_t) * (nw + (size_t)maxscan_blocks((int64_t)nw) + 1));
                 o.kind = DVec::DENSE; o.n = d.n;
                 o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(d.n, 1));
                 o.valid = dev_alloc(c, sizeof(uint64_t) * nw);

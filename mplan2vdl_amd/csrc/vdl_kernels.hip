@@ -978,16 +978,32 @@ __global__ void k_seg_wordhd(const uint64_t *heads, int64_t nw, int64_t *wordhd)
     }
 }
 
-// in-place inclusive max-scan, single block (n/64 entries; 9.4 M for SF100 -> ~9 K iterations)
-__global__ __launch_bounds__(1024) void k_maxscan(int64_t *x, int64_t n) {
+// in-place inclusive max-scan over n int64 (n/64 entries of the head table): block maxima -> one-block
+// scan of the maxima -> per-block scan with carry.  (A single-block version was 1/3 of Q3's kernel time.)
+constexpr int kMxBlock = 1024, kMxItems = 4, kMxTile = kMxBlock * kMxItems;
+
+__global__ __launch_bounds__(kMxBlock) void k_mx_block(const int64_t *x, int64_t n, int64_t *bmax) {
+    __shared__ int64_t red[kMxBlock / kWave];
+    const int64_t base = (int64_t)blockIdx.x * kMxTile + (int64_t)threadIdx.x * kMxItems;
+    int64_t m = INT64_MIN;
+#pragma unroll
+    for (int k = 0; k < kMxItems; k++) if (base + k < n && x[base + k] > m) m = x[base + k];
+    m = wave_reduce(m, R_MAX);
+    if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) { int64_t a = red[0]; for (int w = 1; w < kMxBlock / kWave; w++) a = red[w] > a ? red[w] : a; bmax[blockIdx.x] = a; }
+}
+
+// inclusive max-scan of nb block maxima on one block (nb = n / 4096)
+__global__ __launch_bounds__(1024) void k_mx_scan_blocks(int64_t *x, int64_t n) {
     __shared__ int64_t wmax[1024 / kWave];
     __shared__ int64_t carry;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-    if (tid == 0) carry = -1;
+    if (tid == 0) carry = INT64_MIN;
     __syncthreads();
     for (int64_t base = 0; base < n; base += 1024) {
         const int64_t i = base + tid;
-        int64_t v = i < n ? x[i] : -1;
+        int64_t v = i < n ? x[i] : INT64_MIN;
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) { int64_t y = __shfl_up(v, off, kWave); if (lane >= off && y > v) v = y; }
         if (lane == kWave - 1) wmax[wave] = v;
@@ -1000,6 +1016,37 @@ __global__ __launch_bounds__(1024) void k_maxscan(int64_t *x, int64_t n) {
         if (tid == 1023) carry = v;
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(kMxBlock) void k_mx_apply(int64_t *x, int64_t n, const int64_t *bincl) {
+    __shared__ int64_t wmax[kMxBlock / kWave];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const int64_t base = (int64_t)blockIdx.x * kMxTile + (int64_t)tid * kMxItems;
+    int64_t v[kMxItems], m = INT64_MIN;
+#pragma unroll
+    for (int k = 0; k < kMxItems; k++) { v[k] = (base + k < n) ? x[base + k] : INT64_MIN; if (v[k] > m) m = v[k]; }
+    int64_t incl = m;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) { int64_t y = __shfl_up(incl, off, kWave); if (lane >= off && y > incl) incl = y; }
+    if (lane == kWave - 1) wmax[wave] = incl;
+    __syncthreads();
+    int64_t run = blockIdx.x > 0 ? bincl[blockIdx.x - 1] : INT64_MIN;     // everything before this block
+    for (int w = 0; w < wave; w++) run = wmax[w] > run ? wmax[w] : run;
+    const int64_t prev = __shfl_up(incl, 1, kWave);                        // lanes before me in my wave
+    if (lane > 0 && prev > run) run = prev;
+#pragma unroll
+    for (int k = 0; k < kMxItems; k++) { if (v[k] > run) run = v[k]; if (base + k < n) x[base + k] = run; }
+}
+
+int64_t maxscan_blocks(int64_t n) { return (n + kMxTile - 1) / kMxTile; }
+
+static hipError_t launch_maxscan(int64_t *x, int64_t n, int64_t *scratch /* maxscan_blocks(n) */, hipStream_t s) {
+    const int64_t nb = maxscan_blocks(n);
+    if (nb <= 0) return hipSuccess;
+    k_mx_block<<<(int)nb, kMxBlock, 0, s>>>(x, n, scratch);
+    k_mx_scan_blocks<<<1, 1024, 0, s>>>(scratch, nb);
+    k_mx_apply<<<(int)nb, kMxBlock, 0, s>>>(x, n, scratch);
+    return hipGetLastError();
 }
 
 __device__ __forceinline__ void atomic_combine(int rk, int64_t *addr, int64_t v) {
@@ -1057,7 +1104,7 @@ __global__ void k_seg_choose_fix(Src d, const uint64_t *vout, int64_t n, int64_t
         if (bit(vout, i)) out[i] = ld(d, out[i]);
 }
 
-// scratch: heads bitmap (nwords) and wordhd (nwords int64) supplied by the caller
+// scratch: heads bitmap (nwords) and wordhd (nwords + maxscan_blocks(nwords) int64) supplied by the caller
 hipError_t launch_fold_segmented(int kind, Src ctl, const uint64_t *vc, Src d, const uint64_t *vd, int64_t n,
                                  uint64_t *heads, int64_t *wordhd, int64_t *out, uint64_t *vout /* pre-zeroed */, hipStream_t s) {
     (void)hipGetLastError();   // see launch_status()
@@ -1066,7 +1113,7 @@ hipError_t launch_fold_segmented(int kind, Src ctl, const uint64_t *vc, Src d, c
     const int rk = (kind == 1 || kind == 4) ? R_MIN : kind == 2 ? R_MAX : R_SUM;
     k_seg_heads<<<grid_for(n, 256, 4), 256, 0, s>>>(ctl, vc, n, heads);
     k_seg_wordhd<<<grid_for(nw, 256, 1), 256, 0, s>>>(heads, nw, wordhd);
-    k_maxscan<<<1, 1024, 0, s>>>(wordhd, nw);
+    if (launch_maxscan(wordhd, nw, wordhd + nw, s) != hipSuccess) return hipGetLastError();
     k_seg_fill<<<grid_for(n, 256, 4), 256, 0, s>>>(out, rk == R_SUM ? 0 : rk == R_MIN ? INT64_MAX : INT64_MIN, n);
     k_seg_fold<<<grid_for(n, 256, 4), 256, 0, s>>>(kind, d, vd, vc, heads, wordhd, n, out, vout);
     if (kind == 4) k_seg_choose_fix<<<grid_for(n, 256, 4), 256, 0, s>>>(d, vout, n, out);
