@@ -149,6 +149,34 @@ int  vdl_resolve_first(vdl_ctx *ctx, vdl_plan *plan, void *dev_partials);
 int  vdl_finalize_begin(vdl_ctx *ctx, vdl_plan *plan, const void *dev_partials, int slot);
 int  vdl_finalize_end(vdl_ctx *ctx, vdl_plan *plan, int slot);
 
+/* ---- sharded Partition (joins / sparse GROUP BY, e.g. TPC-H Q3): row exchange -------------------
+ * For plans that are not fused but whose outputs depend on the sharded table only through
+ * Scatter(x, _, Partition(key, RangeC min cnt 1)) -- the group-by lowering of
+ * /root/reference/src/Vlite.hs:1056-1060,1082-1098 -- every rank
+ *   1. vdl_exchange_begin : runs the statements up to the partition key and the scattered vectors on
+ *      its own rows and reports how many rows go to each rank (rank r owns the keys of
+ *      [min + r*cnt/world, min + (r+1)*cnt/world)); rows keep their order inside each destination;
+ *   2. vdl_exchange_pack  : writes the n_send = sum(counts) rows, grouped by destination, into a
+ *      caller-owned device buffer of n_columns x n_send int64 (column c starts at c * n_send):
+ *      key, scattered vectors, one validity word;
+ *   3. (caller) all-to-all of every column over RCCL (torch.distributed.all_to_all_single with the
+ *      counts as split sizes);
+ *   4. vdl_exchange_finish: runs Partition / Scatter / Fold / MaterializeCompact on the received
+ *      rows (n_columns x n_recv int64, same layout).  The outputs of rank 0, 1, ... concatenate to the
+ *      unsharded result (keys ascend across ranks; stability makes FoldChoose pick the same row).
+ * Dimension tables must be replicated on every rank; only the partitioned table is sharded.
+ * vdl_exchange_pack returns when the send buffer is complete; the received rows must be complete
+ * when vdl_exchange_finish is called (synchronise the collective's stream first unless the engine
+ * runs on that stream, vdl_set_stream).
+ * vdl_exchange_spec checks the structure; with sharded_table != NULL ("lineitem") it also verifies
+ * that everything below the Partition is row-local over that table (element-wise operators,
+ * constants, Gathers out of replicated vectors) and returns VDL_ERR_UNSUPPORTED with the reason
+ * otherwise.  world <= 128. */
+int  vdl_exchange_spec(const vdl_plan *plan, const char *sharded_table, int *n_columns);
+int  vdl_exchange_begin(vdl_ctx *ctx, vdl_plan *plan, int world, int64_t *counts_host /* world */);
+int  vdl_exchange_pack(vdl_ctx *ctx, vdl_plan *plan, void *dev_send);
+int  vdl_exchange_finish(vdl_ctx *ctx, vdl_plan *plan, const void *dev_recv, int64_t n_recv);
+
 #ifdef __cplusplus
 }
 #endif

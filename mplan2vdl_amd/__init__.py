@@ -6,6 +6,6 @@ one-process-per-GPU sharding driver.
 """
 from . import datagen  # noqa: F401
 from .engine import Engine, Plan, VdlError  # noqa: F401
-from .sharded import ShardedQuery, merge_partials, shard_rows  # noqa: F401
+from .sharded import ShardedQuery, merge_partials, run_exchange, shard_rows  # noqa: F401
 
-__all__ = ["Engine", "Plan", "VdlError", "ShardedQuery", "merge_partials", "shard_rows", "datagen"]
+__all__ = ["Engine", "Plan", "VdlError", "ShardedQuery", "merge_partials", "run_exchange", "shard_rows", "datagen"]

@@ -135,4 +135,13 @@ int64_t maxscan_blocks(int64_t n);
 hipError_t launch_fold_segmented(int kind, Src ctl, const uint64_t *vc, Src d, const uint64_t *vd, int64_t n, uint64_t *heads,
                                  int64_t *wordhd, int64_t *out, uint64_t *vout, hipStream_t s);
 
+// ---- row exchange for sharded Partition (see vdl_kernels.hip) -------------------------------------
+constexpr int kMaxExSources = 62;
+struct ExValid { int n = 0; const uint64_t *valid[kMaxExSources] = {}; };
+hipError_t launch_ex_dest(Src key, const uint64_t *vkey, int64_t n, int64_t pmin, int64_t pcount, int world, int64_t *dest,
+                          uint64_t *vdest, int64_t *counts /* world, pre-zeroed */, int64_t *oob /* pre-zeroed */, hipStream_t s);
+hipError_t launch_ex_pack(Src src, const uint64_t *vdest, const int64_t *pos, int64_t n, int64_t *out, hipStream_t s);
+hipError_t launch_ex_mask(const ExValid &v, const uint64_t *vdest, const int64_t *pos, int64_t n, int64_t *out, hipStream_t s);
+hipError_t launch_ex_unmask(const int64_t *mask, int64_t n, int j, uint64_t *valid, hipStream_t s);
+
 }  // namespace vdl

@@ -1120,4 +1120,98 @@ hipError_t launch_fold_segmented(int kind, Src ctl, const uint64_t *vc, Src d, c
     return launch_status();
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Row exchange for sharded Partition (Partition / join redistribution over
+// xGMI).  Each rank sends every row of the partition key and of the vectors scattered by it to the
+// rank that owns the row's key range; afterwards Partition / Scatter / Fold run locally on the
+// received rows and the outputs of the ranks concatenate in rank order (keys ascend across ranks).
+//   k_ex_dest   : destination rank of each row = (key - pmin) * world / pcount, EPS for rows that do
+//                 not take part; per-destination row counts by 64-bit atomics (world <= 256)
+//   (stable order inside each destination: launch_partition over the destination vector)
+//   k_ex_pack   : scatter a column into send order; k_ex_mask: validity word of the source vectors
+//   k_ex_unmask : received validity words -> one bitmap per source vector
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ex_dest(Src key, const uint64_t *vkey, int64_t n, int64_t pmin, int64_t pcount, int world,
+                                                 int64_t *dest, uint64_t *vdest, int64_t *counts, int64_t *oob) {
+    const int64_t nw = (n + 63) >> 6;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave);
+    for (int64_t w = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; w < nw; w += wstride) {
+        const int64_t i = (w << 6) + lane;
+        bool ok = i < n && bit(vkey, i);
+        int64_t d = 0;
+        if (ok) {
+            const int64_t b = (int64_t)((uint64_t)ld(key, i) - (uint64_t)pmin);
+            if (b < 0 || b >= pcount) { atomicAdd((unsigned long long *)oob, 1ull); ok = false; }
+            else d = (int64_t)(((unsigned __int128)(uint64_t)b * (uint64_t)world) / (uint64_t)pcount);
+        }
+        if (i < n) dest[i] = d;
+        const uint64_t m = __ballot(ok);
+        if (lane == 0) vdest[w] = m;
+        // one atomic per (wave, destination present in the wave)
+        uint64_t todo = m;
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int64_t dl = __shfl(d, leader, kWave);
+            const uint64_t same = __ballot(ok && d == dl) & todo;
+            if (lane == leader) atomicAdd((unsigned long long *)&counts[dl], (unsigned long long)__popcll(same));
+            todo &= ~same;
+        }
+    }
+}
+hipError_t launch_ex_dest(Src key, const uint64_t *vkey, int64_t n, int64_t pmin, int64_t pcount, int world, int64_t *dest,
+                          uint64_t *vdest, int64_t *counts, int64_t *oob, hipStream_t s) {
+    (void)hipGetLastError();
+    if (n <= 0) return hipSuccess;
+    k_ex_dest<<<grid_for(n, 256, 4), 256, 0, s>>>(key, vkey, n, pmin, pcount, world, dest, vdest, counts, oob);
+    return launch_status();
+}
+
+__global__ __launch_bounds__(256) void k_ex_pack(Src src, const uint64_t *vdest, const int64_t *pos, int64_t n, int64_t *out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        if (bit(vdest, i)) out[pos[i]] = ld(src, i);
+}
+hipError_t launch_ex_pack(Src src, const uint64_t *vdest, const int64_t *pos, int64_t n, int64_t *out, hipStream_t s) {
+    (void)hipGetLastError();
+    if (n <= 0) return hipSuccess;
+    k_ex_pack<<<grid_for(n, 256, 4), 256, 0, s>>>(src, vdest, pos, n, out);
+    return launch_status();
+}
+
+// mask word per row: bit j = source vector j holds a value in that row (j < 63)
+__global__ __launch_bounds__(256) void k_ex_mask(ExValid v, const uint64_t *vdest, const int64_t *pos, int64_t n, int64_t *out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (!bit(vdest, i)) continue;
+        uint64_t m = 0;
+        for (int j = 0; j < v.n; j++) m |= (uint64_t)bit(v.valid[j], i) << j;
+        out[pos[i]] = (int64_t)m;
+    }
+}
+hipError_t launch_ex_mask(const ExValid &v, const uint64_t *vdest, const int64_t *pos, int64_t n, int64_t *out, hipStream_t s) {
+    (void)hipGetLastError();
+    if (n <= 0) return hipSuccess;
+    k_ex_mask<<<grid_for(n, 256, 4), 256, 0, s>>>(v, vdest, pos, n, out);
+    return launch_status();
+}
+
+__global__ __launch_bounds__(256) void k_ex_unmask(const int64_t *mask, int64_t n, int j, uint64_t *valid) {
+    const int64_t nw = (n + 63) >> 6;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave);
+    for (int64_t w = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; w < nw; w += wstride) {
+        const int64_t i = (w << 6) + lane;
+        const uint64_t m = __ballot(i < n && (((uint64_t)mask[i < n ? i : 0] >> j) & 1ull));
+        if (lane == 0) valid[w] = m;
+    }
+}
+hipError_t launch_ex_unmask(const int64_t *mask, int64_t n, int j, uint64_t *valid, hipStream_t s) {
+    (void)hipGetLastError();
+    if (n <= 0) return hipSuccess;
+    k_ex_unmask<<<grid_for(n, 256, 4), 256, 0, s>>>(mask, n, j, valid);
+    return launch_status();
+}
+
 }  // namespace vdl

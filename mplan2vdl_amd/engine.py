@@ -90,6 +90,25 @@ class Plan:
     def resolve_first(self, dev_ptr):
         self._e._check(self._e._L.vdl_resolve_first(self._e._c, self._h, ctypes.c_void_p(dev_ptr)))
 
+    # ---- sharded Partition exchange (joins / sparse GROUP BY) ----
+    def exchange_columns(self, sharded_table=None):
+        n = ctypes.c_int()
+        tbl = sharded_table.encode() if sharded_table else None
+        self._e._check(self._e._L.vdl_exchange_spec(self._h, tbl, ctypes.byref(n)))
+        return n.value
+
+    def exchange_begin(self, world):
+        counts = (ctypes.c_int64 * world)()
+        self._e._check(self._e._L.vdl_exchange_begin(self._e._c, self._h, world, counts))
+        return list(counts)
+
+    def exchange_pack(self, dev_ptr):
+        self._e._check(self._e._L.vdl_exchange_pack(self._e._c, self._h, ctypes.c_void_p(dev_ptr)))
+
+    def exchange_finish(self, dev_ptr, n_recv):
+        self._e._check(self._e._L.vdl_exchange_finish(self._e._c, self._h, ctypes.c_void_p(dev_ptr or 0), int(n_recv)))
+        return self._collect()
+
     def finalize_begin(self, dev_ptr, slot):
         self._e._check(self._e._L.vdl_finalize_begin(self._e._c, self._h, ctypes.c_void_p(dev_ptr), int(slot)))
 

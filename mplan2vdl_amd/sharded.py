@@ -97,3 +97,56 @@ class ShardedQuery:
             if on_result is not None:
                 on_result(out)
         return out
+
+
+def exchange_rows(send, counts, dist, group=None):
+    """All-to-all of the packed rows: `send` is (n_columns, n_send) int64 grouped by destination rank,
+    counts[r] rows go to rank r.  Returns (n_columns, n_recv), the pieces in source-rank order."""
+    import torch
+
+    if send.is_cuda and dist.get_backend(group) == "gloo":       # rehearsal on one GPU: gloo has no device all-to-all
+        return exchange_rows(send.cpu(), counts, dist, group).to(send.device)
+    cnt_in = torch.tensor(counts, dtype=torch.int64, device=send.device)
+    cnt_out = torch.empty_like(cnt_in)
+    dist.all_to_all_single(cnt_out, cnt_in, group=group)
+    recv_counts = [int(x) for x in cnt_out.tolist()]
+    n_recv = sum(recv_counts)
+    ncols = send.shape[0]
+    recv = torch.empty((ncols, max(n_recv, 1)), dtype=torch.int64, device=send.device)[:, :n_recv].contiguous()
+    for c in range(ncols):
+        dist.all_to_all_single(recv[c], send[c], output_split_sizes=recv_counts, input_split_sizes=list(counts), group=group)
+    return recv
+
+
+def run_exchange(plan, dist=None, group=None, device="cuda", sharded_table=None):
+    """Sharded execution of a plan with a Partition (e.g. TPC-H Q3): local phase, all-to-all of the rows
+    by key range over RCCL, local tail.  Returns this rank's slice of the result (the slices of rank 0,
+    1, ... concatenate to the unsharded result).  The partitioned table is sharded by rows; dimension
+    tables are replicated.  With dist=None (single rank) the exchange degenerates to a local compaction."""
+    import torch
+
+    world = dist.get_world_size(group) if dist is not None and dist.is_initialized() else 1
+    ncols = plan.exchange_columns(sharded_table)
+    failure = None
+    try:
+        counts = plan.exchange_begin(world)
+    except Exception as exc:          # keep the ranks in step: everybody learns about the failure before any collective
+        if world == 1:
+            raise
+        failure, counts = exc, [0] * world
+    if world > 1:
+        flag = torch.tensor([1 if failure else 0], dtype=torch.int64, device="cpu" if dist.get_backend(group) == "gloo" else device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        if failure:
+            raise failure
+        if int(flag.item()):
+            raise RuntimeError("sharded Partition exchange failed on another rank")
+    n_send = sum(counts)
+    send = torch.empty((ncols, max(n_send, 1)), dtype=torch.int64, device=device)[:, :n_send].contiguous()
+    plan.exchange_pack(send.data_ptr())
+    if world == 1:
+        return plan.exchange_finish(send.data_ptr(), n_send)
+    recv = exchange_rows(send, counts, dist, group)
+    if recv.is_cuda:
+        torch.cuda.current_stream(recv.device).synchronize()      # the engine may run on a stream of its own
+    return plan.exchange_finish(recv.data_ptr(), recv.shape[1])

@@ -164,3 +164,98 @@ def test_two_rank_merge_of_foldchoose_words():
     single.run_local(0)
     single.resolve_first(0)
     assert outs[0] == outs[1] == single.finalize(0)
+
+
+class ExchangeRunner:
+    """CPU stand-in (TEST ONLY) for a plan with a sharded Partition: GROUP BY key, SUM(v) over keys
+    0..K-1.  Mirrors the engine's contract: rows grouped by destination rank in row order, columns
+    [key, v, validity word]; rank r owns keys [r*K/world, (r+1)*K/world)."""
+
+    K = 97
+
+    def __init__(self, lo, hi, n, fail=False):
+        rng = np.random.default_rng(99)
+        self.key = rng.integers(0, self.K, size=n)[lo:hi].astype(np.int64)
+        self.v = rng.integers(-9, 9, size=n)[lo:hi].astype(np.int64)
+        self.fail = fail
+
+    def exchange_columns(self, sharded_table=None):
+        return 3
+
+    def exchange_begin(self, world):
+        if self.fail:
+            raise m.VdlError(_lib.ERR_UNSUPPORTED if hasattr(_lib, "ERR_UNSUPPORTED") else 3, "1 row(s) carry a partition key outside the pivots")
+        self.dest = self.key * world // self.K
+        self.order = np.argsort(self.dest, kind="stable")
+        return [int((self.dest == r).sum()) for r in range(world)]
+
+    def exchange_pack(self, ptr):
+        o = self.order
+        self.send[0] = torch.from_numpy(self.key[o])
+        self.send[1] = torch.from_numpy(self.v[o])
+        self.send[2] = 1
+
+    def exchange_finish(self, ptr, n_recv):
+        recv = self.recv.numpy()
+        assert recv.shape[1] == n_recv
+        keys = np.unique(recv[0])
+        return {"keys": [int(k) for k in keys], "sums": [int(recv[1][recv[0] == k].sum()) for k in keys]}
+
+
+def _exchange_worker(rank, world, port, n, q, fail_rank):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = m.shard_rows(n, rank, world)
+    runner = ExchangeRunner(lo, hi, n, fail=rank == fail_rank)
+    # the stand-in has no device memory: hand it the tensors run_exchange allocates
+    import mplan2vdl_amd.sharded as sh
+    real_rows = sh.exchange_rows
+
+    def spy(send, counts, dist_, group=None):
+        runner.recv = real_rows(send, counts, dist_, group)
+        return runner.recv
+
+    sh.exchange_rows = spy
+    real_empty = torch.empty
+
+    def empty_spy(*a, **k):
+        t = real_empty(*a, **k)
+        if t.dim() == 2:
+            runner.send = t
+        return t
+
+    torch.empty = empty_spy
+    try:
+        out = m.run_exchange(runner, dist, device="cpu")
+    except Exception as exc:
+        out = "error: %s" % exc
+    finally:
+        torch.empty = real_empty
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("fail_rank", [-1, 1])
+def test_two_rank_gloo_partition_exchange(fail_rank):
+    n = 5003
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33000 + (os.getpid() % 2000) + (7 if fail_rank >= 0 else 0)
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, n, q, fail_rank)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=150) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    if fail_rank >= 0:      # both ranks stop before the first data collective, nobody hangs
+        assert "outside the pivots" in outs[1] and "another rank" in outs[0]
+        return
+    whole = ExchangeRunner(0, n, n)
+    keys = np.unique(whole.key)
+    assert outs[0]["keys"] + outs[1]["keys"] == [int(k) for k in keys]
+    assert outs[0]["sums"] + outs[1]["sums"] == [int(whole.v[whole.key == k].sum()) for k in keys]
+    assert max(outs[0]["keys"]) < min(outs[1]["keys"])

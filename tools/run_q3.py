@@ -1,45 +1,87 @@
 #!/usr/bin/env python3
-"""TPC-H Q3 (machine-generated VDL, tests/golden/q3.vdl) on the GPU at a chosen scale; columns are built
-on the device with torch (join indices are arithmetic), verified against numpy at small scale."""
+"""TPC-H Q3 (machine-generated VDL, tests/golden/q3.vdl) on the GPU at a chosen scale.
+
+    python tools/run_q3.py [n_orders]                                      one GPU, statement by statement
+    python -m torch.distributed.run --nproc-per-node N ... tools/run_q3.py [n_orders]
+                                                                            lineitem sharded by rows, orders and
+                                                                            customer replicated, rows exchanged by
+                                                                            key range (mplan2vdl_amd.run_exchange)
+Columns are built on the device (join indices are arithmetic); the result is verified against a numpy
+evaluation of the SQL at small scale.  VDL_Q3_SHARE_DEVICE=1 + VDL_Q3_BACKEND=gloo rehearse N ranks on one GPU."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch
+import torch.distributed as dist
 import mplan2vdl_amd as m
 from mplan2vdl_amd import datagen
 
 n_orders = int(sys.argv[1]) if len(sys.argv) > 1 else 15000000
-e = m.Engine(0)
+world = int(os.environ.get("WORLD_SIZE", "1"))
+rank = int(os.environ.get("RANK", "0"))
+local = 0 if os.environ.get("VDL_Q3_SHARE_DEVICE") else int(os.environ.get("LOCAL_RANK", "0"))
+torch.cuda.set_device(local)
+if world > 1:
+    dist.init_process_group(os.environ.get("VDL_Q3_BACKEND", "nccl"), rank=rank, world_size=world)
+dev = "cuda:%d" % local
+e = m.Engine(local)
+e.use_torch_stream()
 n_cust, n_li = max(n_orders // 10, 1), 4 * n_orders
+r0, r1 = m.shard_rows(n_li, rank, world)
 keep = {}
 def reg(name, t):
     keep[name] = t; e.register_tensor(name, t)
 e.generate(datagen.CUSTOMER["customer.c_mktsegment"], 0, n_cust)
 for name in datagen.ORDERS: e.generate(datagen.ORDERS[name], 0, n_orders)
 e.generate(datagen.ColumnSpec("orders.orders_customer", np.int64, 0, n_cust - 1, 1, 0), 0, n_orders)
-for name in ("lineitem.l_shipdate", "lineitem.l_extendedprice", "lineitem.l_discount"): e.generate(datagen.LINEITEM[name], 0, n_li)
-reg("customer.customer_c_custkey_pkey", torch.zeros(n_cust, dtype=torch.int64, device="cuda"))
-reg("orders.orders_o_orderkey_pkey", torch.zeros(n_orders, dtype=torch.int64, device="cuda"))
-reg("lineitem.lineitem_l_orderkey_l_linenumber_pkey", torch.zeros(n_li, dtype=torch.int64, device="cuda"))
-lo = torch.arange(n_li, dtype=torch.int64, device="cuda") // 4
+for name in ("lineitem.l_shipdate", "lineitem.l_extendedprice", "lineitem.l_discount"): e.generate(datagen.LINEITEM[name], r0, r1 - r0)
+reg("customer.customer_c_custkey_pkey", torch.zeros(n_cust, dtype=torch.int64, device=dev))
+reg("orders.orders_o_orderkey_pkey", torch.zeros(n_orders, dtype=torch.int64, device=dev))
+reg("lineitem.lineitem_l_orderkey_l_linenumber_pkey", torch.zeros(r1 - r0, dtype=torch.int64, device=dev))
+lo = torch.arange(r0, r1, dtype=torch.int64, device=dev) // 4
 reg("lineitem.lineitem_orders", lo)
 reg("lineitem.l_orderkey", (1 + (lo // 8) * 32 + (lo % 8)).to(torch.int32))
 torch.cuda.synchronize()
 text = open(os.path.join(ROOT, "tests", "golden", "q3.vdl")).read()
 plan = e.parse(text)
-print("fused:", plan.is_fused)
-for it in range(3):
-    t0 = time.perf_counter(); out = plan.run(); dt = time.perf_counter() - t0
-    rows = len(out["results"]["tmp110"][".revenue"])
-    print("run %d: %.1f ms, %d result rows, %.2f M lineitem rows/s" % (it, dt * 1e3, rows, n_li / dt / 1e6))
-if n_orders <= 2000000:
+say = print if rank == 0 else (lambda *a, **k: None)
+say("fused:", plan.is_fused, " exchange columns:", plan.exchange_columns("lineitem"), " ranks:", world)
+
+def timed(label, fn):
+    out = None
+    for it in range(3):
+        if world > 1: dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); out = fn(); torch.cuda.synchronize()
+        if world > 1: dist.barrier()
+        dt = time.perf_counter() - t0
+        rows = len(out["results"]["tmp110"][".revenue"])
+        say("%s run %d: %.1f ms, %d result rows on rank 0, %.2f M lineitem rows/s" % (label, it, dt * 1e3, rows, n_li / dt / 1e6))
+    return out
+
+out = timed("exchange", lambda: m.run_exchange(plan, dist if world > 1 else None, device=dev, sharded_table="lineitem"))
+flat = {list(v.keys())[0][1:]: list(v.values())[0] for v in out["results"].values()}
+if world > 1:
+    parts = [None] * world
+    dist.all_gather_object(parts, flat)
+    flat = {k: sum((p[k] for p in parts), []) for k in flat}
+if world == 1:
+    whole = timed("statement-by-statement", plan.run)
+    same = {list(v.keys())[0][1:]: list(v.values())[0] for v in whole["results"].values()} == flat
+    say("exchange path == unsharded path:", same)
+    if not same: sys.exit(1)
+if n_orders <= 2000000 and rank == 0:
     from helpers import sql_q3
-    t = {k: e.download(k) for k in datagen.Q3_COLUMNS}
-    flat = {list(v.keys())[0][1:]: list(v.values())[0] for v in out["results"].values()}
-    print("matches numpy SQL evaluation:", flat == sql_q3(t))
-plan.set_profiling(True)
-out = plan.run()
-top = sorted(out["timings"].items(), key=lambda kv: -kv[1])[:12]
-print("total profiled us", sum(out["timings"].values()))
-for k, v in top: print("  ", k, v)
+    ok = flat == sql_q3(datagen.q3_tables(n_orders))
+    print("matches numpy SQL evaluation:", ok)
+    if not ok: sys.exit(1)
+if world == 1:
+    plan.set_profiling(True)
+    out = plan.run()
+    top = sorted(out["timings"].items(), key=lambda kv: -kv[1])[:12]
+    print("total profiled us", sum(out["timings"].values()))
+    for k, v in top: print("  ", k, v)
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()
+e.close()
