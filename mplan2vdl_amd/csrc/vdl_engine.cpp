@@ -165,15 +165,20 @@ struct vdl_plan {
     bool slot_pending[2] = {false, false};
     int64_t scan_rows = 0, scan_bytes = 0;
     double scan_usec = 0;
-    hipEvent_t ev0[2] = {nullptr, nullptr}, ev1[2] = {nullptr, nullptr};   // profiling events, alternating per run
-    bool ev_pending[2] = {false, false};
+    static constexpr int kEvRing = 4;   // runs in flight before their timing is read (pipelined callers: up to 3)
+    hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};   // profiling events, one pair per run, ring
+    bool ev_pending[kEvRing] = {}, ev_bound[kEvRing] = {};
+    uint64_t ev_seq[kEvRing] = {};
     unsigned run_seq = 0;
     int last_ev = 0;
+    const void *ev_buf[kEvRing] = {};   // partial-word buffer each event pair's run wrote (pipelined callers finalise out of order)
     int slot_ev_idx[2] = {-1, -1};
     ~vdl_plan() {
         for (int k = 0; k < 2; k++) {
             if (ev0[k]) (void)hipEventDestroy(ev0[k]);
             if (ev1[k]) (void)hipEventDestroy(ev1[k]);
+            if (ev0[k + 2]) (void)hipEventDestroy(ev0[k + 2]);
+            if (ev1[k + 2]) (void)hipEventDestroy(ev1[k + 2]);
             if (slot_ev[k]) (void)hipEventDestroy(slot_ev[k]);
             if (host_words[k]) (void)hipHostFree(host_words[k]);
         }
@@ -368,10 +373,13 @@ void run_fused_local(vdl_ctx *c, vdl_plan *p, int64_t *dev_words, bool single_ra
         bind_fused(c, p);
         p->bound_version = c->catalog_version;
     }
-    const int ei = (int)(p->run_seq++ & 1u);
+    const int ei = (int)(p->run_seq++ % (unsigned)vdl_plan::kEvRing);
     if (p->profiling && !p->ev0[ei]) { HIP_CHECK(hipEventCreate(&p->ev0[ei])); HIP_CHECK(hipEventCreate(&p->ev1[ei])); }
     p->ev_pending[ei] = false;
+    p->ev_bound[ei] = false;
+    p->ev_seq[ei] = p->run_seq;
     p->last_ev = ei;
+    p->ev_buf[ei] = dev_words;
     const size_t ns = p->fused.scans.size(), ng = p->fused.gscans.size();
     for (size_t s = 0; s < ns + ng; s++) {
         const bool grouped = s >= ns;
@@ -418,7 +426,11 @@ void finalize_begin(vdl_ctx *c, vdl_plan *p, const int64_t *dev_words, int slot)
     if (p->n_words) HIP_CHECK(hipMemcpyAsync(p->host_words[slot], dev_words, sizeof(int64_t) * (size_t)p->n_words, hipMemcpyDeviceToHost, c->stream));
     HIP_CHECK(hipEventRecord(p->slot_ev[slot], c->stream));
     p->slot_pending[slot] = true;
-    p->slot_ev_idx[slot] = p->ev_pending[p->last_ev] ? p->last_ev : -1;
+    int ei = -1;
+    for (int k = 0; k < vdl_plan::kEvRing; k++)      // the oldest run into this buffer whose timing nobody has claimed
+        if (p->ev_pending[k] && !p->ev_bound[k] && p->ev_buf[k] == (const void *)dev_words && (ei < 0 || p->ev_seq[k] < p->ev_seq[ei])) ei = k;
+    if (ei >= 0) p->ev_bound[ei] = true;
+    p->slot_ev_idx[slot] = ei;
 }
 
 void finalize_end(vdl_ctx *c, vdl_plan *p, int slot) {

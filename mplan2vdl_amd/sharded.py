@@ -76,26 +76,61 @@ class ShardedQuery:
         self._merge(self.buf)
         return self.runner.finalize(self.buf.data_ptr())
 
-    def run_pipelined(self, steps, bufs, on_result=None):
+    def _merge_is_one_collective(self):
+        classes = set(self.ops)
+        return (self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size(self.group) > 1
+                and len(classes) == 1 and _lib.REDUCE_FIRST not in classes)
+
+    def run_pipelined(self, steps, bufs, on_result=None, overlap_merge=True):
         """`steps` queries back to back with the host side of query k overlapped with the kernels of
         query k+1 (two partial buffers / finalisation slots).  Every query still runs in full and
-        every result is produced; returns the last one."""
+        every result is produced; returns the last one.
+
+        When the merge is a single all-reduce (Q6: two SUM words) and `overlap_merge` is set, it is issued
+        asynchronously: RCCL runs it on its own stream behind the scan of query k while the engine's stream
+        goes on with the scan of query k+1, and the stream only waits for it just before query k is
+        finalised -- the collective's latency (what bounds 8-GPU scaling) is hidden."""
         if len(bufs) != 2:
             raise ValueError("run_pipelined needs two partial buffers")
         out = None
+
+        def emit(slot):
+            res = self.runner.finalize_end(slot)
+            if on_result is not None:
+                on_result(res)
+            return res
+
+        if overlap_merge and self._merge_is_one_collective():
+            op = {_lib.REDUCE_SUM: self.dist.ReduceOp.SUM, _lib.REDUCE_MIN: self.dist.ReduceOp.MIN,
+                  _lib.REDUCE_MAX: self.dist.ReduceOp.MAX}[self.ops[0]]
+            work = [None, None]
+            for k in range(steps):
+                s = k & 1
+                self.runner.run_local(bufs[s].data_ptr())
+                work[s] = self.dist.all_reduce(bufs[s][: self.n_words], op=op, group=self.group, async_op=True)
+                if k >= 1:
+                    work[1 - s].wait()                       # stream-side wait; query k's scan is already queued
+                    self.runner.finalize_begin(bufs[1 - s].data_ptr(), 1 - s)
+                if k >= 2:
+                    out = emit(s)                            # query k-2
+            if steps >= 2:
+                out = emit(steps & 1)                        # query steps-2
+            if steps >= 1:
+                last = (steps - 1) & 1
+                work[last].wait()
+                self.runner.finalize_begin(bufs[last].data_ptr(), last)
+                out = emit(last)
+            return out
+
         for k in range(steps):
             s = k & 1
             self.runner.run_local(bufs[s].data_ptr())
             self._merge(bufs[s])
             self.runner.finalize_begin(bufs[s].data_ptr(), s)
             if k > 0:
-                out = self.runner.finalize_end(1 - s)
-                if on_result is not None:
-                    on_result(out)
+                out = emit(1 - s)
         if steps > 0:
-            out = self.runner.finalize_end((steps - 1) & 1)
-            if on_result is not None:
-                on_result(out)
+            out = emit((steps - 1) & 1)
         return out
 
 

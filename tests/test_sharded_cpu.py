@@ -48,6 +48,32 @@ class OracleShardRunner:
                 "timings": {}, "count": w[0]}
 
 
+class PipelinedSumRunner:
+    """CPU stand-in (TEST ONLY) for a Q6-shaped plan driven through run_pipelined: two SUM words, every
+    query adds its sequence number so that a mixed-up buffer or slot shows."""
+
+    def __init__(self, lo, hi):
+        cols = {c: datagen.generate(datagen.LINEITEM[c], lo, hi - lo) for c in datagen.Q6_COLUMNS}
+        import oracle
+
+        self.rev, self.cnt = oracle.sql_q6(*[cols[c] for c in datagen.Q6_COLUMNS])
+        self.bufs, self.seq, self.slots, self.log = {}, 0, {}, []
+
+    def partial_spec(self):
+        return 2, [_lib.REDUCE_SUM, _lib.REDUCE_SUM]
+
+    def run_local(self, ptr):
+        self.bufs[ptr][:2] = torch.tensor([self.cnt, self.rev + self.seq], dtype=torch.int64)
+        self.seq += 1
+
+    def finalize_begin(self, ptr, slot):
+        assert slot not in self.slots, "slot reused before it was read"
+        self.slots[slot] = [int(x) for x in self.bufs[ptr][:2]]
+
+    def finalize_end(self, slot):
+        return self.slots.pop(slot)
+
+
 def _worker(rank, world, port, n, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -60,6 +86,18 @@ def _worker(rank, world, port, n, q):
     out = None
     for _ in range(2):
         out = query.step()
+    # pipelined drive, merge overlapped with the next query and not: every query's own answer, in order
+    pr = PipelinedSumRunner(lo, hi)
+    bufs = [torch.zeros(2, dtype=torch.int64), torch.zeros(2, dtype=torch.int64)]
+    pr.bufs = {b.data_ptr(): b for b in bufs}
+    pq = m.ShardedQuery(pr, bufs[0], dist)
+    out["pipelined"] = []
+    for overlap in (True, False):
+        for steps in (1, 2, 5):
+            got = []
+            pr.seq = 0
+            pq.run_pipelined(steps, bufs, got.append, overlap_merge=overlap)
+            out["pipelined"].append(got)
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -82,6 +120,11 @@ def test_two_rank_gloo_merge_equals_single_rank():
     want = {"tmp42": {".revenue": [single.rev]}, "tmpX": {".max": [single.mx]}, "tmpY": {".min": [single.mn]}}
     assert outs[0]["results"] == want and outs[1]["results"] == want
     assert outs[0]["count"] == single.cnt
+    want = []
+    for _ in (True, False):
+        for steps in (1, 2, 5):
+            want.append([[single.cnt, single.rev + 2 * k] for k in range(steps)])      # both ranks add k
+    assert outs[0]["pipelined"] == want and outs[1]["pipelined"] == want
 
 
 def test_merge_partials_mixed_ops_single_process():
