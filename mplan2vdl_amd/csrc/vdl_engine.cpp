@@ -722,6 +722,16 @@ struct GenExec {
         case Op::Materialize:
             materialize(n, V(n.a));
             return V(n.a);
+        case Op::Like: {
+            DVec d = densify(V(n.a)), heap = densify(V(n.b));
+            LikePattern pat{};
+            pat.len = (int)n.pattern.size();
+            memcpy(pat.p, n.pattern.data(), n.pattern.size());
+            o.kind = DVec::DENSE; o.n = d.n; o.valid = d.valid;
+            o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(d.n, 1));
+            HIP_CHECK(launch_like(src_of(d), vp(d), d.n, src_of(heap), vp(heap), heap.n, pat, (int64_t *)o.data->p, s));
+            return o;
+        }
         }
         return o;
     }
@@ -878,6 +888,11 @@ ExchangeSpec analyse_exchange(const Program &P, const std::string &table = std::
             case Op::Load: out = n.column.compare(0, table.size() + 1, table + ".") == 0 ? V : R; break;
             case Op::RangeC: break;
             case Op::Project: case Op::Shuffle: case Op::Materialize: out = C(n.a); break;
+            case Op::Like:
+                if (C(n.b) != R) { x.why = "Like over a sharded string heap" + at; return x; }
+                if (C(n.a) == N) { x.why = "Like on row numbers" + at; return x; }
+                out = C(n.a);
+                break;
             case Op::Binary:
                 if (C(n.a) == N || C(n.b) == N) { x.why = "arithmetic on row numbers of the sharded table, which are rank-local" + at; return x; }
                 out = (C(n.a) == V || C(n.b) == V) ? V : R;

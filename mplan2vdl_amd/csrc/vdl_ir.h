@@ -10,7 +10,7 @@ namespace vdl {
 
 enum class Op : int {
     Load, Project, RangeV, RangeC, Binary, FoldSelect, FoldSum, FoldMin, FoldMax, FoldChoose,
-    FoldCount, Gather, Scatter, Partition, Shuffle, Materialize
+    FoldCount, Gather, Scatter, Partition, Shuffle, Materialize, Like
 };
 
 // element-wise binary operators, /root/reference/src/Vdl.hs:110-122
@@ -27,6 +27,7 @@ struct Node {
     int a = -1, b = -1, c = -1;  // operand ids in print order
     int64_t imm0 = 0, imm1 = 0, imm2 = 0;  // RangeV: from, step; RangeC: from, count, step
     std::string column;          // Load: key path
+    std::string pattern;         // Like: SQL LIKE pattern ('%', '_'), no escape character
     std::string field;           // struct field this vector's data lives in after the op
     int line = 0;
 };

@@ -138,6 +138,10 @@ hipError_t launch_fold_segmented(int kind, Src ctl, const uint64_t *vc, Src d, c
 // ---- row exchange for sharded Partition (see vdl_kernels.hip) -------------------------------------
 constexpr int kMaxExSources = 62;
 struct ExValid { int n = 0; const uint64_t *valid[kMaxExSources] = {}; };
+// Like (Vdl.hs:444-447): out[i] = string at byte offset data[i] of `heap` matches the SQL LIKE pattern
+struct LikePattern { unsigned char p[256]; int len; };
+hipError_t launch_like(Src data, const uint64_t *vdata, int64_t n, Src heap, const uint64_t *vheap, int64_t heap_n, const LikePattern &pat,
+                       int64_t *out, hipStream_t s);
 hipError_t launch_ex_dest(Src key, const uint64_t *vkey, int64_t n, int64_t pmin, int64_t pcount, int world, int64_t *dest,
                           uint64_t *vdest, int64_t *counts /* world, pre-zeroed */, int64_t *oob /* pre-zeroed */, hipStream_t s);
 hipError_t launch_ex_pack(Src src, const uint64_t *vdest, const int64_t *pos, int64_t n, int64_t *out, hipStream_t s);

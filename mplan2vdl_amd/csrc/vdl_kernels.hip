@@ -1122,6 +1122,49 @@ hipError_t launch_fold_segmented(int kind, Src ctl, const uint64_t *vc, Src d, c
 
 
 // ------------------------------------------------------------------------------------------
+// Like (/root/reference/src/Vdl.hs:244-247,444-447): data = byte offsets into the column's string
+// heap (one byte per slot, strings end at a 0 byte); SQL LIKE with '%' and '_', no escape.  One
+// lane per row walks its string (dictionary-like heaps are a few KB and stay in L1/L2); greedy
+// match with backtracking to the last '%'.  The pattern travels by value (SGPR/constant reads).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_like(Src data, const uint64_t *vdata, int64_t n, Src heap, const uint64_t *vheap, int64_t heap_n,
+                                              const LikePattern pat, int64_t *out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int plen = pat.len;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (!bit(vdata, i)) { out[i] = 0; continue; }
+        const int64_t off = ld(data, i);
+        int64_t r = 0;
+        if (off >= 0 && off < heap_n) {
+            int64_t si = off, mark = 0;
+            int pi = 0, star = -1;
+            bool dead = false;
+            for (;;) {
+                const int ch = (si < heap_n && bit(vheap, si)) ? (int)(ld(heap, si) & 0xff) : 0;
+                if (!ch) break;
+                const int pc = pi < plen ? (int)pat.p[pi] : -1;
+                if (pc == '%') { star = pi++; mark = si; }
+                else if (pc == '_' || pc == ch) { si++; pi++; }
+                else if (star >= 0) { pi = star + 1; si = ++mark; }
+                else { dead = true; break; }
+            }
+            if (!dead) {
+                while (pi < plen && pat.p[pi] == '%') pi++;
+                r = pi == plen;
+            }
+        }
+        out[i] = r;
+    }
+}
+hipError_t launch_like(Src data, const uint64_t *vdata, int64_t n, Src heap, const uint64_t *vheap, int64_t heap_n, const LikePattern &pat,
+                       int64_t *out, hipStream_t s) {
+    (void)hipGetLastError();
+    if (n <= 0) return hipSuccess;
+    k_like<<<grid_for(n, 256, 1), 256, 0, s>>>(data, vdata, n, heap, vheap, heap_n, pat, out);
+    return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
 // Row exchange for sharded Partition (Partition / join redistribution over
 // xGMI).  Each rank sends every row of the partition key and of the vectors scattered by it to the
 // rank that owns the row's key range; afterwards Partition / Scatter / Fold run locally on the

@@ -31,6 +31,7 @@ const char *op_name(Op op, int bin) {
     case Op::Partition: return "Partition";
     case Op::Shuffle: return "Shuffle";
     case Op::Materialize: return "MaterializeCompact";
+    case Op::Like: return "Like";
     }
     return "?";
 }
@@ -173,7 +174,19 @@ Program parse_program(const char *text, size_t len) {
             n.op = Op::Materialize;
             n.a = to_ref(f[2], lineno);
             n.field = use(n.a, lineno).field;
-        } else if (op == "Like" || op == "CrossProductOuter" || op == "CrossProductInner" || op == "Semisort") {
+        } else if (op == "Like") {                // Like,val,Id data,val,Id dict,val,<pattern>  (Vdl.hs:444-447)
+            if (f.size() < 8) bad(VDL_ERR_PARSE, lineno, "Like expects 8 fields, got " + std::to_string(f.size()));
+            n.op = Op::Like;
+            n.a = to_ref(f[3], lineno);
+            n.b = to_ref(f[5], lineno);
+            need_field(use(n.a, lineno), f[4], lineno, "Like");
+            need_field(use(n.b, lineno), f[6], lineno, "Like");
+            size_t at = 0;                        // the pattern is everything after the 7th comma, commas included
+            for (int k = 0; k < 7; k++) at = s.find(',', at) + 1;
+            n.pattern = s.substr(at);
+            if (n.pattern.size() > 255) bad(VDL_ERR_UNSUPPORTED, lineno, "Like: pattern longer than 255 bytes");
+            n.field = f[2];
+        } else if (op == "CrossProductOuter" || op == "CrossProductInner" || op == "Semisort") {
             bad(VDL_ERR_UNSUPPORTED, lineno, "operator '" + op + "' is not implemented (SURVEY.md section 8(f))");
         } else {
             // <BinOp|Fold|Partition>,val,Id a,val,Id b,val  (Vdl.hs:436-439)

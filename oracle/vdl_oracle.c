@@ -392,6 +392,39 @@ static int op_partition(orc_ctx *c, ovec *out, const ovec *data, const ovec *piv
 
 /* MaterializeCompact v (/root/reference/src/Vdl.hs:41,271-292,452-453): a query output;
  * drops EPS, keeps slot order; named by the operand's field (resolve.py:55-78). */
+/* Like data dict pattern (/root/reference/src/Vdl.hs:39,244-247,444-447; Vlite.hs:113,296,1010-1014;
+ * Mplan.hs:398-417,528-545).  `data` holds byte offsets into the string heap `dict` (the column's
+ * "<table>.<col>.heap" vector, one byte per slot; MonetDB stores var-sized strings this way and the
+ * codes of dictionary.csv are such offsets); the string runs to the next 0 byte or the end of the heap.
+ * SQL LIKE without escape character (Mplan.hs:541-542 requires the empty escape): '%' = any run of bytes,
+ * '_' = any one byte, everything else literal, case-sensitive.  Result 0/1 (Vlite.hs:296 bounds (0,1));
+ * EPS where data is EPS; an offset outside the heap matches nothing. */
+static int like_match(const ovec *heap, int64_t off, const char *pat) {
+    if (off < 0 || off >= heap->n) return 0;
+    const int64_t plen = (int64_t)strlen(pat);
+    int64_t si = off, pi = 0, star = -1, mark = 0;
+    for (;;) {
+        const int ch = (si < heap->n && slot_ok(heap, si)) ? (int)(slot_val(heap, si) & 0xff) : 0;
+        if (!ch) break;
+        if (pi < plen && pat[pi] == '%') { star = pi++; mark = si; }
+        else if (pi < plen && (pat[pi] == '_' || (unsigned char)pat[pi] == ch)) { si++; pi++; }
+        else if (star >= 0) { pi = star + 1; si = ++mark; }
+        else return 0;
+    }
+    while (pi < plen && pat[pi] == '%') pi++;
+    return pi == plen;
+}
+
+static int op_like(orc_ctx *c, ovec *out, const ovec *data, const ovec *heap, const char *pat) {
+    if (alloc_vec(c, out, data->n, data->ok != NULL)) return -1;
+    for (int64_t i = 0; i < data->n; i++) {
+        if (!slot_ok(data, i)) { out->ok[i] = 0; out->val[i] = 0; continue; }
+        if (out->ok) out->ok[i] = 1;
+        out->val[i] = like_match(heap, slot_val(data, i), pat);
+    }
+    return 0;
+}
+
 static int op_materialize(orc_ctx *c, int id, const ovec *v) {
     if (c->nouts == c->capouts) {
         c->capouts = c->capouts ? 2 * c->capouts : 8;
@@ -464,7 +497,7 @@ static int exec_line(orc_ctx *c, char *line, int lineno) {
     char *s = line; while (*s && isspace((unsigned char)*s)) s++;
     if (!*s) return 0;
     char *f[MAXF + 1]; memset(f, 0, sizeof f);
-    int nf = split_fields(s, f, MAXF, 0);
+    int nf = split_fields(s, f, MAXF, MAXF);        /* an 8th field (Like's pattern) keeps its commas */
     int64_t id64;
     if (nf < 2 || parse_int(f[0], &id64) || id64 <= 0 || id64 > (1 << 24)) return fail(c, "line %d: bad id", lineno);
     int id = (int)id64;
@@ -510,6 +543,13 @@ static int exec_line(orc_ctx *c, char *line, int lineno) {
         /* Shuffle v (/root/reference/src/Vdl.hs:40,449-450; Vlite.hs:294): value identity. */
         NEED(3); if (parse_ref(f[2], &a) || !(va = get_vec(c, a))) return c->err[0] ? -1 : fail(c, "line %d: bad operand", lineno);
         out = *va; out.owns = 0; rc = 0;
+    } else if (!strcmp(op, "Like")) {
+        /* Like,val,Id data,val,Id dict,val,<pattern>  (Vdl.hs:444-447) */
+        NEED(8); if (parse_ref(f[3], &a) || parse_ref(f[5], &b)) return fail(c, "line %d: bad operands for Like", lineno);
+        if (!(va = get_vec(c, a)) || !(vb = get_vec(c, b))) return -1;
+        if (need_field(c, va, f[4], op) || need_field(c, vb, f[6], op)) return -1;
+        rc = op_like(c, &out, va, vb, f[7]);
+        if (!rc) snprintf(out.field, sizeof out.field, "%s", f[2]);
     } else if (!strcmp(op, "MaterializeCompact")) {
         NEED(3); if (parse_ref(f[2], &a) || !(va = get_vec(c, a))) return c->err[0] ? -1 : fail(c, "line %d: bad operand", lineno);
         if (op_materialize(c, id, va)) return -1;

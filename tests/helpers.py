@@ -57,3 +57,28 @@ def sql_q3(t):
     return {"l_orderkey__lineitem__l_orderkey": [int(x) for x in l_key[fr]], "revenue": [int(x) for x in rev],
             "o_orderdate__orders__o_orderdate": [int(x) for x in o_date[l_ord[fr]]],
             "o_shippriority__orders__o_shippriority": [int(x) for x in o_prio[l_ord[fr]]]}
+
+
+def make_heap(strings, base=16, align=8):
+    """MonetDB-style string heap: NUL-terminated strings at `align`-byte aligned offsets starting at
+    `base` (the codes of the reference's dictionary.csv are such offsets: 'BUILDING' -> 16).
+    Returns (heap as int8 array, {string: offset})."""
+    buf = bytearray(base)
+    where = {}
+    for s in strings:
+        if s in where:
+            continue
+        while len(buf) % align:
+            buf.append(0)
+        where[s] = len(buf)
+        buf += s.encode() + b"\0"
+    return np.frombuffer(bytes(buf), dtype=np.int8).copy(), where
+
+
+def sql_like(s, pattern):
+    """SQL LIKE ('%', '_', no escape) through a regular expression: an independent statement of the
+    semantics oracle/vdl_oracle.c:like_match implements."""
+    import re
+
+    rx = "".join(".*" if ch == "%" else "." if ch == "_" else re.escape(ch) for ch in pattern)
+    return 1 if re.fullmatch(rx, s, flags=re.S) else 0

@@ -59,12 +59,11 @@ def test_every_emitted_program_parses_in_the_engine(cfg):
     from mplan2vdl_amd import _lib
 
     e = m.Engine(device=None)
-    for n in (1, 3, 4, 5, 6, 10, 11, 12, 15, 18, 19):
+    for n in (1, 3, 4, 5, 6, 9, 10, 11, 12, 14, 15, 16, 18, 19, 20):      # 9, 14, 16, 20 carry LIKE predicates
         assert e.parse(compile_q(cfg, n)).describe()
-    for n in (9, 14, 16, 20):                                 # LIKE predicates: SURVEY.md section 8(f), not implemented
-        with pytest.raises(m.VdlError) as ei:
-            e.parse(compile_q(cfg, n))
-        assert ei.value.code == _lib.VDL_ERR_UNSUPPORTED
+    with pytest.raises(m.VdlError) as ei:                     # the --crossproduct dialect is not implemented
+        e.parse("1,RangeC,val,0,4,1\n2,CrossProductOuter,val,Id 1,val,Id 1,val\n")
+    assert ei.value.code == _lib.VDL_ERR_UNSUPPORTED
 
 
 def test_metadata_suffix_and_flags(cfg):

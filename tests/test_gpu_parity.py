@@ -573,3 +573,28 @@ def test_exchange_grouped_folds_with_holes_match_oracle(world):
         shards.append({name: v[r0:r1] for name, v in cols.items()})
     got, _ = _emulated_exchange(text, shards, "t")
     assert got == want
+
+
+@pytest.mark.parametrize("pattern", ["PROMO%", "%special%requests%", "%green%", "%", "", "_%_", "%abcabd", "x,y,%", "a%b_c"])
+def test_like_over_a_string_heap_matches_oracle(pattern):
+    """Like (Vdl.hs:444-447): byte offsets into the column's heap, SQL LIKE on the GPU, EPS rows kept."""
+    from helpers import make_heap
+    from test_oracle import LIKE_WORDS
+
+    heap, where = make_heap(LIKE_WORDS)
+    rng = np.random.default_rng(5)
+    n = 20000
+    offs = np.array([where[LIKE_WORDS[k]] for k in rng.integers(0, len(LIKE_WORDS), n)], dtype=np.int64)
+    offs[::97] = -1
+    offs[5::101] = len(heap) + 3
+    offs[7::89] += 1                                                       # mid-string offsets
+    cols = {"t.s": offs, "t.s.heap": heap, "t.f": rng.integers(0, 4, n).astype(np.int64)}
+    text = prog("1,Load,t.s", "2,Project,val,Id 1,s", "3,Load,t.s.heap", "4,Project,val,Id 3,s.heap",
+                "5,Load,t.f", "6,Project,val,Id 5,f", "7,RangeV,val,0,Id 6,1", "8,FoldSelect,val,Id 7,val,Id 6,val",
+                "9,Gather,Id 2,Id 8,val", "10,Like,val,Id 9,val,Id 4,val," + pattern,
+                "11,RangeV,val,0,Id 10,0", "12,FoldSum,val,Id 11,val,Id 10,val", "13,MaterializeCompact,Id 12",
+                "14,MaterializeCompact,Id 10")
+    want = oracle_run(text, cols)
+    e = engine_with(cols)
+    assert e.run_vdl(text)["results"] == want
+    e.close()

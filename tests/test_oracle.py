@@ -163,3 +163,42 @@ def test_q3_interpreter_equals_sql_evaluation(n_orders):
     got = oracle_run(golden("q3.vdl"), t)
     flat = {list(v.keys())[0][1:]: list(v.values())[0] for v in got.values()}
     assert flat == sql_q3(t)
+
+
+LIKE_WORDS = ["PROMO BRUSHED TIN", "STANDARD POLISHED COPPER", "MEDIUM POLISHED STEEL", "PROMO", "", "a", "ab", "aab", "a%b_c",
+              "special requests", "the special packages wake requests", "forest green", "green", "Customer Complaints",
+              "Customer xx Complaints yy", "abcabcabd", "x,y,z"]
+LIKE_PATTERNS = ["PROMO%", "%special%requests%", "%green%", "forest%", "%Customer%Complaints%", "MEDIUM POLISHED%", "%", "", "_", "a_",
+                 "%b", "a%", "%abcabd", "%abd%", "_%_", "%%a%%", "PROMO", "x,y,%", "%,z", "a%b_c", "a_b_c"]
+
+
+def like_program(pattern):
+    return prog("1,Load,t.s", "2,Project,val,Id 1,s", "3,Load,t.s.heap", "4,Project,val,Id 3,s.heap",
+                "5,Like,val,Id 2,val,Id 4,val," + pattern, "6,MaterializeCompact,Id 5")
+
+
+@pytest.mark.parametrize("pattern", LIKE_PATTERNS)
+def test_like_matches_regex_statement_of_sql_like(pattern):
+    """Like over a string heap (Vdl.hs:444-447): the oracle against a regular-expression restatement."""
+    from helpers import make_heap, sql_like
+
+    heap, where = make_heap(LIKE_WORDS)
+    rng = np.random.default_rng(3)
+    words = [LIKE_WORDS[k] for k in rng.integers(0, len(LIKE_WORDS), 200)]
+    cols = {"t.s": np.array([where[w] for w in words], dtype=np.int64), "t.s.heap": heap}
+    got = oracle_run(like_program(pattern), cols)
+    assert list(got.values())[0][".val"] == [sql_like(w, pattern) for w in words]
+
+
+def test_like_offsets_outside_the_heap_and_holes():
+    from helpers import make_heap
+
+    heap, where = make_heap(["abc", "abd"])
+    cols = {"t.s": np.array([where["abc"], -5, len(heap), len(heap) + 7, where["abd"], where["abc"] + 1], dtype=np.int64),
+            "t.s.heap": heap, "t.f": np.array([1, 1, 1, 1, 0, 1], dtype=np.int64)}
+    text = prog("1,Load,t.s", "2,Project,val,Id 1,s", "3,Load,t.s.heap", "4,Project,val,Id 3,s.heap",
+                "5,Load,t.f", "6,Project,val,Id 5,f", "7,RangeV,val,0,Id 6,1", "8,FoldSelect,val,Id 7,val,Id 6,val",
+                "9,Gather,Id 2,Id 8,val",                                   # row 4 becomes EPS
+                "10,Like,val,Id 9,val,Id 4,val,%c", "11,MaterializeCompact,Id 10")
+    got = oracle_run(text, cols)
+    assert list(got.values())[0][".val"] == [1, 0, 0, 0, 1]               # "abc", out of heap x3, (hole dropped), "bc"
