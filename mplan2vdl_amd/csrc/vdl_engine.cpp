@@ -722,6 +722,15 @@ struct GenExec {
         case Op::Materialize:
             materialize(n, V(n.a));
             return V(n.a);
+        case Op::Cross: {
+            const int64_t m = V(n.a).n, k = V(n.b).n;
+            if (k > 0 && m > ((int64_t)1 << 40) / k)
+                throw Error(VDL_ERR_NOMEM, "CrossProduct (Id " + std::to_string(n.id) + "): " + std::to_string(m) + " x " + std::to_string(k) + " slots");
+            o.kind = DVec::DENSE; o.n = m * k;
+            o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(o.n, 1));
+            HIP_CHECK(launch_cross(o.n, k, n.bin, (int64_t *)o.data->p, s));
+            return o;
+        }
         case Op::Like: {
             DVec d = densify(V(n.a)), heap = densify(V(n.b));
             LikePattern pat{};

@@ -10,7 +10,7 @@ namespace vdl {
 
 enum class Op : int {
     Load, Project, RangeV, RangeC, Binary, FoldSelect, FoldSum, FoldMin, FoldMax, FoldChoose,
-    FoldCount, Gather, Scatter, Partition, Shuffle, Materialize, Like
+    FoldCount, Gather, Scatter, Partition, Shuffle, Materialize, Like, Cross
 };
 
 // element-wise binary operators, /root/reference/src/Vdl.hs:110-122

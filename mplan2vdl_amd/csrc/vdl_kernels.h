@@ -138,6 +138,8 @@ hipError_t launch_fold_segmented(int kind, Src ctl, const uint64_t *vc, Src d, c
 // ---- row exchange for sharded Partition (see vdl_kernels.hip) -------------------------------------
 constexpr int kMaxExSources = 62;
 struct ExValid { int n = 0; const uint64_t *valid[kMaxExSources] = {}; };
+// CrossProductOuter / Inner (Vdl.hs:412-416; Vlite.hs:278-289): positions i / k and i % k over n = m * k slots
+hipError_t launch_cross(int64_t n, int64_t k, int inner, int64_t *out, hipStream_t s);
 // Like (Vdl.hs:444-447): out[i] = string at byte offset data[i] of `heap` matches the SQL LIKE pattern
 struct LikePattern { unsigned char p[256]; int len; };
 hipError_t launch_like(Src data, const uint64_t *vdata, int64_t n, Src heap, const uint64_t *vheap, int64_t heap_n, const LikePattern &pat,

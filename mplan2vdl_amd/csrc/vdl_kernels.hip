@@ -1122,6 +1122,23 @@ hipError_t launch_fold_segmented(int kind, Src ctl, const uint64_t *vc, Src d, c
 
 
 // ------------------------------------------------------------------------------------------
+// CrossProductOuter / CrossProductInner (/root/reference/src/Vdl.hs:412-416, Vlite.hs:89-95,278-289;
+// emitted for joins only under --crossproduct, Mplan.hs / Vlite.hs:671-680): for left of m slots and
+// right of k slots, m*k slots holding the left position i / k (outer) or the right position i % k
+// (inner); only the operand lengths matter, so no slot is ever EPS.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cross(int64_t n, int64_t k, int inner, int64_t *out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = inner ? i % k : i / k;
+}
+hipError_t launch_cross(int64_t n, int64_t k, int inner, int64_t *out, hipStream_t s) {
+    (void)hipGetLastError();
+    if (n <= 0) return hipSuccess;
+    k_cross<<<grid_for(n, 256, 4), 256, 0, s>>>(n, k, inner, out);
+    return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
 // Like (/root/reference/src/Vdl.hs:244-247,444-447): data = byte offsets into the column's string
 // heap (one byte per slot, strings end at a 0 byte); SQL LIKE with '%' and '_', no escape.  One
 // lane per row walks its string (dictionary-like heaps are a few KB and stay in L1/L2); greedy

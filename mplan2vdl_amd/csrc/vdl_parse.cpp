@@ -32,6 +32,7 @@ const char *op_name(Op op, int bin) {
     case Op::Shuffle: return "Shuffle";
     case Op::Materialize: return "MaterializeCompact";
     case Op::Like: return "Like";
+    case Op::Cross: return bin ? "CrossProductInner" : "CrossProductOuter";
     }
     return "?";
 }
@@ -186,7 +187,15 @@ Program parse_program(const char *text, size_t len) {
             n.pattern = s.substr(at);
             if (n.pattern.size() > 255) bad(VDL_ERR_UNSUPPORTED, lineno, "Like: pattern longer than 255 bytes");
             n.field = f[2];
-        } else if (op == "CrossProductOuter" || op == "CrossProductInner" || op == "Semisort") {
+        } else if (op == "CrossProductOuter" || op == "CrossProductInner") {   // <op>,Id left,Id right  (Vdl.hs:412-416)
+            arity(4);
+            n.op = Op::Cross;
+            n.bin = op == "CrossProductInner" ? 1 : 0;
+            n.a = to_ref(f[2], lineno);
+            n.b = to_ref(f[3], lineno);
+            use(n.a, lineno); use(n.b, lineno);
+            n.field = "val";
+        } else if (op == "Semisort") {
             bad(VDL_ERR_UNSUPPORTED, lineno, "operator '" + op + "' is not implemented (SURVEY.md section 8(f))");
         } else {
             // <BinOp|Fold|Partition>,val,Id a,val,Id b,val  (Vdl.hs:436-439)

@@ -543,6 +543,15 @@ static int exec_line(orc_ctx *c, char *line, int lineno) {
         /* Shuffle v (/root/reference/src/Vdl.hs:40,449-450; Vlite.hs:294): value identity. */
         NEED(3); if (parse_ref(f[2], &a) || !(va = get_vec(c, a))) return c->err[0] ? -1 : fail(c, "line %d: bad operand", lineno);
         out = *va; out.owns = 0; rc = 0;
+    } else if (!strcmp(op, "CrossProductOuter") || !strcmp(op, "CrossProductInner")) {
+        /* <op>,Id left,Id right (Vdl.hs:412-416).  Vlite.hs:278-289: "0,1,2,3 X 0,1 = 0,0,1,1,2,2,3,3 (outer)
+         * 0,1,0,1,0,1,0,1 (inner)": positions into left / right over len(left)*len(right) slots, never EPS. */
+        NEED(4); if (parse_ref(f[2], &a) || parse_ref(f[3], &b)) return fail(c, "line %d: bad operands for %s", lineno, op);
+        if (!(va = get_vec(c, a)) || !(vb = get_vec(c, b))) return -1;
+        if (vb->n > 0 && va->n > ((int64_t)1 << 24) / vb->n) return fail(c, "line %d: cross product of %lld x %lld slots", lineno, (long long)va->n, (long long)vb->n);
+        if (alloc_vec(c, &out, va->n * vb->n, 0)) return -1;
+        for (int64_t i = 0; i < out.n; i++) out.val[i] = op[12] == 'I' ? i % vb->n : i / vb->n;
+        rc = 0;
     } else if (!strcmp(op, "Like")) {
         /* Like,val,Id data,val,Id dict,val,<pattern>  (Vdl.hs:444-447) */
         NEED(8); if (parse_ref(f[3], &a) || parse_ref(f[5], &b)) return fail(c, "line %d: bad operands for Like", lineno);

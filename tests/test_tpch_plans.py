@@ -18,6 +18,11 @@ def cfg():
     return frontend.load_metadata(META)
 
 
+FLAG_SETS = {"hierarchical": {"aggregation_strategy": ("AggHierarchical", 5)}, "shuffle": {"aggregation_strategy": ("AggShuffle",)},
+             "crossproduct": {"cross_product": True}}
+CROSS_PLANS = [3, 11, 12, 14, 15, 16, 19, 20]          # the others multiply into more than 2^24 slots even at 600 lineitems
+
+
 def program_and_columns(cfg, n, scale, seed=1):
     text = frontend.compile_plan(open(os.path.join(META, "%02d.sql.mplan" % n)).read(), cfg)
     return text, catalog.synth_columns(META, cfg, text, scale=scale, seed=seed)
@@ -70,3 +75,31 @@ def test_engine_matches_oracle_on_every_compiled_plan(cfg, n, scale, seed):
     got = e.run_vdl(text)["results"]
     e.close()
     assert got == want
+
+
+def test_cross_product_lowering_agrees_with_join_index_lowering(cfg):
+    """--crossproduct (Vlite.hs:671-680) and the FK join-index lowering are two programs for the same SQL;
+    where the join is over an FK index they must select the same rows (Q15 joins on values, which the
+    synthetic catalog does not keep consistent with the indices, and is left out)."""
+    xcfg = frontend.load_metadata(META, cross_product=True)
+    for n in (3, 11, 12, 14, 16, 19, 20):
+        a_text, a_cols = program_and_columns(xcfg, n, 1e-5)
+        b_text, b_cols = program_and_columns(cfg, n, 1e-5)
+        assert "CrossProductOuter" in a_text and "CrossProduct" not in b_text
+        a, b = oracle_run(a_text, a_cols), oracle_run(b_text, b_cols)
+        assert [list(v.values())[0] for v in a.values()] == [list(v.values())[0] for v in b.values()], n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", sorted(FLAG_SETS))
+def test_engine_matches_oracle_under_compiler_flags(flags):
+    """AggHierarchical (two-level folds, Vlite.hs:1181-1192), AggShuffle (Shuffle before every Partition) and
+    --crossproduct (CrossProductOuter/Inner + filters instead of join-index gathers)."""
+    fcfg = frontend.load_metadata(META, **FLAG_SETS[flags])
+    for n in (CROSS_PLANS if flags == "crossproduct" else PLANS):
+        text, cols = program_and_columns(fcfg, n, 1e-5 if flags == "crossproduct" else 2e-4)
+        want = oracle_run(text, cols)
+        e = engine_with(cols)
+        got = e.run_vdl(text)["results"]
+        e.close()
+        assert got == want, (flags, n)
