@@ -160,3 +160,27 @@ def synth_columns(meta_dir, cfg, vdl_text, scale=2e-4, seed=1):
             vals = (rng.integers(a, b + 1, n, dtype=np.int64)) << tz
         out[path] = vals.astype(np.int32 if ci.stype == ("SInt32",) else np.int64)
     return out
+
+
+def export_columns(cols, directory):
+    """Writes {key path: array} as raw little-endian `<key path>.bin` files plus `columns.csv`
+    (name, bytes per element, rows): the layout `vdlrun --data DIR` and `load_columns` read."""
+    os.makedirs(directory, exist_ok=True)
+    with open(os.path.join(directory, "columns.csv"), "w") as fh:
+        for name in sorted(cols):
+            v = np.ascontiguousarray(cols[name])
+            v.astype(v.dtype.newbyteorder("<"), copy=False).tofile(os.path.join(directory, name + ".bin"))
+            fh.write("%s,%d,%d\n" % (name, v.dtype.itemsize, v.shape[0]))
+
+
+def load_columns(directory, names=None):
+    """{key path: array} from a directory written by export_columns (memory-mapped)."""
+    out = {}
+    with open(os.path.join(directory, "columns.csv")) as fh:
+        for line in fh:
+            name, width, rows = line.strip().split(",")
+            if names is not None and name not in names:
+                continue
+            dt = {1: np.int8, 2: np.int16, 4: np.int32, 8: np.int64}[int(width)]
+            out[name] = np.memmap(os.path.join(directory, name + ".bin"), dtype=dt, mode="r", shape=(int(rows),)) if int(rows) else np.zeros(0, dt)
+    return out
