@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvdl.so")
+LIB_PATH = os.environ.get("VDL_LIB") or os.path.join(_HERE, "lib", "libvdl.so")      # VDL_LIB: kernel experiments (tools/build_variant.sh)
 
 VDL_OK, VDL_ERR_PARSE, VDL_ERR_COLUMN, VDL_ERR_UNSUPPORTED, VDL_ERR_DEVICE, VDL_ERR_ARG, VDL_ERR_SHAPE, VDL_ERR_NOMEM = range(8)
 REDUCE_NONE, REDUCE_SUM, REDUCE_MIN, REDUCE_MAX, REDUCE_FIRST = range(5)

@@ -34,6 +34,18 @@ RowP mk_bin(int op, RowP l, RowP r) {
     auto p = std::make_shared<Row>(); p->k = Row::BIN; p->bin = op; p->l = std::move(l); p->r = std::move(r); return p;
 }
 
+
+// SUM of a constant k over the selected rows = k * (number of selected rows), and every scan already carries
+// that count as word 0 of its partials (count(*) lowers to FoldSum of ones, Vlite.hs:1044-1046): no aggregate
+// slot, no per-row work.  agg == -1 addresses the count word (eval_scalar is handed a pointer to word 1).
+static ScalarP count_times(int64_t k) {
+    auto cnt = std::make_shared<Scalar>(); cnt->k = Scalar::AGG; cnt->agg = -1;
+    if (k == 1) return cnt;
+    auto kk = std::make_shared<Scalar>(); kk->k = Scalar::CONST; kk->c = k;
+    auto m = std::make_shared<Scalar>(); m->k = Scalar::BIN; m->bin = B_MUL; m->l = cnt; m->r = kk;
+    return m;
+}
+
 struct Sym {
     //  RANGEC : RangeC from count step (pivots)
     //  PART   : Partition(ROW key, RangeC min cnt 1) -- positions that sort the selected rows by key
@@ -305,6 +317,10 @@ struct Builder {
                 int kind = n.op == Op::FoldMin ? AGG_MIN : n.op == Op::FoldMax ? AGG_MAX : n.op == Op::FoldChoose ? AGG_FIRST : AGG_SUM;
                 if (kind == AGG_FIRST && d.e->k != Row::COL) return out;
                 RowP data = n.op == Op::FoldCount ? mk_const(1) : d.e;
+                if (kind == AGG_SUM && data->k == Row::CONST) {
+                    out.kind = Sym::GFOLD; out.table = pt.table; out.sel = pt.sel; out.scan = g; out.sc = count_times(data->c0);
+                    return out;
+                }
                 int idx = -1;      // the emitter repeats folds (CSE keyed on metadata, Vdl.hs:302,314-320): share them
                 for (size_t i = 0; i < pg.data.size(); i++) if (pg.kind[i] == kind && row_equal(pg.data[i], data)) idx = (int)i;
                 if (idx < 0) { pg.data.push_back(data); pg.kind.push_back(kind); idx = (int)pg.data.size() - 1; }
@@ -320,6 +336,10 @@ struct Builder {
             PendingScan &ps = scans[(size_t)sc];
             int kind = n.op == Op::FoldMin ? AGG_MIN : n.op == Op::FoldMax ? AGG_MAX : AGG_SUM;
             RowP data = n.op == Op::FoldCount ? mk_const(1) : d.e;
+            if (kind == AGG_SUM && data->k == Row::CONST) {
+                out.kind = Sym::FOLD; out.table = d.table; out.sel = ctl.sel; out.scan = sc; out.sc = count_times(data->c0);
+                return out;
+            }
             int idx = -1;
             for (size_t i = 0; i < ps.data.size(); i++) if (ps.kind[i] == kind && row_equal(ps.data[i], data)) idx = (int)i;
             if (idx < 0) { ps.data.push_back(data); ps.kind.push_back(kind); idx = (int)ps.data.size() - 1; }
@@ -501,7 +521,7 @@ FusedPlan fuse_program(const Program &P) {
 
 static void show_scalar(const Scalar &s, std::ostringstream &o) {
     switch (s.k) {
-    case Scalar::AGG: o << "agg" << s.agg; break;
+    case Scalar::AGG: if (s.agg < 0) o << "count"; else o << "agg" << s.agg; break;
     case Scalar::CONST: o << s.c; break;
     default: o << kBinNames[s.bin] << "("; show_scalar(*s.l, o); o << ","; show_scalar(*s.r, o); o << ")"; break;
     }

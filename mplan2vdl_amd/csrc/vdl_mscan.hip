@@ -217,7 +217,7 @@ __device__ __forceinline__ void eval_term(const MAggDesc &d, const int64_t (&v)[
     }
 }
 
-// LDS use: global form (1 + nagg) * 256 lane slots; grouped form replicas * (pcount * (1 + nagg) | 1)
+// LDS use: global form (1 + nagg) * 256 lane slots; grouped form replicas * (pcount * (1 + nagg) | 1) + 256 + nagg + 1 trash words
 template <int NC, int U, bool VEC, bool NT, bool GROUPED>
 __global__ __launch_bounds__(kMsBlock) void k_mscan(const MScanCols C, const MScanDesc *__restrict__ Dp) {
     extern __shared__ int64_t lds[];
@@ -242,8 +242,10 @@ __global__ __launch_bounds__(kMsBlock) void k_mscan(const MScanCols C, const MSc
             }
         mytab = lds + (int64_t)(tid % R) * rstride;
         // per-lane trash rows (W words each) live behind the replicas; offset relative to mytab
-        trash = (int)((int64_t)R * rstride + (int64_t)tid * W - (int64_t)(tid % R) * rstride);
-        for (int w = 0; w < W; w++) lds[(int64_t)R * rstride + (int64_t)tid * W + w] = 0;
+        // lane t's trash row is words [t, t + W) of the trash area: rows of neighbouring lanes overlap, but within one
+        // atomic instruction every lane addresses its own word (same 1 + j for all), so there is no conflict
+        trash = (int)((int64_t)R * rstride + (int64_t)tid - (int64_t)(tid % R) * rstride);
+        for (int64_t i = tid; i < BS + W; i += BS) lds[(int64_t)R * rstride + i] = 0;
     } else {
         for (int j = 0; j < nagg; j++) lds[(int64_t)j * BS + tid] = r_identity(rk_of(D.agg[j].kind));
     }
@@ -288,8 +290,8 @@ __global__ __launch_bounds__(kMsBlock) void k_mscan(const MScanCols C, const MSc
                 oob += (pass[r] && !in) ? 1 : 0;
                 pass[r] = pass[r] && in;
                 // rows that do not count go to this lane's own trash slot with the identity: no branches
-                off[r] = pass[r] ? (int)b * W : trash;
-                atomicAdd((unsigned long long *)&mytab[off[r]], pass[r] ? 1ull : 0ull);
+                off[r] = pass[r] ? (int)b * W : trash;         // the trash row absorbs whatever is added: no selects below
+                atomicAdd((unsigned long long *)&mytab[off[r]], 1ull);
             }
         } else {
 #pragma unroll
@@ -303,13 +305,13 @@ __global__ __launch_bounds__(kMsBlock) void k_mscan(const MScanCols C, const MSc
             if (GROUPED) {
                 if (rk == R_SUM) {
 #pragma unroll
-                    for (int r = 0; r < RW; r++) atomicAdd((unsigned long long *)&mytab[off[r] + 1 + j], (unsigned long long)(pass[r] ? t[r] : 0));
+                    for (int r = 0; r < RW; r++) atomicAdd((unsigned long long *)&mytab[off[r] + 1 + j], (unsigned long long)t[r]);
                 } else if (rk == R_MAX) {
 #pragma unroll
-                    for (int r = 0; r < RW; r++) atomicMax((long long *)&mytab[off[r] + 1 + j], (long long)(pass[r] ? t[r] : INT64_MIN));
+                    for (int r = 0; r < RW; r++) atomicMax((long long *)&mytab[off[r] + 1 + j], (long long)t[r]);
                 } else {
 #pragma unroll
-                    for (int r = 0; r < RW; r++) atomicMin((long long *)&mytab[off[r] + 1 + j], (long long)(pass[r] ? t[r] : INT64_MAX));
+                    for (int r = 0; r < RW; r++) atomicMin((long long *)&mytab[off[r] + 1 + j], (long long)t[r]);
                 }
             } else {
                 int64_t s = r_identity(rk);
@@ -427,14 +429,15 @@ struct MsVariant { int nc, u; bool vec, grouped; mscan_fn fn; const char *name; 
 const MsVariant kMsVariants[] = {
     VDL_MS(4, 6, true, true, false),  VDL_MS(8, 4, true, true, false),
     VDL_MS(4, 4, false, false, false), VDL_MS(8, 4, false, false, false),
-    VDL_MS(4, 6, true, true, true),   VDL_MS(8, 4, true, true, true),
+    VDL_MS(4, 6, true, true, true),   VDL_MS(8, 2, true, true, true),   VDL_MS(8, 4, true, true, true),
     VDL_MS(4, 4, false, false, true),  VDL_MS(8, 4, false, false, true),
+    VDL_MS(8, 1, true, true, true),   VDL_MS(8, 3, true, true, true),      // VDL_GROUP_U sweeps (tools/q1_ab.sh)
 };
 #undef VDL_MS
 constexpr int kNumMsVariants = sizeof(kMsVariants) / sizeof(kMsVariants[0]);
 
 size_t ms_lds_bytes(const MScanDesc &d, bool grouped) {
-    if (grouped) return ((size_t)((d.pcount * (d.nagg + 1)) | 1) * (size_t)d.replicas + (size_t)kMsBlock * (size_t)(d.nagg + 1)) * sizeof(int64_t);
+    if (grouped) return ((size_t)((d.pcount * (d.nagg + 1)) | 1) * (size_t)d.replicas + (size_t)kMsBlock + (size_t)(d.nagg + 1)) * sizeof(int64_t);
     return (size_t)(d.nagg > 0 ? d.nagg : 1) * kMsBlock * sizeof(int64_t);
 }
 
@@ -446,14 +449,21 @@ ScanLaunch mscan_launch_config(const MScanCols &cols, MScanDesc &d, bool grouped
         if (((uintptr_t)cols.ptr[c]) % (uintptr_t)(2 * cols.width[c]) != 0) vec = false;
     ScanLaunch cfg;
     cfg.variant = -1;
-    for (int i = 0; i < kNumMsVariants; i++)
-        if (kMsVariants[i].vec == vec && kMsVariants[i].grouped == grouped && cols.ncol <= kMsVariants[i].nc) { cfg.variant = i; break; }
+    const char *want_u = getenv("VDL_GROUP_U");
+    for (int pass = 0; pass < 2 && cfg.variant < 0; pass++)
+        for (int i = 0; i < kNumMsVariants; i++) {
+            const MsVariant &v = kMsVariants[i];
+            if (v.vec != vec || v.grouped != grouped || cols.ncol > v.nc) continue;
+            if (pass == 0 && want_u && grouped && v.u != atoi(want_u)) continue;
+            cfg.variant = i;
+            break;
+        }
     if (cfg.variant < 0) return cfg;
     d.replicas = 1;
     if (grouped) {
         const int64_t words = d.pcount * (d.nagg + 1);
-        int r = 16;
-        while (r > 1 && words * r > 4096) r >>= 1;         // replicas <= 32 KiB, + 256 trash rows; <= 64 KiB per block
+        int r = 8;
+        while (r > 1 && words * r > 2304) r >>= 1;         // replicas <= 18 KiB (+ 2 KiB of trash rows): LDS never caps the occupancy
         const char *tune = getenv("VDL_GROUP_TUNE");
         if (tune) { int v = atoi(tune); if (v >= 1 && v <= 64 && words * v <= 8192) r = v; }
         d.replicas = r;

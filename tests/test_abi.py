@@ -52,10 +52,10 @@ def test_q1_fuses_into_one_grouped_scan(q1_text):
     assert "group-scan 0 table=lineitem buckets=[0,31]" in d                 # RangeC 0 32 1 pivots
     assert "lineitem.l_shipdate in [-inf,729999]" in d
     assert "acc=BitwiseAnd(acc,31)" in d                                     # size hint evaluated, Vlite.hs:1111-1115
-    assert d.count(" sum ") == 6 and d.count(" first ") == 2                 # duplicate FoldSums shared
-    assert "Divide(agg2,agg6)" in d                                          # avg = sum / count, Vlite.hs:1038-1041
-    nw, ops = p.partial_spec()                                               # 32 buckets x (count + 8 aggregates) + out-of-domain count
-    assert nw == 32 * 9 + 1 and ops[:9] == [_lib.REDUCE_SUM, _lib.REDUCE_FIRST, _lib.REDUCE_FIRST] + [_lib.REDUCE_SUM] * 6
+    assert d.count(" sum ") == 5 and d.count(" first ") == 2                 # duplicate FoldSums shared, count(*) = the row-count word
+    assert "Divide(agg2,count)" in d                                         # avg = sum / count, Vlite.hs:1038-1041
+    nw, ops = p.partial_spec()                                               # 32 buckets x (count + 7 aggregates) + out-of-domain count
+    assert nw == 32 * 8 + 1 and ops[:8] == [_lib.REDUCE_SUM, _lib.REDUCE_FIRST, _lib.REDUCE_FIRST] + [_lib.REDUCE_SUM] * 5
 
 
 def test_unsupported_shapes_stay_on_the_general_path():
@@ -77,7 +77,6 @@ def test_unsupported_shapes_stay_on_the_general_path():
     ("1,Load,t.a\n2,Project,val,Id 1,b\n", _lib.VDL_ERR_SHAPE),
     ("1,Load,t.a\n2,Greater,val,Id 1,val,Id 1,val\n", _lib.VDL_ERR_SHAPE),
     ("1,Load,t.a\n2,Frob,val,Id 1,a,Id 1,a\n", _lib.VDL_ERR_PARSE),
-    ("1,RangeC,val,0,4,1\n2,CrossProductInner,val,Id 1,val,Id 1,val\n", _lib.VDL_ERR_UNSUPPORTED),
     ("1,Load,t.a\n2,Semisort,Id 1\n", _lib.VDL_ERR_UNSUPPORTED),
 ])
 def test_parse_errors_carry_codes(text, code):
