@@ -1267,7 +1267,7 @@ int vdl_exchange_spec(const vdl_plan *p, const char *sharded_table, int *n_colum
 }
 
 int vdl_exchange_begin(vdl_ctx *c, vdl_plan *p, int world, int64_t *counts_host) {
-    if (!c || !p || !counts_host || world < 1 || world > 128) return VDL_ERR_ARG;
+    if (!c || !p || !counts_host || world < 1 || world > kMaxExWorld) return VDL_ERR_ARG;
     return guard(c, [&] {
         need_device(c);
         ExchangeSpec x = analyse_exchange(p->prog);

@@ -1194,30 +1194,41 @@ hipError_t launch_like(Src data, const uint64_t *vdata, int64_t n, Src heap, con
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ex_dest(Src key, const uint64_t *vkey, int64_t n, int64_t pmin, int64_t pcount, int world,
                                                  int64_t *dest, uint64_t *vdest, int64_t *counts, int64_t *oob) {
+    __shared__ unsigned long long cnt[kMaxExWorld + 1];       // per-block row counts per destination (+ out-of-range keys)
+    for (int i = threadIdx.x; i <= kMaxExWorld; i += blockDim.x) cnt[i] = 0;
+    __syncthreads();
     const int64_t nw = (n + 63) >> 6;
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave);
     for (int64_t w = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; w < nw; w += wstride) {
         const int64_t i = (w << 6) + lane;
         bool ok = i < n && bit(vkey, i);
+        bool out_of_range = false;
         int64_t d = 0;
         if (ok) {
             const int64_t b = (int64_t)((uint64_t)ld(key, i) - (uint64_t)pmin);
-            if (b < 0 || b >= pcount) { atomicAdd((unsigned long long *)oob, 1ull); ok = false; }
+            if (b < 0 || b >= pcount) { out_of_range = true; ok = false; }
             else d = (int64_t)(((unsigned __int128)(uint64_t)b * (uint64_t)world) / (uint64_t)pcount);
         }
         if (i < n) dest[i] = d;
         const uint64_t m = __ballot(ok);
         if (lane == 0) vdest[w] = m;
-        // one atomic per (wave, destination present in the wave)
+        const uint64_t bad = __ballot(out_of_range);
+        if (bad && lane == 0) atomicAdd(&cnt[kMaxExWorld], (unsigned long long)__popcll(bad));
+        // one LDS atomic per (wave, destination present in the wave)
         uint64_t todo = m;
         while (todo) {
             const int leader = __ffsll((long long)todo) - 1;
             const int64_t dl = __shfl(d, leader, kWave);
             const uint64_t same = __ballot(ok && d == dl) & todo;
-            if (lane == leader) atomicAdd((unsigned long long *)&counts[dl], (unsigned long long)__popcll(same));
+            if (lane == leader) atomicAdd(&cnt[dl], (unsigned long long)__popcll(same));
             todo &= ~same;
         }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= kMaxExWorld; i += blockDim.x) {
+        const unsigned long long c = cnt[i];
+        if (c) atomicAdd((unsigned long long *)(i == kMaxExWorld ? oob : &counts[i]), c);
     }
 }
 hipError_t launch_ex_dest(Src key, const uint64_t *vkey, int64_t n, int64_t pmin, int64_t pcount, int world, int64_t *dest,

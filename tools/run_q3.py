@@ -60,12 +60,18 @@ def timed(label, fn):
         say("%s run %d: %.1f ms, %d result rows on rank 0, %.2f M lineitem rows/s" % (label, it, dt * 1e3, rows, n_li / dt / 1e6))
     return out
 
+only = os.environ.get("Q3_ONLY")            # "exchange" / "general": one path only (for rocprofv3 runs)
+if only == "general":
+    timed("statement-by-statement", plan.run)
+    e.close(); sys.exit(0)
 out = timed("exchange", lambda: m.run_exchange(plan, dist if world > 1 else None, device=dev, sharded_table="lineitem"))
 flat = {list(v.keys())[0][1:]: list(v.values())[0] for v in out["results"].values()}
 if world > 1:
     parts = [None] * world
     dist.all_gather_object(parts, flat)
     flat = {k: sum((p[k] for p in parts), []) for k in flat}
+if only == "exchange":
+    e.close(); sys.exit(0)
 if world == 1:
     whole = timed("statement-by-statement", plan.run)
     same = {list(v.keys())[0][1:]: list(v.values())[0] for v in whole["results"].values()} == flat
