@@ -81,8 +81,9 @@ def _vocabulary(patterns, rng, n_fill):
     return out
 
 
-def _build_heap(placed, free, base):
-    """placed: {string: fixed offset}; free: strings to put at the next 8-byte aligned free offsets >= base."""
+def _build_heap(placed, free, base, limit=None):
+    """placed: {string: fixed offset}; free: strings to put at the next 8-byte aligned free offsets >= base,
+    as long as the offset stays <= limit (the column's upper bound in bounds.csv)."""
     where = dict(placed)
     end = max([o + len(s.encode()) + 1 for s, o in placed.items()] + [base])
     buf = bytearray(end)
@@ -97,6 +98,8 @@ def _build_heap(placed, free, base):
             continue
         while len(buf) % 8:
             buf.append(0)
+        if limit is not None and len(buf) > limit and where:
+            break
         where[s] = len(buf)
         buf += s.encode() + b"\0"
     return np.frombuffer(bytes(buf), dtype=np.int8).copy(), where
@@ -122,7 +125,9 @@ def synth_columns(meta_dir, cfg, vdl_text, scale=2e-4, seed=1):
             ci = info[key]
             fixed = codes.get(key, {})
             free = [] if fixed and not patterns.get("%s.%s.heap" % key) else _vocabulary(patterns.get("%s.%s.heap" % key, []), rng, 24)
-            heaps[key] = _build_heap(fixed, free, max(int(ci.bounds[0]), 8) if not fixed else 8)
+            if not fixed and int(ci.bounds[1]) - int(ci.bounds[0]) < 4096:        # a narrow code range: short strings so several fit
+                free = [w[:6] for w in free]
+            heaps[key] = _build_heap(fixed, free, max(int(ci.bounds[0]), 8) if not fixed else 8, int(ci.bounds[1]))
         return heaps[key]
 
     for path in wanted:
@@ -183,4 +188,17 @@ def load_columns(directory, names=None):
                 continue
             dt = {1: np.int8, 2: np.int16, 4: np.int32, 8: np.int64}[int(width)]
             out[name] = np.memmap(os.path.join(directory, name + ".bin"), dtype=dt, mode="r", shape=(int(rows),)) if int(rows) else np.zeros(0, dt)
+    return out
+
+
+def scaled_config(cfg, scale):
+    """A copy of the catalog whose row counts are those of the scaled tables `synth_columns` generates.
+    Needed for the VLite output format, which prints table lengths into the program (reference vectors
+    become `RangeC 0 <rows> 1`, Vlite.hs:740) instead of loading a primary-key column for its length."""
+    import copy
+
+    from .frontend.config import NameTable
+
+    out = copy.copy(cfg)
+    out.colinfo = NameTable.from_list([(name, ci._replace(count=scaled_rows(ci.count, scale))) for name, ci in cfg.colinfo.to_list()])
     return out

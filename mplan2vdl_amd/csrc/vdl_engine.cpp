@@ -607,6 +607,30 @@ struct GenExec {
         p->outs.push_back(std::move(o));
     }
 
+    // Partition positions of `data` over the pivots RangeC pmin pcount 1 (EPS in -> EPS out)
+    DVec partition_positions(const DVec &data, int64_t pmin, int64_t pcount) {
+        DVec o;
+        o.kind = DVec::DENSE; o.n = data.n; o.valid = data.valid;
+        o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(o.n, 1));
+        if (o.n > 0) {
+            const int passes = partition_passes(pcount);
+            const int64_t hn = 256 * partition_tiles(o.n);
+            BufP hist = dev_alloc(c, sizeof(int64_t) * (size_t)(hn + 1));
+            BufP scr = dev_alloc(c, sizeof(int64_t) * (size_t)(prefix_sum_blocks(hn) + 2));
+            BufP nvalid = dev_alloc(c, sizeof(int64_t));
+            BufP ka, sa, kb, sb;
+            if (passes > 1) {
+                ka = dev_alloc(c, sizeof(int64_t) * (size_t)o.n); sa = dev_alloc(c, sizeof(int64_t) * (size_t)o.n);
+                kb = dev_alloc(c, sizeof(int64_t) * (size_t)o.n); sb = dev_alloc(c, sizeof(int64_t) * (size_t)o.n);
+            }
+            HIP_CHECK(launch_partition(src_of(data), vp(data), o.n, pmin, pcount, (int64_t *)hist->p, (int64_t *)scr->p,
+                                       ka ? (uint64_t *)ka->p : nullptr, sa ? (int64_t *)sa->p : nullptr,
+                                       kb ? (uint64_t *)kb->p : nullptr, sb ? (int64_t *)sb->p : nullptr,
+                                       (int64_t *)nvalid->p, (int64_t *)o.data->p, s));
+        }
+        return o;
+    }
+
     DVec exec(const Node &n) {
         auto V = [&](int id) -> const DVec & { return vec[(size_t)id]; };
         DVec o;
@@ -699,24 +723,30 @@ struct GenExec {
             if (!(piv.kind == DVec::RANGE && piv.step == 1 && !piv.valid))
                 throw Error(VDL_ERR_UNSUPPORTED, "Partition (Id " + std::to_string(n.id) +
                                                      "): pivots must be a RangeC with step 1 (what mplan2vdl emits, Vlite.hs:1088-1091)");
-            o.kind = DVec::DENSE; o.n = data.n; o.valid = data.valid;
-            o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(o.n, 1));
-            if (o.n > 0) {
-                const int passes = partition_passes(piv.n);
-                const int64_t hn = 256 * partition_tiles(o.n);
-                BufP hist = dev_alloc(c, sizeof(int64_t) * (size_t)(hn + 1));
-                BufP scr = dev_alloc(c, sizeof(int64_t) * (size_t)(prefix_sum_blocks(hn) + 2));
-                BufP nvalid = dev_alloc(c, sizeof(int64_t));
-                BufP ka, sa, kb, sb;
-                if (passes > 1) {
-                    ka = dev_alloc(c, sizeof(int64_t) * (size_t)o.n); sa = dev_alloc(c, sizeof(int64_t) * (size_t)o.n);
-                    kb = dev_alloc(c, sizeof(int64_t) * (size_t)o.n); sb = dev_alloc(c, sizeof(int64_t) * (size_t)o.n);
-                }
-                HIP_CHECK(launch_partition(src_of(data), vp(data), o.n, piv.from, piv.n, (int64_t *)hist->p, (int64_t *)scr->p,
-                                           ka ? (uint64_t *)ka->p : nullptr, sa ? (int64_t *)sa->p : nullptr,
-                                           kb ? (uint64_t *)kb->p : nullptr, sb ? (int64_t *)sb->p : nullptr,
-                                           (int64_t *)nvalid->p, (int64_t *)o.data->p, s));
-            }
+            return partition_positions(data, piv.from, piv.n);
+        }
+        case Op::Semisort: {
+            // gather mask that sorts the non-EPS values (stable): positions over [min, max] of the data, inverted
+            DVec d = densify(V(n.a));
+            o.kind = DVec::DENSE; o.n = d.n;
+            o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(d.n, 1));
+            o.valid = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(d.n), 1));
+            HIP_CHECK(launch_fill_words((uint64_t *)o.valid->p, 0, nwords(d.n), s));
+            if (d.n == 0) return o;
+            BufP scratch = dev_alloc(c, sizeof(int64_t) * 3 * (size_t)fold_scratch_blocks());
+            BufP mm = dev_alloc(c, 6 * sizeof(int64_t));
+            HIP_CHECK(launch_fold_global(1, src_of(d), vp(d), nullptr, d.n, (int64_t *)scratch->p, (int64_t *)mm->p, s));
+            HIP_CHECK(launch_fold_global(2, src_of(d), vp(d), nullptr, d.n, (int64_t *)scratch->p, (int64_t *)mm->p + 3, s));
+            int64_t h[6];
+            HIP_CHECK(hipMemcpyAsync(h, mm->p, sizeof h, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            if (h[2] == 0) return o;                                      // nothing but EPS
+            const uint64_t span = (uint64_t)h[3] - (uint64_t)h[0];
+            if (span >= ((uint64_t)1 << 62))
+                throw Error(VDL_ERR_UNSUPPORTED, "Semisort (Id " + std::to_string(n.id) + "): value range wider than 2^62");
+            DVec pos = partition_positions(d, h[0], (int64_t)span + 1);
+            Src iota; iota.kind = SRC_RANGE; iota.from = 0; iota.step = 1;
+            HIP_CHECK(launch_scatter(iota, vp(d), src_of(pos), vp(pos), d.n, d.n, (int64_t *)o.data->p, (uint64_t *)o.valid->p, s));
             return o;
         }
         case Op::Materialize:

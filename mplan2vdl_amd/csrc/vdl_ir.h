@@ -10,7 +10,7 @@ namespace vdl {
 
 enum class Op : int {
     Load, Project, RangeV, RangeC, Binary, FoldSelect, FoldSum, FoldMin, FoldMax, FoldChoose,
-    FoldCount, Gather, Scatter, Partition, Shuffle, Materialize, Like, Cross
+    FoldCount, Gather, Scatter, Partition, Shuffle, Materialize, Like, Cross, Semisort
 };
 
 // element-wise binary operators, /root/reference/src/Vdl.hs:110-122

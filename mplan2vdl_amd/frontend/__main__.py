@@ -19,12 +19,14 @@ def main(argv=None):
     ap.add_argument("--aggshuffle", action="store_true")
     ap.add_argument("--agghierarchical", action="store_true")
     ap.add_argument("-g", "--grainsize", type=int, default=8192)
+    ap.add_argument("--vliteformat", action="store_true", help="lighter syntax (one value per vector), MainFuns.hs:70")
+    ap.add_argument("--vdlformat", action="store_true", help="the default")
     a = ap.parse_args(argv)
     strat = ("AggSerial",)
     if a.aggshuffle: strat = ("AggShuffle",)
     if a.agghierarchical: strat = ("AggHierarchical", a.grainsize.bit_length() - 1)
     cfg = load_metadata(a.metadata_dir, show_metadata=a.show_metadata, cross_product=a.use_cross_product,
-                        gboffset=a.goffset, aggregation_strategy=strat)
+                        gboffset=a.goffset, aggregation_strategy=strat, format="vlite" if a.vliteformat else "vdl")
     text = sys.stdin.read() if a.plan == "-" else open(a.plan).read()
     print(compile_plan(text, cfg, apply_passes=not a.no_cleanup_passes, push_joins=a.push_joins))
 

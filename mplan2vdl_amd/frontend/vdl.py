@@ -103,6 +103,8 @@ class Emitter:
             return ("Like", d, ldict, vx[2])
         if k == "VShuffle":
             return ("VShuffle", self.from_vexp(vx[1]))
+        if k == "Semisort":                               # Vdl.hs:205-207
+            return ("Semisort", self.from_vexp(vx[1]))
         if k == "Fold":
             g = self.from_vexp(vx[2])
             d = self.from_vexp(vx[3])
@@ -180,6 +182,24 @@ class Emitter:
         if k == "VShuffle": return ["Shuffle", r[0]]
         if k == "MaterializeCompact": return ["MaterializeCompact", r[0]]
         if k == "CrossProduct": return ["CrossProductOuter" if vd[3] == "COuter" else "CrossProductInner", r[0], r[1]]
+        if k == "Semisort": return ["Semisort", r[0]]
+        raise FrontendError("printing of %s" % k)
+
+    def vlite_fields(self, vd, refs):
+        """Vdl.hs:370-408 (toVList): "lighter syntax (one value per vector)", MainFuns.hs:70 -- no field names."""
+        k = vd[0]
+        r = ["Id %d" % x for x in refs]
+        if k == "Load": return ["Load", show_name(vd[1])]
+        if k == "Project": return ["Project", r[0]]
+        if k == "RangeV": return ["RangeV", str(vd[1]), r[0], str(vd[2])]
+        if k == "RangeC": return ["RangeC", str(vd[1]), str(vd[3]), str(vd[2])]
+        if k == "Semisort": return ["Semisort", r[0]]
+        if k == "Binary": return [vd[1], r[0], r[1]]
+        if k == "Scatter": return ["Scatter", r[0], r[1], r[2]]
+        if k == "Like": return ["Like", r[0], r[1], vd[3]]
+        if k == "VShuffle": return ["Shuffle", r[0]]
+        if k == "MaterializeCompact": return ["Output", r[0]]
+        if k == "CrossProduct": return ["CrossProductOuter" if vd[3] == "COuter" else "CrossProductInner", r[0], r[1]]
         raise FrontendError("printing of %s" % k)
 
 
@@ -194,13 +214,22 @@ def _show_meta(meta):
 
 def vdl_from_vexps(vexps, config):
     """Vdl.hs:490-495: the program text, one statement per line."""
-    if config.format != "vdl":
-        raise FrontendError("only the VDL output format is implemented")
     em = Emitter(config)
     log = em.number(em.outputs(vexps))
     lines = []
     for ident, vd, refs, meta in log:
-        s = ",".join([str(ident)] + em.fields(vd, refs))
+        if config.format == "vlite":
+            # Vdl.hs:455-475 (printLine): named outputs print as "<name>,Output,<display type>,Id x"
+            strs = em.vlite_fields(vd, refs)
+            if vd[0] == "MaterializeCompact" and meta is not None and meta[2] is not None:
+                dt = meta[3]
+                typ = "decimal_%d" % dt[1] if dt[0] == "DDecimal" else "string_%s" % show_name(dt[1]) if dt[0] == "DString" else "date"
+                fstrs = [meta[2][-1], "Output", typ] + strs[1:]
+            else:
+                fstrs = [str(ident)] + strs
+            s = ",".join(fstrs)
+        else:
+            s = ",".join([str(ident)] + em.fields(vd, refs))
         if config.show_metadata:
             s += _show_meta(meta)
         lines.append(s)

@@ -27,7 +27,7 @@ class Vexp:
 
 # vx tuples:  ("Load", name) ("RangeV", rmin, rstep, rref) ("RangeC", rmin, rstep, rcount) ("Binop", op, l, r)
 #             ("Shuffle", "Gather"|"Scatter", source, pos) ("Fold", op, groups, data) ("Partition", pivots, data)
-#             ("VShuffle", arg) ("Like", data, pattern, col) ("CrossProduct", l, r, variant)
+#             ("VShuffle", arg) ("Like", data, pattern, col) ("CrossProduct", l, r, variant) ("Semisort", data)
 _INTERN = {}
 
 
@@ -140,7 +140,7 @@ def infer_metadata(vx):
         return ColInfo(b, 0, lp.info.count * rp.info.count, S_INT32, dec0)
     if k == "Load":
         raise FrontendError("at the moment, should not be called with Load")
-    if k == "VShuffle":
+    if k in ("VShuffle", "Semisort"):        # Vlite.hs:294,322: keeps all current metadata the same
         return vx[1].info
     if k == "Like":
         return ColInfo((0, 1), 0, vx[1].info.count, S_INT32, dec0)
@@ -422,8 +422,9 @@ def solve_agg(config, env, after, gkey, agg):
 
     def default():
         gdata = sc(env, expr)
-        if config.format == "vlite":
-            raise FrontendError("vlite output format is not implemented")
+        if config.format == "vlite":             # Vlite.hs:1061-1064: sort-based grouping, no Partition / Scatter
+            gmask = complete(("Semisort", gkey))
+            return complete(("Fold", op, gather(gkey, gmask), gather(gdata, gmask)))
         mask, sparsity = get_scatter_mask(config, gkey)
         return make_2level_fold(sparsity, config, op, scattered_to(gkey, mask), scattered_to(gdata, mask))
 
@@ -564,8 +565,8 @@ def deduce_masks(config, spec):
     dimprime = spec["dimmask"]
     if dimprime.quant != "Unique":
         raise FrontendError("the dimension column is not known to be unique")
-    if config.format == "vlite":
-        raise FrontendError("vlite output format is not implemented")
+    # Vlite.hs:1270-1275: the VLite format scatters with an explicit shape (tfScatterTo); the shape is dropped
+    # again when the Scatter is lowered (Vdl.hs:234-242 ignores shshape), so both formats build the same vector
     valid = scattered_to(ones_(dimprime), dimprime)
     didx = scattered_to(pos_(dimprime), dimprime)
     return gather(valid, fprime_dim_idx), gather(didx, fprime_dim_idx)
@@ -671,7 +672,7 @@ def _transform_vx(fn, vx, memo):
         l = _transform(fn, vx[1], memo)
         new = (k, l, _transform(fn, vx[2], memo), vx[3])
     elif k == "Like": new = (k, _transform(fn, vx[1], memo), vx[2], vx[3])
-    elif k == "VShuffle": new = (k, _transform(fn, vx[1], memo))
+    elif k in ("VShuffle", "Semisort"): new = (k, _transform(fn, vx[1], memo))      # Vlite.hs:1386-1388
     else: raise FrontendError("transform of %s" % k)
     out = fn(new)
     return out if out is not None else complete(new)

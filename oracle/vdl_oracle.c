@@ -425,6 +425,23 @@ static int op_like(orc_ctx *c, ovec *out, const ovec *data, const ovec *heap, co
     return 0;
 }
 
+/* Semisort data (/root/reference/src/Vdl.hs:42,205-207,377; Vlite.hs:109,322,1061-1064; VLite format only):
+ * a gather mask that brings equal values together -- "gmask = Semisort gkeyvec; fgroups = gkeyvec @@ gmask;
+ * fdata = gdata @@ gmask; Fold fgroups fdata".  Normative reading: the slots of the non-EPS values in stable
+ * ascending value order, packed at the front; the remaining slots EPS (so the gathered vectors are sorted
+ * prefixes and the folds see one run per distinct value, in value order like the Partition lowering). */
+static int op_semisort(orc_ctx *c, ovec *out, const ovec *d) {
+    if (alloc_vec(c, out, d->n, 1)) return -1;
+    bpair *tmp = (bpair *)malloc(sizeof(bpair) * (size_t)(d->n > 0 ? d->n : 1));
+    if (!tmp) return fail(c, "out of memory");
+    int64_t m = 0;
+    for (int64_t i = 0; i < d->n; i++) if (slot_ok(d, i)) { tmp[m].bucket = slot_val(d, i); tmp[m].idx = i; m++; }
+    qsort(tmp, (size_t)m, sizeof(bpair), cmp_bpair);
+    for (int64_t k = 0; k < d->n; k++) { out->ok[k] = k < m; out->val[k] = k < m ? tmp[k].idx : 0; }
+    free(tmp);
+    return 0;
+}
+
 static int op_materialize(orc_ctx *c, int id, const ovec *v) {
     if (c->nouts == c->capouts) {
         c->capouts = c->capouts ? 2 * c->capouts : 8;
@@ -590,17 +607,111 @@ static int exec_line(orc_ctx *c, char *line, int lineno) {
     return 0;
 }
 
+/* ---- the VLite dialect ("lighter syntax (one value per vector)", /root/reference/src/MainFuns.hs:70) --------
+ * Printed by toVList / printLine (Vdl.hs:370-408,455-475): no field names, operands in the same order,
+ *   <id>,Load,<name> | <id>,Project,Id v | <id>,RangeV,<from>,Id v,<step> | <id>,RangeC,<from>,<count>,<step>
+ *   <id>,<BinOp|Fold*|Partition|Gather>,Id a,Id b | <id>,Scatter,Id src,Id fold,Id pos | <id>,Semisort,Id v
+ *   <id>,Shuffle,Id v | <id>,Like,Id data,Id dict,<pattern> | <id>,CrossProduct{Outer,Inner},Id l,Id r
+ *   <id>,Output,Id v     or     <name>,Output,<display type>,Id v    (the id of a named output is not printed:
+ *                                                                    it is the previous statement's id + 1)
+ * A program is read as VLite when it has an Output statement. */
+static int exec_line_vlite(orc_ctx *c, char *line, int lineno, int *last_id) {
+    char *cut = strstr(line, ";;"); if (cut) *cut = 0;
+    size_t L = strlen(line);
+    while (L && isspace((unsigned char)line[L - 1])) line[--L] = 0;
+    char *s = line; while (*s && isspace((unsigned char)*s)) s++;
+    if (!*s) return 0;
+    char *f[MAXF + 1]; memset(f, 0, sizeof f);
+    int nf = split_fields(s, f, MAXF, 5);            /* a 5th field (Like's pattern) keeps its commas */
+    if (nf < 3) return fail(c, "line %d: expected '<id>,<Op>,...'", lineno);
+    const char *op = f[1];
+    int64_t id64 = 0;
+    const char *outname = "val";
+    if (!strcmp(op, "Output") && parse_int(f[0], &id64)) { id64 = *last_id + 1; outname = f[0]; }
+    else if (parse_int(f[0], &id64) || id64 <= 0 || id64 > (1 << 24)) return fail(c, "line %d: bad id", lineno);
+    int id = (int)id64;
+    *last_id = id;
+    if (id >= c->nvecs) {
+        int newn = id + 64;
+        c->vecs = (ovec *)realloc(c->vecs, sizeof(ovec) * (size_t)newn);
+        memset(c->vecs + c->nvecs, 0, sizeof(ovec) * (size_t)(newn - c->nvecs));
+        c->nvecs = newn;
+    }
+    if (c->vecs[id].defined) return fail(c, "line %d: Id %d defined twice", lineno, id);
+    ovec out; memset(&out, 0, sizeof out);
+    int rc = -1, a, b, d;
+    int64_t x, y, cnt;
+    const ovec *va, *vb, *vd;
+    c->ops_executed++;
+#define NEED(k) if (nf != (k)) return fail(c, "line %d: %s expects %d fields, got %d", lineno, op, (k), nf)
+#define REF1(k) if (parse_ref(f[k], &a) || !(va = get_vec(c, a))) return c->err[0] ? -1 : fail(c, "line %d: bad operand", lineno)
+    if (!strcmp(op, "Load")) { NEED(3); rc = op_load(c, &out, f[2]); }
+    else if (!strcmp(op, "Project") || !strcmp(op, "Shuffle")) { NEED(3); REF1(2); out = *va; out.owns = 0; rc = 0; }
+    else if (!strcmp(op, "Semisort")) { NEED(3); REF1(2); rc = op_semisort(c, &out, va); }
+    else if (!strcmp(op, "RangeV")) {
+        NEED(5); if (parse_int(f[2], &x) || parse_int(f[4], &y)) return fail(c, "line %d: bad RangeV", lineno);
+        REF1(3); rc = op_rangev(c, &out, x, va, y);
+    } else if (!strcmp(op, "RangeC")) {
+        NEED(5); if (parse_int(f[2], &x) || parse_int(f[3], &cnt) || parse_int(f[4], &y)) return fail(c, "line %d: bad RangeC", lineno);
+        rc = op_rangec(c, &out, x, cnt, y);
+    } else if (!strcmp(op, "Scatter")) {
+        NEED(5); if (parse_ref(f[2], &a) || parse_ref(f[3], &b) || parse_ref(f[4], &d)) return fail(c, "line %d: bad Scatter", lineno);
+        if (!(va = get_vec(c, a)) || !(vb = get_vec(c, b)) || !(vd = get_vec(c, d))) return -1;
+        rc = op_scatter(c, &out, va, vb, vd);
+    } else if (!strcmp(op, "Like")) {
+        NEED(5); if (parse_ref(f[2], &a) || parse_ref(f[3], &b)) return fail(c, "line %d: bad operands for Like", lineno);
+        if (!(va = get_vec(c, a)) || !(vb = get_vec(c, b))) return -1;
+        rc = op_like(c, &out, va, vb, f[4]);
+    } else if (!strcmp(op, "Output")) {
+        if (nf != 3 && nf != 4) return fail(c, "line %d: Output expects 3 or 4 fields, got %d", lineno, nf);
+        REF1(nf - 1);
+        ovec named = *va; named.owns = 0;
+        snprintf(named.field, sizeof named.field, "%s", outname);
+        if (op_materialize(c, id, &named)) return -1;
+        out = named; rc = 0;
+    } else {
+        NEED(4); if (parse_ref(f[2], &a) || parse_ref(f[3], &b)) return fail(c, "line %d: bad operands for %s", lineno, op);
+        if (!(va = get_vec(c, a)) || !(vb = get_vec(c, b))) return -1;
+        int bop = -1, fold = -1;
+        for (int k = 0; k < OP_NBIN; k++) if (!strcmp(op, BIN_NAMES[k])) bop = k;
+        if      (!strcmp(op, "FoldSelect")) fold = F_SEL;
+        else if (!strcmp(op, "FoldSum"))    fold = F_SUM;
+        else if (!strcmp(op, "FoldMin"))    fold = F_MIN;
+        else if (!strcmp(op, "FoldMax"))    fold = F_MAX;
+        else if (!strcmp(op, "FoldChoose")) fold = F_CHOOSE;
+        else if (!strcmp(op, "FoldCount"))  fold = F_COUNT;
+        if (bop >= 0) rc = op_binary(c, &out, bop, va, vb);
+        else if (fold >= 0) rc = op_fold(c, &out, fold, va, vb);
+        else if (!strcmp(op, "Partition")) rc = op_partition(c, &out, va, vb);
+        else if (!strcmp(op, "Gather")) rc = op_gather(c, &out, va, vb);
+        else if (!strcmp(op, "CrossProductOuter") || !strcmp(op, "CrossProductInner")) {
+            if (vb->n > 0 && va->n > ((int64_t)1 << 24) / vb->n) return fail(c, "line %d: cross product of %lld x %lld slots", lineno, (long long)va->n, (long long)vb->n);
+            if (alloc_vec(c, &out, va->n * vb->n, 0)) return -1;
+            for (int64_t i = 0; i < out.n; i++) out.val[i] = op[12] == 'I' ? i % vb->n : i / vb->n;
+            rc = 0;
+        } else return fail(c, "line %d: unsupported operator '%s'", lineno, op);
+    }
+#undef NEED
+#undef REF1
+    if (rc) return -1;
+    snprintf(out.field, sizeof out.field, "%s", !strcmp(op, "Output") ? outname : "val");
+    out.defined = 1;
+    c->vecs[id] = out;
+    return 0;
+}
+
 int orc_run(orc_ctx *c, const char *text, size_t len) {
     clear_run_state(c);
     c->err[0] = 0; c->ops_executed = 0;
     char *buf = (char *)malloc(len + 1);
     memcpy(buf, text, len); buf[len] = 0;
     double t0 = now_s();
-    int rc = 0, lineno = 0;
+    int rc = 0, lineno = 0, last_id = 0;
+    const int vlite = strstr(buf, ",Output,") != NULL;
     char *save = NULL;
     for (char *ln = strtok_r(buf, "\n", &save); ln; ln = strtok_r(NULL, "\n", &save)) {
         lineno++;
-        if ((rc = exec_line(c, ln, lineno))) break;
+        if ((rc = vlite ? exec_line_vlite(c, ln, lineno, &last_id) : exec_line(c, ln, lineno))) break;
     }
     c->last_seconds = now_s() - t0;
     free(buf);

@@ -77,7 +77,7 @@ def test_unsupported_shapes_stay_on_the_general_path():
     ("1,Load,t.a\n2,Project,val,Id 1,b\n", _lib.VDL_ERR_SHAPE),
     ("1,Load,t.a\n2,Greater,val,Id 1,val,Id 1,val\n", _lib.VDL_ERR_SHAPE),
     ("1,Load,t.a\n2,Frob,val,Id 1,a,Id 1,a\n", _lib.VDL_ERR_PARSE),
-    ("1,Load,t.a\n2,Semisort,Id 1\n", _lib.VDL_ERR_UNSUPPORTED),
+    ("1,Load,t.a\n2,Project,val,Id 1,a\n3,Like,val,Id 2,val,Id 2,val," + "x" * 300 + "\n", _lib.VDL_ERR_UNSUPPORTED),
 ])
 def test_parse_errors_carry_codes(text, code):
     e = m.Engine(device=None)

@@ -202,3 +202,15 @@ def test_like_offsets_outside_the_heap_and_holes():
                 "10,Like,val,Id 9,val,Id 4,val,%c", "11,MaterializeCompact,Id 10")
     got = oracle_run(text, cols)
     assert list(got.values())[0][".val"] == [1, 0, 0, 0, 1]               # "abc", out of heap x3, (hole dropped), "bc"
+
+
+def test_semisort_gathers_equal_values_together():
+    """Semisort (Vdl.hs:42; Vlite.hs:109-111 "a permutation such that when the input is gathered with it, the output
+    has all instances of an equal value be contiguous"): stable ascending order of the non-EPS slots, VLite dialect."""
+    cols = {"t.k": np.array([5, 3, 5, -2, 3, 9, 5], dtype=np.int64), "t.f": np.array([1, 1, 1, 1, 0, 1, 1], dtype=np.int64)}
+    text = prog("1,Load,t.k", "2,Project,Id 1", "3,Load,t.f", "4,Project,Id 3", "5,RangeV,0,Id 4,1", "6,FoldSelect,Id 5,Id 4",
+                "7,Gather,Id 2,Id 6",                    # slot 4 becomes EPS
+                "8,Semisort,Id 7", "9,Output,Id 8", "10,Gather,Id 7,Id 8", "sorted,Output,decimal_0,Id 10",
+                "12,RangeV,1,Id 10,0", "13,FoldSum,Id 10,Id 12", "counts,Output,decimal_0,Id 13")
+    got = oracle_run(text, cols)
+    assert got == {"tmp9": {".val": [3, 1, 0, 2, 6, 5]}, "tmp11": {".sorted": [-2, 3, 5, 5, 5, 9]}, "tmp14": {".counts": [1, 1, 3, 1]}}
