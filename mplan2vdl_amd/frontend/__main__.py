@@ -21,7 +21,7 @@ def main(argv=None):
     ap.add_argument("-g", "--grainsize", type=int, default=8192)
     ap.add_argument("--vliteformat", action="store_true", help="lighter syntax (one value per vector), MainFuns.hs:70")
     ap.add_argument("--vdlformat", action="store_true", help="the default")
-    a = ap.parse_args(argv)
+    a = ap.parse_intermixed_args(argv)
     strat = ("AggSerial",)
     if a.aggshuffle: strat = ("AggShuffle",)
     if a.agghierarchical: strat = ("AggHierarchical", a.grainsize.bit_length() - 1)
