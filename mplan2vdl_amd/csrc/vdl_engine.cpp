@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <memory>
 #include <sstream>
 #include <string>
@@ -88,9 +89,24 @@ struct Column {
 };
 
 // device-side vector of the general path
+// A selection: m of n slots, ascending.  Vectors that hold values only on a sparse selection (after a selective
+// filter, Vlite.hs:721-730) are stored as SPARSE: the m values of the selected slots, so that everything
+// downstream of the filter touches m instead of n elements (GenExec: "sparse vectors").
+struct Sel {
+    int64_t n = 0, m = 0;
+    BufP idx;                       // the m slot ids; null = the prefix 0 .. m-1
+    BufP bitmap;                    // n bits with exactly the selected slots set (prefix selections: built on demand)
+    std::shared_ptr<Sel> parent;    // the selection this one was filtered from, and
+    BufP ppos;                      // for each of the m slots its entry number inside the parent
+    bool worth = true;              // false: too dense to be worth compacting (only m is known)
+};
+using SelP = std::shared_ptr<Sel>;
+
 struct DVec {
-    enum Kind { NONE, DENSE, COLUMN, RANGE, ONEHOT, OHCONST } kind = NONE;
+    enum Kind { NONE, DENSE, COLUMN, RANGE, ONEHOT, OHCONST, SPARSE } kind = NONE;
     int64_t n = 0;
+    SelP sel;                   // SPARSE: data = the sel->m values; valid = bitmap over those m entries (null = all hold a value)
+    bool perm = false;          // SPARSE: the values are a permutation of 0 .. m-1 (Partition positions)
     BufP data;                  // DENSE: n int64; ONEHOT/OHCONST: {value, slot, count}
     const void *ptr = nullptr;  // COLUMN: borrowed catalog pointer
     int width = 8;
@@ -103,6 +119,10 @@ struct Output {
     int node = 0;
     std::string name, tmp;
     std::vector<int64_t> vals;
+    const int64_t *big = nullptr;      // large results land in a pinned buffer the plan keeps (pageable copies run at a few GB/s)
+    size_t big_n = 0;
+    const int64_t *ptr() const { return big ? big : vals.data(); }
+    size_t count() const { return big ? big_n : vals.size(); }
 };
 struct Timing { std::string label; double usec; };
 
@@ -173,7 +193,21 @@ struct vdl_plan {
     int last_ev = 0;
     const void *ev_buf[kEvRing] = {};   // partial-word buffer each event pair's run wrote (pipelined callers finalise out of order)
     int slot_ev_idx[2] = {-1, -1};
+    // pinned result buffers of the general path, one per output ordinal, grown on demand
+    std::vector<std::pair<int64_t *, size_t>> out_pinned;
+    int64_t *pinned_out(size_t ordinal, size_t count) {
+        if (out_pinned.size() <= ordinal) out_pinned.resize(ordinal + 1, {nullptr, 0});
+        auto &b = out_pinned[ordinal];
+        if (b.second < count) {
+            if (b.first) (void)hipHostFree(b.first);
+            b.first = nullptr; b.second = 0;
+            if (hipHostMalloc((void **)&b.first, sizeof(int64_t) * count, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); b.first = nullptr; return nullptr; }
+            b.second = count;
+        }
+        return b.first;
+    }
     ~vdl_plan() {
+        for (auto &b : out_pinned) if (b.first) (void)hipHostFree(b.first);
         for (int k = 0; k < 2; k++) {
             if (ev0[k]) (void)hipEventDestroy(ev0[k]);
             if (ev1[k]) (void)hipEventDestroy(ev1[k]);
@@ -508,15 +542,167 @@ struct GenExec {
         return r;
     }
 
-    BufP and_valid(const DVec &a, const DVec &b, int64_t n) {
-        if (!a.valid) return b.valid;
-        if (!b.valid || a.valid == b.valid) return a.valid;
+    // ---- validity bitmaps: which ones are known to be subsets of which (filters nest) ------------------
+    std::map<const void *, std::set<const void *>> supers;      // bitmap -> bitmaps known to contain it
+    std::map<const void *, SelP> sel_of_bitmap;                 // bitmaps whose population / slot list is known
+    std::vector<BufP> keep_alive;                               // keys above stay valid for the whole run
+    bool sparse_on = !getenv("VDL_NO_SPARSE");
+    bool trace_forms = getenv("VDL_TRACE_FORMS") != nullptr;      // one line per statement: the form of its result
+    int densified = 0;                                             // SPARSE -> DENSE conversions (each is a scatter over n slots)
+
+    bool subset(const BufP &a, const BufP &b) {                 // a (null = all slots) inside b?
+        if (!b || a == b) return true;
+        if (!a) return false;
+        auto it = supers.find(a->p);
+        return it != supers.end() && it->second.count(b->p);
+    }
+    void note_subset(const BufP &child, const BufP &parent) {
+        if (!child || !parent || child == parent) return;
+        keep_alive.push_back(child); keep_alive.push_back(parent);
+        std::set<const void *> &sup = supers[child->p];
+        sup.insert(parent->p);
+        auto it = supers.find(parent->p);
+        if (it != supers.end()) sup.insert(it->second.begin(), it->second.end());
+    }
+    BufP and_bitmaps(const BufP &a, const BufP &b, int64_t n) {
+        if (subset(a, b)) return a;
+        if (subset(b, a)) return b;
         BufP o = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(n), 1));
-        HIP_CHECK(launch_and_words((const uint64_t *)a.valid->p, (const uint64_t *)b.valid->p, (uint64_t *)o->p, nwords(n), s));
+        HIP_CHECK(launch_and_words((const uint64_t *)a->p, (const uint64_t *)b->p, (uint64_t *)o->p, nwords(n), s));
+        note_subset(o, a); note_subset(o, b);
+        return o;
+    }
+    BufP and_valid(const DVec &a, const DVec &b, int64_t n) { return and_bitmaps(a.valid, b.valid, n); }
+
+    // ---- sparse vectors --------------------------------------------------------------------------------
+    BufP zero_bitmap(int64_t n) {
+        BufP o = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(n), 1));
+        HIP_CHECK(launch_fill_words((uint64_t *)o->p, 0, nwords(n), s));
+        return o;
+    }
+    // population of a bitmap over n slots; leaves the per-tile offsets for compact_write in *offsets
+    int64_t popcount(const BufP &bits, int64_t n, BufP *offsets) {
+        const int64_t nb = (n + compact_tile() - 1) / compact_tile();
+        if (nb <= 0) return 0;
+        BufP counts = dev_alloc(c, sizeof(int64_t) * (size_t)(nb + 1));
+        HIP_CHECK(launch_compact_count(bits ? (const uint64_t *)bits->p : nullptr, n, (int64_t *)counts->p, s));
+        HIP_CHECK(launch_compact_scan((int64_t *)counts->p, nb, s));
+        int64_t total = 0;
+        HIP_CHECK(hipMemcpyAsync(&total, (int64_t *)counts->p + nb, sizeof total, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (offsets) *offsets = counts;
+        return total;
+    }
+    // the entries of `v` (any addressable form, length n) where `bits` is set, packed (total > 0 of them)
+    BufP compact_write(Src v, const BufP &bits, int64_t n, const BufP &offsets, int64_t total) {
+        BufP out = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(total, 1));
+        if (total > 0)
+            HIP_CHECK(launch_compact_write(v, bits ? (const uint64_t *)bits->p : nullptr, n, (const int64_t *)offsets->p, (int64_t *)out->p, s));
+        return out;
+    }
+    static Src iota_src() { Src r; r.kind = SRC_RANGE; r.from = 0; r.step = 1; return r; }
+    static Src i64_src(const BufP &b) { Src r; r.p = b ? b->p : nullptr; r.kind = SRC_I64; return r; }
+    Src idx_src(const Sel &sel) const { return sel.idx ? i64_src(sel.idx) : iota_src(); }
+
+    // the selection a validity bitmap describes (population counted once per bitmap); worth = sparse enough to compact
+    SelP sel_for(const BufP &bits, int64_t n) {
+        auto it = sel_of_bitmap.find(bits->p);
+        if (it != sel_of_bitmap.end()) return it->second;
+        SelP sel = std::make_shared<Sel>();
+        sel->n = n; sel->bitmap = bits;
+        BufP offsets;
+        sel->m = popcount(bits, n, &offsets);
+        // a subset of a known selection with the same population IS that selection (two routes to one filter)
+        auto sup = supers.find(bits->p);
+        if (sup != supers.end())
+            for (const void *q : sup->second) {
+                auto known = sel_of_bitmap.find(q);
+                if (known != sel_of_bitmap.end() && known->second->n == n && known->second->m == sel->m && known->second->bitmap) {
+                    keep_alive.push_back(bits);
+                    sel_of_bitmap[bits->p] = known->second;
+                    note_subset(known->second->bitmap, bits);
+                    return known->second;
+                }
+            }
+        sel->worth = sel->m * 8 <= n || getenv("VDL_SPARSE_ALWAYS") != nullptr;      // the env switch makes the tests cover every path
+        if (sel->worth) sel->idx = compact_write(iota_src(), bits, n, offsets, sel->m);
+        keep_alive.push_back(bits);
+        sel_of_bitmap[bits->p] = sel;
+        return sel;
+    }
+    const BufP &bitmap_of(const SelP &sel) {                     // derived / prefix selections get their bitmap on first use
+        if (!sel->bitmap) {
+            sel->bitmap = zero_bitmap(sel->n);
+            if (sel->m > 0) {
+                BufP ids = sel->idx;
+                if (!ids) {
+                    ids = dev_alloc(c, sizeof(int64_t) * (size_t)sel->m);
+                    Src z; z.kind = SRC_RANGE; z.from = 0; z.step = 0;
+                    HIP_CHECK(launch_binary(B_ADD, iota_src(), z, (int64_t *)ids->p, sel->m, s));   // ids = 0 .. m-1
+                }
+                HIP_CHECK(launch_set_bits((const int64_t *)ids->p, sel->m, (uint64_t *)sel->bitmap->p, s));
+            }
+            keep_alive.push_back(sel->bitmap);
+            sel_of_bitmap[sel->bitmap->p] = sel;
+            if (sel->parent) note_subset(sel->bitmap, bitmap_of(sel->parent));
+        }
+        return sel->bitmap;
+    }
+    SelP prefix_selection(int64_t n, int64_t m) {
+        for (const SelP &x : prefixes) if (x->n == n && x->m == m) return x;
+        SelP x = std::make_shared<Sel>();
+        x->n = n; x->m = m;
+        prefixes.push_back(x);
+        return x;
+    }
+    std::vector<SelP> prefixes;
+    // the selection made of the entries of `ps` flagged in `flags` (a bitmap over its m entries)
+    SelP child_selection(const SelP &ps, const BufP &flags, int64_t count, const BufP &offsets) {
+        SelP ch = std::make_shared<Sel>();
+        ch->n = ps->n; ch->parent = ps; ch->m = count;
+        ch->idx = compact_write(idx_src(*ps), flags, ps->m, offsets, count);
+        ch->ppos = compact_write(iota_src(), flags, ps->m, offsets, count);
+        return ch;                                              // its n-bit bitmap is built when somebody asks (bitmap_of)
+    }
+    // SPARSE vectors hold a value in every entry: entries that turned EPS (a gather out of range / from an EPS
+    // slot) leave the selection
+    DVec sparse_normalised(const SelP &sel, const BufP &data, const BufP &sub) {
+        BufP offsets;
+        const int64_t live = popcount(sub, sel->m, &offsets);
+        if (live == sel->m) return make_sparse(sel, data);
+        SelP ch = child_selection(sel, sub, live, offsets);
+        return make_sparse(ch, compact_write(i64_src(data), sub, sel->m, offsets, live));
+    }
+    // m-entry view of a SPARSE vector as an ordinary dense one (for the kernels that take Src + bitmap + length)
+    DVec entries(const DVec &v) const {
+        DVec o; o.kind = DVec::DENSE; o.n = v.sel->m; o.data = v.data;
+        return o;
+    }
+    DVec make_sparse(const SelP &sel, BufP data) {
+        DVec o; o.kind = DVec::SPARSE; o.n = sel->n; o.sel = sel; o.data = std::move(data);
+        return o;
+    }
+    // values of a dense-form vector on a selection (its validity must cover the selection)
+    DVec sparse_take(const DVec &src, const SelP &sel) {
+        BufP data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(sel->m, 1));
+        BufP junk = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(sel->m), 1));
+        HIP_CHECK(launch_gather(src_of(src), nullptr, src.n, idx_src(*sel), nullptr, sel->m, (int64_t *)data->p, (uint64_t *)junk->p, s));
+        return make_sparse(sel, data);
+    }
+    // SPARSE -> DENSE + bitmap over the n slots
+    DVec sparse_to_dense(const DVec &v) {
+        densified++;
+        DVec o; o.kind = DVec::DENSE; o.n = v.n;
+        o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(v.n, 1));
+        o.valid = zero_bitmap(v.n);
+        HIP_CHECK(launch_scatter(i64_src(v.data), nullptr, idx_src(*v.sel), nullptr, v.sel->m, v.n, (int64_t *)o.data->p, (uint64_t *)o.valid->p, s));
+        if (v.sel->bitmap) { note_subset(o.valid, v.sel->bitmap); note_subset(v.sel->bitmap, o.valid); }
+        else { v.sel->bitmap = o.valid; keep_alive.push_back(o.valid); sel_of_bitmap[o.valid->p] = v.sel; }      // exactly the selected slots
         return o;
     }
 
     DVec densify(const DVec &v) {
+        if (v.kind == DVec::SPARSE) return sparse_to_dense(v);
         if (v.kind != DVec::ONEHOT && v.kind != DVec::OHCONST) return v;
         DVec src = v;
         if (v.kind == DVec::OHCONST) {   // materialise the constant into a one-hot record first
@@ -533,8 +719,46 @@ struct GenExec {
         return o;
     }
 
+    bool descends(const SelP &x, const SelP &from) const {
+        for (SelP k = x; k; k = k->parent) if (k == from) return true;
+        return false;
+    }
+    // SPARSE op SPARSE (on one selection, or one selection filtered out of the other), or SPARSE op constant
+    // whose validity covers the selection
+    bool sparse_binary(const Node &n, const DVec &a0, const DVec &b0, DVec &o) {
+        DVec a = a0, b = b0;
+        if (a.kind == DVec::SPARSE && b.kind == DVec::SPARSE && a.sel != b.sel) {
+            DVec t;
+            if (descends(b.sel, a.sel) && sparse_narrow(a, b.sel, t)) a = t;
+            else if (descends(a.sel, b.sel) && sparse_narrow(b, a.sel, t)) b = t;
+            else return false;
+        }
+        const SelP sel = a.kind == DVec::SPARSE ? a.sel : b.sel;
+        auto as_const = [&](const DVec &k, Src &out) {
+            if (!(k.kind == DVec::RANGE && k.step == 0)) return false;
+            if (k.valid && !subset(bitmap_of(sel), k.valid)) return false;
+            out.kind = SRC_RANGE; out.from = k.from; out.step = 0;
+            return true;
+        };
+        Src sa, sb;
+        if (a.kind == DVec::SPARSE) sa = i64_src(a.data); else if (!as_const(a, sa)) return false;
+        if (b.kind == DVec::SPARSE) sb = i64_src(b.data); else if (!as_const(b, sb)) return false;
+        BufP data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(sel->m, 1));
+        HIP_CHECK(launch_binary(n.bin, sa, sb, (int64_t *)data->p, sel->m, s));
+        o = make_sparse(sel, data);
+        return true;
+    }
+
     DVec binary(const Node &n, const DVec &a0, const DVec &b0) {
         DVec a = a0, b = b0;
+        if (a.kind == DVec::SPARSE || b.kind == DVec::SPARSE) {
+            if (a.n != b.n)
+                throw Error(VDL_ERR_SHAPE, std::string(kBinNames[n.bin]) + " (Id " + std::to_string(n.id) + "): operand lengths differ (" +
+                                               std::to_string(a.n) + " vs " + std::to_string(b.n) + ")");
+            DVec o;
+            if (sparse_binary(n, a, b, o)) return o;
+            a = densify(a); b = densify(b);
+        }
         const bool a_oh = a.kind == DVec::ONEHOT || a.kind == DVec::OHCONST;
         const bool b_oh = b.kind == DVec::ONEHOT || b.kind == DVec::OHCONST;
         if (a.n != b.n)
@@ -574,12 +798,30 @@ struct GenExec {
         return o;
     }
 
+    // where the values of an output go on the host: a pinned buffer of the plan when large
+    int64_t *host_out(Output &o, size_t count) {
+        if (count >= (1u << 16)) {
+            int64_t *pin = p->pinned_out(p->outs.size(), count);
+            if (pin) { o.big = pin; o.big_n = count; return pin; }
+        }
+        o.vals.resize(count);
+        return o.vals.data();
+    }
+
     void materialize(const Node &n, const DVec &v0) {
         Output o;
         o.node = n.id;
         o.name = n.field;
         o.tmp = "tmp" + std::to_string(n.id);
         DVec v = v0;
+        if (v.kind == DVec::SPARSE) {                       // every entry holds a value: the output is the entries
+            if (v.sel->m > 0) {
+                HIP_CHECK(hipMemcpyAsync(host_out(o, (size_t)v.sel->m), v.data->p, sizeof(int64_t) * (size_t)v.sel->m, hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+            }
+            p->outs.push_back(std::move(o));
+            return;
+        }
         if (v.kind == DVec::OHCONST) v = densify(v);
         if (v.kind == DVec::ONEHOT) {
             int64_t h[3];
@@ -598,13 +840,63 @@ struct GenExec {
                 if (total > 0) {
                     BufP outb = dev_alloc(c, sizeof(int64_t) * (size_t)total);
                     HIP_CHECK(launch_compact_write(src_of(v), vp(v), v.n, (const int64_t *)counts->p, (int64_t *)outb->p, s));
-                    o.vals.resize((size_t)total);
-                    HIP_CHECK(hipMemcpyAsync(o.vals.data(), outb->p, sizeof(int64_t) * (size_t)total, hipMemcpyDeviceToHost, s));
+                    HIP_CHECK(hipMemcpyAsync(host_out(o, (size_t)total), outb->p, sizeof(int64_t) * (size_t)total, hipMemcpyDeviceToHost, s));
                     HIP_CHECK(hipStreamSynchronize(s));
                 }
             }
         }
         p->outs.push_back(std::move(o));
+    }
+
+    // entries of a SPARSE vector on a selection filtered (possibly in several steps) out of its own
+    bool sparse_narrow(const DVec &src, const SelP &to, DVec &o) {
+        std::vector<SelP> chain;
+        for (SelP x = to; x && x != src.sel; x = x->parent) chain.push_back(x);
+        if (chain.empty() || chain.back()->parent != src.sel) return false;
+        BufP cur = src.data;
+        int64_t cur_m = src.sel->m;
+        for (size_t k = chain.size(); k-- > 0;) {
+            const SelP &step = chain[k];
+            BufP d = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(step->m, 1));
+            BufP junk = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(step->m), 1));
+            HIP_CHECK(launch_gather(i64_src(cur), nullptr, cur_m, i64_src(step->ppos), nullptr, step->m, (int64_t *)d->p, (uint64_t *)junk->p, s));
+            cur = d; cur_m = step->m;
+        }
+        o = make_sparse(to, cur);
+        return true;
+    }
+
+    // Gather with a sparse side: the filter idiom Gather(x, FoldSelect(..)) producing or narrowing a SPARSE vector,
+    // and gathers through sparse positions (FK joins of filtered fact rows).  false = take the general route.
+    bool sparse_gather(const DVec &src, const DVec &pos, DVec &o) {
+        const bool identity = pos.kind == DVec::RANGE && pos.from == 0 && pos.step == 1 && pos.n == src.n;
+        if (identity) {
+            if (!pos.valid) return false;
+            if (src.kind == DVec::SPARSE) {
+                if (subset(bitmap_of(src.sel), pos.valid)) { o = src; return true; }             // the filter keeps every entry
+                auto it = sel_of_bitmap.find(pos.valid->p);
+                if (it != sel_of_bitmap.end() && sparse_narrow(src, it->second, o)) return true;
+                return false;
+            }
+            if (!(src.kind == DVec::DENSE || src.kind == DVec::COLUMN || src.kind == DVec::RANGE)) return false;
+            BufP both = src.valid ? and_bitmaps(src.valid, pos.valid, src.n) : pos.valid;
+            SelP sel = sel_for(both, src.n);
+            if (!sel->worth) return false;
+            if (src.kind == DVec::RANGE && src.step == 0) return false;                        // constants stay virtual
+            o = sparse_take(src, sel);
+            return true;
+        }
+        if (pos.kind == DVec::SPARSE) {
+            DVec from = densify(src);
+            if (!(from.kind == DVec::DENSE || from.kind == DVec::COLUMN || from.kind == DVec::RANGE)) return false;
+            const SelP &sel = pos.sel;
+            BufP data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(sel->m, 1));
+            BufP sub = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(sel->m), 1));
+            HIP_CHECK(launch_gather(src_of(from), vp(from), from.n, i64_src(pos.data), nullptr, sel->m, (int64_t *)data->p, (uint64_t *)sub->p, s));
+            o = sparse_normalised(sel, data, sub);
+            return true;
+        }
+        return false;
     }
 
     // Partition positions of `data` over the pivots RangeC pmin pcount 1 (EPS in -> EPS out)
@@ -650,6 +942,10 @@ struct GenExec {
                 o.kind = DVec::RANGE; o.n = d.n; o.from = n.imm0; o.step = n.imm1; o.valid = d.valid;
                 return o;
             }
+            if (r.kind == DVec::SPARSE) {
+                o.kind = DVec::RANGE; o.n = r.n; o.from = n.imm0; o.step = n.imm1; o.valid = bitmap_of(r.sel);
+                return o;
+            }
             o.kind = DVec::RANGE; o.n = r.n; o.from = n.imm0; o.step = n.imm1; o.valid = r.valid;
             return o;
         }
@@ -659,6 +955,21 @@ struct GenExec {
         case Op::Binary:
             return binary(n, V(n.a), V(n.b));
         case Op::FoldSelect: {
+            if (V(n.b).kind == DVec::SPARSE) {
+                // filter of a filtered vector: the new selection is carved out of the entries, not out of the n slots
+                const DVec &sd = V(n.b);
+                DVec ctl0 = densify(V(n.a));
+                if (ctl0.n == sd.n && ctl0.kind == DVec::RANGE && ctl0.step != 0 && subset(bitmap_of(sd.sel), ctl0.valid)) {
+                    const SelP &ps = sd.sel;
+                    BufP flags = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(ps->m), 1));
+                    HIP_CHECK(launch_select_bitmap(i64_src(sd.data), nullptr, nullptr, (uint64_t *)flags->p, ps->m, s));
+                    BufP offsets;
+                    const int64_t count = popcount(flags, ps->m, &offsets);
+                    SelP ch = child_selection(ps, flags, count, offsets);
+                    o.kind = DVec::RANGE; o.n = sd.n; o.from = 0; o.step = 1; o.valid = bitmap_of(ch);
+                    return o;
+                }
+            }
             DVec ctl = densify(V(n.a)), d = densify(V(n.b));
             if (ctl.n != d.n) throw Error(VDL_ERR_SHAPE, "FoldSelect (Id " + std::to_string(n.id) + "): operand lengths differ");
             if (!(ctl.kind == DVec::RANGE && ctl.step != 0))
@@ -667,9 +978,14 @@ struct GenExec {
             o.kind = DVec::RANGE; o.n = d.n; o.from = 0; o.step = 1;
             o.valid = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(d.n), 1));
             HIP_CHECK(launch_select_bitmap(src_of(d), vp(d), vp(ctl), (uint64_t *)o.valid->p, d.n, s));
+            note_subset(o.valid, d.valid); note_subset(o.valid, ctl.valid);
             return o;
         }
         case Op::Gather: {
+            if (sparse_on) {
+                DVec fast;
+                if (sparse_gather(V(n.a), V(n.b), fast)) return fast;
+            }
             DVec src = densify(V(n.a)), pos = densify(V(n.b));
             if (pos.kind == DVec::RANGE && pos.from == 0 && pos.step == 1 && pos.n == src.n) {
                 // positions are the slot ids themselves (a filter): a view, no data movement
@@ -681,9 +997,42 @@ struct GenExec {
             o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(o.n, 1));
             o.valid = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(o.n), 1));
             HIP_CHECK(launch_gather(src_of(src), vp(src), src.n, src_of(pos), vp(pos), pos.n, (int64_t *)o.data->p, (uint64_t *)o.valid->p, s));
+            note_subset(o.valid, pos.valid);
             return o;
         }
         case Op::Scatter: {
+            if (sparse_on && V(n.c).kind == DVec::SPARSE) {
+                // positions known only on a selection: m writes instead of n
+                const DVec &sp = V(n.c);
+                DVec sv = V(n.a);
+                const int64_t nout = V(n.b).n;
+                bool ok = sv.n == sp.n;
+                if (ok && sv.kind == DVec::SPARSE && sv.sel != sp.sel) {
+                    DVec t;
+                    if (descends(sp.sel, sv.sel) && sparse_narrow(sv, sp.sel, t)) sv = t; else ok = false;
+                }
+                Src ssrc;
+                if (ok && sv.kind == DVec::SPARSE) ssrc = i64_src(sv.data);
+                else if (ok && sv.kind == DVec::RANGE && sv.step == 0 && subset(bitmap_of(sp.sel), sv.valid)) { ssrc.kind = SRC_RANGE; ssrc.from = sv.from; ssrc.step = 0; }
+                else if (ok && sv.kind == DVec::RANGE && sv.from == 0 && sv.step == 1 && subset(bitmap_of(sp.sel), sv.valid)) ssrc = idx_src(*sp.sel);   // row ids
+                else ok = false;
+                if (ok) {
+                    const int64_t m = sp.sel->m;
+                    if (sp.perm && m <= nout) {
+                        // the positions are a permutation of 0 .. m-1 (Partition): the result lives on the prefix selection
+                        SelP pre = prefix_selection(nout, m);
+                        BufP data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(m, 1));
+                        BufP junk = zero_bitmap(m);
+                        HIP_CHECK(launch_scatter(ssrc, nullptr, i64_src(sp.data), nullptr, m, m, (int64_t *)data->p, (uint64_t *)junk->p, s));
+                        return make_sparse(pre, data);
+                    }
+                    o.kind = DVec::DENSE; o.n = nout;
+                    o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(nout, 1));
+                    o.valid = zero_bitmap(nout);
+                    HIP_CHECK(launch_scatter(ssrc, nullptr, i64_src(sp.data), nullptr, m, nout, (int64_t *)o.data->p, (uint64_t *)o.valid->p, s));
+                    return o;
+                }
+            }
             DVec src = densify(V(n.a)), pos = densify(V(n.c));
             const DVec &fold = V(n.b);
             if (src.n != pos.n) throw Error(VDL_ERR_SHAPE, "Scatter (Id " + std::to_string(n.id) + "): source and position lengths differ");
@@ -695,6 +1044,25 @@ struct GenExec {
             return o;
         }
         case Op::FoldSum: case Op::FoldMin: case Op::FoldMax: case Op::FoldCount: case Op::FoldChoose: {
+            const bool data_on_sel = V(n.a).kind == DVec::SPARSE &&
+                                     ((V(n.b).kind == DVec::SPARSE && V(n.a).sel == V(n.b).sel) ||
+                                      (V(n.b).kind == DVec::RANGE && V(n.b).step == 0 && V(n.b).n == V(n.a).n && subset(bitmap_of(V(n.a).sel), V(n.b).valid)));
+            if (sparse_on && data_on_sel) {
+                // runs skip EPS slots, so folding the m entries gives the same runs; results sit at run-first entries
+                const DVec &sc = V(n.a), &sd = V(n.b);
+                const SelP &sel = sc.sel;
+                Src dsrc = sd.kind == DVec::SPARSE ? i64_src(sd.data) : src_of(sd);
+                const int64_t m = sel->m;
+                const int kind = n.op == Op::FoldSum ? 0 : n.op == Op::FoldMin ? 1 : n.op == Op::FoldMax ? 2 : n.op == Op::FoldCount ? 3 : 4;
+                const size_t nw = (size_t)std::max<int64_t>(nwords(m), 1);
+                BufP heads = dev_alloc(c, sizeof(uint64_t) * nw);
+                BufP wordhd = dev_alloc(c, sizeof(int64_t) * (nw + (size_t)maxscan_blocks((int64_t)nw) + 1));
+                BufP data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(m, 1));
+                BufP vout = zero_bitmap(m);
+                HIP_CHECK(launch_fold_segmented(kind, i64_src(sc.data), nullptr, dsrc, nullptr, m, (uint64_t *)heads->p,
+                                                (int64_t *)wordhd->p, (int64_t *)data->p, (uint64_t *)vout->p, s));
+                return sparse_normalised(sel, data, vout);
+            }
             DVec ctl = densify(V(n.a)), d = densify(V(n.b));
             if (ctl.n != d.n) throw Error(VDL_ERR_SHAPE, std::string(op_name(n.op, -1)) + " (Id " + std::to_string(n.id) + "): operand lengths differ");
             const int kind = n.op == Op::FoldSum ? 0 : n.op == Op::FoldMin ? 1 : n.op == Op::FoldMax ? 2 : n.op == Op::FoldCount ? 3 : 4;
@@ -718,6 +1086,16 @@ struct GenExec {
             return o;
         }
         case Op::Partition: {
+            if (sparse_on && V(n.a).kind == DVec::SPARSE) {
+                const DVec &sd = V(n.a);
+                const DVec &pv = V(n.b);
+                if (pv.kind == DVec::RANGE && pv.step == 1 && !pv.valid) {
+                    DVec pos = partition_positions(entries(sd), pv.from, pv.n);       // every entry holds a value: a permutation of 0 .. m-1
+                    DVec r = make_sparse(sd.sel, pos.data);
+                    r.perm = true;
+                    return r;
+                }
+            }
             DVec data = densify(V(n.a));
             const DVec &piv = V(n.b);
             if (!(piv.kind == DVec::RANGE && piv.step == 1 && !piv.valid))
@@ -762,6 +1140,16 @@ struct GenExec {
             return o;
         }
         case Op::Like: {
+            if (sparse_on && V(n.a).kind == DVec::SPARSE) {
+                const DVec &sd = V(n.a);
+                DVec heap = densify(V(n.b));
+                LikePattern pat{};
+                pat.len = (int)n.pattern.size();
+                memcpy(pat.p, n.pattern.data(), n.pattern.size());
+                BufP data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(sd.sel->m, 1));
+                HIP_CHECK(launch_like(i64_src(sd.data), nullptr, sd.sel->m, src_of(heap), vp(heap), heap.n, pat, (int64_t *)data->p, s));
+                return make_sparse(sd.sel, data);
+            }
             DVec d = densify(V(n.a)), heap = densify(V(n.b));
             LikePattern pat{};
             pat.len = (int)n.pattern.size();
@@ -805,6 +1193,13 @@ struct GenExec {
             if (overrides && overrides->count(n.id)) { vec[(size_t)n.id] = overrides->at(n.id); continue; }
             if (p->profiling) HIP_CHECK(hipEventRecord(e0, s));
             vec[(size_t)n.id] = exec(n);
+            if (trace_forms) {
+                const DVec &r = vec[(size_t)n.id];
+                static const char *const kn[] = {"none", "dense", "column", "range", "onehot", "ohconst", "sparse"};
+                std::fprintf(stderr, "  Id %-4d %-18s -> %-7s n=%lld", n.id, op_name(n.op, n.bin), kn[r.kind], (long long)r.n);
+                if (r.kind == DVec::SPARSE) std::fprintf(stderr, " m=%lld%s%s", (long long)r.sel->m, r.sel->idx ? "" : " (prefix)", r.perm ? " perm" : "");
+                std::fprintf(stderr, "  scatters so far %d\n", densified);
+            }
             if (p->profiling) {
                 HIP_CHECK(hipEventRecord(e1, s));
                 HIP_CHECK(hipEventSynchronize(e1));
@@ -1207,8 +1602,8 @@ int vdl_output(const vdl_plan *p, int k, const char **name, const char **tmp, co
     const Output &o = p->outs[(size_t)k];
     if (name) *name = o.name.c_str();
     if (tmp) *tmp = o.tmp.c_str();
-    if (vals) *vals = o.vals.data();
-    if (n) *n = o.vals.size();
+    if (vals) *vals = o.ptr();
+    if (n) *n = o.count();
     return VDL_OK;
 }
 int vdl_n_timings(const vdl_plan *p) { return p ? (int)p->timings.size() : 0; }

@@ -117,6 +117,8 @@ hipError_t launch_gather(Src src, const uint64_t *vsrc, int64_t nsrc, Src pos, c
 hipError_t launch_scatter(Src src, const uint64_t *vsrc, Src pos, const uint64_t *vpos, int64_t n, int64_t nout,
                           int64_t *out, uint64_t *vout /* pre-zeroed */, hipStream_t s);
 hipError_t launch_fill_words(uint64_t *p, uint64_t v, int64_t nwords, hipStream_t s);
+// bitmap[idx[k]] = 1 for k < m (bitmap pre-zeroed; idx ascending, so neighbours often share a word)
+hipError_t launch_set_bits(const int64_t *idx, int64_t m, uint64_t *bitmap, hipStream_t s);
 
 // device-wide exclusive prefix sum (in place); sums = prefix_sum_blocks(n) + 1 int64 of scratch
 int64_t prefix_sum_blocks(int64_t n);

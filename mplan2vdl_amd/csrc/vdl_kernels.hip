@@ -699,6 +699,20 @@ hipError_t launch_compact_write(Src v, const uint64_t *valid, int64_t n, const i
     return launch_status();
 }
 
+__global__ __launch_bounds__(256) void k_set_bits(const int64_t *idx, int64_t m, uint64_t *bitmap) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += stride) {
+        const int64_t i = idx[k];
+        atomicOr((unsigned long long *)&bitmap[i >> 6], 1ull << (i & 63));
+    }
+}
+hipError_t launch_set_bits(const int64_t *idx, int64_t m, uint64_t *bitmap, hipStream_t s) {
+    (void)hipGetLastError();
+    if (m <= 0) return hipSuccess;
+    k_set_bits<<<grid_for(m, 256, 4), 256, 0, s>>>(idx, m, bitmap);
+    return launch_status();
+}
+
 // Gather (/root/reference/src/Vdl.hs:438): out_i = src[pos_i]; EPS if pos_i is EPS / out of range /
 // the source slot is EPS.  One ballot per wave writes the validity word.
 __global__ __launch_bounds__(256) void k_gather(Src src, const uint64_t *vsrc, int64_t nsrc, Src pos, const uint64_t *vpos,

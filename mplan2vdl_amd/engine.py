@@ -66,6 +66,13 @@ class Plan:
             timings[label.value.decode()] = int(round(us.value))
         return {"results": results, "timings": timings}
 
+    def execute(self):
+        """vdl_run only: the outputs stay in the plan (borrowed until the next run); `collect()` converts them."""
+        self._e._check(self._e._L.vdl_run(self._e._c, self._h))
+
+    def collect(self):
+        return self._collect()
+
     def run(self):
         """Execute on the GPU; returns {"results": {tmpN: {".name": [ints]}}, "timings": {...}}."""
         self._e._check(self._e._L.vdl_run(self._e._c, self._h))

@@ -13,8 +13,9 @@ for path in general exchange; do
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-print("%s: %.2f ms of kernels per run (3 runs)" % (sys.argv[2], tot / 3e6))
+runs = 8 if sys.argv[2] == "general" else 3        # tools/run_q3.py: 3 timed runs (+ 5 vdl_run-only runs on the general route)
+print("%s: %.2f ms of kernels per run (%d runs)" % (sys.argv[2], tot / runs / 1e6, runs))
 for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:8]:
-    print("   %-70s calls %5s  %8.3f ms/run" % (r["Name"][:70], r["Calls"], float(r["TotalDurationNs"]) / 3e6))
+    print("   %-70s calls %5s  %8.3f ms/run" % (r["Name"][:70], r["Calls"], float(r["TotalDurationNs"]) / runs / 1e6))
 PY
 done

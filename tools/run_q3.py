@@ -63,6 +63,9 @@ def timed(label, fn):
 only = os.environ.get("Q3_ONLY")            # "exchange" / "general": one path only (for rocprofv3 runs)
 if only == "general":
     timed("statement-by-statement", plan.run)
+    for it in range(5):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); plan.execute(); dt = time.perf_counter() - t0
+        say("vdl_run alone (outputs left in the plan) run %d: %.2f ms, %.2f M lineitem rows/s" % (it, dt * 1e3, n_li / dt / 1e6))
     e.close(); sys.exit(0)
 out = timed("exchange", lambda: m.run_exchange(plan, dist if world > 1 else None, device=dev, sharded_table="lineitem"))
 flat = {list(v.keys())[0][1:]: list(v.values())[0] for v in out["results"].values()}
