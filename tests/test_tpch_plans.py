@@ -156,3 +156,26 @@ def test_engine_matches_oracle_on_the_vlite_dialect(cfg, n):
     assert (oracle_err is None) == (engine_err is None), (oracle_err, engine_err)
     if oracle_err is None:
         assert got == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["VDL_SPARSE_ALWAYS", "VDL_NO_SPARSE"])
+def test_sparse_vector_routes_agree(cfg, monkeypatch, mode):
+    """The general executor keeps vectors that only hold values on a selection in compact form after selective
+    filters.  Forced on for every filter, and switched off entirely: same answers for every plan."""
+    monkeypatch.setenv(mode, "1")
+    for n in PLANS:
+        text, cols = program_and_columns(cfg, n, 5e-4, seed=3)
+        want = oracle_run(text, cols)
+        e = engine_with(cols)
+        got = e.run_vdl(text)["results"]
+        e.close()
+        assert got == want, (mode, n)
+    fcfg = frontend.load_metadata(META, aggregation_strategy=("AggHierarchical", 5))
+    for n in (1, 3, 10, 16):
+        text, cols = program_and_columns(fcfg, n, 5e-4, seed=3)
+        want = oracle_run(text, cols)
+        e = engine_with(cols)
+        got = e.run_vdl(text)["results"]
+        e.close()
+        assert got == want, (mode, "hierarchical", n)
