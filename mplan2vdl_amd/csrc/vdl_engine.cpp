@@ -1702,7 +1702,13 @@ int vdl_exchange_begin(vdl_ctx *c, vdl_plan *p, int world, int64_t *counts_host)
         vdl_plan::ExState &ex = p->ex;
         ex = vdl_plan::ExState{};
         ex.world = world; ex.nodes = x.sources; ex.pmin = x.pmin; ex.pcount = x.pcount;
-        for (int id : x.sources) ex.src.push_back(g.densify(g.vec[(size_t)id]));
+        // sources that live on one sparse selection travel as their entries (m rows instead of n slots to route and pack)
+        bool all_sparse = !x.sources.empty();
+        for (int id : x.sources) {
+            const DVec &v = g.vec[(size_t)id];
+            all_sparse = all_sparse && v.kind == DVec::SPARSE && v.sel == g.vec[(size_t)x.sources[0]].sel;
+        }
+        for (int id : x.sources) ex.src.push_back(all_sparse ? g.entries(g.vec[(size_t)id]) : g.densify(g.vec[(size_t)id]));
         const DVec &key = ex.src[0];
         ex.n = key.n;
         for (const DVec &v : ex.src)
