@@ -624,7 +624,8 @@ struct GenExec {
                     return known->second;
                 }
             }
-        sel->worth = sel->m * 8 <= n || getenv("VDL_SPARSE_ALWAYS") != nullptr;      // the env switch makes the tests cover every path
+        const char *den = getenv("VDL_SPARSE_DEN");                                 // compaction threshold m <= n / den (default 8)
+        sel->worth = sel->m * (den && atoi(den) > 0 ? atoi(den) : 8) <= n || getenv("VDL_SPARSE_ALWAYS") != nullptr;      // the env switch makes the tests cover every path
         if (sel->worth) sel->idx = compact_write(iota_src(), bits, n, offsets, sel->m);
         keep_alive.push_back(bits);
         sel_of_bitmap[bits->p] = sel;

@@ -50,14 +50,17 @@ class Plan:
     def set_profiling(self, enabled):
         self._e._check(self._e._L.vdl_plan_set_profiling(self._h, int(bool(enabled))))
 
-    def _collect(self):
+    def _collect(self, as_numpy=False):
         L = self._e._L
         results = {}
         for k in range(L.vdl_n_outputs(self._h)):
             name, tmp = ctypes.c_char_p(), ctypes.c_char_p()
             vals, n = ctypes.POINTER(ctypes.c_int64)(), ctypes.c_size_t()
             L.vdl_output(self._h, k, ctypes.byref(name), ctypes.byref(tmp), ctypes.byref(vals), ctypes.byref(n))
-            arr = np.ctypeslib.as_array(vals, shape=(n.value,)).tolist() if n.value else []
+            if as_numpy:
+                arr = np.ctypeslib.as_array(vals, shape=(n.value,)).copy() if n.value else np.zeros(0, np.int64)
+            else:
+                arr = np.ctypeslib.as_array(vals, shape=(n.value,)).tolist() if n.value else []
             results[tmp.value.decode()] = {"." + name.value.decode(): arr}
         timings = {}
         for k in range(L.vdl_n_timings(self._h)):
@@ -70,13 +73,15 @@ class Plan:
         """vdl_run only: the outputs stay in the plan (borrowed until the next run); `collect()` converts them."""
         self._e._check(self._e._L.vdl_run(self._e._c, self._h))
 
-    def collect(self):
-        return self._collect()
+    def collect(self, as_numpy=False):
+        return self._collect(as_numpy)
 
-    def run(self):
-        """Execute on the GPU; returns {"results": {tmpN: {".name": [ints]}}, "timings": {...}}."""
+    def run(self, as_numpy=False):
+        """Execute on the GPU; returns {"results": {tmpN: {".name": [ints]}}, "timings": {...}} (the reply shape of
+        /root/reference/resolve.py:8-32).  as_numpy=True keeps the value lists as int64 arrays: converting millions
+        of result rows to Python ints costs far more than computing them."""
         self._e._check(self._e._L.vdl_run(self._e._c, self._h))
-        return self._collect()
+        return self._collect(as_numpy)
 
     # ---- sharded execution (one process per GPU) ----
     def partial_spec(self):

@@ -598,3 +598,16 @@ def test_like_over_a_string_heap_matches_oracle(pattern):
     e = engine_with(cols)
     assert e.run_vdl(text)["results"] == want
     e.close()
+
+
+def test_results_as_numpy_arrays_and_execute_collect(q6_text):
+    cols = lineitem(datagen.Q6_COLUMNS, 5000)
+    e = engine_with(cols)
+    p = e.parse(q6_text)
+    want = p.run()
+    arr = p.run(as_numpy=True)["results"]
+    assert {k: {f: v.tolist() for f, v in d.items()} for k, d in arr.items()} == want["results"]
+    assert all(v.dtype == np.int64 for d in arr.values() for v in d.values())
+    p.execute()
+    assert p.collect()["results"] == want["results"]
+    e.close()
