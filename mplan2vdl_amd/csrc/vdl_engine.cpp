@@ -107,6 +107,7 @@ struct DVec {
     int64_t n = 0;
     SelP sel;                   // SPARSE: data = the sel->m values; valid = bitmap over those m entries (null = all hold a value)
     bool perm = false;          // SPARSE: the values are a permutation of 0 .. m-1 (Partition positions)
+    bool ids = false;           // SPARSE: every value is its own slot id (row ids gathered through a filter)
     BufP data;                  // DENSE: n int64; ONEHOT/OHCONST: {value, slot, count}
     const void *ptr = nullptr;  // COLUMN: borrowed catalog pointer
     int width = 8;
@@ -695,10 +696,14 @@ struct GenExec {
         densified++;
         DVec o; o.kind = DVec::DENSE; o.n = v.n;
         o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(v.n, 1));
-        o.valid = zero_bitmap(v.n);
-        HIP_CHECK(launch_scatter(i64_src(v.data), nullptr, idx_src(*v.sel), nullptr, v.sel->m, v.n, (int64_t *)o.data->p, (uint64_t *)o.valid->p, s));
-        if (v.sel->bitmap) { note_subset(o.valid, v.sel->bitmap); note_subset(v.sel->bitmap, o.valid); }
-        else { v.sel->bitmap = o.valid; keep_alive.push_back(o.valid); sel_of_bitmap[o.valid->p] = v.sel; }      // exactly the selected slots
+        if (v.sel->bitmap) {                                   // the slots that get written are exactly the selection's bitmap
+            o.valid = v.sel->bitmap;
+            HIP_CHECK(launch_scatter(i64_src(v.data), nullptr, idx_src(*v.sel), nullptr, v.sel->m, v.n, (int64_t *)o.data->p, nullptr, s));
+        } else {
+            o.valid = zero_bitmap(v.n);
+            HIP_CHECK(launch_scatter(i64_src(v.data), nullptr, idx_src(*v.sel), nullptr, v.sel->m, v.n, (int64_t *)o.data->p, (uint64_t *)o.valid->p, s));
+            v.sel->bitmap = o.valid; keep_alive.push_back(o.valid); sel_of_bitmap[o.valid->p] = v.sel;
+        }
         return o;
     }
 
@@ -864,6 +869,7 @@ struct GenExec {
             cur = d; cur_m = step->m;
         }
         o = make_sparse(to, cur);
+        o.ids = src.ids;
         return true;
     }
 
@@ -884,6 +890,11 @@ struct GenExec {
             SelP sel = sel_for(both, src.n);
             if (!sel->worth) return false;
             if (src.kind == DVec::RANGE && src.step == 0) return false;                        // constants stay virtual
+            if (src.kind == DVec::RANGE && src.from == 0 && src.step == 1 && sel->idx) {        // row ids through a filter = the selection's slot list
+                o = make_sparse(sel, sel->idx);
+                o.ids = true;
+                return true;
+            }
             o = sparse_take(src, sel);
             return true;
         }
@@ -904,6 +915,7 @@ struct GenExec {
     DVec partition_positions(const DVec &data, int64_t pmin, int64_t pcount) {
         DVec o;
         o.kind = DVec::DENSE; o.n = data.n; o.valid = data.valid;
+        o.perm = !data.valid;                                   // every slot gets a rank: a permutation of 0 .. n-1
         o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(o.n, 1));
         if (o.n > 0) {
             const int passes = partition_passes(pcount);
@@ -1002,6 +1014,24 @@ struct GenExec {
             return o;
         }
         case Op::Scatter: {
+            {
+                // positions that are the slots' own ids (the dim side of a join scatters ones / row ids back by
+                // Gather(rowids, FoldSelect(..)), Vlite.hs:1268-1275): the result is the source restricted to those slots
+                const DVec &ps = V(n.c), &sv = V(n.a);
+                const int64_t nout = V(n.b).n;
+                BufP where;
+                bool identity = false;
+                if (ps.kind == DVec::RANGE && ps.from == 0 && ps.step == 1 && ps.n == nout) { identity = true; where = ps.valid; }
+                else if (sparse_on && ps.kind == DVec::SPARSE && ps.ids && ps.n == nout) { identity = true; where = bitmap_of(ps.sel); }
+                if (identity && sv.n == ps.n) {
+                    if (sv.kind == DVec::RANGE || sv.kind == DVec::DENSE || sv.kind == DVec::COLUMN) {
+                        o = sv;
+                        o.valid = sv.valid && where ? and_bitmaps(sv.valid, where, nout) : (sv.valid ? sv.valid : where);
+                        return o;
+                    }
+                    if (sv.kind == DVec::SPARSE && ps.kind == DVec::SPARSE && sv.sel == ps.sel) return sv;
+                }
+            }
             if (sparse_on && V(n.c).kind == DVec::SPARSE) {
                 // positions known only on a selection: m writes instead of n
                 const DVec &sp = V(n.c);
@@ -1023,8 +1053,7 @@ struct GenExec {
                         // the positions are a permutation of 0 .. m-1 (Partition): the result lives on the prefix selection
                         SelP pre = prefix_selection(nout, m);
                         BufP data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(m, 1));
-                        BufP junk = zero_bitmap(m);
-                        HIP_CHECK(launch_scatter(ssrc, nullptr, i64_src(sp.data), nullptr, m, m, (int64_t *)data->p, (uint64_t *)junk->p, s));
+                        HIP_CHECK(launch_scatter(ssrc, nullptr, i64_src(sp.data), nullptr, m, m, (int64_t *)data->p, nullptr, s));
                         return make_sparse(pre, data);
                     }
                     o.kind = DVec::DENSE; o.n = nout;
@@ -1039,6 +1068,10 @@ struct GenExec {
             if (src.n != pos.n) throw Error(VDL_ERR_SHAPE, "Scatter (Id " + std::to_string(n.id) + "): source and position lengths differ");
             o.kind = DVec::DENSE; o.n = fold.n;
             o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(o.n, 1));
+            if (pos.perm && !pos.valid && !src.valid && src.n == o.n) {      // a permutation of all slots: every slot is written
+                HIP_CHECK(launch_scatter(src_of(src), nullptr, src_of(pos), nullptr, src.n, o.n, (int64_t *)o.data->p, nullptr, s));
+                return o;
+            }
             o.valid = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(o.n), 1));
             HIP_CHECK(launch_fill_words((uint64_t *)o.valid->p, 0, nwords(o.n), s));
             HIP_CHECK(launch_scatter(src_of(src), vp(src), src_of(pos), vp(pos), src.n, o.n, (int64_t *)o.data->p, (uint64_t *)o.valid->p, s));

@@ -115,7 +115,7 @@ hipError_t launch_compact_write(Src v, const uint64_t *valid, int64_t n, const i
 hipError_t launch_gather(Src src, const uint64_t *vsrc, int64_t nsrc, Src pos, const uint64_t *vpos, int64_t n,
                          int64_t *out, uint64_t *vout, hipStream_t s);
 hipError_t launch_scatter(Src src, const uint64_t *vsrc, Src pos, const uint64_t *vpos, int64_t n, int64_t nout,
-                          int64_t *out, uint64_t *vout /* pre-zeroed */, hipStream_t s);
+                          int64_t *out, uint64_t *vout /* pre-zeroed; null = not wanted */, hipStream_t s);
 hipError_t launch_fill_words(uint64_t *p, uint64_t v, int64_t nwords, hipStream_t s);
 // bitmap[idx[k]] = 1 for k < m (bitmap pre-zeroed; idx ascending, so neighbours often share a word)
 hipError_t launch_set_bits(const int64_t *idx, int64_t m, uint64_t *bitmap, hipStream_t s);

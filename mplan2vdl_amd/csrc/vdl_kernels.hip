@@ -749,7 +749,7 @@ __global__ __launch_bounds__(256) void k_scatter(Src src, const uint64_t *vsrc, 
         const int64_t p = ld(pos, i);
         if (p < 0 || p >= nout) continue;
         out[p] = ld(src, i);
-        atomicOr((unsigned long long *)&vout[p >> 6], 1ull << (p & 63));
+        if (vout) atomicOr((unsigned long long *)&vout[p >> 6], 1ull << (p & 63));    // null: the caller knows which slots get written
     }
 }
 hipError_t launch_scatter(Src src, const uint64_t *vsrc, Src pos, const uint64_t *vpos, int64_t n, int64_t nout, int64_t *out,
