@@ -1805,10 +1805,22 @@ int vdl_exchange_finish(vdl_ctx *c, vdl_plan *p, const void *dev_recv, int64_t n
         const int64_t *in = (const int64_t *)dev_recv;
         const size_t m = ex.src.size();
         std::map<int, DVec> over;
+        // usually every travelling row holds a value in every vector (mask word = all ones): no bitmaps needed then
+        bool all_valid = n_recv == 0 || m <= 1;
+        if (!all_valid) {
+            BufP scratch = dev_alloc(c, sizeof(int64_t) * 3 * (size_t)fold_scratch_blocks());
+            BufP r = dev_alloc(c, 3 * sizeof(int64_t));
+            Src mk; mk.p = in + (int64_t)m * n_recv; mk.kind = SRC_I64;
+            HIP_CHECK(launch_fold_global(1 /* min */, mk, nullptr, nullptr, n_recv, (int64_t *)scratch->p, (int64_t *)r->p, c->stream));
+            int64_t h[3];
+            HIP_CHECK(hipMemcpyAsync(h, r->p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            all_valid = h[0] == (int64_t)(((uint64_t)1 << (m - 1)) - 1);
+        }
         for (size_t k = 0; k < m; k++) {
             DVec v;
             v.kind = DVec::COLUMN; v.n = n_recv; v.ptr = in + (int64_t)k * n_recv; v.width = 8;
-            if (k > 0) {      // source vectors may have had EPS rows: rebuild their bitmaps from the mask column
+            if (k > 0 && !all_valid) {      // source vectors had EPS rows: rebuild their bitmaps from the mask column
                 v.valid = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(GenExec::nwords(n_recv), 1));
                 HIP_CHECK(launch_ex_unmask(in + (int64_t)m * n_recv, n_recv, (int)k - 1, (uint64_t *)v.valid->p, c->stream));
             }
