@@ -102,18 +102,30 @@ struct Sel {
 };
 using SelP = std::shared_ptr<Sel>;
 
+struct ExprNode;
+
 struct DVec {
-    enum Kind { NONE, DENSE, COLUMN, RANGE, ONEHOT, OHCONST, SPARSE } kind = NONE;
+    enum Kind { NONE, DENSE, COLUMN, RANGE, ONEHOT, OHCONST, SPARSE, EXPR } kind = NONE;
     int64_t n = 0;
     SelP sel;                   // SPARSE: data = the sel->m values; valid = bitmap over those m entries (null = all hold a value)
     bool perm = false;          // SPARSE: the values are a permutation of 0 .. m-1 (Partition positions)
     bool ids = false;           // SPARSE: every value is its own slot id (row ids gathered through a filter)
+    std::shared_ptr<ExprNode> ex;   // EXPR: a not yet evaluated tree of element-wise operators (fused when somebody needs the values)
     BufP data;                  // DENSE: n int64; ONEHOT/OHCONST: {value, slot, count}
     const void *ptr = nullptr;  // COLUMN: borrowed catalog pointer
     int width = 8;
     int64_t from = 0, step = 0; // RANGE; OHCONST: from = the constant
     BufP valid;                 // bitmap, null = every slot holds a value
     BufP keep;                  // COLUMN: keeps an engine-owned column alive
+};
+
+// Element-wise operators whose only reader is another element-wise operator are not run one by one: they pile up
+// in a tree whose leaves are stored vectors, and the tree runs as one kernel (k_expr) when its root is needed.
+struct ExprNode {
+    int bin = -1;                          // -1: leaf
+    std::shared_ptr<ExprNode> l, r;
+    DVec leaf;                             // DENSE / COLUMN / RANGE
+    int leaves = 1, instrs = 1, depth = 1;
 };
 
 struct Output {
@@ -707,7 +719,79 @@ struct GenExec {
         return o;
     }
 
+    // ---- fused element-wise trees -------------------------------------------------------------------------
+    bool fuse_on = !getenv("VDL_NO_EXPR_FUSION");
+    std::vector<int> n_uses;                 // readers of each statement in this run (targets count as one more)
+    std::vector<char> read_by_binary_only;
+    static bool leafable(const DVec &v) { return v.kind == DVec::DENSE || v.kind == DVec::COLUMN || v.kind == DVec::RANGE; }
+    std::shared_ptr<ExprNode> expr_of(const DVec &v) {
+        if (v.kind == DVec::EXPR) return v.ex;
+        auto e = std::make_shared<ExprNode>();
+        e->leaf = v;
+        return e;
+    }
+    BufP expr_valid(const ExprNode &e, int64_t n) {               // AND of the leaves' validity (null = all slots)
+        if (e.bin < 0) return e.leaf.valid;
+        BufP a = expr_valid(*e.l, n), b = expr_valid(*e.r, n);
+        if (!a) return b;
+        if (!b) return a;
+        return and_bitmaps(a, b, n);
+    }
+    void expr_emit(const ExprNode &e, ExprProg &prog) {
+        if (e.bin < 0) {
+            const Src sv = src_of(e.leaf);
+            int at = -1;
+            for (int k = 0; k < prog.n_leaf; k++)
+                if (prog.leaf[k].p == sv.p && prog.leaf[k].kind == sv.kind && prog.leaf[k].from == sv.from && prog.leaf[k].step == sv.step) at = k;
+            if (at < 0) { at = prog.n_leaf++; prog.leaf[at] = sv; }
+            prog.code[prog.n_instr++] = (signed char)(-at - 1);
+            return;
+        }
+        expr_emit(*e.l, prog);
+        expr_emit(*e.r, prog);
+        prog.code[prog.n_instr++] = (signed char)e.bin;
+    }
+    DVec expr_force(const DVec &v) {
+        const ExprNode &e = *v.ex;
+        DVec o; o.kind = DVec::DENSE; o.n = v.n;
+        o.valid = expr_valid(e, v.n);
+        o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(v.n, 1));
+        ExprProg prog;
+        expr_emit(e, prog);
+        HIP_CHECK(launch_expr(prog, (int64_t *)o.data->p, v.n, s));
+        return o;
+    }
+    // Binary over stored vectors / pending trees: extend the tree; run it unless the only reader is another Binary
+    bool expr_binary(const Node &n, const DVec &a, const DVec &b, DVec &o) {
+        if (!fuse_on) return false;
+        const bool ta = a.kind == DVec::EXPR, tb = b.kind == DVec::EXPR;
+        if (!(ta || leafable(a)) || !(tb || leafable(b)) || a.n != b.n) return false;
+        if (!ta && !tb && a.kind == DVec::RANGE && b.kind == DVec::RANGE && a.step == 0 && b.step == 0) return false;   // constant folding stays
+        const bool lazy = n_uses[(size_t)n.id] == 1 && read_by_binary_only[(size_t)n.id];
+        if (!lazy && !ta && !tb) return false;                   // a lone operator: the plain kernel
+        DVec x = a, y = b;
+        for (;;) {
+            auto el = expr_of(x), er = expr_of(y);
+            auto t = std::make_shared<ExprNode>();
+            t->bin = n.bin; t->l = el; t->r = er;
+            t->leaves = el->leaves + er->leaves;
+            t->instrs = el->instrs + er->instrs + 1;
+            t->depth = std::max(el->depth, er->depth + 1);
+            if (t->leaves <= kExprLeaves && t->instrs <= kExprInstrs && t->depth <= kExprDepth) {
+                o = DVec{};
+                o.kind = DVec::EXPR; o.n = a.n; o.ex = t;
+                if (!lazy) o = expr_force(o);
+                return true;
+            }
+            // too big for one kernel: run the larger side now and keep it as a leaf
+            if (x.kind == DVec::EXPR && (y.kind != DVec::EXPR || el->instrs >= er->instrs)) x = expr_force(x);
+            else if (y.kind == DVec::EXPR) y = expr_force(y);
+            else return false;
+        }
+    }
+
     DVec densify(const DVec &v) {
+        if (v.kind == DVec::EXPR) return expr_force(v);
         if (v.kind == DVec::SPARSE) return sparse_to_dense(v);
         if (v.kind != DVec::ONEHOT && v.kind != DVec::OHCONST) return v;
         DVec src = v;
@@ -764,6 +848,12 @@ struct GenExec {
             DVec o;
             if (sparse_binary(n, a, b, o)) return o;
             a = densify(a); b = densify(b);
+        }
+        {
+            DVec o;
+            if (expr_binary(n, a, b, o)) return o;
+            if (a.kind == DVec::EXPR) a = expr_force(a);
+            if (b.kind == DVec::EXPR) b = expr_force(b);
         }
         const bool a_oh = a.kind == DVec::ONEHOT || a.kind == DVec::OHCONST;
         const bool b_oh = b.kind == DVec::ONEHOT || b.kind == DVec::OHCONST;
@@ -955,6 +1045,10 @@ struct GenExec {
                 o.kind = DVec::RANGE; o.n = d.n; o.from = n.imm0; o.step = n.imm1; o.valid = d.valid;
                 return o;
             }
+            if (r.kind == DVec::EXPR) {
+                o.kind = DVec::RANGE; o.n = r.n; o.from = n.imm0; o.step = n.imm1; o.valid = expr_valid(*r.ex, r.n);
+                return o;
+            }
             if (r.kind == DVec::SPARSE) {
                 o.kind = DVec::RANGE; o.n = r.n; o.from = n.imm0; o.step = n.imm1; o.valid = bitmap_of(r.sel);
                 return o;
@@ -1078,6 +1172,19 @@ struct GenExec {
             return o;
         }
         case Op::FoldSum: case Op::FoldMin: case Op::FoldMax: case Op::FoldCount: case Op::FoldChoose: {
+            if (sparse_on && V(n.b).kind == DVec::SPARSE && V(n.a).kind == DVec::RANGE && V(n.a).step == 0 && V(n.a).n == V(n.b).n &&
+                V(n.b).sel->m > 0 && V(n.b).sel->idx && V(n.a).valid && V(n.a).valid == V(n.b).sel->bitmap) {
+                // one run over exactly the selected slots (the ungrouped aggregate of a filtered table, Vlite.hs:636-639):
+                // fold the entries; the result sits at the run's first slot = the selection's first slot
+                const DVec &sd = V(n.b);
+                const int kind = n.op == Op::FoldSum ? 0 : n.op == Op::FoldMin ? 1 : n.op == Op::FoldMax ? 2 : n.op == Op::FoldCount ? 3 : 4;
+                BufP scratch = dev_alloc(c, sizeof(int64_t) * 3 * (size_t)fold_scratch_blocks());
+                o.kind = DVec::ONEHOT; o.n = sd.n;
+                o.data = dev_alloc(c, 3 * sizeof(int64_t));
+                HIP_CHECK(launch_fold_global(kind, i64_src(sd.data), nullptr, nullptr, sd.sel->m, (int64_t *)scratch->p, (int64_t *)o.data->p, s));
+                HIP_CHECK(hipMemcpyAsync((int64_t *)o.data->p + 1, sd.sel->idx->p, sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+                return o;
+            }
             const bool data_on_sel = V(n.a).kind == DVec::SPARSE &&
                                      ((V(n.b).kind == DVec::SPARSE && V(n.a).sel == V(n.b).sel) ||
                                       (V(n.b).kind == DVec::RANGE && V(n.b).step == 0 && V(n.b).n == V(n.a).n && subset(bitmap_of(V(n.a).sel), V(n.b).valid)));
@@ -1217,6 +1324,16 @@ struct GenExec {
             for (int opnd : {n.a, n.b, n.c}) if (opnd > 0) last_use[(size_t)opnd] = (int)k;
         }
         for (int id : targets) last_use[(size_t)id] = 1 << 30;      // targets stay alive for the caller
+        n_uses.assign(P.nodes.size(), 0);
+        read_by_binary_only.assign(P.nodes.size(), 1);
+        for (size_t k = 0; k < P.order.size(); k++) {
+            const Node &n = P.at(P.order[k]);
+            if (!needed[(size_t)n.id] || (overrides && overrides->count(n.id))) continue;
+            for (int opnd : {n.a, n.b, n.c})
+                if (opnd > 0) { n_uses[(size_t)opnd]++; if (n.op != Op::Binary) read_by_binary_only[(size_t)opnd] = 0; }
+            if (n.op == Op::Binary && n.a == n.b && n.a > 0) n_uses[(size_t)n.a]--;       // x op x: both operands are one reader
+        }
+        for (int id : targets) n_uses[(size_t)id] += 2;
         p->outs.clear();
         p->timings.clear();
         hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -88,6 +88,15 @@ hipError_t launch_gen_column(void *out, int elem_bytes, int64_t row0, int64_t n,
 // ---- per-operator kernels -----------------------------------------------------------------
 // validity bitmaps: bit (i & 63) of word (i >> 6); nullptr = every slot holds a value.
 hipError_t launch_binary(int op, Src a, Src b, int64_t *out, int64_t n, hipStream_t s);
+// A tree of element-wise operators over up to kExprLeaves vectors of one length, in postfix order, evaluated in one
+// pass (the general path fuses chains of single-use Binary statements into this instead of one kernel per operator).
+constexpr int kExprLeaves = 12, kExprInstrs = 48, kExprDepth = 8;
+struct ExprProg {
+    int n_instr = 0, n_leaf = 0;
+    Src leaf[kExprLeaves];
+    signed char code[kExprInstrs] = {};      // >= 0: apply BinOp code to the two topmost values; < 0: push leaf (-code - 1)
+};
+hipError_t launch_expr(const ExprProg &prog, int64_t *out, int64_t n, hipStream_t s);
 hipError_t launch_and_words(const uint64_t *a, const uint64_t *b, uint64_t *out, int64_t nwords, hipStream_t s);
 // FoldSelect with unit-length runs: out bitmap = (d != 0) & vd & vc
 hipError_t launch_select_bitmap(Src d, const uint64_t *vd, const uint64_t *vc, uint64_t *out, int64_t n, hipStream_t s);

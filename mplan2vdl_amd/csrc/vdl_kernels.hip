@@ -445,6 +445,45 @@ hipError_t launch_binary(int op, Src a, Src b, int64_t *out, int64_t n, hipStrea
     return launch_status();
 }
 
+// Fused element-wise expression tree.  The postfix program is wave-uniform, so the operand stack lives in
+// registers with compile-time indices: every instruction switches (scalar branches) on the stack height it runs
+// at and on its operator.  Each lane evaluates kExprRows rows at once to amortise the scalar work.
+constexpr int kExprRows = 4;
+#define VDL_EX_PUSH(K) case K: _Pragma("unroll") for (int r = 0; r < kExprRows; r++) st[K][r] = row[r] < n ? ld(lf, row[r]) : 0; break;
+#define VDL_EX_BIN(K) case K: _Pragma("unroll") for (int r = 0; r < kExprRows; r++) st[K - 2][r] = apply_bin(op, st[K - 2][r], st[K - 1][r]); break;
+__global__ __launch_bounds__(256) void k_expr(const ExprProg P, int64_t *__restrict__ out, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; base < n; base += kExprRows * stride) {
+        int64_t row[kExprRows];
+#pragma unroll
+        for (int r = 0; r < kExprRows; r++) row[r] = base + r * stride;
+        int64_t st[kExprDepth][kExprRows];
+        int sp = 0;
+        for (int k = 0; k < P.n_instr; k++) {
+            const int code = P.code[k];                 // wave-uniform
+            if (code < 0) {
+                const Src lf = P.leaf[-code - 1];
+                switch (sp) { VDL_EX_PUSH(0) VDL_EX_PUSH(1) VDL_EX_PUSH(2) VDL_EX_PUSH(3) VDL_EX_PUSH(4) VDL_EX_PUSH(5) VDL_EX_PUSH(6) VDL_EX_PUSH(7) }
+                sp++;
+            } else {
+                const int op = code;
+                switch (sp) { VDL_EX_BIN(2) VDL_EX_BIN(3) VDL_EX_BIN(4) VDL_EX_BIN(5) VDL_EX_BIN(6) VDL_EX_BIN(7) VDL_EX_BIN(8) }
+                sp--;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kExprRows; r++) if (row[r] < n) out[row[r]] = st[0][r];
+    }
+}
+#undef VDL_EX_PUSH
+#undef VDL_EX_BIN
+hipError_t launch_expr(const ExprProg &prog, int64_t *out, int64_t n, hipStream_t s) {
+    (void)hipGetLastError();
+    if (n <= 0) return hipSuccess;
+    k_expr<<<grid_for(n, 256, kExprRows), 256, 0, s>>>(prog, out, n);
+    return launch_status();
+}
+
 __global__ void k_and_words(const uint64_t *a, const uint64_t *b, uint64_t *out, int64_t nw) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += stride) out[i] = a[i] & b[i];
