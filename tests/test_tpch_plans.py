@@ -159,10 +159,11 @@ def test_engine_matches_oracle_on_the_vlite_dialect(cfg, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["VDL_SPARSE_ALWAYS", "VDL_NO_SPARSE"])
+@pytest.mark.parametrize("mode", ["VDL_SPARSE_ALWAYS", "VDL_NO_SPARSE", "VDL_NO_EXPR_FUSION"])
 def test_sparse_vector_routes_agree(cfg, monkeypatch, mode):
     """The general executor keeps vectors that only hold values on a selection in compact form after selective
-    filters.  Forced on for every filter, and switched off entirely: same answers for every plan."""
+    filters, and runs chains of single-reader element-wise operators as one fused kernel.  Sparse forced on for
+    every filter, sparse switched off, fusion switched off: same answers for every plan."""
     monkeypatch.setenv(mode, "1")
     for n in PLANS:
         text, cols = program_and_columns(cfg, n, 5e-4, seed=3)
