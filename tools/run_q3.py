@@ -29,6 +29,10 @@ e = m.Engine(local)
 e.use_torch_stream()
 n_cust, n_li = max(n_orders // 10, 1), 4 * n_orders
 r0, r1 = m.shard_rows(n_li, rank, world)
+if os.environ.get("Q3_FAKE_SHARD"):            # "k/N": time what ONE of N ranks would do locally (its lineitem shard, full dimension tables)
+    k, N = [int(x) for x in os.environ["Q3_FAKE_SHARD"].split("/")]
+    r0, r1 = m.shard_rows(n_li, k, N)
+    n_li = r1 - r0
 keep = {}
 def reg(name, t):
     keep[name] = t; e.register_tensor(name, t)
