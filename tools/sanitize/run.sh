@@ -7,8 +7,19 @@ OUT=/tmp/vdl_sanitize
 mkdir -p $OUT
 g++ -std=c++17 -g -O1 -fsanitize=address,undefined -fno-omit-frame-pointer -I$HERE/include -I$HERE/mplan2vdl_amd/csrc \
     $HERE/tools/sanitize/parse_fuse_main.cpp $HERE/mplan2vdl_amd/csrc/vdl_parse.cpp $HERE/mplan2vdl_amd/csrc/vdl_fuse.cpp -o $OUT/parse_fuse
-$OUT/parse_fuse $HERE/tests/golden/q6.vdl $HERE/tests/golden/q1.vdl $HERE/tests/golden/q3.vdl
+# every plan the front end compiles, in both dialects, goes through the sanitized parser + planner too
+PYTHONPATH=$HERE python3 - $HERE $OUT <<'PY'
+import os, sys
+from mplan2vdl_amd import frontend
+here, out = sys.argv[1:3]
+meta = os.path.join(here, "tests", "golden", "tpch10noorder")
+for fmt in ("vdl", "vlite"):
+    cfg = frontend.load_metadata(meta, format=fmt)
+    for n in (1, 3, 4, 5, 6, 9, 10, 11, 12, 14, 15, 16, 18, 19, 20):
+        open(os.path.join(out, "q%02d.%s" % (n, fmt)), "w").write(frontend.compile_plan(open(os.path.join(meta, "%02d.sql.mplan" % n)).read(), cfg))
+PY
+$OUT/parse_fuse $HERE/tests/golden/q6.vdl $HERE/tests/golden/q1.vdl $HERE/tests/golden/q3.vdl $OUT/q*.vdl $OUT/q*.vlite
 gcc -std=c11 -g -O1 -fsanitize=address,undefined -fno-omit-frame-pointer -fopenmp -shared -fPIC $HERE/oracle/vdl_oracle.c -o $OUT/libvdl_oracle_asan.so
 echo "oracle ASan build ok: $OUT/libvdl_oracle_asan.so"
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0 VDL_ORACLE_SO=$OUT/libvdl_oracle_asan.so \
-    python3 -m pytest $HERE/tests/test_oracle.py $HERE/tests/test_datagen.py -x -q -p no:cacheprovider
+    python3 -m pytest $HERE/tests/test_oracle.py $HERE/tests/test_datagen.py $HERE/tests/test_tpch_plans.py -m "not gpu" -x -q -p no:cacheprovider
