@@ -18,7 +18,11 @@
  *       orc_sql_q1), written from the SQL text in the plan headers
  *       (/root/reference/tests/tpch10noorder/06.sql.mplan:1-9, 01.sql.mplan:1-18),
  *       must agree bit-for-bit with this interpreter running the VDL programs;
- *   (3) constants                : /root/reference/README.md:44,48 (dates).
+ *   (3) constants                : /root/reference/README.md:44,48 (dates);
+ *   (4) independent lowerings    : the same SQL compiled three ways by the front end restatement (FK join-index
+ *       gathers, --crossproduct, the VLite format's Semisort grouping) must give the same answers through this
+ *       interpreter (tests/test_tpch_plans.py), Q3 must equal a numpy evaluation of its SQL (tests/helpers.py:sql_q3),
+ *       and Like must equal a regular-expression statement of SQL LIKE (tests/test_oracle.py).
  *
  * Vector model (normative for this repo, see DESIGN.md "Semantics"):
  *   a vector has n slots, each an int64 value or EPS (empty).  Filters never
