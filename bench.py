@@ -25,6 +25,53 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+def secondary_measurements(eng, rows):
+    """Not the headline metric: the other two single-GPU configurations of BASELINE.json on the same box, measured
+    after the timed region (Q1 grouped fused scan over the same lineitem rows; Q3 at SF10 through the statement-by-
+    statement executor).  Parity for both is the job of tests/; a failure here is reported, not fatal."""
+    import torch
+
+    from mplan2vdl_amd import datagen
+
+    also = {}
+    try:
+        for name in datagen.Q1_COLUMNS:
+            if name not in datagen.Q6_COLUMNS:
+                eng.generate(datagen.LINEITEM[name], 0, rows)
+        q1 = eng.parse(open(os.path.join(ROOT, "tests", "golden", "q1.vdl")).read())
+        q1.set_profiling(True)
+        us, wall = [], []
+        for k in range(12):
+            torch.cuda.synchronize(); t0 = time.perf_counter(); r = q1.run(); wall.append(time.perf_counter() - t0)
+            us.append(next(v for lbl, v in r["timings"].items() if "FusedScan" in lbl))
+        k_us = sum(us[2:]) / len(us[2:])
+        also["tpch_q1_same_rows"] = {"rows": rows, "ms_per_query": 1e3 * sum(wall[2:]) / len(wall[2:]), "rows_per_s": rows / (sum(wall[2:]) / len(wall[2:])),
+                                     "kernel_us": k_us, "bytes_per_row": datagen.Q1_BYTES_PER_ROW,
+                                     "roofline_frac": rows * datagen.Q1_BYTES_PER_ROW / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                     "groups": len(r["results"]["tmp101"][".count_order"])}
+        q1.close()
+        for name in datagen.Q1_COLUMNS:
+            eng.drop(name)
+    except Exception as exc:                      # noqa: BLE001 -- secondary numbers must never take the headline line down
+        also["tpch_q1_same_rows"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    try:
+        n_orders = 15000000                       # SF10: 60 M lineitems, 15 M orders, 1.5 M customers
+        keep = datagen.register_q3_columns(eng, n_orders)
+        q3 = eng.parse(open(os.path.join(ROOT, "tests", "golden", "q3.vdl")).read())
+        wall = []
+        for k in range(7):
+            torch.cuda.synchronize(); t0 = time.perf_counter(); q3.execute(); wall.append(time.perf_counter() - t0)
+        res = q3.collect(as_numpy=True)["results"]
+        dt = sum(wall[2:]) / len(wall[2:])
+        also["tpch_q3_sf10"] = {"lineitem_rows": 4 * n_orders, "ms_per_query": 1e3 * dt, "lineitem_rows_per_s": 4 * n_orders / dt,
+                                "result_rows": int(len(res["tmp110"][".revenue"])), "path": "statement by statement (not fused)"}
+        q3.close()
+        del keep
+    except Exception as exc:                      # noqa: BLE001
+        also["tpch_q3_sf10"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    return also
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -34,6 +81,7 @@ def main():
     ap.add_argument("--sf", type=str, default="sf100", help="sf0.01 | sf1 | sf10 | sf100")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=59986052, help="rows of the CPU-baseline sample (default SF10)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the Q1 / Q3 numbers reported under \"also\" (N=1 only)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--query", default="q6", choices=["q6", "q1"],
                     help="q6 (default, BASELINE.json's metric) or q1 (grouped fused scan; secondary measurement)")
@@ -204,6 +252,8 @@ def main():
             "cpu_baseline": cpu_baseline,
             "revenue": (revenue[0] if revenue else None), "verified_bit_exact_vs_cpu": verified,
         }
+        if world == 1 and args.query == "q6" and not args.no_secondary:
+            out["also"] = secondary_measurements(eng, total_rows)
     eng.close()
     if world > 1:
         dist.barrier()

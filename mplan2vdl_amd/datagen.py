@@ -112,3 +112,33 @@ def q3_tables(n_orders, seed=SEED):
     for name in ("lineitem.l_shipdate", "lineitem.l_extendedprice", "lineitem.l_discount"):
         t[name] = generate(LINEITEM[name], 0, n_li, seed)
     return t
+
+
+def register_q3_columns(engine, n_orders, li_rows=None, device="cuda", seed=SEED):
+    """The Q3 catalog of `q3_tables` built in place on the GPU (counter-based generator + arithmetic join indices):
+    customer / orders in full, lineitem rows [li_rows[0], li_rows[1]) (default: all 4 * n_orders).
+    Returns the tensors that back the registered columns (keep them alive while the engine uses them)."""
+    import torch
+
+    n_cust, n_li = max(n_orders // 10, 1), 4 * n_orders
+    r0, r1 = li_rows if li_rows is not None else (0, n_li)
+    keep = {}
+
+    def reg(name, t):
+        keep[name] = t
+        engine.register_tensor(name, t)
+
+    engine.generate(CUSTOMER["customer.c_mktsegment"], 0, n_cust, seed)
+    for name in ORDERS:
+        engine.generate(ORDERS[name], 0, n_orders, seed)
+    engine.generate(ColumnSpec("orders.orders_customer", np.int64, 0, n_cust - 1, 1, 0), 0, n_orders, seed)
+    for name in ("lineitem.l_shipdate", "lineitem.l_extendedprice", "lineitem.l_discount"):
+        engine.generate(LINEITEM[name], r0, r1 - r0, seed)
+    reg("customer.customer_c_custkey_pkey", torch.zeros(n_cust, dtype=torch.int64, device=device))
+    reg("orders.orders_o_orderkey_pkey", torch.zeros(n_orders, dtype=torch.int64, device=device))
+    reg("lineitem.lineitem_l_orderkey_l_linenumber_pkey", torch.zeros(r1 - r0, dtype=torch.int64, device=device))
+    lo = torch.arange(r0, r1, dtype=torch.int64, device=device) // 4
+    reg("lineitem.lineitem_orders", lo)
+    reg("lineitem.l_orderkey", (1 + (lo // 8) * 32 + (lo % 8)).to(torch.int32))
+    torch.cuda.synchronize()
+    return keep

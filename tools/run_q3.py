@@ -33,20 +33,7 @@ if os.environ.get("Q3_FAKE_SHARD"):            # "k/N": time what ONE of N ranks
     k, N = [int(x) for x in os.environ["Q3_FAKE_SHARD"].split("/")]
     r0, r1 = m.shard_rows(n_li, k, N)
     n_li = r1 - r0
-keep = {}
-def reg(name, t):
-    keep[name] = t; e.register_tensor(name, t)
-e.generate(datagen.CUSTOMER["customer.c_mktsegment"], 0, n_cust)
-for name in datagen.ORDERS: e.generate(datagen.ORDERS[name], 0, n_orders)
-e.generate(datagen.ColumnSpec("orders.orders_customer", np.int64, 0, n_cust - 1, 1, 0), 0, n_orders)
-for name in ("lineitem.l_shipdate", "lineitem.l_extendedprice", "lineitem.l_discount"): e.generate(datagen.LINEITEM[name], r0, r1 - r0)
-reg("customer.customer_c_custkey_pkey", torch.zeros(n_cust, dtype=torch.int64, device=dev))
-reg("orders.orders_o_orderkey_pkey", torch.zeros(n_orders, dtype=torch.int64, device=dev))
-reg("lineitem.lineitem_l_orderkey_l_linenumber_pkey", torch.zeros(r1 - r0, dtype=torch.int64, device=dev))
-lo = torch.arange(r0, r1, dtype=torch.int64, device=dev) // 4
-reg("lineitem.lineitem_orders", lo)
-reg("lineitem.l_orderkey", (1 + (lo // 8) * 32 + (lo % 8)).to(torch.int32))
-torch.cuda.synchronize()
+keep = datagen.register_q3_columns(e, n_orders, (r0, r1), device=dev)
 text = open(os.path.join(ROOT, "tests", "golden", "q3.vdl")).read()
 plan = e.parse(text)
 say = print if rank == 0 else (lambda *a, **k: None)
