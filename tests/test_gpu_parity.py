@@ -611,3 +611,23 @@ def test_results_as_numpy_arrays_and_execute_collect(q6_text):
     p.execute()
     assert p.collect()["results"] == want["results"]
     e.close()
+
+
+def test_device_q3_catalog_equals_host_catalog():
+    """datagen.register_q3_columns (what bench.py and tools/run_q3.py use) builds the same columns as datagen.q3_tables."""
+    import mplan2vdl_amd as m
+
+    n_orders = 777
+    host = datagen.q3_tables(n_orders)
+    e = m.Engine(0)
+    keep = datagen.register_q3_columns(e, n_orders)
+    for name in datagen.Q3_COLUMNS:
+        assert np.array_equal(e.download(name).astype(np.int64), host[name].astype(np.int64)), name
+    from conftest import golden
+    from helpers import sql_q3
+
+    out = e.run_vdl(golden("q3.vdl"))["results"]
+    flat = {list(v.keys())[0][1:]: list(v.values())[0] for v in out.values()}
+    assert flat == sql_q3(host)
+    e.close()
+    del keep
