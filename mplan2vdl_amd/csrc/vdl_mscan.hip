@@ -339,6 +339,9 @@ __global__ __launch_bounds__(kMsBlock) void k_mscan(const MScanCols C, const MSc
         for (int u = 0; u < U; u++) { rowid[2 * u] = C.row0 + base + (int64_t)u * (BS * 2); rowid[2 * u + 1] = rowid[2 * u] + 1; }
         load_tile<NC, U, VEC, NT>(C, base, v);
         process(std::integral_constant<int, ROWS>{}, v, rowid);
+#ifdef VDL_MS_REPEAT          // timing experiment only (results are wrong): how much of the kernel is the per-tile work?
+        for (int rep = 1; rep < VDL_MS_REPEAT; rep++) process(std::integral_constant<int, ROWS>{}, v, rowid);
+#endif
     }
     if (blockIdx.x == gridDim.x - 1) {                     // tail rows, one per lane
         for (int64_t i = ntiles * TILE + tid; i < C.n; i += BS) {
