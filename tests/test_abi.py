@@ -149,3 +149,18 @@ def test_unfiltered_aggregate_and_min_max_fuse():
                  "10,FoldMin,val,Id 7,val,Id 4,val", "11,MaterializeCompact,Id 10"])
     assert p.is_fused
     assert p.partial_spec() == (3, [_lib.REDUCE_SUM, _lib.REDUCE_MAX, _lib.REDUCE_MIN])
+
+
+def test_header_is_plain_c_and_a_c_program_links(tmp_path):
+    """The boundary is a C ABI: include/vdl.h compiles as C11 and a C program links against libvdl.so (host-only
+    context: parse, describe, and a loud VDL_ERR_DEVICE from vdl_run -- no CPU fallback)."""
+    import subprocess
+
+    hdr = os.path.join(ROOT, "include", "vdl.h")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-fsyntax-only", "-x", "c", hdr], check=True)
+    exe = str(tmp_path / "host_only")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "host_only.c"),
+                    "-o", exe, "-L" + libdir, "-lvdl", "-Wl,-rpath," + libdir], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert "general: 3 statement(s)" in out and "vdl_run without a device -> 4" in out

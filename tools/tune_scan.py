@@ -16,6 +16,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sf", default="sf100")
+    ap.add_argument("--rows", type=int, default=0, help="row count instead of a scale factor (e.g. one of eight shards of SF100)")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "tune.json"))
     ap.add_argument("--quick", action="store_true")
@@ -24,7 +25,7 @@ def main():
     import mplan2vdl_amd as m
     from mplan2vdl_amd import datagen
 
-    n = datagen.LINEITEM_ROWS[args.sf]
+    n = args.rows or datagen.LINEITEM_ROWS[args.sf]
     eng = m.Engine(device=0)
     for name in datagen.Q6_COLUMNS:
         eng.generate(datagen.LINEITEM[name], 0, n)
