@@ -202,3 +202,27 @@ def scaled_config(cfg, scale):
     out = copy.copy(cfg)
     out.colinfo = NameTable.from_list([(name, ci._replace(count=scaled_rows(ci.count, scale))) for name, ci in cfg.colinfo.to_list()])
     return out
+
+
+def tpch_scaled_config(cfg, factor):
+    """The catalog at `factor` times its scale factor (the metadata under tests/golden/tpch10noorder describes SF10;
+    factor 10 = SF100): row counts of every table but nation / region, and the upper bounds of surrogate keys and
+    join indices, grow with the scale factor (TPC-H specification 4.2.5); everything else keeps its range.  The
+    compiled program depends on these bounds (group-key widths, Partition pivots), so a program compiled for SF10
+    must not be run over SF100 keys."""
+    import copy
+
+    from .frontend.config import NameTable
+
+    def grow(name, ci):
+        table, col = name[0], name[-1]
+        count = ci.count if ci.count <= 64 else int(ci.count * factor)
+        lo, hi = ci.bounds
+        is_key = col.endswith("key") or col.startswith("%")
+        if is_key and ci.trailing_zeros < 63 and hi > lo and ci.count > 64:
+            hi = int(hi * factor)
+        return ci._replace(count=count, bounds=(lo, hi))
+
+    out = copy.copy(cfg)
+    out.colinfo = NameTable.from_list([(name, grow(name, ci)) for name, ci in cfg.colinfo.to_list()])
+    return out

@@ -114,14 +114,18 @@ def q3_tables(n_orders, seed=SEED):
     return t
 
 
-def register_q3_columns(engine, n_orders, li_rows=None, device="cuda", seed=SEED):
+def register_q3_columns(engine, n_orders, li_rows=None, device="cuda", seed=SEED, copartition=False):
     """The Q3 catalog of `q3_tables` built in place on the GPU (counter-based generator + arithmetic join indices):
     customer / orders in full, lineitem rows [li_rows[0], li_rows[1]) (default: all 4 * n_orders).
+    copartition=True keeps only the orders rows the lineitem shard references (lineitem is clustered by order, so
+    that is one contiguous range) and rebases the join index to it: the co-located placement of a sharded star
+    schema, under which no rank repeats the orders-side work of another.
     Returns the tensors that back the registered columns (keep them alive while the engine uses them)."""
     import torch
 
     n_cust, n_li = max(n_orders // 10, 1), 4 * n_orders
     r0, r1 = li_rows if li_rows is not None else (0, n_li)
+    o0, o1 = (r0 // 4, max((r1 - 1) // 4 + 1, r0 // 4)) if copartition and r1 > r0 else (0, n_orders)
     keep = {}
 
     def reg(name, t):
@@ -130,15 +134,15 @@ def register_q3_columns(engine, n_orders, li_rows=None, device="cuda", seed=SEED
 
     engine.generate(CUSTOMER["customer.c_mktsegment"], 0, n_cust, seed)
     for name in ORDERS:
-        engine.generate(ORDERS[name], 0, n_orders, seed)
-    engine.generate(ColumnSpec("orders.orders_customer", np.int64, 0, n_cust - 1, 1, 0), 0, n_orders, seed)
+        engine.generate(ORDERS[name], o0, o1 - o0, seed)
+    engine.generate(ColumnSpec("orders.orders_customer", np.int64, 0, n_cust - 1, 1, 0), o0, o1 - o0, seed)
     for name in ("lineitem.l_shipdate", "lineitem.l_extendedprice", "lineitem.l_discount"):
         engine.generate(LINEITEM[name], r0, r1 - r0, seed)
     reg("customer.customer_c_custkey_pkey", torch.zeros(n_cust, dtype=torch.int64, device=device))
-    reg("orders.orders_o_orderkey_pkey", torch.zeros(n_orders, dtype=torch.int64, device=device))
+    reg("orders.orders_o_orderkey_pkey", torch.zeros(o1 - o0, dtype=torch.int64, device=device))
     reg("lineitem.lineitem_l_orderkey_l_linenumber_pkey", torch.zeros(r1 - r0, dtype=torch.int64, device=device))
     lo = torch.arange(r0, r1, dtype=torch.int64, device=device) // 4
-    reg("lineitem.lineitem_orders", lo)
+    reg("lineitem.lineitem_orders", lo - o0)
     reg("lineitem.l_orderkey", (1 + (lo // 8) * 32 + (lo % 8)).to(torch.int32))
     torch.cuda.synchronize()
     return keep

@@ -117,9 +117,9 @@ class Plan:
     def exchange_pack(self, dev_ptr):
         self._e._check(self._e._L.vdl_exchange_pack(self._e._c, self._h, ctypes.c_void_p(dev_ptr)))
 
-    def exchange_finish(self, dev_ptr, n_recv):
+    def exchange_finish(self, dev_ptr, n_recv, as_numpy=False):
         self._e._check(self._e._L.vdl_exchange_finish(self._e._c, self._h, ctypes.c_void_p(dev_ptr or 0), int(n_recv)))
-        return self._collect()
+        return self._collect(as_numpy)
 
     def finalize_begin(self, dev_ptr, slot):
         self._e._check(self._e._L.vdl_finalize_begin(self._e._c, self._h, ctypes.c_void_p(dev_ptr), int(slot)))

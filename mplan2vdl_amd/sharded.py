@@ -153,7 +153,7 @@ def exchange_rows(send, counts, dist, group=None):
     return recv
 
 
-def run_exchange(plan, dist=None, group=None, device="cuda", sharded_table=None):
+def run_exchange(plan, dist=None, group=None, device="cuda", sharded_table=None, as_numpy=False):
     """Sharded execution of a plan with a Partition (e.g. TPC-H Q3): local phase, all-to-all of the rows
     by key range over RCCL, local tail.  Returns this rank's slice of the result (the slices of rank 0,
     1, ... concatenate to the unsharded result).  The partitioned table is sharded by rows; dimension
@@ -180,8 +180,8 @@ def run_exchange(plan, dist=None, group=None, device="cuda", sharded_table=None)
     send = torch.empty((ncols, max(n_send, 1)), dtype=torch.int64, device=device)[:, :n_send].contiguous()
     plan.exchange_pack(send.data_ptr())
     if world == 1:
-        return plan.exchange_finish(send.data_ptr(), n_send)
+        return plan.exchange_finish(send.data_ptr(), n_send, as_numpy)
     recv = exchange_rows(send, counts, dist, group)
     if recv.is_cuda:
         torch.cuda.current_stream(recv.device).synchronize()      # the engine may run on a stream of its own
-    return plan.exchange_finish(recv.data_ptr(), recv.shape[1])
+    return plan.exchange_finish(recv.data_ptr(), recv.shape[1], as_numpy)

@@ -496,6 +496,41 @@ def _q3_shards(t, world):
     return shards
 
 
+def _q3_shards_copartitioned(t, world):
+    """Each rank holds its lineitem rows and exactly the orders rows they reference (lineitem is clustered by order),
+    with the join index rebased: the co-located placement of a sharded star schema."""
+    from mplan2vdl_amd import shard_rows
+
+    n_li = len(t["lineitem.l_orderkey"])
+    shards = []
+    for r in range(world):
+        r0, r1 = shard_rows(n_li, r, world)
+        fk = t["lineitem.lineitem_orders"][r0:r1]
+        o0, o1 = (int(fk.min()), int(fk.max()) + 1) if r1 > r0 else (0, 0)
+        cols = {}
+        for k, v in t.items():
+            if k.startswith("lineitem."):
+                cols[k] = v[r0:r1]
+            elif k.startswith("orders."):
+                cols[k] = v[o0:o1]
+            else:
+                cols[k] = v
+        cols["lineitem.lineitem_orders"] = fk - o0
+        shards.append(cols)
+    return shards
+
+
+@pytest.mark.parametrize("world,n_orders", [(2, 15000), (4, 40000)])
+def test_q3_sharded_with_copartitioned_orders_matches_oracle(world, n_orders):
+    from conftest import golden
+
+    text = golden("q3.vdl")
+    t = datagen.q3_tables(n_orders)
+    want = oracle_run(text, t)
+    got, _ = _emulated_exchange(text, _q3_shards_copartitioned(t, world), "lineitem")
+    assert got == want
+
+
 @pytest.mark.parametrize("world,n_orders", [(1, 1000), (2, 1), (2, 15000), (3, 40000), (5, 150000)])
 def test_q3_sharded_partition_exchange_matches_oracle(world, n_orders):
     """Sharded Q3: lineitem split by rows, orders/customer replicated, rows exchanged

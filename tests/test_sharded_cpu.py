@@ -238,7 +238,7 @@ class ExchangeRunner:
         self.send[1] = torch.from_numpy(self.v[o])
         self.send[2] = 1
 
-    def exchange_finish(self, ptr, n_recv):
+    def exchange_finish(self, ptr, n_recv, as_numpy=False):
         recv = self.recv.numpy()
         assert recv.shape[1] == n_recv
         keys = np.unique(recv[0])
