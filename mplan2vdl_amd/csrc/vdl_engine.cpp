@@ -1001,6 +1001,48 @@ struct GenExec {
         return false;
     }
 
+    // FoldSelect over general runs (oracle/vdl_oracle.c:op_fold F_SEL): inside every run of the control vector (EPS
+    // control slots skipped) the slot ids of the non-zero data are packed into the run's first member slots.
+    // On the m non-EPS control slots: run number by a prefix sum over the run heads; a stable Partition by
+    // (run, not selected) ranks the selected entries of a run first, in order, so rank = the member slot to write.
+    DVec fold_select_runs(const DVec &ctl, const DVec &d) {
+        const int64_t n = d.n;
+        DVec o; o.kind = DVec::DENSE; o.n = n;
+        o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(n, 1));
+        o.valid = zero_bitmap(n);
+        BufP offsets;
+        const int64_t m = popcount(ctl.valid, n, &offsets);
+        if (m == 0) return o;
+        BufP idx = compact_write(iota_src(), ctl.valid, n, offsets, m);             // member slots
+        auto at_members = [&](const DVec &v, BufP &vals, BufP &vbits) {
+            vals = dev_alloc(c, sizeof(int64_t) * (size_t)m);
+            vbits = dev_alloc(c, sizeof(uint64_t) * (size_t)nwords(m));
+            HIP_CHECK(launch_gather(src_of(v), vp(v), v.n, i64_src(idx), nullptr, m, (int64_t *)vals->p, (uint64_t *)vbits->p, s));
+        };
+        BufP ce, cv, de, dv;
+        at_members(ctl, ce, cv);
+        at_members(d, de, dv);
+        BufP flags = dev_alloc(c, sizeof(int64_t) * (size_t)m), excl = dev_alloc(c, sizeof(int64_t) * (size_t)m);
+        HIP_CHECK(launch_run_heads((const int64_t *)ce->p, m, (int64_t *)flags->p, (int64_t *)excl->p, s));
+        BufP sums = dev_alloc(c, sizeof(int64_t) * (size_t)(prefix_sum_blocks(m) + 2));
+        HIP_CHECK(launch_prefix_sum((int64_t *)excl->p, m, (int64_t *)sums->p, s));
+        BufP keys = dev_alloc(c, sizeof(int64_t) * (size_t)m);
+        BufP selected = dev_alloc(c, sizeof(uint64_t) * (size_t)nwords(m));
+        HIP_CHECK(launch_fsel_keys((const int64_t *)excl->p, (const int64_t *)flags->p, (const int64_t *)de->p, (const uint64_t *)dv->p, m,
+                                   (int64_t *)keys->p, (uint64_t *)selected->p, s));
+        int64_t last[2];
+        HIP_CHECK(hipMemcpyAsync(&last[0], (const int64_t *)excl->p + (m - 1), sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(&last[1], (const int64_t *)flags->p + (m - 1), sizeof(int64_t), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        const int64_t nruns = last[0] + last[1];
+        DVec kv; kv.kind = DVec::DENSE; kv.n = m; kv.data = keys;
+        DVec rank = partition_positions(kv, 0, 2 * nruns);
+        BufP target = dev_alloc(c, sizeof(int64_t) * (size_t)m), junk = dev_alloc(c, sizeof(uint64_t) * (size_t)nwords(m));
+        HIP_CHECK(launch_gather(i64_src(idx), nullptr, m, i64_src(rank.data), nullptr, m, (int64_t *)target->p, (uint64_t *)junk->p, s));
+        HIP_CHECK(launch_scatter(i64_src(idx), (const uint64_t *)selected->p, i64_src(target), nullptr, m, n, (int64_t *)o.data->p, (uint64_t *)o.valid->p, s));
+        return o;
+    }
+
     // Partition positions of `data` over the pivots RangeC pmin pcount 1 (EPS in -> EPS out)
     DVec partition_positions(const DVec &data, int64_t pmin, int64_t pcount) {
         DVec o;
@@ -1079,9 +1121,7 @@ struct GenExec {
             }
             DVec ctl = densify(V(n.a)), d = densify(V(n.b));
             if (ctl.n != d.n) throw Error(VDL_ERR_SHAPE, "FoldSelect (Id " + std::to_string(n.id) + "): operand lengths differ");
-            if (!(ctl.kind == DVec::RANGE && ctl.step != 0))
-                throw Error(VDL_ERR_UNSUPPORTED, "FoldSelect (Id " + std::to_string(n.id) +
-                                                     "): only unit-length runs (control = RangeV with non-zero step) are implemented");
+            if (!(ctl.kind == DVec::RANGE && ctl.step != 0)) return fold_select_runs(ctl, d);
             o.kind = DVec::RANGE; o.n = d.n; o.from = 0; o.step = 1;
             o.valid = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(d.n), 1));
             HIP_CHECK(launch_select_bitmap(src_of(d), vp(d), vp(ctl), (uint64_t *)o.valid->p, d.n, s));

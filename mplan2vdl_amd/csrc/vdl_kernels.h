@@ -129,6 +129,12 @@ hipError_t launch_fill_words(uint64_t *p, uint64_t v, int64_t nwords, hipStream_
 // bitmap[idx[k]] = 1 for k < m (bitmap pre-zeroed; idx ascending, so neighbours often share a word)
 hipError_t launch_set_bits(const int64_t *idx, int64_t m, uint64_t *bitmap, hipStream_t s);
 
+// FoldSelect over general runs (vdl_engine.cpp: fold_select_runs): head flags of the runs of `ctl` (m entries, all valid),
+// then the sort key 2 * run + (entry not selected) and the bitmap of selected entries
+hipError_t launch_run_heads(const int64_t *ctl, int64_t m, int64_t *flags, int64_t *flags_copy, hipStream_t s);
+hipError_t launch_fsel_keys(const int64_t *excl_heads, const int64_t *flags, const int64_t *d, const uint64_t *vd, int64_t m,
+                            int64_t *keys, uint64_t *selected, hipStream_t s);
+
 // device-wide exclusive prefix sum (in place); sums = prefix_sum_blocks(n) + 1 int64 of scratch
 int64_t prefix_sum_blocks(int64_t n);
 hipError_t launch_prefix_sum(int64_t *x, int64_t n, int64_t *sums, hipStream_t s);

@@ -738,6 +738,41 @@ hipError_t launch_compact_write(Src v, const uint64_t *valid, int64_t n, const i
     return launch_status();
 }
 
+// ---- FoldSelect over general runs (never emitted by mplan2vdl, whose six call sites use unit runs: Vlite.hs:702-1228) ----
+__global__ __launch_bounds__(256) void k_run_heads(const int64_t *ctl, int64_t m, int64_t *flags, int64_t *flags_copy) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < m; e += stride) {
+        const int64_t f = (e == 0 || ctl[e] != ctl[e - 1]) ? 1 : 0;
+        flags[e] = f; flags_copy[e] = f;
+    }
+}
+hipError_t launch_run_heads(const int64_t *ctl, int64_t m, int64_t *flags, int64_t *flags_copy, hipStream_t s) {
+    (void)hipGetLastError();
+    if (m <= 0) return hipSuccess;
+    k_run_heads<<<grid_for(m, 256, 4), 256, 0, s>>>(ctl, m, flags, flags_copy);
+    return launch_status();
+}
+__global__ __launch_bounds__(256) void k_fsel_keys(const int64_t *excl_heads, const int64_t *flags, const int64_t *d, const uint64_t *vd, int64_t m,
+                                                   int64_t *keys, uint64_t *selected) {
+    const int64_t nw = (m + 63) >> 6;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave);
+    for (int64_t w = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; w < nw; w += wstride) {
+        const int64_t e = (w << 6) + lane;
+        const bool sel = e < m && bit(vd, e) && d[e] != 0;
+        if (e < m) keys[e] = 2 * (excl_heads[e] + flags[e] - 1) + (sel ? 0 : 1);      // run number, selected entries first
+        const uint64_t mk = __ballot(sel);
+        if (lane == 0) selected[w] = mk;
+    }
+}
+hipError_t launch_fsel_keys(const int64_t *excl_heads, const int64_t *flags, const int64_t *d, const uint64_t *vd, int64_t m,
+                            int64_t *keys, uint64_t *selected, hipStream_t s) {
+    (void)hipGetLastError();
+    if (m <= 0) return hipSuccess;
+    k_fsel_keys<<<grid_for(m, 256, 4), 256, 0, s>>>(excl_heads, flags, d, vd, m, keys, selected);
+    return launch_status();
+}
+
 __global__ __launch_bounds__(256) void k_set_bits(const int64_t *idx, int64_t m, uint64_t *bitmap) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += stride) {

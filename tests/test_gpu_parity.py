@@ -666,3 +666,26 @@ def test_device_q3_catalog_equals_host_catalog():
     assert flat == sql_q3(host)
     e.close()
     del keep
+
+
+@pytest.mark.parametrize("n,keys", [(1, 1), (64, 3), (5000, 7), (70000, 40)])
+def test_foldselect_over_general_runs_matches_oracle(n, keys):
+    """FoldSelect with runs longer than one slot (never emitted by mplan2vdl, Vlite.hs:702-1228, but part of the
+    operator): per run of the control vector, EPS control slots skipped, the positions of the non-zero data packed
+    at the run's first member slots."""
+    rng = np.random.default_rng(n)
+    ctl = np.sort(rng.integers(0, keys, n)).astype(np.int64)
+    ctl[rng.integers(0, n, n // 3)] = rng.integers(0, keys, n // 3)              # runs of the same key may come back later
+    cols = {"t.c": ctl, "t.d": rng.integers(0, 3, n).astype(np.int64), "t.f": rng.integers(0, 4, n).astype(np.int64),
+            "t.g": rng.integers(0, 5, n).astype(np.int64)}
+    text = prog("1,Load,t.c", "2,Project,val,Id 1,c", "3,Load,t.d", "4,Project,val,Id 3,d", "5,Load,t.f", "6,Project,val,Id 5,f",
+                "7,Load,t.g", "8,Project,val,Id 7,g",
+                "9,RangeV,val,0,Id 6,1", "10,FoldSelect,val,Id 9,val,Id 6,val", "11,Gather,Id 2,Id 10,val",      # control with holes
+                "12,RangeV,val,0,Id 8,1", "13,FoldSelect,val,Id 12,val,Id 8,val", "14,Gather,Id 4,Id 13,val",    # data with other holes
+                "15,FoldSelect,val,Id 2,val,Id 4,val", "16,MaterializeCompact,Id 15",                             # plain
+                "17,FoldSelect,val,Id 11,val,Id 14,val", "18,MaterializeCompact,Id 17",                           # holes on both sides
+                "19,Gather,Id 4,Id 17,val", "20,MaterializeCompact,Id 19")                                        # and used as positions
+    want = oracle_run(text, cols)
+    e = engine_with(cols)
+    assert e.run_vdl(text)["results"] == want
+    e.close()

@@ -50,7 +50,7 @@ class Gen:
     def step(self):
         r = self.rng
         tab = "t" if r.random() < 0.75 else "u"
-        kind = r.choice(["bin", "bin", "const", "filter", "fk", "dimmask", "group", "fold", "out"])
+        kind = r.choice(["bin", "bin", "const", "filter", "fk", "dimmask", "group", "fold", "out", "selruns"])
         if kind == "bin":
             a, b = self.pick(tab), self.pick(tab)
             if r.random() < 0.4:
@@ -85,6 +85,9 @@ class Gen:
                 x = self.pick(tab)
                 sx = self.emit("Scatter,Id %d,Id %d,val,Id %d,val" % (x, self.rangev(0, x, 1), part))
                 self.output(self.emit("%s,val,Id %d,val,Id %d,val" % (r.choice(FOLDS), skey, sx)))
+        elif kind == "selruns":                      # FoldSelect over runs of a low-cardinality control vector
+            ctl = self.binary("BitwiseAnd", self.pick(tab), self.rangev(int(r.choice([1, 3])), self.pick(tab), 0))
+            self.pool[tab].append(self.emit("FoldSelect,val,Id %d,val,Id %d,val" % (ctl, self.pick(tab))))
         elif kind == "fold":
             x = self.pick(tab)
             self.output(self.emit("%s,val,Id %d,val,Id %d,val" % (r.choice(FOLDS[:3]), self.rangev(0, x, 0), x)))
