@@ -96,7 +96,9 @@ int  vdl_download_column(vdl_ctx *ctx, const char *name, void *host_ptr, size_t 
 /* ---- plans --------------------------------------------------------------------- */
 
 /* Parse the VDL text, check it, and build the execution plan (operator fusion included).
- * Needs no device. */
+ * Needs no device.  Both output formats of the compiler are accepted: the default VDL lines
+ * (/root/reference/src/Vdl.hs:410-453) and the --vliteformat lines (Vdl.hs:370-408,455-475; recognised by
+ * their Output statements). */
 int  vdl_parse(vdl_ctx *ctx, const char *vdl_text, size_t len, vdl_plan **out);
 void vdl_plan_free(vdl_plan *plan);
 
