@@ -144,6 +144,8 @@ struct Timing { std::string label; double usec; };
 struct vdl_ctx {
     int device = -1;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t copy_stream = nullptr;     // result copies of the general path run here, behind an event, while later statements compute
+    hipEvent_t copy_ev = nullptr;
     int num_cus = 256;
     std::map<std::string, Column> cols;
     uint64_t catalog_version = 1;      // bumped on every catalog change: plans re-bind only when it moved
@@ -537,6 +539,7 @@ struct GenExec {
     hipStream_t s;
 
     GenExec(vdl_ctx *ctx, vdl_plan *plan) : c(ctx), p(plan), vec(plan->prog.nodes.size()), last_use(plan->prog.nodes.size(), -1), s(ctx->stream) {}
+    ~GenExec() { if (!copies_in_flight.empty() && c->copy_stream) (void)hipStreamSynchronize(c->copy_stream); }     // error exits
 
     static int64_t nwords(int64_t n) { return (n + 63) >> 6; }
     const uint64_t *vp(const DVec &v) const { return v.valid ? (const uint64_t *)v.valid->p : nullptr; }
@@ -894,6 +897,31 @@ struct GenExec {
         return o;
     }
 
+    // Result transfers of pinned outputs are queued on the context's copy stream behind the kernels that produced them
+    // and overlap the statements that follow; the run waits for them at its end.
+    std::vector<BufP> copies_in_flight;
+    void copy_out(Output &o, const BufP &dev, size_t count) {
+        int64_t *dst = host_out(o, count);
+        if (!o.big) {                                   // small / pageable: the plain blocking route
+            HIP_CHECK(hipMemcpyAsync(dst, dev->p, sizeof(int64_t) * count, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            return;
+        }
+        if (!c->copy_stream) {
+            HIP_CHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+            HIP_CHECK(hipEventCreateWithFlags(&c->copy_ev, hipEventDisableTiming));
+        }
+        HIP_CHECK(hipEventRecord(c->copy_ev, s));
+        HIP_CHECK(hipStreamWaitEvent(c->copy_stream, c->copy_ev, 0));
+        HIP_CHECK(hipMemcpyAsync(dst, dev->p, sizeof(int64_t) * count, hipMemcpyDeviceToHost, c->copy_stream));
+        copies_in_flight.push_back(dev);                // the pool must not hand the buffer out again before the copy ran
+    }
+    void finish_copies() {
+        if (copies_in_flight.empty()) return;
+        HIP_CHECK(hipStreamSynchronize(c->copy_stream));
+        copies_in_flight.clear();
+    }
+
     // where the values of an output go on the host: a pinned buffer of the plan when large
     int64_t *host_out(Output &o, size_t count) {
         if (count >= (1u << 16)) {
@@ -911,10 +939,7 @@ struct GenExec {
         o.tmp = "tmp" + std::to_string(n.id);
         DVec v = v0;
         if (v.kind == DVec::SPARSE) {                       // every entry holds a value: the output is the entries
-            if (v.sel->m > 0) {
-                HIP_CHECK(hipMemcpyAsync(host_out(o, (size_t)v.sel->m), v.data->p, sizeof(int64_t) * (size_t)v.sel->m, hipMemcpyDeviceToHost, s));
-                HIP_CHECK(hipStreamSynchronize(s));
-            }
+            if (v.sel->m > 0) copy_out(o, v.data, (size_t)v.sel->m);
             p->outs.push_back(std::move(o));
             return;
         }
@@ -936,8 +961,7 @@ struct GenExec {
                 if (total > 0) {
                     BufP outb = dev_alloc(c, sizeof(int64_t) * (size_t)total);
                     HIP_CHECK(launch_compact_write(src_of(v), vp(v), v.n, (const int64_t *)counts->p, (int64_t *)outb->p, s));
-                    HIP_CHECK(hipMemcpyAsync(host_out(o, (size_t)total), outb->p, sizeof(int64_t) * (size_t)total, hipMemcpyDeviceToHost, s));
-                    HIP_CHECK(hipStreamSynchronize(s));
+                    copy_out(o, outb, (size_t)total);
                 }
             }
         }
@@ -1402,6 +1426,7 @@ struct GenExec {
                 if (opnd > 0 && last_use[(size_t)opnd] == (int)k) vec[(size_t)opnd] = DVec{};
         }
         HIP_CHECK(hipStreamSynchronize(s));
+        finish_copies();
         if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
     }
 };
@@ -1630,6 +1655,8 @@ void vdl_close(vdl_ctx *c) {
         c->pool->trim();
         c->pool->closed = true;
         if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+        if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+        if (c->copy_ev) (void)hipEventDestroy(c->copy_ev);
     }
     delete c;
 }
