@@ -665,6 +665,8 @@ struct GenExec {
         }
         return sel->bitmap;
     }
+    struct RunHeads { BufP ctl, heads, wordhd, offsets; int64_t count = 0; SelP child; };
+    std::map<const void *, RunHeads> heads_of;                  // control entries buffer -> its run heads (kept alive by .ctl)
     SelP prefix_selection(int64_t n, int64_t m) {
         for (const SelP &x : prefixes) if (x->n == n && x->m == m) return x;
         SelP x = std::make_shared<Sel>();
@@ -1259,14 +1261,24 @@ struct GenExec {
                 Src dsrc = sd.kind == DVec::SPARSE ? i64_src(sd.data) : src_of(sd);
                 const int64_t m = sel->m;
                 const int kind = n.op == Op::FoldSum ? 0 : n.op == Op::FoldMin ? 1 : n.op == Op::FoldMax ? 2 : n.op == Op::FoldCount ? 3 : 4;
-                const size_t nw = (size_t)std::max<int64_t>(nwords(m), 1);
-                BufP heads = dev_alloc(c, sizeof(uint64_t) * nw);
-                BufP wordhd = dev_alloc(c, sizeof(int64_t) * (nw + (size_t)maxscan_blocks((int64_t)nw) + 1));
+                // every entry holds a datum, so each run yields a result at its head: the run heads of this control
+                // vector -- and the selection they form -- are computed once and shared by all folds over it
+                // (a GROUP BY folds every aggregate over the same sorted key, Vlite.hs:1056-1060)
+                RunHeads &rh = heads_of[sc.data->p];
+                if (!rh.heads) {
+                    const size_t nw = (size_t)std::max<int64_t>(nwords(m), 1);
+                    rh.ctl = sc.data;
+                    rh.heads = dev_alloc(c, sizeof(uint64_t) * nw);
+                    rh.wordhd = dev_alloc(c, sizeof(int64_t) * (nw + (size_t)maxscan_blocks((int64_t)nw) + 1));
+                    HIP_CHECK(launch_fold_heads(i64_src(sc.data), nullptr, m, (uint64_t *)rh.heads->p, (int64_t *)rh.wordhd->p, s));
+                    rh.count = popcount(rh.heads, m, &rh.offsets);
+                    rh.child = child_selection(sel, rh.heads, rh.count, rh.offsets);
+                }
                 BufP data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(m, 1));
                 BufP vout = zero_bitmap(m);
-                HIP_CHECK(launch_fold_segmented(kind, i64_src(sc.data), nullptr, dsrc, nullptr, m, (uint64_t *)heads->p,
-                                                (int64_t *)wordhd->p, (int64_t *)data->p, (uint64_t *)vout->p, s));
-                return sparse_normalised(sel, data, vout);
+                HIP_CHECK(launch_fold_runs(kind, dsrc, nullptr, nullptr, (const uint64_t *)rh.heads->p, (const int64_t *)rh.wordhd->p, m,
+                                           (int64_t *)data->p, (uint64_t *)vout->p, s));
+                return make_sparse(rh.child, compact_write(i64_src(data), rh.heads, m, rh.offsets, rh.count));
             }
             DVec ctl = densify(V(n.a)), d = densify(V(n.b));
             if (ctl.n != d.n) throw Error(VDL_ERR_SHAPE, std::string(op_name(n.op, -1)) + " (Id " + std::to_string(n.id) + "): operand lengths differ");

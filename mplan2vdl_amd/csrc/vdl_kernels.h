@@ -149,6 +149,9 @@ hipError_t launch_partition(Src data, const uint64_t *valid, int64_t n, int64_t 
 // Fold over a general control vector; kind 0 sum, 1 min, 2 max, 3 count, 4 choose
 // heads: nwords uint64; wordhd: nwords + maxscan_blocks(nwords) int64
 int64_t maxscan_blocks(int64_t n);
+hipError_t launch_fold_heads(Src ctl, const uint64_t *vc, int64_t n, uint64_t *heads, int64_t *wordhd, hipStream_t s);
+hipError_t launch_fold_runs(int kind, Src d, const uint64_t *vd, const uint64_t *vc, const uint64_t *heads, const int64_t *wordhd, int64_t n,
+                            int64_t *out, uint64_t *vout, hipStream_t s);
 hipError_t launch_fold_segmented(int kind, Src ctl, const uint64_t *vc, Src d, const uint64_t *vd, int64_t n, uint64_t *heads,
                                  int64_t *wordhd, int64_t *out, uint64_t *vout, hipStream_t s);
 

@@ -1193,19 +1193,32 @@ __global__ void k_seg_choose_fix(Src d, const uint64_t *vout, int64_t n, int64_t
 }
 
 // scratch: heads bitmap (nwords) and wordhd (nwords + maxscan_blocks(nwords) int64) supplied by the caller
-hipError_t launch_fold_segmented(int kind, Src ctl, const uint64_t *vc, Src d, const uint64_t *vd, int64_t n,
-                                 uint64_t *heads, int64_t *wordhd, int64_t *out, uint64_t *vout /* pre-zeroed */, hipStream_t s) {
+// run heads of a control vector (first slot of every run, EPS control slots skipped) + the per-word lookup the fold needs
+hipError_t launch_fold_heads(Src ctl, const uint64_t *vc, int64_t n, uint64_t *heads, int64_t *wordhd, hipStream_t s) {
     (void)hipGetLastError();   // see launch_status()
     if (n <= 0) return hipSuccess;
     const int64_t nw = (n + 63) >> 6;
-    const int rk = (kind == 1 || kind == 4) ? R_MIN : kind == 2 ? R_MAX : R_SUM;
     k_seg_heads<<<grid_for(n, 256, 4), 256, 0, s>>>(ctl, vc, n, heads);
     k_seg_wordhd<<<grid_for(nw, 256, 1), 256, 0, s>>>(heads, nw, wordhd);
     if (launch_maxscan(wordhd, nw, wordhd + nw, s) != hipSuccess) return hipGetLastError();
+    return launch_status();
+}
+// the fold itself, over heads computed by launch_fold_heads for the same control vector (several folds share them)
+hipError_t launch_fold_runs(int kind, Src d, const uint64_t *vd, const uint64_t *vc, const uint64_t *heads, const int64_t *wordhd, int64_t n,
+                            int64_t *out, uint64_t *vout /* pre-zeroed */, hipStream_t s) {
+    (void)hipGetLastError();
+    if (n <= 0) return hipSuccess;
+    const int rk = (kind == 1 || kind == 4) ? R_MIN : kind == 2 ? R_MAX : R_SUM;
     k_seg_fill<<<grid_for(n, 256, 4), 256, 0, s>>>(out, rk == R_SUM ? 0 : rk == R_MIN ? INT64_MAX : INT64_MIN, n);
     k_seg_fold<<<grid_for(n, 256, 4), 256, 0, s>>>(kind, d, vd, vc, heads, wordhd, n, out, vout);
     if (kind == 4) k_seg_choose_fix<<<grid_for(n, 256, 4), 256, 0, s>>>(d, vout, n, out);
     return launch_status();
+}
+hipError_t launch_fold_segmented(int kind, Src ctl, const uint64_t *vc, Src d, const uint64_t *vd, int64_t n,
+                                 uint64_t *heads, int64_t *wordhd, int64_t *out, uint64_t *vout /* pre-zeroed */, hipStream_t s) {
+    hipError_t e = launch_fold_heads(ctl, vc, n, heads, wordhd, s);
+    if (e != hipSuccess) return e;
+    return launch_fold_runs(kind, d, vd, vc, heads, wordhd, n, out, vout, s);
 }
 
 
