@@ -103,13 +103,15 @@ struct Sel {
 using SelP = std::shared_ptr<Sel>;
 
 struct ExprNode;
+struct LazyGather;
 
 struct DVec {
-    enum Kind { NONE, DENSE, COLUMN, RANGE, ONEHOT, OHCONST, SPARSE, EXPR } kind = NONE;
+    enum Kind { NONE, DENSE, COLUMN, RANGE, ONEHOT, OHCONST, SPARSE, EXPR, LAZYG } kind = NONE;
     int64_t n = 0;
     SelP sel;                   // SPARSE: data = the sel->m values; valid = bitmap over those m entries (null = all hold a value)
     bool perm = false;          // SPARSE: the values are a permutation of 0 .. m-1 (Partition positions)
     bool ids = false;           // SPARSE: every value is its own slot id (row ids gathered through a filter)
+    std::shared_ptr<LazyGather> lg; // LAZYG: Gather(src, pos) not run yet: its only reader is a filter that needs few (or none) of its values
     std::shared_ptr<ExprNode> ex;   // EXPR: a not yet evaluated tree of element-wise operators (fused when somebody needs the values)
     BufP data;                  // DENSE: n int64; ONEHOT/OHCONST: {value, slot, count}
     const void *ptr = nullptr;  // COLUMN: borrowed catalog pointer
@@ -127,6 +129,8 @@ struct ExprNode {
     DVec leaf;                             // DENSE / COLUMN / RANGE
     int leaves = 1, instrs = 1, depth = 1;
 };
+
+struct LazyGather { DVec src, pos; };        // both in dense form (DENSE / COLUMN / RANGE)
 
 struct Output {
     int node = 0;
@@ -795,7 +799,20 @@ struct GenExec {
         }
     }
 
+    DVec gather_now(const DVec &src, const DVec &pos) {
+        DVec o; o.kind = DVec::DENSE; o.n = pos.n;
+        o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(o.n, 1));
+        o.valid = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(o.n), 1));
+        HIP_CHECK(launch_gather(src_of(src), vp(src), src.n, src_of(pos), vp(pos), pos.n, (int64_t *)o.data->p, (uint64_t *)o.valid->p, s));
+        note_subset(o.valid, pos.valid);
+        return o;
+    }
+    // Gather statements that need not run: read only by `Gather(this, filter)`, or only by the filter idiom
+    // FoldSelect(RangeV 0 1 this, this) (the RangeV then only lends its length and an upper bound of the validity)
+    std::vector<char> lazy_gather_ok;
+
     DVec densify(const DVec &v) {
+        if (v.kind == DVec::LAZYG) return gather_now(v.lg->src, v.lg->pos);
         if (v.kind == DVec::EXPR) return expr_force(v);
         if (v.kind == DVec::SPARSE) return sparse_to_dense(v);
         if (v.kind != DVec::ONEHOT && v.kind != DVec::OHCONST) return v;
@@ -995,6 +1012,19 @@ struct GenExec {
         const bool identity = pos.kind == DVec::RANGE && pos.from == 0 && pos.step == 1 && pos.n == src.n;
         if (identity) {
             if (!pos.valid) return false;
+            if (src.kind == DVec::LAZYG) {
+                // Gather(Gather(x, p), filter): only the filter's rows of the inner gather are ever needed
+                const LazyGather &lg = *src.lg;
+                if (!subset(pos.valid, lg.pos.valid)) return false;
+                SelP sel = sel_for(pos.valid, src.n);
+                if (!sel->worth) return false;
+                DVec pe = sparse_take(lg.pos, sel);                                            // the inner positions on the selection
+                BufP data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(sel->m, 1));
+                BufP sub = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(sel->m), 1));
+                HIP_CHECK(launch_gather(src_of(lg.src), vp(lg.src), lg.src.n, i64_src(pe.data), nullptr, sel->m, (int64_t *)data->p, (uint64_t *)sub->p, s));
+                o = sparse_normalised(sel, data, sub);
+                return true;
+            }
             if (src.kind == DVec::SPARSE) {
                 if (subset(bitmap_of(src.sel), pos.valid)) { o = src; return true; }             // the filter keeps every entry
                 auto it = sel_of_bitmap.find(pos.valid->p);
@@ -1117,6 +1147,10 @@ struct GenExec {
                 o.kind = DVec::RANGE; o.n = r.n; o.from = n.imm0; o.step = n.imm1; o.valid = expr_valid(*r.ex, r.n);
                 return o;
             }
+            if (r.kind == DVec::LAZYG) {          // only as the control of FoldSelect over the same gather (lazy_gather_ok): an upper bound will do
+                o.kind = DVec::RANGE; o.n = r.n; o.from = n.imm0; o.step = n.imm1; o.valid = r.lg->pos.valid;
+                return o;
+            }
             if (r.kind == DVec::SPARSE) {
                 o.kind = DVec::RANGE; o.n = r.n; o.from = n.imm0; o.step = n.imm1; o.valid = bitmap_of(r.sel);
                 return o;
@@ -1145,6 +1179,17 @@ struct GenExec {
                     return o;
                 }
             }
+            if (V(n.b).kind == DVec::LAZYG) {
+                DVec ctl0 = densify(V(n.a));
+                const LazyGather &lg = *V(n.b).lg;
+                if (ctl0.n == V(n.b).n && ctl0.kind == DVec::RANGE && ctl0.step != 0) {
+                    o.kind = DVec::RANGE; o.n = ctl0.n; o.from = 0; o.step = 1;
+                    o.valid = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(o.n), 1));
+                    HIP_CHECK(launch_select_gather(src_of(lg.src), vp(lg.src), lg.src.n, src_of(lg.pos), vp(lg.pos), vp(ctl0), (uint64_t *)o.valid->p, o.n, s));
+                    note_subset(o.valid, lg.pos.valid); note_subset(o.valid, ctl0.valid);
+                    return o;
+                }
+            }
             DVec ctl = densify(V(n.a)), d = densify(V(n.b));
             if (ctl.n != d.n) throw Error(VDL_ERR_SHAPE, "FoldSelect (Id " + std::to_string(n.id) + "): operand lengths differ");
             if (!(ctl.kind == DVec::RANGE && ctl.step != 0)) return fold_select_runs(ctl, d);
@@ -1166,12 +1211,15 @@ struct GenExec {
                 o.valid = and_valid(src, pos, src.n);
                 return o;
             }
-            o.kind = DVec::DENSE; o.n = pos.n;
-            o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(o.n, 1));
-            o.valid = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(o.n), 1));
-            HIP_CHECK(launch_gather(src_of(src), vp(src), src.n, src_of(pos), vp(pos), pos.n, (int64_t *)o.data->p, (uint64_t *)o.valid->p, s));
-            note_subset(o.valid, pos.valid);
-            return o;
+            // a gather whose only reader is a filter (FoldSelect over it, or Gather of it through a filter) is not run:
+            // the reader evaluates it where it needs it
+            if (fuse_on && lazy_gather_ok[(size_t)n.id]) {
+                o.kind = DVec::LAZYG; o.n = pos.n;
+                o.lg = std::make_shared<LazyGather>();
+                o.lg->src = src; o.lg->pos = pos;
+                return o;
+            }
+            return gather_now(src, pos);
         }
         case Op::Scatter: {
             {
@@ -1402,14 +1450,38 @@ struct GenExec {
         for (int id : targets) last_use[(size_t)id] = 1 << 30;      // targets stay alive for the caller
         n_uses.assign(P.nodes.size(), 0);
         read_by_binary_only.assign(P.nodes.size(), 1);
+        std::vector<std::vector<std::pair<int, int>>> readers(P.nodes.size());      // (reader id, operand slot)
         for (size_t k = 0; k < P.order.size(); k++) {
             const Node &n = P.at(P.order[k]);
             if (!needed[(size_t)n.id] || (overrides && overrides->count(n.id))) continue;
-            for (int opnd : {n.a, n.b, n.c})
-                if (opnd > 0) { n_uses[(size_t)opnd]++; if (n.op != Op::Binary) read_by_binary_only[(size_t)opnd] = 0; }
+            int slot = 0;
+            for (int opnd : {n.a, n.b, n.c}) {
+                if (opnd > 0) {
+                    n_uses[(size_t)opnd]++;
+                    if (n.op != Op::Binary) read_by_binary_only[(size_t)opnd] = 0;
+                    readers[(size_t)opnd].push_back({n.id, slot});
+                }
+                slot++;
+            }
             if (n.op == Op::Binary && n.a == n.b && n.a > 0) n_uses[(size_t)n.a]--;       // x op x: both operands are one reader
         }
         for (int id : targets) n_uses[(size_t)id] += 2;
+        lazy_gather_ok.assign(P.nodes.size(), 0);
+        for (int id : P.order) {
+            const Node &g = P.at(id);
+            if (g.op != Op::Gather || !needed[(size_t)id] || n_uses[(size_t)id] != (int)readers[(size_t)id].size()) continue;   // targets excluded
+            const auto &rd = readers[(size_t)id];
+            if (rd.size() == 1 && P.at(rd[0].first).op == Op::Gather && rd[0].second == 0 && P.at(rd[0].first).b != id) lazy_gather_ok[(size_t)id] = 1;
+            if (rd.size() == 2) {
+                int rv = -1, fs = -1;
+                for (const auto &r : rd) {
+                    const Node &x = P.at(r.first);
+                    if (x.op == Op::RangeV && x.imm1 != 0 && r.second == 0) rv = r.first;
+                    if (x.op == Op::FoldSelect && r.second == 1 && x.b == id) fs = r.first;
+                }
+                if (rv >= 0 && fs >= 0 && P.at(fs).a == rv && readers[(size_t)rv].size() == 1 && n_uses[(size_t)rv] == 1) lazy_gather_ok[(size_t)id] = 1;
+            }
+        }
         p->outs.clear();
         p->timings.clear();
         hipEvent_t e0 = nullptr, e1 = nullptr;

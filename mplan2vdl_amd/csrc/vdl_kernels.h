@@ -126,6 +126,9 @@ hipError_t launch_gather(Src src, const uint64_t *vsrc, int64_t nsrc, Src pos, c
 hipError_t launch_scatter(Src src, const uint64_t *vsrc, Src pos, const uint64_t *vpos, int64_t n, int64_t nout,
                           int64_t *out, uint64_t *vout /* pre-zeroed; null = not wanted */, hipStream_t s);
 hipError_t launch_fill_words(uint64_t *p, uint64_t v, int64_t nwords, hipStream_t s);
+// FoldSelect (unit runs) straight over Gather(src, pos): out bit i = vc[i] & (src[pos[i]] exists and != 0); the gathered vector is never stored
+hipError_t launch_select_gather(Src src, const uint64_t *vsrc, int64_t nsrc, Src pos, const uint64_t *vpos, const uint64_t *vc, uint64_t *out,
+                                int64_t n, hipStream_t s);
 // bitmap[idx[k]] = 1 for k < m (bitmap pre-zeroed; idx ascending, so neighbours often share a word)
 hipError_t launch_set_bits(const int64_t *idx, int64_t m, uint64_t *bitmap, hipStream_t s);
 

@@ -773,6 +773,29 @@ hipError_t launch_fsel_keys(const int64_t *excl_heads, const int64_t *flags, con
     return launch_status();
 }
 
+__global__ __launch_bounds__(256) void k_select_gather(Src src, const uint64_t *vsrc, int64_t nsrc, Src pos, const uint64_t *vpos, const uint64_t *vc,
+                                                       uint64_t *out, int64_t n) {
+    const int64_t nw = (n + 63) >> 6;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave);
+    for (int64_t w = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; w < nw; w += wstride) {
+        const int64_t i = (w << 6) + lane;
+        bool ok = i < n && bit(vpos, i) && bit(vc, i);
+        const int64_t p = ok ? ld(pos, i) : 0;
+        ok = ok && p >= 0 && p < nsrc && bit(vsrc, p);
+        ok = ok && ld(src, ok ? p : 0) != 0;
+        const uint64_t m = __ballot(ok);
+        if (lane == 0) out[w] = m;
+    }
+}
+hipError_t launch_select_gather(Src src, const uint64_t *vsrc, int64_t nsrc, Src pos, const uint64_t *vpos, const uint64_t *vc, uint64_t *out,
+                                int64_t n, hipStream_t s) {
+    (void)hipGetLastError();
+    if (n <= 0) return hipSuccess;
+    k_select_gather<<<grid_for(n, 256, 4), 256, 0, s>>>(src, vsrc, nsrc, pos, vpos, vc, out, n);
+    return launch_status();
+}
+
 __global__ __launch_bounds__(256) void k_set_bits(const int64_t *idx, int64_t m, uint64_t *bitmap) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += stride) {
