@@ -450,7 +450,16 @@ hipError_t launch_binary(int op, Src a, Src b, int64_t *out, int64_t n, hipStrea
 // at and on its operator.  Each lane evaluates kExprRows rows at once to amortise the scalar work.
 constexpr int kExprRows = 4;
 #define VDL_EX_PUSH(K) case K: _Pragma("unroll") for (int r = 0; r < kExprRows; r++) st[K][r] = row[r] < n ? ld(lf, row[r]) : 0; break;
-#define VDL_EX_BIN(K) case K: _Pragma("unroll") for (int r = 0; r < kExprRows; r++) st[K - 2][r] = apply_bin(op, st[K - 2][r], st[K - 1][r]); break;
+// a (x) b for the lane's rows; the operator switch is wave-uniform and sits outside the row loop
+#define VDL_EX_OP(OP) case OP: _Pragma("unroll") for (int r = 0; r < kExprRows; r++) a[r] = apply_bin(OP, a[r], b[r]); break;
+__device__ __forceinline__ void expr_rows(int op, int64_t (&a)[kExprRows], const int64_t (&b)[kExprRows]) {
+    switch (op) {
+        VDL_EX_OP(B_LAND) VDL_EX_OP(B_LOR) VDL_EX_OP(B_BAND) VDL_EX_OP(B_BOR) VDL_EX_OP(B_SHIFT) VDL_EX_OP(B_EQ)
+        VDL_EX_OP(B_ADD) VDL_EX_OP(B_SUB) VDL_EX_OP(B_GT) VDL_EX_OP(B_MUL) VDL_EX_OP(B_DIV) VDL_EX_OP(B_MOD)
+    }
+}
+#undef VDL_EX_OP
+#define VDL_EX_BIN(K) case K: expr_rows(op, st[K - 2], st[K - 1]); break;
 __global__ __launch_bounds__(256) void k_expr(const ExprProg P, int64_t *__restrict__ out, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t base = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; base < n; base += kExprRows * stride) {
