@@ -772,7 +772,7 @@ struct GenExec {
     }
     // Binary over stored vectors / pending trees: extend the tree; run it unless the only reader is another Binary
     bool expr_binary(const Node &n, const DVec &a, const DVec &b, DVec &o) {
-        if (!fuse_on) return false;
+        if (!fuse_on || n.bin == B_DIV || n.bin == B_MOD) return false;      // division stays in k_binary (code size, see k_expr)
         const bool ta = a.kind == DVec::EXPR, tb = b.kind == DVec::EXPR;
         if (!(ta || leafable(a)) || !(tb || leafable(b)) || a.n != b.n) return false;
         if (!ta && !tb && a.kind == DVec::RANGE && b.kind == DVec::RANGE && a.step == 0 && b.step == 0) return false;   // constant folding stays
