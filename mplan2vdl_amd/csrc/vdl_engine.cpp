@@ -756,6 +756,26 @@ struct GenExec {
             prog.code[prog.n_instr++] = (signed char)(-at - 1);
             return;
         }
+        // the emitter's sugar recognised back (Vdl.hs:139-152): a >= b arrives as LogicalOr(Greater(a,b), Equals(b,a)) (in either
+        // operand order), a != b as Subtract(1, Equals(a,b))
+        auto same_leaf = [&](const ExprNode &x, const ExprNode &y) {
+            if (x.bin >= 0 || y.bin >= 0) return false;
+            const Src p = src_of(x.leaf), q = src_of(y.leaf);
+            return p.p == q.p && p.kind == q.kind && p.from == q.from && p.step == q.step && x.leaf.n == y.leaf.n;
+        };
+        if (e.bin == B_LOR && e.l->bin == B_GT && e.r->bin == B_EQ) {
+            const ExprNode &g = *e.l, &q = *e.r;
+            if ((same_leaf(*g.l, *q.r) && same_leaf(*g.r, *q.l)) || (same_leaf(*g.l, *q.l) && same_leaf(*g.r, *q.r))) {
+                expr_emit(*g.l, prog); expr_emit(*g.r, prog);
+                prog.code[prog.n_instr++] = (signed char)X_GE;
+                return;
+            }
+        }
+        if (e.bin == B_SUB && e.l->bin < 0 && e.l->leaf.kind == DVec::RANGE && e.l->leaf.step == 0 && e.l->leaf.from == 1 && e.r->bin == B_EQ) {
+            expr_emit(*e.r->l, prog); expr_emit(*e.r->r, prog);
+            prog.code[prog.n_instr++] = (signed char)X_NE;
+            return;
+        }
         expr_emit(*e.l, prog);
         expr_emit(*e.r, prog);
         prog.code[prog.n_instr++] = (signed char)e.bin;

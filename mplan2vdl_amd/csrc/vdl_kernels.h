@@ -91,6 +91,9 @@ hipError_t launch_binary(int op, Src a, Src b, int64_t *out, int64_t n, hipStrea
 // A tree of element-wise operators over up to kExprLeaves vectors of one length, in postfix order, evaluated in one
 // pass (the general path fuses chains of single-use Binary statements into this instead of one kernel per operator).
 constexpr int kExprLeaves = 12, kExprInstrs = 48, kExprDepth = 8;
+// operators that exist only inside fused trees: the emitter's sugar (a >= b is printed as LogicalOr(Greater(a,b), Equals(b,a)),
+// /root/reference/src/Vdl.hs:139-152) recognised back, one interpreted instruction instead of three
+enum : int { X_GE = 32, X_NE = 33 };
 struct ExprProg {
     int n_instr = 0, n_leaf = 0;
     Src leaf[kExprLeaves];

@@ -456,6 +456,8 @@ __device__ __forceinline__ void expr_rows(int op, int64_t (&a)[kExprRows], const
     switch (op) {
         VDL_EX_OP(B_LAND) VDL_EX_OP(B_LOR) VDL_EX_OP(B_BAND) VDL_EX_OP(B_BOR) VDL_EX_OP(B_SHIFT) VDL_EX_OP(B_EQ)
         VDL_EX_OP(B_ADD) VDL_EX_OP(B_SUB) VDL_EX_OP(B_GT) VDL_EX_OP(B_MUL)
+        case X_GE: _Pragma("unroll") for (int r = 0; r < kExprRows; r++) a[r] = a[r] >= b[r]; break;
+        case X_NE: _Pragma("unroll") for (int r = 0; r < kExprRows; r++) a[r] = a[r] != b[r]; break;
         // Divide / Modulo are kept out of fused trees (vdl_engine.cpp expr_binary): the 64-bit division routine inlined
         // at every stack height tripled the size of the kernel
     }
