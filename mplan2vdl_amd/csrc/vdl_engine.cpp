@@ -827,6 +827,10 @@ struct GenExec {
         note_subset(o.valid, pos.valid);
         return o;
     }
+    // FoldSelect statements the planner could turn into a filter over raw table columns (FusedPlan::filters): they
+    // read the columns themselves, so the comparison / connective statements feeding them need not run for their sake
+    bool filter_on = !getenv("VDL_NO_FILTER_FUSION");
+    bool column_filter(const Node &n) const { return filter_on && n.op == Op::FoldSelect && p->fused.filters.count(n.id) != 0; }
     // Gather statements that need not run: read only by `Gather(this, filter)`, or only by the filter idiom
     // FoldSelect(RangeV 0 1 this, this) (the RangeV then only lends its length and an upper bound of the validity)
     std::vector<char> lazy_gather_ok;
@@ -1184,6 +1188,26 @@ struct GenExec {
         case Op::Binary:
             return binary(n, V(n.a), V(n.b));
         case Op::FoldSelect: {
+            if (column_filter(n)) {
+                const FilterSpec &fs = p->fused.filters.at(n.id);
+                FilterArgs fa;
+                fa.ncol = (int)fs.cols.size(); fa.never = fs.never ? 1 : 0;
+                int64_t rows = -1;
+                for (int k = 0; k < fa.ncol; k++) {
+                    const Column &col = find_col(c, fs.cols[(size_t)k].name);
+                    if (rows >= 0 && col.n != rows)
+                        throw Error(VDL_ERR_SHAPE, "columns of table '" + fs.table + "' have different lengths in the catalog");
+                    rows = col.n;
+                    fa.col[k].p = col.dev;
+                    fa.col[k].kind = col.width == 8 ? SRC_I64 : col.width == 4 ? SRC_I32 : col.width == 2 ? SRC_I16 : SRC_I8;
+                    fa.nint[k] = fs.cols[(size_t)k].n;
+                    for (int j = 0; j < fa.nint[k]; j++) { fa.lo[k][j] = fs.cols[(size_t)k].lo[j]; fa.hi[k][j] = fs.cols[(size_t)k].hi[j]; }
+                }
+                o.kind = DVec::RANGE; o.n = rows; o.from = 0; o.step = 1;
+                o.valid = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(rows), 1));
+                HIP_CHECK(launch_filter_columns(fa, (uint64_t *)o.valid->p, rows, s));
+                return o;
+            }
             if (V(n.b).kind == DVec::SPARSE) {
                 // filter of a filtered vector: the new selection is carved out of the entries, not out of the n slots
                 const DVec &sd = V(n.b);
@@ -1460,11 +1484,12 @@ struct GenExec {
             const Node &n = P.at(*it);
             if (!needed[(size_t)n.id]) continue;
             if (overrides && overrides->count(n.id)) continue;
+            if (column_filter(n)) continue;
             for (int opnd : {n.a, n.b, n.c}) if (opnd > 0) needed[(size_t)opnd] = 1;
         }
         for (size_t k = 0; k < P.order.size(); k++) {
             const Node &n = P.at(P.order[k]);
-            if (!needed[(size_t)n.id] || (overrides && overrides->count(n.id))) continue;
+            if (!needed[(size_t)n.id] || (overrides && overrides->count(n.id)) || column_filter(n)) continue;
             for (int opnd : {n.a, n.b, n.c}) if (opnd > 0) last_use[(size_t)opnd] = (int)k;
         }
         for (int id : targets) last_use[(size_t)id] = 1 << 30;      // targets stay alive for the caller
@@ -1473,7 +1498,7 @@ struct GenExec {
         std::vector<std::vector<std::pair<int, int>>> readers(P.nodes.size());      // (reader id, operand slot)
         for (size_t k = 0; k < P.order.size(); k++) {
             const Node &n = P.at(P.order[k]);
-            if (!needed[(size_t)n.id] || (overrides && overrides->count(n.id))) continue;
+            if (!needed[(size_t)n.id] || (overrides && overrides->count(n.id)) || column_filter(n)) continue;
             int slot = 0;
             for (int opnd : {n.a, n.b, n.c}) {
                 if (opnd > 0) {

@@ -206,6 +206,7 @@ struct Builder {
     struct PendingGroup { int part; std::string table; int sel; RowP key; int64_t pmin, pcount; std::vector<RowP> data; std::vector<int> kind; };
     std::vector<PendingGroup> groups;
     std::string why;
+    std::map<int, FilterSpec> filters;
 
     explicit Builder(const Program &p) : P(p), sym(p.nodes.size()) {}
 
@@ -291,6 +292,23 @@ struct Builder {
             if (ctl.e->k != Row::IOTA || ctl.e->c1 == 0) return out;      // runs of length one only
             int base = combine_sel(d.table, ctl.sel, d.sel);
             RowP pred = base ? mk_bin(B_LAND, pred_of(base), d.e) : d.e;
+            if (!base) {
+                Clause cl;
+                if (to_clause(d.e, cl) && (cl.never || (!cl.cols.empty() && (int)cl.cols.size() <= kMaxFilterCols))) {
+                    FilterSpec fs;
+                    fs.table = d.table; fs.never = cl.never;
+                    bool fits = true;
+                    for (auto &kv : cl.cols) {
+                        FilterColumn fc;
+                        fc.name = kv.first;
+                        if ((int)kv.second.size() > kMaxFilterIvs) { fits = false; break; }
+                        if (kv.second.empty()) fs.never = true;
+                        for (auto &iv : kv.second) { fc.lo[fc.n] = iv.first; fc.hi[fc.n] = iv.second; fc.n++; }
+                        fs.cols.push_back(fc);
+                    }
+                    if (fits && !fs.cols.empty()) filters[n.id] = fs;
+                }
+            }
             out.kind = Sym::ROW; out.table = d.table; out.e = mk_iota(0, 1);
             out.sel = new_sel(d.table, pred);
             return out;
@@ -469,6 +487,7 @@ FusedPlan fuse_program(const Program &P) {
     FusedPlan F;
     Builder B(P);
     for (int id : P.order) B.sym[(size_t)id] = B.visit(P.at(id));
+    F.filters = B.filters;
     if (P.outputs.empty()) { F.why_not = "program has no MaterializeCompact output"; return F; }
     for (int id : P.outputs) {
         const Sym &s = B.sym[(size_t)id];

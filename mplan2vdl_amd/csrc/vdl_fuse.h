@@ -86,7 +86,15 @@ struct FusedOutput {
     ScalarP value;
 };
 
+// A first-level filter (FoldSelect of a predicate over unfiltered table columns) whose predicate is a conjunction of
+// per-column interval sets: it can be evaluated straight off the columns in one pass, whatever the rest of the
+// program looks like (plans with joins do not fuse as a whole, but their Select steps do).
+constexpr int kMaxFilterCols = 6, kMaxFilterIvs = 4;
+struct FilterColumn { std::string name; int n = 0; int64_t lo[kMaxFilterIvs] = {}, hi[kMaxFilterIvs] = {}; };
+struct FilterSpec { std::string table; std::vector<FilterColumn> cols; bool never = false; };
+
 struct FusedPlan {
+    std::map<int, FilterSpec> filters;   // FoldSelect statement id -> its column filter (filled whether or not the plan fuses)
     bool ok = false;
     std::string why_not;         // reason the program did not fuse (reported by describe)
     std::vector<ScanPlan> scans;

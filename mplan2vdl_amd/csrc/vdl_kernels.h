@@ -101,6 +101,14 @@ struct ExprProg {
 };
 hipError_t launch_expr(const ExprProg &prog, int64_t *out, int64_t n, hipStream_t s);
 hipError_t launch_and_words(const uint64_t *a, const uint64_t *b, uint64_t *out, int64_t nwords, hipStream_t s);
+// A first-level filter evaluated straight off its columns: bit i = every column's value lies in one of its intervals
+struct FilterArgs {
+    int ncol = 0, never = 0;
+    Src col[kMaxFilterCols];
+    int nint[kMaxFilterCols] = {};
+    int64_t lo[kMaxFilterCols][kMaxFilterIvs] = {}, hi[kMaxFilterCols][kMaxFilterIvs] = {};
+};
+hipError_t launch_filter_columns(const FilterArgs &a, uint64_t *out, int64_t n, hipStream_t s);
 // FoldSelect with unit-length runs: out bitmap = (d != 0) & vd & vc
 hipError_t launch_select_bitmap(Src d, const uint64_t *vd, const uint64_t *vc, uint64_t *out, int64_t n, hipStream_t s);
 // Global (single-run) fold of `d` over slots valid in both bitmaps.

@@ -497,6 +497,68 @@ hipError_t launch_expr(const ExprProg &prog, int64_t *out, int64_t n, hipStream_
     return launch_status();
 }
 
+// Select over unfiltered table columns (Vlite.hs:721-730) when the predicate is a conjunction of per-column interval
+// sets: one pass over the columns, one ballot per 64 rows, instead of a kernel per comparison / connective.
+constexpr int kFilterUnroll = 4;                       // words (of 64 rows) per wave iteration: that many loads per column in flight
+// NC columns, NI intervals per column (unused intervals are empty: lo > hi), no data-independent branches in the loop
+template <int NC, int NI>
+__global__ __launch_bounds__(256) void k_filter_columns(const FilterArgs A, uint64_t *out, int64_t n) {
+    const int64_t nw = (n + 63) >> 6;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave);
+    for (int64_t w0 = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; w0 < nw; w0 += kFilterUnroll * wstride) {
+        int64_t v[NC][kFilterUnroll];
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+#pragma unroll
+            for (int u = 0; u < kFilterUnroll; u++) {
+                const int64_t i = ((w0 + u * wstride) << 6) + lane;
+                v[c][u] = ld(A.col[c], i < n ? i : 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kFilterUnroll; u++) {
+            const int64_t w = w0 + u * wstride;
+            const int64_t i = (w << 6) + lane;
+            bool ok = i < n && !A.never;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                bool in = false;
+#pragma unroll
+                for (int k = 0; k < NI; k++) in = in | ((v[c][u] >= A.lo[c][k]) & (v[c][u] <= A.hi[c][k]));
+                ok = ok & in;
+            }
+            const uint64_t m = __ballot(ok);
+            if (lane == 0 && w < nw) out[w] = m;
+        }
+    }
+}
+hipError_t launch_filter_columns(const FilterArgs &a0, uint64_t *out, int64_t n, hipStream_t s) {
+    (void)hipGetLastError();
+    if (n <= 0) return hipSuccess;
+    FilterArgs a = a0;
+    int ni = 1;
+    for (int c = 0; c < a.ncol; c++) ni = a.nint[c] > ni ? a.nint[c] : ni;
+    ni = ni <= 1 ? 1 : ni <= 2 ? 2 : kMaxFilterIvs;
+    for (int c = 0; c < a.ncol; c++)
+        for (int k = a.nint[c]; k < kMaxFilterIvs; k++) { a.lo[c][k] = 1; a.hi[c][k] = 0; }       // empty
+    const int grid = grid_for((n + 63) >> 6, 4, kFilterUnroll);
+#define VDL_FC(NC, NI) k_filter_columns<NC, NI><<<grid, 256, 0, s>>>(a, out, n)
+#define VDL_FN(NC) if (ni == 1) VDL_FC(NC, 1); else if (ni == 2) VDL_FC(NC, 2); else VDL_FC(NC, kMaxFilterIvs)
+    switch (a.ncol) {
+    case 1: VDL_FN(1); break;
+    case 2: VDL_FN(2); break;
+    case 3: VDL_FN(3); break;
+    case 4: VDL_FN(4); break;
+    case 5: VDL_FN(5); break;
+    case 6: VDL_FN(6); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef VDL_FN
+#undef VDL_FC
+    return launch_status();
+}
+
 __global__ void k_and_words(const uint64_t *a, const uint64_t *b, uint64_t *out, int64_t nw) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += stride) out[i] = a[i] & b[i];

@@ -689,3 +689,42 @@ def test_foldselect_over_general_runs_matches_oracle(n, keys):
     e = engine_with(cols)
     assert e.run_vdl(text)["results"] == want
     e.close()
+
+
+def test_first_level_filters_run_straight_off_the_columns():
+    """Select steps whose predicate is a conjunction of per-column interval sets (IN lists, ranges, several columns) are
+    evaluated in one pass over the columns even in programs that do not fuse as a whole; anything else (column against
+    column, more than four intervals) takes the operator-by-operator route.  Same answers either way."""
+    rng = np.random.default_rng(11)
+    n = 50000
+    cols = {"t.a": rng.integers(0, 40, n).astype(np.int32), "t.b": rng.integers(-5, 6, n).astype(np.int64),
+            "t.c": rng.integers(0, 1000, n).astype(np.int16), "t.d": rng.integers(0, 3, n).astype(np.int8)}
+    head = ["1,Load,t.a", "2,Project,val,Id 1,a", "3,Load,t.b", "4,Project,val,Id 3,b", "5,Load,t.c", "6,Project,val,Id 5,c", "7,Load,t.d", "8,Project,val,Id 7,d"]
+
+    def eq_any(col, values, k):          # col in (v1, v2, ...) as the compiler prints it: LogicalOr of Equals
+        lines, acc = [], None
+        for v in values:
+            lines += ["%d,RangeV,val,%d,Id %d,0" % (k, v, col), "%d,Equals,val,Id %d,val,Id %d,val" % (k + 1, col, k)]
+            cur = k + 1
+            k += 2
+            if acc is not None:
+                lines.append("%d,LogicalOr,val,Id %d,val,Id %d,val" % (k, acc, cur)); cur = k; k += 1
+            acc = cur
+        return lines, acc, k
+
+    for values in ([3], [3, 17], [3, 17, 18, 30], [1, 5, 9, 13, 21]):          # the last one has five intervals: falls back
+        l1, in_a, k = eq_any(2, values, 9)
+        body = l1 + ["%d,RangeV,val,0,Id 4,0" % k, "%d,Greater,val,Id 4,val,Id %d,val" % (k + 1, k),                    # b > 0
+                     "%d,RangeV,val,500,Id 6,0" % (k + 2), "%d,Greater,val,Id %d,val,Id 6,val" % (k + 3, k + 2),        # c < 500
+                     "%d,LogicalAnd,val,Id %d,val,Id %d,val" % (k + 4, in_a, k + 1), "%d,LogicalAnd,val,Id %d,val,Id %d,val" % (k + 5, k + 4, k + 3),
+                     "%d,LogicalAnd,val,Id %d,val,Id 8,val" % (k + 6, k + 5),                                            # and d != 0
+                     "%d,RangeV,val,0,Id %d,1" % (k + 7, k + 6), "%d,FoldSelect,val,Id %d,val,Id %d,val" % (k + 8, k + 7, k + 6),
+                     "%d,Gather,Id 6,Id %d,val" % (k + 9, k + 8), "%d,MaterializeCompact,Id %d" % (k + 10, k + 9),
+                     "%d,Greater,val,Id 2,val,Id 6,val" % (k + 11),                                                      # a > c: column against column
+                     "%d,RangeV,val,0,Id %d,1" % (k + 12, k + 11), "%d,FoldSelect,val,Id %d,val,Id %d,val" % (k + 13, k + 12, k + 11),
+                     "%d,Gather,Id 4,Id %d,val" % (k + 14, k + 13), "%d,MaterializeCompact,Id %d" % (k + 15, k + 14)]
+        text = prog(*(head + body))
+        want = oracle_run(text, cols)
+        e = engine_with(cols)
+        assert e.run_vdl(text)["results"] == want, values
+        e.close()
