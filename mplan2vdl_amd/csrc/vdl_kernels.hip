@@ -1242,13 +1242,20 @@ __device__ __forceinline__ void atomic_combine(int rk, int64_t *addr, int64_t v)
 }
 
 // kind: 0 sum, 1 min, 2 max, 3 count, 4 choose-pass (min over slot index of the data)
+// Each wave walks a contiguous chunk of words and carries the value of the run that is open at a word's last lane
+// into the next word, so a run costs one atomic per wave it touches instead of one per 64 slots: with few long runs
+// (dense GROUP BY domains) the per-word atomics all landed on the same handful of addresses and serialised.
 __global__ __launch_bounds__(256) void k_seg_fold(int kind, Src d, const uint64_t *vd, const uint64_t *vc, const uint64_t *heads,
                                                   const int64_t *wordhd, int64_t n, int64_t *out, uint64_t *vout) {
     const int rk = (kind == 1 || kind == 4) ? R_MIN : kind == 2 ? R_MAX : R_SUM;
     const int64_t nw = (n + 63) >> 6;
     const int lane = threadIdx.x & (kWave - 1);
-    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave);
-    for (int64_t w = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; w < nw; w += wstride) {
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / kWave);
+    const int64_t g = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    const int64_t per = (nw + nwaves - 1) / nwaves;
+    const int64_t w_end = (g + 1) * per < nw ? (g + 1) * per : nw;
+    int64_t carry_h = -1, carry_x = r_identity(rk);           // wave-uniform: the run still open after the previous word
+    for (int64_t w = g * per; w < w_end; w++) {
         const int64_t i = (w << 6) + lane;
         const uint64_t hm = heads[w] & (lane == 63 ? ~0ull : ((2ull << lane) - 1));   // heads at or before this lane
         int64_t h = hm ? (w << 6) + 63 - __clzll((long long)hm) : (w > 0 ? wordhd[w - 1] : -1);
@@ -1270,11 +1277,28 @@ __global__ __launch_bounds__(256) void k_seg_fold(int kind, Src d, const uint64_
         const int64_t hn = __shfl_down(h, 1, kWave);
         const bool okn = __shfl_down((int)ok, 1, kWave) != 0;
         const bool tail = ok && (lane == kWave - 1 || !okn || hn != h);
-        // EPS slots inside a run split it into several lane segments with the same head: each adds its part
-        if (tail) {
+        // the run carried over from the previous word: continue it in this word's first segment, or write it out
+        if (carry_h >= 0) {
+            const bool ok0 = __shfl((int)ok, 0, kWave) != 0;
+            const int64_t h0 = __shfl(h, 0, kWave);
+            if (ok0 && h0 == carry_h) {
+                if (tail && seg0 == 0) x = r_combine(rk, x, carry_x);
+            } else if (lane == 0) {
+                atomic_combine(rk, &out[carry_h], carry_x);
+                atomicOr((unsigned long long *)&vout[carry_h >> 6], 1ull << (carry_h & 63));
+            }
+            carry_h = -1;
+        }
+        const bool ok63 = __shfl((int)ok, kWave - 1, kWave) != 0;
+        if (ok63) { carry_h = __shfl(h, kWave - 1, kWave); carry_x = __shfl(x, kWave - 1, kWave); }   // lane 63 is that segment's tail
+        if (tail && lane != kWave - 1) {
             atomic_combine(rk, &out[h], x);
             atomicOr((unsigned long long *)&vout[h >> 6], 1ull << (h & 63));
         }
+    }
+    if (carry_h >= 0 && lane == 0) {
+        atomic_combine(rk, &out[carry_h], carry_x);
+        atomicOr((unsigned long long *)&vout[carry_h >> 6], 1ull << (carry_h & 63));
     }
 }
 
@@ -1288,6 +1312,13 @@ __global__ void k_seg_choose_fix(Src d, const uint64_t *vout, int64_t n, int64_t
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
         if (bit(vout, i)) out[i] = ld(d, out[i]);
+}
+
+static int seg_fold_grid(int64_t n) {            // a few thousand waves, each with a contiguous chunk of at least a few words
+    const int64_t nw = (n + 63) >> 6;
+    int64_t g = (nw + 15) / 16;                  // >= 4 words per wave (4 waves per block)
+    if (g > 2048) g = 2048;
+    return (int)(g < 1 ? 1 : g);
 }
 
 // scratch: heads bitmap (nwords) and wordhd (nwords + maxscan_blocks(nwords) int64) supplied by the caller
@@ -1308,7 +1339,7 @@ hipError_t launch_fold_runs(int kind, Src d, const uint64_t *vd, const uint64_t 
     if (n <= 0) return hipSuccess;
     const int rk = (kind == 1 || kind == 4) ? R_MIN : kind == 2 ? R_MAX : R_SUM;
     k_seg_fill<<<grid_for(n, 256, 4), 256, 0, s>>>(out, rk == R_SUM ? 0 : rk == R_MIN ? INT64_MAX : INT64_MIN, n);
-    k_seg_fold<<<grid_for(n, 256, 4), 256, 0, s>>>(kind, d, vd, vc, heads, wordhd, n, out, vout);
+    k_seg_fold<<<seg_fold_grid(n), 256, 0, s>>>(kind, d, vd, vc, heads, wordhd, n, out, vout);
     if (kind == 4) k_seg_choose_fix<<<grid_for(n, 256, 4), 256, 0, s>>>(d, vout, n, out);
     return launch_status();
 }
