@@ -119,6 +119,13 @@ int  vdl_n_outputs(const vdl_plan *plan);
  * "__"), `tmp` the "tmpN" result key (N = id of the MaterializeCompact line). */
 int  vdl_output(const vdl_plan *plan, int k, const char **name, const char **tmp,
                 const int64_t **vals, size_t *n);
+/* Results that stay in HBM.  With device outputs enabled, an output of 65536 values or more is not copied to the
+ * host: vdl_output reports its length with *vals == NULL and vdl_output_device hands out the device pointer (int64
+ * values, owned by the plan until it is run again or freed; the run has completed on the context's stream when
+ * vdl_run returns).  Smaller outputs stay host-side (*dev_vals == NULL).  Q3 at SF100 returns 4 x 13.9M values:
+ * 445 MB over PCIe is a quarter of the run. */
+int  vdl_plan_set_device_outputs(vdl_plan *plan, int enabled);
+int  vdl_output_device(const vdl_plan *plan, int k, const int64_t **dev_vals, size_t *n);
 int  vdl_n_timings(const vdl_plan *plan);
 int  vdl_timing(const vdl_plan *plan, int k, const char **label, double *usec);
 

@@ -132,14 +132,17 @@ struct ExprNode {
 
 struct LazyGather { DVec src, pos; };        // both in dense form (DENSE / COLUMN / RANGE)
 
+constexpr size_t kBigOutput = 1u << 16;     // values; from here on results use pinned host memory (or stay on the device)
 struct Output {
     int node = 0;
     std::string name, tmp;
     std::vector<int64_t> vals;
     const int64_t *big = nullptr;      // large results land in a pinned buffer the plan keeps (pageable copies run at a few GB/s)
     size_t big_n = 0;
-    const int64_t *ptr() const { return big ? big : vals.data(); }
-    size_t count() const { return big ? big_n : vals.size(); }
+    std::shared_ptr<void> dev_keep;    // vdl_plan_set_device_outputs: large results stay in HBM, owned by the plan until its next run
+    const int64_t *dev = nullptr;
+    const int64_t *ptr() const { return dev ? nullptr : big ? big : vals.data(); }
+    size_t count() const { return (dev || big) ? big_n : vals.size(); }
 };
 struct Timing { std::string label; double usec; };
 
@@ -164,6 +167,7 @@ struct vdl_plan {
     FusedPlan fused;
     bool use_fusion = true;
     bool profiling = false;
+    bool device_outputs = false;
     std::string description;
     std::vector<Output> outs;
     std::vector<Timing> timings;
@@ -944,6 +948,10 @@ struct GenExec {
     // and overlap the statements that follow; the run waits for them at its end.
     std::vector<BufP> copies_in_flight;
     void copy_out(Output &o, const BufP &dev, size_t count) {
+        if (p->device_outputs && count >= kBigOutput) {  // the caller reads it where it is
+            o.dev_keep = dev; o.dev = (const int64_t *)dev->p; o.big_n = count;
+            return;
+        }
         int64_t *dst = host_out(o, count);
         if (!o.big) {                                   // small / pageable: the plain blocking route
             HIP_CHECK(hipMemcpyAsync(dst, dev->p, sizeof(int64_t) * count, hipMemcpyDeviceToHost, s));
@@ -967,7 +975,7 @@ struct GenExec {
 
     // where the values of an output go on the host: a pinned buffer of the plan when large
     int64_t *host_out(Output &o, size_t count) {
-        if (count >= (1u << 16)) {
+        if (count >= kBigOutput) {
             int64_t *pin = p->pinned_out(p->outs.size(), count);
             if (pin) { o.big = pin; o.big_n = count; return pin; }
         }
@@ -1913,6 +1921,18 @@ int vdl_plan_set_fusion(vdl_plan *p, int enabled) {
     if (!p) return VDL_ERR_ARG;
     p->use_fusion = enabled != 0;
     p->description = describe_plan(p);
+    return VDL_OK;
+}
+int vdl_plan_set_device_outputs(vdl_plan *p, int enabled) {
+    if (!p) return VDL_ERR_ARG;
+    p->device_outputs = enabled != 0;
+    return VDL_OK;
+}
+int vdl_output_device(const vdl_plan *p, int k, const int64_t **dev_vals, size_t *n) {
+    if (!p || k < 0 || k >= (int)p->outs.size()) return VDL_ERR_ARG;
+    const Output &o = p->outs[(size_t)k];
+    if (dev_vals) *dev_vals = o.dev;
+    if (n) *n = o.count();
     return VDL_OK;
 }
 int vdl_plan_set_profiling(vdl_plan *p, int enabled) {

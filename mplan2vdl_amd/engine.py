@@ -20,6 +20,20 @@ class VdlError(RuntimeError):
         self.code = code
 
 
+class DeviceValues:
+    """An output left in device memory (Plan.set_device_outputs): int64 values at `ptr`, valid until the plan runs again."""
+
+    def __init__(self, ptr, n, owner):
+        self.ptr, self.n, self._owner = int(ptr), int(n), owner
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": (self.n,), "typestr": "<i8", "data": (self.ptr, False), "version": 3, "strides": None}
+
+    def __len__(self):
+        return self.n
+
+
 class Plan:
     def __init__(self, engine, handle, text):
         self._e = engine
@@ -50,6 +64,12 @@ class Plan:
     def set_profiling(self, enabled):
         self._e._check(self._e._L.vdl_plan_set_profiling(self._h, int(bool(enabled))))
 
+    def set_device_outputs(self, enabled):
+        """Large outputs (>= 65536 values) stay in HBM: `collect()` returns them as `DeviceValues` (device pointer +
+        length, `__cuda_array_interface__`: `torch.as_tensor(v, device=...)` wraps them without a copy).  They belong
+        to the plan until its next run."""
+        self._e._check(self._e._L.vdl_plan_set_device_outputs(self._h, int(bool(enabled))))
+
     def _collect(self, as_numpy=False):
         L = self._e._L
         results = {}
@@ -57,7 +77,11 @@ class Plan:
             name, tmp = ctypes.c_char_p(), ctypes.c_char_p()
             vals, n = ctypes.POINTER(ctypes.c_int64)(), ctypes.c_size_t()
             L.vdl_output(self._h, k, ctypes.byref(name), ctypes.byref(tmp), ctypes.byref(vals), ctypes.byref(n))
-            if as_numpy:
+            if n.value and not vals:
+                dev = ctypes.POINTER(ctypes.c_int64)()
+                L.vdl_output_device(self._h, k, ctypes.byref(dev), ctypes.byref(n))
+                arr = DeviceValues(ctypes.cast(dev, ctypes.c_void_p).value, n.value, self)
+            elif as_numpy:
                 arr = np.ctypeslib.as_array(vals, shape=(n.value,)).copy() if n.value else np.zeros(0, np.int64)
             else:
                 arr = np.ctypeslib.as_array(vals, shape=(n.value,)).tolist() if n.value else []

@@ -648,6 +648,37 @@ def test_results_as_numpy_arrays_and_execute_collect(q6_text):
     e.close()
 
 
+def test_large_outputs_can_stay_on_the_device():
+    """vdl_plan_set_device_outputs: outputs of >= 65536 values are handed out as device pointers, smaller ones stay
+    host-side; the values are those of the host route."""
+    import torch
+
+    n = 300000
+    rng = np.random.default_rng(12)
+    cols = {"t.a": rng.integers(0, 1000, n), "t.b": rng.integers(0, 50, n)}
+    e = engine_with(cols)
+    text = prog("1,Load,t.a", "2,Project,val,Id 1,a", "3,Load,t.b", "4,Project,val,Id 3,b",
+                "5,Add,val,Id 2,val,Id 4,val", "6,MaterializeCompact,Id 5",                       # n values
+                "7,RangeV,val,500,Id 2,0", "8,Greater,val,Id 2,val,Id 7,val", "9,RangeV,val,0,Id 2,1",
+                "10,FoldSelect,val,Id 9,val,Id 8,val", "11,Gather,Id 4,Id 10,val", "12,MaterializeCompact,Id 11",   # ~n/2 values
+                "13,RangeV,val,0,Id 2,0", "14,FoldSum,val,Id 13,val,Id 2,val", "15,MaterializeCompact,Id 14")      # 1 value
+    p = e.parse(text)
+    want = p.run(as_numpy=True)["results"]
+    p.set_device_outputs(True)
+    got = p.run(as_numpy=True)["results"]
+    kinds = {k: type(list(d.values())[0]).__name__ for k, d in got.items()}
+    assert kinds == {"tmp6": "DeviceValues", "tmp12": "DeviceValues", "tmp15": "ndarray"}
+    for k, d in got.items():
+        for f, v in d.items():
+            host = torch.as_tensor(v, device="cuda:0").cpu().numpy() if kinds[k] == "DeviceValues" else v
+            assert np.array_equal(host, want[k][f]), k
+    assert np.array_equal(want["tmp6"][".val"], cols["t.a"] + cols["t.b"])
+    p.set_device_outputs(False)
+    back = p.run(as_numpy=True)["results"]
+    assert all(np.array_equal(back[k][f], want[k][f]) for k in want for f in want[k])
+    e.close()
+
+
 def test_device_q3_catalog_equals_host_catalog():
     """datagen.register_q3_columns (what bench.py and tools/run_q3.py use) builds the same columns as datagen.q3_tables."""
     import mplan2vdl_amd as m

@@ -46,6 +46,8 @@ if n_orders > 15000000:
     factor = -(-n_orders // 15000000)
     text = frontend.compile_plan(open(os.path.join(meta, "03.sql.mplan")).read(), catalog.tpch_scaled_config(frontend.load_metadata(meta), factor))
 plan = e.parse(text)
+if os.environ.get("Q3_DEVICE_OUTPUTS"):        # the 4 result columns stay in HBM (vdl_plan_set_device_outputs)
+    plan.set_device_outputs(True)
 say = print if rank == 0 else (lambda *a, **k: None)
 say("fused:", plan.is_fused, " exchange columns:", plan.exchange_columns("lineitem"), " ranks:", world)
 
@@ -67,6 +69,12 @@ if only == "general":
     for it in range(5):
         torch.cuda.synchronize(); t0 = time.perf_counter(); plan.execute(); dt = time.perf_counter() - t0
         say("vdl_run alone (outputs left in the plan) run %d: %.2f ms, %.2f M lineitem rows/s" % (it, dt * 1e3, n_li / dt / 1e6))
+    if os.environ.get("Q3_STATEMENTS"):         # where the time goes, statement by statement (vdl_set_profiling)
+        plan.set_profiling(True); plan.execute()
+        t = plan.collect(as_numpy=True)["timings"]
+        say("sum of statement times %.2f ms" % (sum(t.values()) / 1e3))
+        for k, v in sorted(t.items(), key=lambda kv: -kv[1])[:int(os.environ["Q3_STATEMENTS"])]:
+            say("  %-60s %7.0f us" % (k.replace("timeInMicrosecondsForStatement", ""), v))
     e.close(); sys.exit(0)
 out = timed("exchange", lambda: m.run_exchange(plan, dist if world > 1 else None, device=dev, sharded_table="lineitem", as_numpy=True))
 flat = {list(v.keys())[0][1:]: list(v.values())[0].tolist() for v in out["results"].values()}
