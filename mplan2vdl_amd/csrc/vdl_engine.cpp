@@ -571,7 +571,7 @@ struct GenExec {
     std::map<const void *, SelP> sel_of_bitmap;                 // bitmaps whose population / slot list is known
     std::vector<BufP> keep_alive;                               // keys above stay valid for the whole run
     bool sparse_on = !getenv("VDL_NO_SPARSE");
-    bool trace_forms = getenv("VDL_TRACE_FORMS") != nullptr;      // one line per statement: the form of its result
+    bool trace_forms = getenv("VDL_TRACE_FORMS") && std::strcmp(getenv("VDL_TRACE_FORMS"), "0") != 0;      // one line per statement: the form of its result
     int densified = 0;                                             // SPARSE -> DENSE conversions (each is a scatter over n slots)
 
     bool subset(const BufP &a, const BufP &b) {                 // a (null = all slots) inside b?
@@ -1547,7 +1547,8 @@ struct GenExec {
             vec[(size_t)n.id] = exec(n);
             if (trace_forms) {
                 const DVec &r = vec[(size_t)n.id];
-                static const char *const kn[] = {"none", "dense", "column", "range", "onehot", "ohconst", "sparse"};
+                static const char *const kn[] = {"none", "dense", "column", "range", "onehot", "ohconst", "sparse", "expr", "lazy"};
+                static_assert(sizeof kn / sizeof kn[0] == DVec::LAZYG + 1, "one name per vector form");
                 std::fprintf(stderr, "  Id %-4d %-18s -> %-7s n=%lld", n.id, op_name(n.op, n.bin), kn[r.kind], (long long)r.n);
                 if (r.kind == DVec::SPARSE) std::fprintf(stderr, " m=%lld%s%s", (long long)r.sel->m, r.sel->idx ? "" : " (prefix)", r.perm ? " perm" : "");
                 std::fprintf(stderr, "  scatters so far %d\n", densified);

@@ -407,6 +407,78 @@ __device__ __forceinline__ int64_t ld(const Src &s, int64_t i) {
 }
 __device__ __forceinline__ bool bit(const uint64_t *v, int64_t i) { return v ? ((v[i >> 6] >> (i & 63)) & 1ull) : true; }
 
+// Element loads with the representation fixed at compile time, and a dispatcher that runs a body once with the
+// wave-uniform kind turned into a constant.  Written with ld()/bit() and `&&`, a gather is a chain of exec-masked
+// regions, each load waited for before the next test; with unconditional loads (masked lanes read slot 0) and bitwise
+// tests the loads of several bitmap words are in flight together.
+template <int K> __device__ __forceinline__ int64_t ldk(const Src &s, int64_t i) {
+    if (K == SRC_I64) return ((const int64_t *)s.p)[i];
+    if (K == SRC_I32) return ((const int32_t *)s.p)[i];
+    if (K == SRC_I16) return ((const int16_t *)s.p)[i];
+    if (K == SRC_I8) return ((const int8_t *)s.p)[i];
+    return (int64_t)((uint64_t)s.from + (uint64_t)i * (uint64_t)s.step);
+}
+template <class F> __device__ __forceinline__ void by_kind(int kind, F f) {
+    switch (kind) {
+    case SRC_I64: f(std::integral_constant<int, SRC_I64>{}); break;
+    case SRC_I32: f(std::integral_constant<int, SRC_I32>{}); break;
+    case SRC_I16: f(std::integral_constant<int, SRC_I16>{}); break;
+    case SRC_I8: f(std::integral_constant<int, SRC_I8>{}); break;
+    default: f(std::integral_constant<int, SRC_RANGE>{}); break;
+    }
+}
+constexpr int kGatherUnroll = 4;      // bitmap words (64 positions each) a wave has in flight
+
+// positions of U consecutive words -> clamped source slots pc[] and lane flags ok[] (position present, in range,
+// source slot holds a value); `extra` = a second validity bitmap over the positions (may be null)
+template <int KP, bool VS>
+__device__ __forceinline__ void gather_slots(const Src &pos, const uint64_t *vpos, const uint64_t *extra, const uint64_t *vsrc, int64_t nsrc,
+                                             int64_t n, int64_t nw, int64_t w0, int lane, int64_t (&pc)[kGatherUnroll], bool (&ok)[kGatherUnroll]) {
+    constexpr int U = kGatherUnroll;
+    int64_t p[U], w[U];
+    uint64_t a[U];
+    bool in[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {                                  // the position loads go out first ...
+        w[u] = w0 + u < nw ? w0 + u : nw - 1;                      // wave-uniform; spare words repeat the last one and are not stored
+        a[u] = w0 + u < nw ? ~0ull : 0ull;
+        const int64_t i = (w[u] << 6) + lane;
+        in[u] = i < n;
+        p[u] = ldk<KP>(pos, in[u] ? i : 0);
+    }
+    if (vpos) {                                                    // ... then the bitmap words, U loads under one branch
+        uint64_t t[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) t[u] = vpos[w[u]];
+#pragma unroll
+        for (int u = 0; u < U; u++) a[u] &= t[u];
+    }
+    if (extra) {
+        uint64_t t[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) t[u] = extra[w[u]];
+#pragma unroll
+        for (int u = 0; u < U; u++) a[u] &= t[u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) ok[u] = in[u] & (((a[u] >> lane) & 1ull) != 0);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        ok[u] = ok[u] & (p[u] >= 0) & (p[u] < nsrc);
+        pc[u] = ok[u] ? p[u] : 0;
+    }
+    if (VS) {
+        uint64_t vw[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) vw[u] = vsrc[pc[u] >> 6];
+#pragma unroll
+        for (int u = 0; u < U; u++) ok[u] = ok[u] & (((vw[u] >> (pc[u] & 63)) & 1ull) != 0);
+    }
+}
+__device__ __forceinline__ int64_t wave_index() {               // in an SGPR: the bitmap words of a wave are scalar loads
+    return (int64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave));
+}
+
 static inline int grid_for(int64_t n, int block, int per_thread) {
     int64_t g = (n + (int64_t)block * per_thread - 1) / ((int64_t)block * per_thread);
     if (g > 256 * 16) g = 256 * 16;
@@ -850,18 +922,36 @@ hipError_t launch_fsel_keys(const int64_t *excl_heads, const int64_t *flags, con
 
 __global__ __launch_bounds__(256) void k_select_gather(Src src, const uint64_t *vsrc, int64_t nsrc, Src pos, const uint64_t *vpos, const uint64_t *vc,
                                                        uint64_t *out, int64_t n) {
+    constexpr int U = kGatherUnroll;
     const int64_t nw = (n + 63) >> 6;
     const int lane = threadIdx.x & (kWave - 1);
-    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave);
-    for (int64_t w = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; w < nw; w += wstride) {
-        const int64_t i = (w << 6) + lane;
-        bool ok = i < n && bit(vpos, i) && bit(vc, i);
-        const int64_t p = ok ? ld(pos, i) : 0;
-        ok = ok && p >= 0 && p < nsrc && bit(vsrc, p);
-        ok = ok && ld(src, ok ? p : 0) != 0;
-        const uint64_t m = __ballot(ok);
-        if (lane == 0) out[w] = m;
+    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave) * U;
+    const int64_t w_first = wave_index() * U;
+    if (nsrc <= 0) {                                        // nothing to read from: nothing is selected
+        for (int64_t w = w_first + lane; w < nw; w += wstride) if (lane < U) out[w] = 0;
+        return;
     }
+    auto body = [&](auto kp, auto ks, auto vs) {
+        for (int64_t w0 = w_first; w0 < nw; w0 += wstride) {
+            int64_t pc[U];
+            bool ok[U];
+            gather_slots<decltype(kp)::value, decltype(vs)::value>(pos, vpos, vc, vsrc, nsrc, n, nw, w0, lane, pc, ok);
+            int64_t x[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) x[u] = ldk<decltype(ks)::value>(src, pc[u]);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint64_t m = __ballot(ok[u] & (x[u] != 0));
+                if (lane == 0 && w0 + u < nw) out[w0 + u] = m;
+            }
+        }
+    };
+    by_kind(pos.kind, [&](auto kp) {
+        by_kind(src.kind, [&](auto ks) {
+            if (vsrc) body(kp, ks, std::true_type{});
+            else body(kp, ks, std::false_type{});
+        });
+    });
 }
 hipError_t launch_select_gather(Src src, const uint64_t *vsrc, int64_t nsrc, Src pos, const uint64_t *vpos, const uint64_t *vc, uint64_t *out,
                                 int64_t n, hipStream_t s) {
@@ -889,18 +979,43 @@ hipError_t launch_set_bits(const int64_t *idx, int64_t m, uint64_t *bitmap, hipS
 // the source slot is EPS.  One ballot per wave writes the validity word.
 __global__ __launch_bounds__(256) void k_gather(Src src, const uint64_t *vsrc, int64_t nsrc, Src pos, const uint64_t *vpos,
                                                 int64_t n, int64_t *out, uint64_t *vout) {
+    constexpr int U = kGatherUnroll;
     const int64_t nw = (n + 63) >> 6;
     const int lane = threadIdx.x & (kWave - 1);
-    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave);
-    for (int64_t w = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; w < nw; w += wstride) {
-        const int64_t i = (w << 6) + lane;
-        bool ok = i < n && bit(vpos, i);
-        int64_t p = ok ? ld(pos, i) : 0;
-        ok = ok && p >= 0 && p < nsrc && bit(vsrc, p);
-        if (i < n) out[i] = ok ? ld(src, p) : 0;
-        const uint64_t m = __ballot(ok);
-        if (lane == 0) vout[w] = m;
+    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave) * U;
+    const int64_t w_first = wave_index() * U;
+    if (nsrc <= 0) {                                        // nothing to read from: every slot is EPS
+        for (int64_t w0 = w_first; w0 < nw; w0 += wstride)
+            for (int u = 0; u < U && w0 + u < nw; u++) {
+                const int64_t i = ((w0 + u) << 6) + lane;
+                if (i < n) out[i] = 0;
+                if (lane == 0) vout[w0 + u] = 0;
+            }
+        return;
     }
+    auto body = [&](auto kp, auto ks, auto vs) {
+        for (int64_t w0 = w_first; w0 < nw; w0 += wstride) {
+            int64_t pc[U];
+            bool ok[U];
+            gather_slots<decltype(kp)::value, decltype(vs)::value>(pos, vpos, nullptr, vsrc, nsrc, n, nw, w0, lane, pc, ok);
+            int64_t x[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) x[u] = ldk<decltype(ks)::value>(src, pc[u]);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int64_t i = ((w0 + u) << 6) + lane;
+                if (i < n) out[i] = ok[u] ? x[u] : 0;
+                const uint64_t m = __ballot(ok[u]);
+                if (lane == 0 && w0 + u < nw) vout[w0 + u] = m;
+            }
+        }
+    };
+    by_kind(pos.kind, [&](auto kp) {
+        by_kind(src.kind, [&](auto ks) {
+            if (vsrc) body(kp, ks, std::true_type{});
+            else body(kp, ks, std::false_type{});
+        });
+    });
 }
 hipError_t launch_gather(Src src, const uint64_t *vsrc, int64_t nsrc, Src pos, const uint64_t *vpos, int64_t n, int64_t *out,
                          uint64_t *vout, hipStream_t s) {
