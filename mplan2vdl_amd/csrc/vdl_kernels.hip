@@ -1101,8 +1101,7 @@ hipError_t launch_prefix_sum(int64_t *x, int64_t n, int64_t *sums, hipStream_t s
 // that stably group `data` by pivot bucket.  Pivots are the emitted RangeC min cnt 1, so
 // bucket = clamp(data - min, 0, cnt).  Implemented as an LSD radix sort of (bucket, slot) over the
 // non-EPS slots, 8 bits per pass; each pass = tile histogram (LDS atomics) -> device-wide prefix
-// sum in digit-major order -> stable scatter (per-wave peer masks from 8 ballots, cross-wave
-// order through LDS).  The last pass writes out[slot] = rank instead of the sorted pair.
+// sum in digit-major order -> stable scatter (see k_part_scatter).  The last pass writes out[slot] = rank instead of the sorted pair.
 // Dense group-by domains (Q1: 32 buckets) need one pass, Q3's 2^38 domain five.
 // ------------------------------------------------------------------------------------------
 constexpr int kPartBlock = 256, kPartSteps = 16, kPartTile = kPartBlock * kPartSteps, kRadix = 256;
@@ -1150,45 +1149,126 @@ __global__ __launch_bounds__(kPartBlock) void k_part_hist(PartIn in, int64_t nti
     hist[(int64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
 }
 
+// Each wave owns a contiguous quarter of the tile (16 steps of 64 slots), so the stable order inside a tile is wave,
+// step, lane.  A wave ranks its slots on its own (peer masks from 8 ballots, its running digit counts in its row of
+// whist: LDS operations of one wave execute in order); one barrier later the rows are turned into per-wave offsets
+// and every slot knows its destination.  (A version that kept the block in step order needed three barriers per
+// step, 48 per tile, and was twice as slow.)
 template <bool FIRST, bool LAST>
 __global__ __launch_bounds__(kPartBlock) void k_part_scatter(PartIn in, int64_t ntiles, const int64_t *offsets,
                                                               uint64_t *keys_out, int64_t *slots_out, int64_t *pos_out) {
-    __shared__ int64_t running[kRadix];
-    __shared__ unsigned int whist[kPartBlock / kWave][kRadix];
+    constexpr int NW = kPartBlock / kWave;
+    __shared__ int64_t woff[NW][kRadix];
+    __shared__ unsigned int whist[NW][kRadix];
     const int64_t n = FIRST ? in.n : *in.n_dev;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-    running[tid] = offsets[(int64_t)tid * ntiles + blockIdx.x];
 #pragma unroll
-    for (int w = 0; w < kPartBlock / kWave; w++) whist[w][tid] = 0;
+    for (int w = 0; w < NW; w++) whist[w][tid] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * kPartTile;
+    const int64_t wbase = (int64_t)blockIdx.x * kPartTile + (int64_t)wave * (kPartSteps * kWave) + lane;
+    uint64_t keys[kPartSteps];
+    int64_t slots[kPartSteps];
+    bool oks[kPartSteps];
+#pragma unroll
+    for (int st = 0; st < kPartSteps; st++) {                   // the whole share is fetched up front
+        keys[st] = 0; slots[st] = 0;
+        const int64_t i = wbase + st * kWave;
+        if (FIRST) {
+            oks[st] = part_fetch<true>(in, i, n, keys[st], slots[st]);
+        } else {
+            oks[st] = i < n;
+            const int64_t ii = oks[st] ? i : 0;
+            keys[st] = in.keys[ii]; slots[st] = in.slots[ii];
+        }
+    }
+    unsigned int local[kPartSteps];                             // rank among this wave's slots with the same digit
+    volatile unsigned int *mine = whist[wave];
+#pragma unroll
     for (int st = 0; st < kPartSteps; st++) {
-        uint64_t key = 0; int64_t slot = 0;
-        const bool ok = part_fetch<FIRST>(in, base + st * kPartBlock + tid, n, key, slot);
-        const unsigned d = (unsigned)((key >> in.shift) & (kRadix - 1));
-        // peers = lanes of this wave holding the same digit (and a value)
-        uint64_t peers = __ballot(ok);
+        const unsigned d = (unsigned)((keys[st] >> in.shift) & (kRadix - 1));
+        uint64_t peers = __ballot(oks[st]);                     // lanes of this wave holding the same digit (and a value)
 #pragma unroll
         for (int b = 0; b < 8; b++) {
             const uint64_t m = __ballot((d >> b) & 1u);
             peers &= ((d >> b) & 1u) ? m : ~m;
         }
-        const int rank = __popcll(peers & ((1ull << lane) - 1));
-        if (ok && rank == 0) whist[wave][d] = (unsigned)__popcll(peers);    // one leader per digit
-        __syncthreads();
-        if (ok) {
-            int64_t dest = running[d] + rank;
-            for (int w = 0; w < wave; w++) dest += whist[w][d];
-            if (LAST) pos_out[slot] = dest;
-            else { keys_out[dest] = key; slots_out[dest] = slot; }
+        const unsigned rank = (unsigned)__popcll(peers & ((1ull << lane) - 1));
+        const unsigned pre = oks[st] ? mine[d] : 0u;
+        if (oks[st] && rank == 0) mine[d] = pre + (unsigned)__popcll(peers);     // one leader per digit
+        local[st] = pre + rank;
+    }
+    __syncthreads();
+    if (LAST) {                                                 // ranks go to out[slot]: scattered whatever the order
+        {
+            int64_t run = offsets[(int64_t)tid * ntiles + blockIdx.x];          // where this tile's slots of digit `tid` start
+#pragma unroll
+            for (int w = 0; w < NW; w++) { woff[w][tid] = run; run += whist[w][tid]; }
         }
         __syncthreads();
-        unsigned add = 0;
 #pragma unroll
-        for (int w = 0; w < kPartBlock / kWave; w++) { add += whist[w][tid]; whist[w][tid] = 0; }
-        running[tid] += add;
+        for (int st = 0; st < kPartSteps; st++) {
+            if (oks[st]) {
+                const unsigned d = (unsigned)((keys[st] >> in.shift) & (kRadix - 1));
+                pos_out[slots[st]] = woff[wave][d] + local[st];
+            }
+        }
+        return;
+    }
+    // The tile is put into digit order in LDS first (keys, then slots through the same buffer): a digit's slots of
+    // one tile are neighbours at the destination, so consecutive lanes then store consecutive words instead of 64
+    // scattered ones.
+    __shared__ uint64_t stage[kPartTile];
+    __shared__ unsigned int wtot[NW];
+    __shared__ int64_t gdelta[kRadix];                          // destination of sorted index idx with digit d = gdelta[d] + idx
+    unsigned total;
+    {
+        unsigned cnt = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) cnt += whist[w][tid];
+        unsigned incl = cnt;                                    // exclusive scan of the tile's digit counts over the block
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) { const unsigned y = __shfl_up(incl, off, kWave); if (lane >= off) incl += y; }
+        if (lane == kWave - 1) wtot[wave] = incl;
+        __syncthreads();
+        unsigned pre = 0;
+        for (int w = 0; w < wave; w++) pre += wtot[w];
+        total = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) total += wtot[w];
+        const unsigned tstart = pre + incl - cnt;               // where digit `tid` starts inside the sorted tile
+        unsigned run = tstart;
+#pragma unroll
+        for (int w = 0; w < NW; w++) { woff[w][tid] = run; run += whist[w][tid]; }                            // tile-local
+        gdelta[tid] = offsets[(int64_t)tid * ntiles + blockIdx.x] - (int64_t)tstart;
         __syncthreads();
     }
+    unsigned lpos[kPartSteps];
+#pragma unroll
+    for (int st = 0; st < kPartSteps; st++) {
+        const unsigned d = (unsigned)((keys[st] >> in.shift) & (kRadix - 1));
+        lpos[st] = (unsigned)woff[wave][d] + local[st];
+        if (oks[st]) stage[lpos[st]] = keys[st];
+    }
+    __syncthreads();
+    int64_t dest[kPartSteps];
+#pragma unroll
+    for (int k = 0; k < kPartSteps; k++) {
+        const unsigned idx = (unsigned)k * kPartBlock + tid;
+        dest[k] = -1;
+        if (idx < total) {
+            const uint64_t key = stage[idx];
+            dest[k] = gdelta[(key >> in.shift) & (kRadix - 1)] + idx;
+            keys_out[dest[k]] = key;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < kPartSteps; st++)
+        if (oks[st]) stage[lpos[st]] = (uint64_t)slots[st];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kPartSteps; k++)
+        if (dest[k] >= 0) slots_out[dest[k]] = (int64_t)stage[(unsigned)k * kPartBlock + tid];
 }
 
 // scratch layout is owned by the caller (vdl_engine.cpp); see launch_partition's arguments.
