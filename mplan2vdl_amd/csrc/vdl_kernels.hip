@@ -582,11 +582,13 @@ __global__ __launch_bounds__(256) void k_filter_columns(const FilterArgs A, uint
         int64_t v[NC][kFilterUnroll];
 #pragma unroll
         for (int c = 0; c < NC; c++) {
+            by_kind(A.col[c].kind, [&](auto k) {        // one dispatch per column, its loads back to back
 #pragma unroll
-            for (int u = 0; u < kFilterUnroll; u++) {
-                const int64_t i = ((w0 + u * wstride) << 6) + lane;
-                v[c][u] = ld(A.col[c], i < n ? i : 0);
-            }
+                for (int u = 0; u < kFilterUnroll; u++) {
+                    const int64_t i = ((w0 + u * wstride) << 6) + lane;
+                    v[c][u] = ldk<decltype(k)::value>(A.col[c], i < n ? i : 0);
+                }
+            });
         }
 #pragma unroll
         for (int u = 0; u < kFilterUnroll; u++) {
@@ -814,15 +816,18 @@ hipError_t launch_compact_count(const uint64_t *valid, int64_t n, int64_t *count
 
 // single-block exclusive scan (in place); total written at [nblocks]
 __global__ __launch_bounds__(1024) void k_scan_counts(int64_t *c, int64_t nb) {
+    constexpr int K = 8;                                        // consecutive entries per thread: 8192 per trip of the block
     __shared__ int64_t wsum[1024 / kWave];
     __shared__ int64_t carry;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     if (tid == 0) carry = 0;
     __syncthreads();
-    for (int64_t base = 0; base < nb; base += 1024) {
-        const int64_t i = base + tid;
-        const int64_t x = i < nb ? c[i] : 0;
-        int64_t incl = x;
+    for (int64_t base = 0; base < nb; base += 1024 * K) {
+        const int64_t i0 = base + (int64_t)tid * K;
+        int64_t x[K], sum = 0;
+#pragma unroll
+        for (int k = 0; k < K; k++) { x[k] = i0 + k < nb ? c[i0 + k] : 0; sum += x[k]; }
+        int64_t incl = sum;
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) {
             int64_t y = __shfl_up(incl, off, kWave);
@@ -832,10 +837,11 @@ __global__ __launch_bounds__(1024) void k_scan_counts(int64_t *c, int64_t nb) {
         __syncthreads();
         int64_t wprefix = 0;
         for (int w = 0; w < wave; w++) wprefix += wsum[w];
-        const int64_t excl = carry + wprefix + incl - x;
+        int64_t run = carry + wprefix + incl - sum;
         __syncthreads();
-        if (i < nb) c[i] = excl;
-        if (tid == 1023) carry = excl + x;
+#pragma unroll
+        for (int k = 0; k < K; k++) { if (i0 + k < nb) c[i0 + k] = run; run += x[k]; }
+        if (tid == 1023) carry = run;
         __syncthreads();
     }
     if (tid == 0) c[nb] = carry;
@@ -849,6 +855,7 @@ hipError_t launch_compact_scan(int64_t *counts, int64_t nb, hipStream_t s) {
 __global__ __launch_bounds__(256) void k_compact_write(Src v, const uint64_t *valid, int64_t n, const int64_t *offsets, int64_t *out) {
     __shared__ int wcount[kCompactWords];
     __shared__ int wprefix[kCompactWords];
+    __shared__ uint64_t wmask[kCompactWords];
     const int64_t nw = (n + 63) >> 6;
     const int64_t w0 = (int64_t)blockIdx.x * kCompactWords;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
@@ -860,22 +867,33 @@ __global__ __launch_bounds__(256) void k_compact_write(Src v, const uint64_t *va
             const int64_t rem = n - (w << 6);
             if (rem < 64) m &= (1ull << rem) - 1;
         }
+        wmask[tid] = m;
         wcount[tid] = __popcll(m);
     }
     __syncthreads();
     if (tid == 0) { int run = 0; for (int k = 0; k < kCompactWords; k++) { wprefix[k] = run; run += wcount[k]; } }
     __syncthreads();
     const int64_t base = offsets[blockIdx.x];
-    for (int k = wave; k < kCompactWords; k += 256 / kWave) {
-        const int64_t w = w0 + k;
-        if (w >= nw) break;
-        uint64_t m = valid ? valid[w] : ~0ull;
-        const int64_t i = (w << 6) + lane;
-        if (i < n && ((m >> lane) & 1ull)) {
-            const int rank = __popcll(m & ((1ull << lane) - 1));
-            out[base + wprefix[k] + rank] = ld(v, i);
+    constexpr int U = 4, NW = 256 / kWave;
+    static_assert(kCompactWords % (U * NW) == 0, "each wave takes whole groups of U words");
+    by_kind(v.kind, [&](auto kv) {
+        for (int k0 = wave * U; k0 < kCompactWords; k0 += NW * U) {     // U words per trip: their loads are issued together
+            int64_t x[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int64_t i = ((w0 + k0 + u) << 6) + lane;
+                x[u] = ldk<decltype(kv)::value>(v, i < n ? i : 0);       // masked lanes read slot 0 (n > 0 here)
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint64_t m = wmask[k0 + u];                        // already cut at n
+                if ((m >> lane) & 1ull) {
+                    const int rank = __popcll(m & ((1ull << lane) - 1));
+                    out[base + wprefix[k0 + u] + rank] = x[u];
+                }
+            }
         }
-    }
+    });
 }
 hipError_t launch_compact_write(Src v, const uint64_t *valid, int64_t n, const int64_t *offsets, int64_t *out, hipStream_t s) {
     (void)hipGetLastError();   // see launch_status()
@@ -1030,14 +1048,34 @@ hipError_t launch_gather(Src src, const uint64_t *vsrc, int64_t nsrc, Src pos, c
 // bitmap is set with 64-bit atomic OR.
 __global__ __launch_bounds__(256) void k_scatter(Src src, const uint64_t *vsrc, Src pos, const uint64_t *vpos, int64_t n,
                                                  int64_t nout, int64_t *out, uint64_t *vout) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        if (!bit(vsrc, i) || !bit(vpos, i)) continue;
-        const int64_t p = ld(pos, i);
-        if (p < 0 || p >= nout) continue;
-        out[p] = ld(src, i);
-        if (vout) atomicOr((unsigned long long *)&vout[p >> 6], 1ull << (p & 63));    // null: the caller knows which slots get written
-    }
+    constexpr int U = kGatherUnroll;
+    const int64_t nw = (n + 63) >> 6;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave) * U;
+    const int64_t w_first = wave_index() * U;
+    by_kind(pos.kind, [&](auto kp) {
+        by_kind(src.kind, [&](auto ks) {
+            for (int64_t w0 = w_first; w0 < nw; w0 += wstride) {
+                int64_t x[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {                   // values and positions are loaded whether or not the slot takes part
+                    const int64_t w = w0 + u < nw ? w0 + u : nw - 1;
+                    const int64_t i = (w << 6) + lane;
+                    x[u] = ldk<decltype(ks)::value>(src, i < n ? i : 0);
+                }
+                int64_t p[U];
+                bool ok[U];
+                gather_slots<decltype(kp)::value, false>(pos, vpos, vsrc, nullptr, nout, n, nw, w0, lane, p, ok);
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    if (ok[u]) {
+                        out[p[u]] = x[u];
+                        if (vout) atomicOr((unsigned long long *)&vout[p[u] >> 6], 1ull << (p[u] & 63));    // null: the caller knows which slots get written
+                    }
+                }
+            }
+        });
+    });
 }
 hipError_t launch_scatter(Src src, const uint64_t *vsrc, Src pos, const uint64_t *vpos, int64_t n, int64_t nout, int64_t *out,
                           uint64_t *vout, hipStream_t s) {
