@@ -685,23 +685,58 @@ int fold_scratch_blocks() { return kFoldBlocks; }
 
 __global__ __launch_bounds__(256) void k_fold_global(int kind, Src d, const uint64_t *vd, const uint64_t *vc, int64_t n,
                                                      int64_t *scratch) {
+    constexpr int U = kGatherUnroll;
     const int rk = kind == 1 ? R_MIN : kind == 2 ? R_MAX : R_SUM;
-    int64_t acc = kind == 4 ? INT64_MAX : r_identity(rk);   // choose: smallest slot index holding a datum
-    int64_t first = INT64_MAX, cnt = 0;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const bool c_ok = bit(vc, i);
-        if (c_ok && i < first) first = i;
-        if (c_ok && bit(vd, i)) {
-            cnt++;
-            if (kind == 3) acc += 1;
-            else if (kind == 4) acc = i < acc ? i : acc;
-            else acc = r_combine(rk, acc, ld(d, i));
-        }
-    }
-    __shared__ int64_t red[3][256 / kWave];
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const int ak = kind == 4 ? R_MIN : rk;
+    const int64_t nw = (n + 63) >> 6;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave) * U;
+    // per lane: the fold of its data; per wave (kept uniform, lane 0 reports them): first control slot, number of data
+    // slots, and for count / choose the result itself -- all three come from the bitmap words, not from the rows
+    int64_t acc = r_identity(rk);
+    int64_t first = INT64_MAX, cnt = 0, chosen = INT64_MAX;
+    by_kind(d.kind, [&](auto kd) {
+        for (int64_t w0 = wave_index() * U; w0 < nw; w0 += wstride) {
+            int64_t x[U];
+            uint64_t mc[U], md[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int64_t w = w0 + u < nw ? w0 + u : nw - 1;
+                const int64_t i = (w << 6) + lane;
+                x[u] = kind < 3 ? ldk<decltype(kd)::value>(d, i < n ? i : 0) : 0;     // wave-uniform test; masked lanes read slot 0
+                const int64_t rem = n - (w << 6);
+                mc[u] = w0 + u < nw ? (rem < 64 ? (1ull << rem) - 1 : ~0ull) : 0ull;
+            }
+            if (vc) {
+                uint64_t t[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) t[u] = vc[w0 + u < nw ? w0 + u : nw - 1];
+#pragma unroll
+                for (int u = 0; u < U; u++) mc[u] &= t[u];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) md[u] = mc[u];
+            if (vd) {
+                uint64_t t[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) t[u] = vd[w0 + u < nw ? w0 + u : nw - 1];
+#pragma unroll
+                for (int u = 0; u < U; u++) md[u] &= t[u];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int64_t wbase = (w0 + u) << 6;
+                if (mc[u] && first == INT64_MAX) first = wbase + __ffsll((long long)mc[u]) - 1;      // words come in ascending order per wave
+                if (md[u] && chosen == INT64_MAX) chosen = wbase + __ffsll((long long)md[u]) - 1;
+                cnt += __popcll(md[u]);
+                if ((md[u] >> lane) & 1ull) acc = r_combine(rk, acc, x[u]);
+            }
+        }
+    });
+    if (kind == 3) acc = lane == 0 ? cnt : 0;
+    else if (kind == 4) acc = lane == 0 ? chosen : INT64_MAX;
+    if (lane != 0) { first = INT64_MAX; cnt = 0; }
+    __shared__ int64_t red[3][256 / kWave];
     acc = wave_reduce(acc, ak); first = wave_reduce(first, R_MIN); cnt = wave_reduce(cnt, R_SUM);
     if (lane == 0) { red[0][wave] = acc; red[1][wave] = first; red[2][wave] = cnt; }
     __syncthreads();
@@ -1156,35 +1191,65 @@ struct PartIn {
     int shift;
 };
 
+// A wave's share of a tile: kPartSteps x 64 consecutive slots starting at a multiple of 64, fetched with every load
+// issued before the first use (the validity word of a step is the same for all lanes).
 template <bool FIRST>
-__device__ __forceinline__ bool part_fetch(const PartIn &in, int64_t i, int64_t n, uint64_t &key, int64_t &slot) {
-    if (i >= n) return false;
+__device__ __forceinline__ void part_fetch_share(const PartIn &in, int64_t n, int64_t share0 /* multiple of 64 */, int lane,
+                                                 uint64_t (&keys)[kPartSteps], int64_t (&slots)[kPartSteps], bool (&oks)[kPartSteps]) {
     if (FIRST) {
-        if (!bit(in.valid, i)) return false;
-        const int64_t x = ld(in.data, i);
-        int64_t b = 0;
-        if (x > in.pmin) { b = (int64_t)((uint64_t)x - (uint64_t)in.pmin); if (b < 0 || b > in.pcount) b = in.pcount; }
-        key = (uint64_t)b; slot = i;
+        by_kind(in.data.kind, [&](auto kd) {
+#pragma unroll
+            for (int st = 0; st < kPartSteps; st++) {
+                const int64_t i = share0 + st * kWave + lane;
+                oks[st] = i < n;
+                slots[st] = i;
+                keys[st] = (uint64_t)ldk<decltype(kd)::value>(in.data, oks[st] ? i : 0);
+            }
+        });
+        if (in.valid) {
+            const int64_t nw = (n + 63) >> 6;
+            uint64_t t[kPartSteps];
+#pragma unroll
+            for (int st = 0; st < kPartSteps; st++) { const int64_t w = (share0 >> 6) + st; t[st] = in.valid[w < nw ? w : nw - 1]; }
+#pragma unroll
+            for (int st = 0; st < kPartSteps; st++) oks[st] = oks[st] & (((t[st] >> lane) & 1ull) != 0);
+        }
+#pragma unroll
+        for (int st = 0; st < kPartSteps; st++) {                // bucket = clamp(data - min, 0, cnt)
+            const int64_t x = (int64_t)keys[st];
+            int64_t b = 0;
+            if (x > in.pmin) { b = (int64_t)((uint64_t)x - (uint64_t)in.pmin); if (b < 0 || b > in.pcount) b = in.pcount; }
+            keys[st] = (uint64_t)b;
+        }
     } else {
-        key = in.keys[i]; slot = in.slots[i];
+#pragma unroll
+        for (int st = 0; st < kPartSteps; st++) {
+            const int64_t i = share0 + st * kWave + lane;
+            oks[st] = i < n;
+            const int64_t ii = oks[st] ? i : 0;                  // n > 0 here
+            keys[st] = in.keys[ii]; slots[st] = in.slots[ii];
+        }
     }
-    return true;
 }
 
 template <bool FIRST>
 __global__ __launch_bounds__(kPartBlock) void k_part_hist(PartIn in, int64_t ntiles, int64_t *hist /*[256][ntiles]*/) {
     __shared__ unsigned int h[kRadix];
     const int64_t n = FIRST ? in.n : *in.n_dev;
-    h[threadIdx.x] = 0;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    h[tid] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * kPartTile;
-    for (int st = 0; st < kPartSteps; st++) {
-        uint64_t key; int64_t slot;
-        if (part_fetch<FIRST>(in, base + st * kPartBlock + threadIdx.x, n, key, slot))
-            atomicAdd(&h[(key >> in.shift) & (kRadix - 1)], 1u);
+    if ((int64_t)blockIdx.x * kPartTile < n) {                   // (n = 0 leaves the key buffers unwritten)
+        uint64_t keys[kPartSteps];
+        int64_t slots[kPartSteps];
+        bool oks[kPartSteps];
+        part_fetch_share<FIRST>(in, n, (int64_t)blockIdx.x * kPartTile + (int64_t)wave * (kPartSteps * kWave), lane, keys, slots, oks);
+#pragma unroll
+        for (int st = 0; st < kPartSteps; st++)
+            if (oks[st]) atomicAdd(&h[(keys[st] >> in.shift) & (kRadix - 1)], 1u);
     }
     __syncthreads();
-    hist[(int64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+    hist[(int64_t)tid * ntiles + blockIdx.x] = h[tid];
 }
 
 // Each wave owns a contiguous quarter of the tile (16 steps of 64 slots), so the stable order inside a tile is wave,
@@ -1203,22 +1268,13 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(PartIn in, int64_t 
 #pragma unroll
     for (int w = 0; w < NW; w++) whist[w][tid] = 0;
     __syncthreads();
-    const int64_t wbase = (int64_t)blockIdx.x * kPartTile + (int64_t)wave * (kPartSteps * kWave) + lane;
     uint64_t keys[kPartSteps];
     int64_t slots[kPartSteps];
     bool oks[kPartSteps];
 #pragma unroll
-    for (int st = 0; st < kPartSteps; st++) {                   // the whole share is fetched up front
-        keys[st] = 0; slots[st] = 0;
-        const int64_t i = wbase + st * kWave;
-        if (FIRST) {
-            oks[st] = part_fetch<true>(in, i, n, keys[st], slots[st]);
-        } else {
-            oks[st] = i < n;
-            const int64_t ii = oks[st] ? i : 0;
-            keys[st] = in.keys[ii]; slots[st] = in.slots[ii];
-        }
-    }
+    for (int st = 0; st < kPartSteps; st++) { keys[st] = 0; slots[st] = 0; oks[st] = false; }
+    if ((int64_t)blockIdx.x * kPartTile < n)                    // the whole share is fetched up front
+        part_fetch_share<FIRST>(in, n, (int64_t)blockIdx.x * kPartTile + (int64_t)wave * (kPartSteps * kWave), lane, keys, slots, oks);
     unsigned int local[kPartSteps];                             // rank among this wave's slots with the same digit
     volatile unsigned int *mine = whist[wave];
 #pragma unroll
