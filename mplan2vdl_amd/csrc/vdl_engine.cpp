@@ -5,268 +5,9 @@
 //               per table (vdl_fuse.cpp decides, k_scan executes);
 //   * general : any other program runs statement by statement with one kernel per operator;
 //               RangeV/RangeC, Project, Shuffle and identity Gathers never touch memory.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <set>
-#include <memory>
-#include <sstream>
-#include <string>
-#include <vector>
-
-#include "vdl.h"
-#include "vdl_fuse.h"
-#include "vdl_ir.h"
-#include "vdl_kernels.h"
-
-using namespace vdl;
+#include "vdl_genexec.h"
 
 namespace {
-
-#define HIP_CHECK(expr)                                                                                         \
-    do {                                                                                                        \
-        hipError_t e_ = (expr);                                                                                 \
-        if (e_ != hipSuccess)                                                                                   \
-            throw Error(VDL_ERR_DEVICE, std::string(#expr) + " failed: " + hipGetErrorString(e_));              \
-    } while (0)
-
-// ---- HBM pool: size-class free lists; everything runs on one stream, so a buffer released on the
-// host can be handed to a later launch without extra synchronisation (stream order protects it).
-struct Pool {
-    std::multimap<size_t, void *> free_list;
-    size_t live_bytes = 0, peak_bytes = 0;
-    static size_t round_up(size_t b) {
-        size_t c = 256;
-        while (c < b) c <<= 1;
-        if (c > (size_t(1) << 26)) c = (b + (size_t(1) << 26) - 1) & ~((size_t(1) << 26) - 1);   // 64 MiB granules above 64 MiB
-        return c;
-    }
-    void *alloc(size_t bytes, size_t *cls) {
-        size_t c = round_up(bytes ? bytes : 1);
-        *cls = c;
-        auto it = free_list.find(c);
-        void *p = nullptr;
-        if (it != free_list.end()) { p = it->second; free_list.erase(it); }
-        else {
-            hipError_t e = hipMalloc(&p, c);
-            if (e != hipSuccess) {
-                trim();
-                e = hipMalloc(&p, c);
-                if (e != hipSuccess) throw Error(VDL_ERR_NOMEM, "hipMalloc of " + std::to_string(c) + " bytes failed");
-            }
-        }
-        live_bytes += c;
-        peak_bytes = std::max(peak_bytes, live_bytes);
-        return p;
-    }
-    void release(void *p, size_t cls) {
-        if (closed) { (void)hipFree(p); return; }        // the context is gone: give the memory back at once
-        free_list.emplace(cls, p);
-        live_bytes -= cls;
-    }
-    void trim() { for (auto &kv : free_list) (void)hipFree(kv.second); free_list.clear(); }
-    bool closed = false;
-    ~Pool() { trim(); }
-};
-
-struct DevBuf {
-    void *p = nullptr;
-    size_t cls = 0;
-    std::shared_ptr<Pool> pool;       // buffers (held by plans) may outlive their context
-    ~DevBuf() { if (p && pool) pool->release(p, cls); }
-};
-using BufP = std::shared_ptr<DevBuf>;
-
-struct Column {
-    const void *dev = nullptr;
-    int width = 0;
-    int64_t n = 0;
-    BufP owned;
-};
-
-// device-side vector of the general path
-// A selection: m of n slots, ascending.  Vectors that hold values only on a sparse selection (after a selective
-// filter, Vlite.hs:721-730) are stored as SPARSE: the m values of the selected slots, so that everything
-// downstream of the filter touches m instead of n elements (GenExec: "sparse vectors").
-struct Sel {
-    int64_t n = 0, m = 0;
-    BufP idx;                       // the m slot ids; null = the prefix 0 .. m-1
-    BufP bitmap;                    // n bits with exactly the selected slots set (prefix selections: built on demand)
-    std::shared_ptr<Sel> parent;    // the selection this one was filtered from, and
-    BufP ppos;                      // for each of the m slots its entry number inside the parent
-    bool worth = true;              // false: too dense to be worth compacting (only m is known)
-};
-using SelP = std::shared_ptr<Sel>;
-
-struct ExprNode;
-struct LazyGather;
-
-struct DVec {
-    enum Kind { NONE, DENSE, COLUMN, RANGE, ONEHOT, OHCONST, SPARSE, EXPR, LAZYG } kind = NONE;
-    int64_t n = 0;
-    SelP sel;                   // SPARSE: data = the sel->m values; valid = bitmap over those m entries (null = all hold a value)
-    bool perm = false;          // SPARSE: the values are a permutation of 0 .. m-1 (Partition positions)
-    bool ids = false;           // SPARSE: every value is its own slot id (row ids gathered through a filter)
-    std::shared_ptr<LazyGather> lg; // LAZYG: Gather(src, pos) not run yet: its only reader is a filter that needs few (or none) of its values
-    std::shared_ptr<ExprNode> ex;   // EXPR: a not yet evaluated tree of element-wise operators (fused when somebody needs the values)
-    BufP data;                  // DENSE: n int64; ONEHOT/OHCONST: {value, slot, count}
-    const void *ptr = nullptr;  // COLUMN: borrowed catalog pointer
-    int width = 8;
-    int64_t from = 0, step = 0; // RANGE; OHCONST: from = the constant
-    BufP valid;                 // bitmap, null = every slot holds a value
-    BufP keep;                  // COLUMN: keeps an engine-owned column alive
-};
-
-// Element-wise operators whose only reader is another element-wise operator are not run one by one: they pile up
-// in a tree whose leaves are stored vectors, and the tree runs as one kernel (k_expr) when its root is needed.
-struct ExprNode {
-    int bin = -1;                          // -1: leaf
-    std::shared_ptr<ExprNode> l, r;
-    DVec leaf;                             // DENSE / COLUMN / RANGE
-    int leaves = 1, instrs = 1, depth = 1;
-};
-
-struct LazyGather { DVec src, pos; };        // both in dense form (DENSE / COLUMN / RANGE)
-
-constexpr size_t kBigOutput = 1u << 16;     // values; from here on results use pinned host memory (or stay on the device)
-struct Output {
-    int node = 0;
-    std::string name, tmp;
-    std::vector<int64_t> vals;
-    const int64_t *big = nullptr;      // large results land in a pinned buffer the plan keeps (pageable copies run at a few GB/s)
-    size_t big_n = 0;
-    std::shared_ptr<void> dev_keep;    // vdl_plan_set_device_outputs: large results stay in HBM, owned by the plan until its next run
-    const int64_t *dev = nullptr;
-    const int64_t *ptr() const { return dev ? nullptr : big ? big : vals.data(); }
-    size_t count() const { return (dev || big) ? big_n : vals.size(); }
-};
-struct Timing { std::string label; double usec; };
-
-}  // namespace
-
-struct vdl_ctx {
-    int device = -1;
-    hipStream_t own_stream = nullptr, stream = nullptr;
-    hipStream_t copy_stream = nullptr;     // result copies of the general path run here, behind an event, while later statements compute
-    hipEvent_t copy_ev = nullptr;
-    int num_cus = 256;
-    std::map<std::string, Column> cols;
-    uint64_t catalog_version = 1;      // bumped on every catalog change: plans re-bind only when it moved
-    std::shared_ptr<Pool> pool = std::make_shared<Pool>();
-    std::string err;
-};
-
-struct vdl_plan {
-    vdl_ctx *ctx = nullptr;          // only dereferenced inside calls that receive the live context
-    int device = -1;                 // copied at parse time: the plan may outlive its context
-    Program prog;
-    FusedPlan fused;
-    bool use_fusion = true;
-    bool profiling = false;
-    bool device_outputs = false;
-    std::string description;
-    std::vector<Output> outs;
-    std::vector<Timing> timings;
-    // fused state
-    std::vector<ScanArgs> sargs;
-    std::vector<ScanLaunch> scfg;
-    std::vector<BufP> block_partials;
-    std::vector<int32_t> reduce_ops;
-    std::vector<int64_t> word_offset;
-    std::vector<MScanCols> mcols;            // [scans..., gscans...] entries that run on k_mscan
-    std::vector<MScanDesc> mdesc;
-    std::vector<ScanLaunch> mcfg;
-    std::vector<BufP> mparts, mdev;
-    std::vector<int64_t> gword_offset;
-    int dominant = -1;
-    std::string dominant_kernel;
-    int64_t n_words = 0;
-    int64_t row_offset = 0;                  // global index of this rank's first row (sharded FoldChoose)
-    // sharded Partition exchange (vdl_exchange_*)
-    struct ExState {
-        bool active = false;
-        int world = 0;
-        int64_t n = 0, n_send = 0;
-        std::vector<DVec> src;             // [0] = key, then the other scattered vectors
-        BufP vdest, pos;
-        std::vector<int> nodes;
-        int64_t pmin = 0, pcount = 0;
-    } ex;
-    BufP words;
-    int64_t words_cap = 0;
-    std::string fallback_note;
-    bool bound = false;
-    uint64_t bound_version = 0;
-    // pipelined finalisation: two pinned host slots, one event each
-    int64_t *host_words[2] = {nullptr, nullptr};
-    int64_t host_cap = 0;
-    hipEvent_t slot_ev[2] = {nullptr, nullptr};
-    bool slot_pending[2] = {false, false};
-    int64_t scan_rows = 0, scan_bytes = 0;
-    double scan_usec = 0;
-    static constexpr int kEvRing = 4;   // runs in flight before their timing is read (pipelined callers: up to 3)
-    hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};   // profiling events, one pair per run, ring
-    bool ev_pending[kEvRing] = {}, ev_bound[kEvRing] = {};
-    uint64_t ev_seq[kEvRing] = {};
-    unsigned run_seq = 0;
-    int last_ev = 0;
-    const void *ev_buf[kEvRing] = {};   // partial-word buffer each event pair's run wrote (pipelined callers finalise out of order)
-    int slot_ev_idx[2] = {-1, -1};
-    // pinned result buffers of the general path, one per output ordinal, grown on demand
-    std::vector<std::pair<int64_t *, size_t>> out_pinned;
-    int64_t *pinned_out(size_t ordinal, size_t count) {
-        if (out_pinned.size() <= ordinal) out_pinned.resize(ordinal + 1, {nullptr, 0});
-        auto &b = out_pinned[ordinal];
-        if (b.second < count) {
-            if (b.first) (void)hipHostFree(b.first);
-            b.first = nullptr; b.second = 0;
-            if (hipHostMalloc((void **)&b.first, sizeof(int64_t) * count, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); b.first = nullptr; return nullptr; }
-            b.second = count;
-        }
-        return b.first;
-    }
-    ~vdl_plan() {
-        for (auto &b : out_pinned) if (b.first) (void)hipHostFree(b.first);
-        for (int k = 0; k < 2; k++) {
-            if (ev0[k]) (void)hipEventDestroy(ev0[k]);
-            if (ev1[k]) (void)hipEventDestroy(ev1[k]);
-            if (ev0[k + 2]) (void)hipEventDestroy(ev0[k + 2]);
-            if (ev1[k + 2]) (void)hipEventDestroy(ev1[k + 2]);
-            if (slot_ev[k]) (void)hipEventDestroy(slot_ev[k]);
-            if (host_words[k]) (void)hipHostFree(host_words[k]);
-        }
-    }
-};
-
-namespace {
-
-BufP dev_alloc(vdl_ctx *c, size_t bytes) {
-    auto b = std::make_shared<DevBuf>();
-    b->pool = c->pool;
-    b->p = c->pool->alloc(bytes, &b->cls);
-    return b;
-}
-
-void need_device(vdl_ctx *c) {
-    if (c->device < 0) throw Error(VDL_ERR_DEVICE, "this context has no HIP device (opened with device < 0)");
-    HIP_CHECK(hipSetDevice(c->device));
-}
-
-uint64_t fnv1a(const std::string &s) {
-    uint64_t h = 0xCBF29CE484222325ULL;
-    for (unsigned char ch : s) { h ^= ch; h *= 0x100000001B3ULL; }
-    return h;
-}
-
-const Column &find_col(vdl_ctx *c, const std::string &name) {
-    auto it = c->cols.find(name);
-    if (it == c->cols.end()) throw Error(VDL_ERR_COLUMN, "Load: column '" + name + "' is not in the catalog");
-    return it->second;
-}
 
 // ------------------------------------------------------------------------------------------------
 // fused execution
@@ -536,1185 +277,10 @@ void finalize_end(vdl_ctx *c, vdl_plan *p, int slot) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// general (per-operator) execution
-// ------------------------------------------------------------------------------------------------
-struct GenExec {
-    vdl_ctx *c;
-    vdl_plan *p;
-    std::vector<DVec> vec;
-    std::vector<int> last_use;
-    hipStream_t s;
+}  // namespace
 
-    GenExec(vdl_ctx *ctx, vdl_plan *plan) : c(ctx), p(plan), vec(plan->prog.nodes.size()), last_use(plan->prog.nodes.size(), -1), s(ctx->stream) {}
-    ~GenExec() { if (!copies_in_flight.empty() && c->copy_stream) (void)hipStreamSynchronize(c->copy_stream); }     // error exits
-
-    static int64_t nwords(int64_t n) { return (n + 63) >> 6; }
-    const uint64_t *vp(const DVec &v) const { return v.valid ? (const uint64_t *)v.valid->p : nullptr; }
-
-    Src src_of(const DVec &v) const {
-        Src r;
-        switch (v.kind) {
-        case DVec::DENSE: r.p = v.data->p; r.kind = SRC_I64; break;
-        case DVec::COLUMN:
-            r.p = v.ptr;
-            r.kind = v.width == 8 ? SRC_I64 : v.width == 4 ? SRC_I32 : v.width == 2 ? SRC_I16 : SRC_I8;
-            break;
-        case DVec::RANGE: r.kind = SRC_RANGE; r.from = v.from; r.step = v.step; break;
-        default: throw Error(VDL_ERR_UNSUPPORTED, "internal: operand form not addressable");
-        }
-        return r;
-    }
-
-    // ---- validity bitmaps: which ones are known to be subsets of which (filters nest) ------------------
-    std::map<const void *, std::set<const void *>> supers;      // bitmap -> bitmaps known to contain it
-    std::map<const void *, SelP> sel_of_bitmap;                 // bitmaps whose population / slot list is known
-    std::vector<BufP> keep_alive;                               // keys above stay valid for the whole run
-    bool sparse_on = !getenv("VDL_NO_SPARSE");
-    bool trace_forms = getenv("VDL_TRACE_FORMS") && std::strcmp(getenv("VDL_TRACE_FORMS"), "0") != 0;      // one line per statement: the form of its result
-    int densified = 0;                                             // SPARSE -> DENSE conversions (each is a scatter over n slots)
-
-    bool subset(const BufP &a, const BufP &b) {                 // a (null = all slots) inside b?
-        if (!b || a == b) return true;
-        if (!a) return false;
-        auto it = supers.find(a->p);
-        return it != supers.end() && it->second.count(b->p);
-    }
-    void note_subset(const BufP &child, const BufP &parent) {
-        if (!child || !parent || child == parent) return;
-        keep_alive.push_back(child); keep_alive.push_back(parent);
-        std::set<const void *> &sup = supers[child->p];
-        sup.insert(parent->p);
-        auto it = supers.find(parent->p);
-        if (it != supers.end()) sup.insert(it->second.begin(), it->second.end());
-    }
-    BufP and_bitmaps(const BufP &a, const BufP &b, int64_t n) {
-        if (subset(a, b)) return a;
-        if (subset(b, a)) return b;
-        BufP o = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(n), 1));
-        HIP_CHECK(launch_and_words((const uint64_t *)a->p, (const uint64_t *)b->p, (uint64_t *)o->p, nwords(n), s));
-        note_subset(o, a); note_subset(o, b);
-        return o;
-    }
-    BufP and_valid(const DVec &a, const DVec &b, int64_t n) { return and_bitmaps(a.valid, b.valid, n); }
-
-    // ---- sparse vectors --------------------------------------------------------------------------------
-    BufP zero_bitmap(int64_t n) {
-        BufP o = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(n), 1));
-        HIP_CHECK(launch_fill_words((uint64_t *)o->p, 0, nwords(n), s));
-        return o;
-    }
-    // population of a bitmap over n slots; leaves the per-tile offsets for compact_write in *offsets
-    int64_t popcount(const BufP &bits, int64_t n, BufP *offsets) {
-        const int64_t nb = (n + compact_tile() - 1) / compact_tile();
-        if (nb <= 0) return 0;
-        BufP counts = dev_alloc(c, sizeof(int64_t) * (size_t)(nb + 1));
-        HIP_CHECK(launch_compact_count(bits ? (const uint64_t *)bits->p : nullptr, n, (int64_t *)counts->p, s));
-        HIP_CHECK(launch_compact_scan((int64_t *)counts->p, nb, s));
-        int64_t total = 0;
-        HIP_CHECK(hipMemcpyAsync(&total, (int64_t *)counts->p + nb, sizeof total, hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipStreamSynchronize(s));
-        if (offsets) *offsets = counts;
-        return total;
-    }
-    // the entries of `v` (any addressable form, length n) where `bits` is set, packed (total > 0 of them)
-    BufP compact_write(Src v, const BufP &bits, int64_t n, const BufP &offsets, int64_t total) {
-        BufP out = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(total, 1));
-        if (total > 0)
-            HIP_CHECK(launch_compact_write(v, bits ? (const uint64_t *)bits->p : nullptr, n, (const int64_t *)offsets->p, (int64_t *)out->p, s));
-        return out;
-    }
-    static Src iota_src() { Src r; r.kind = SRC_RANGE; r.from = 0; r.step = 1; return r; }
-    static Src i64_src(const BufP &b) { Src r; r.p = b ? b->p : nullptr; r.kind = SRC_I64; return r; }
-    Src idx_src(const Sel &sel) const { return sel.idx ? i64_src(sel.idx) : iota_src(); }
-
-    // the selection a validity bitmap describes (population counted once per bitmap); worth = sparse enough to compact
-    SelP sel_for(const BufP &bits, int64_t n) {
-        auto it = sel_of_bitmap.find(bits->p);
-        if (it != sel_of_bitmap.end()) return it->second;
-        SelP sel = std::make_shared<Sel>();
-        sel->n = n; sel->bitmap = bits;
-        BufP offsets;
-        sel->m = popcount(bits, n, &offsets);
-        // a subset of a known selection with the same population IS that selection (two routes to one filter)
-        auto sup = supers.find(bits->p);
-        if (sup != supers.end())
-            for (const void *q : sup->second) {
-                auto known = sel_of_bitmap.find(q);
-                if (known != sel_of_bitmap.end() && known->second->n == n && known->second->m == sel->m && known->second->bitmap) {
-                    keep_alive.push_back(bits);
-                    sel_of_bitmap[bits->p] = known->second;
-                    note_subset(known->second->bitmap, bits);
-                    return known->second;
-                }
-            }
-        const char *den = getenv("VDL_SPARSE_DEN");                                 // compaction threshold m <= n / den (default 8)
-        sel->worth = sel->m * (den && atoi(den) > 0 ? atoi(den) : 8) <= n || getenv("VDL_SPARSE_ALWAYS") != nullptr;      // the env switch makes the tests cover every path
-        if (sel->worth) sel->idx = compact_write(iota_src(), bits, n, offsets, sel->m);
-        keep_alive.push_back(bits);
-        sel_of_bitmap[bits->p] = sel;
-        return sel;
-    }
-    const BufP &bitmap_of(const SelP &sel) {                     // derived / prefix selections get their bitmap on first use
-        if (!sel->bitmap) {
-            sel->bitmap = zero_bitmap(sel->n);
-            if (sel->m > 0) {
-                BufP ids = sel->idx;
-                if (!ids) {
-                    ids = dev_alloc(c, sizeof(int64_t) * (size_t)sel->m);
-                    Src z; z.kind = SRC_RANGE; z.from = 0; z.step = 0;
-                    HIP_CHECK(launch_binary(B_ADD, iota_src(), z, (int64_t *)ids->p, sel->m, s));   // ids = 0 .. m-1
-                }
-                HIP_CHECK(launch_set_bits((const int64_t *)ids->p, sel->m, (uint64_t *)sel->bitmap->p, s));
-            }
-            keep_alive.push_back(sel->bitmap);
-            sel_of_bitmap[sel->bitmap->p] = sel;
-            if (sel->parent) note_subset(sel->bitmap, bitmap_of(sel->parent));
-        }
-        return sel->bitmap;
-    }
-    struct RunHeads { BufP ctl, heads, wordhd, offsets; int64_t count = 0; SelP child; };
-    std::map<const void *, RunHeads> heads_of;                  // control entries buffer -> its run heads (kept alive by .ctl)
-    SelP prefix_selection(int64_t n, int64_t m) {
-        for (const SelP &x : prefixes) if (x->n == n && x->m == m) return x;
-        SelP x = std::make_shared<Sel>();
-        x->n = n; x->m = m;
-        prefixes.push_back(x);
-        return x;
-    }
-    std::vector<SelP> prefixes;
-    // the selection made of the entries of `ps` flagged in `flags` (a bitmap over its m entries)
-    SelP child_selection(const SelP &ps, const BufP &flags, int64_t count, const BufP &offsets) {
-        SelP ch = std::make_shared<Sel>();
-        ch->n = ps->n; ch->parent = ps; ch->m = count;
-        ch->idx = compact_write(idx_src(*ps), flags, ps->m, offsets, count);
-        ch->ppos = compact_write(iota_src(), flags, ps->m, offsets, count);
-        return ch;                                              // its n-bit bitmap is built when somebody asks (bitmap_of)
-    }
-    // SPARSE vectors hold a value in every entry: entries that turned EPS (a gather out of range / from an EPS
-    // slot) leave the selection
-    DVec sparse_normalised(const SelP &sel, const BufP &data, const BufP &sub) {
-        BufP offsets;
-        const int64_t live = popcount(sub, sel->m, &offsets);
-        if (live == sel->m) return make_sparse(sel, data);
-        SelP ch = child_selection(sel, sub, live, offsets);
-        return make_sparse(ch, compact_write(i64_src(data), sub, sel->m, offsets, live));
-    }
-    // m-entry view of a SPARSE vector as an ordinary dense one (for the kernels that take Src + bitmap + length)
-    DVec entries(const DVec &v) const {
-        DVec o; o.kind = DVec::DENSE; o.n = v.sel->m; o.data = v.data;
-        return o;
-    }
-    DVec make_sparse(const SelP &sel, BufP data) {
-        DVec o; o.kind = DVec::SPARSE; o.n = sel->n; o.sel = sel; o.data = std::move(data);
-        return o;
-    }
-    // values of a dense-form vector on a selection (its validity must cover the selection)
-    DVec sparse_take(const DVec &src, const SelP &sel) {
-        BufP data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(sel->m, 1));
-        BufP junk = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(sel->m), 1));
-        HIP_CHECK(launch_gather(src_of(src), nullptr, src.n, idx_src(*sel), nullptr, sel->m, (int64_t *)data->p, (uint64_t *)junk->p, s));
-        return make_sparse(sel, data);
-    }
-    // SPARSE -> DENSE + bitmap over the n slots
-    DVec sparse_to_dense(const DVec &v) {
-        densified++;
-        DVec o; o.kind = DVec::DENSE; o.n = v.n;
-        o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(v.n, 1));
-        if (v.sel->bitmap) {                                   // the slots that get written are exactly the selection's bitmap
-            o.valid = v.sel->bitmap;
-            HIP_CHECK(launch_scatter(i64_src(v.data), nullptr, idx_src(*v.sel), nullptr, v.sel->m, v.n, (int64_t *)o.data->p, nullptr, s));
-        } else {
-            o.valid = zero_bitmap(v.n);
-            HIP_CHECK(launch_scatter(i64_src(v.data), nullptr, idx_src(*v.sel), nullptr, v.sel->m, v.n, (int64_t *)o.data->p, (uint64_t *)o.valid->p, s));
-            v.sel->bitmap = o.valid; keep_alive.push_back(o.valid); sel_of_bitmap[o.valid->p] = v.sel;
-        }
-        return o;
-    }
-
-    // ---- fused element-wise trees -------------------------------------------------------------------------
-    bool fuse_on = !getenv("VDL_NO_EXPR_FUSION");
-    std::vector<int> n_uses;                 // readers of each statement in this run (targets count as one more)
-    std::vector<char> read_by_binary_only;
-    static bool leafable(const DVec &v) { return v.kind == DVec::DENSE || v.kind == DVec::COLUMN || v.kind == DVec::RANGE; }
-    std::shared_ptr<ExprNode> expr_of(const DVec &v) {
-        if (v.kind == DVec::EXPR) return v.ex;
-        auto e = std::make_shared<ExprNode>();
-        e->leaf = v;
-        return e;
-    }
-    BufP expr_valid(const ExprNode &e, int64_t n) {               // AND of the leaves' validity (null = all slots)
-        if (e.bin < 0) return e.leaf.valid;
-        BufP a = expr_valid(*e.l, n), b = expr_valid(*e.r, n);
-        if (!a) return b;
-        if (!b) return a;
-        return and_bitmaps(a, b, n);
-    }
-    void expr_emit(const ExprNode &e, ExprProg &prog) {
-        if (e.bin < 0) {
-            const Src sv = src_of(e.leaf);
-            int at = -1;
-            for (int k = 0; k < prog.n_leaf; k++)
-                if (prog.leaf[k].p == sv.p && prog.leaf[k].kind == sv.kind && prog.leaf[k].from == sv.from && prog.leaf[k].step == sv.step) at = k;
-            if (at < 0) { at = prog.n_leaf++; prog.leaf[at] = sv; }
-            prog.code[prog.n_instr++] = (signed char)(-at - 1);
-            return;
-        }
-        // the emitter's sugar recognised back (Vdl.hs:139-152): a >= b arrives as LogicalOr(Greater(a,b), Equals(b,a)) (in either
-        // operand order), a != b as Subtract(1, Equals(a,b))
-        auto same_leaf = [&](const ExprNode &x, const ExprNode &y) {
-            if (x.bin >= 0 || y.bin >= 0) return false;
-            const Src p = src_of(x.leaf), q = src_of(y.leaf);
-            return p.p == q.p && p.kind == q.kind && p.from == q.from && p.step == q.step && x.leaf.n == y.leaf.n;
-        };
-        if (e.bin == B_LOR && e.l->bin == B_GT && e.r->bin == B_EQ) {
-            const ExprNode &g = *e.l, &q = *e.r;
-            if ((same_leaf(*g.l, *q.r) && same_leaf(*g.r, *q.l)) || (same_leaf(*g.l, *q.l) && same_leaf(*g.r, *q.r))) {
-                expr_emit(*g.l, prog); expr_emit(*g.r, prog);
-                prog.code[prog.n_instr++] = (signed char)X_GE;
-                return;
-            }
-        }
-        if (e.bin == B_SUB && e.l->bin < 0 && e.l->leaf.kind == DVec::RANGE && e.l->leaf.step == 0 && e.l->leaf.from == 1 && e.r->bin == B_EQ) {
-            expr_emit(*e.r->l, prog); expr_emit(*e.r->r, prog);
-            prog.code[prog.n_instr++] = (signed char)X_NE;
-            return;
-        }
-        expr_emit(*e.l, prog);
-        expr_emit(*e.r, prog);
-        prog.code[prog.n_instr++] = (signed char)e.bin;
-    }
-    DVec expr_force(const DVec &v) {
-        const ExprNode &e = *v.ex;
-        DVec o; o.kind = DVec::DENSE; o.n = v.n;
-        o.valid = expr_valid(e, v.n);
-        o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(v.n, 1));
-        ExprProg prog;
-        expr_emit(e, prog);
-        HIP_CHECK(launch_expr(prog, (int64_t *)o.data->p, v.n, s));
-        return o;
-    }
-    // Binary over stored vectors / pending trees: extend the tree; run it unless the only reader is another Binary
-    bool expr_binary(const Node &n, const DVec &a, const DVec &b, DVec &o) {
-        if (!fuse_on || n.bin == B_DIV || n.bin == B_MOD) return false;      // division stays in k_binary (code size, see k_expr)
-        const bool ta = a.kind == DVec::EXPR, tb = b.kind == DVec::EXPR;
-        if (!(ta || leafable(a)) || !(tb || leafable(b)) || a.n != b.n) return false;
-        if (!ta && !tb && a.kind == DVec::RANGE && b.kind == DVec::RANGE && a.step == 0 && b.step == 0) return false;   // constant folding stays
-        const bool lazy = n_uses[(size_t)n.id] == 1 && read_by_binary_only[(size_t)n.id];
-        if (!lazy && !ta && !tb) return false;                   // a lone operator: the plain kernel
-        DVec x = a, y = b;
-        for (;;) {
-            auto el = expr_of(x), er = expr_of(y);
-            auto t = std::make_shared<ExprNode>();
-            t->bin = n.bin; t->l = el; t->r = er;
-            t->leaves = el->leaves + er->leaves;
-            t->instrs = el->instrs + er->instrs + 1;
-            t->depth = std::max(el->depth, er->depth + 1);
-            if (t->leaves <= kExprLeaves && t->instrs <= kExprInstrs && t->depth <= kExprDepth) {
-                o = DVec{};
-                o.kind = DVec::EXPR; o.n = a.n; o.ex = t;
-                if (!lazy) o = expr_force(o);
-                return true;
-            }
-            // too big for one kernel: run the larger side now and keep it as a leaf
-            if (x.kind == DVec::EXPR && (y.kind != DVec::EXPR || el->instrs >= er->instrs)) x = expr_force(x);
-            else if (y.kind == DVec::EXPR) y = expr_force(y);
-            else return false;
-        }
-    }
-
-    DVec gather_now(const DVec &src, const DVec &pos) {
-        DVec o; o.kind = DVec::DENSE; o.n = pos.n;
-        o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(o.n, 1));
-        o.valid = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(o.n), 1));
-        HIP_CHECK(launch_gather(src_of(src), vp(src), src.n, src_of(pos), vp(pos), pos.n, (int64_t *)o.data->p, (uint64_t *)o.valid->p, s));
-        note_subset(o.valid, pos.valid);
-        return o;
-    }
-    // FoldSelect statements the planner could turn into a filter over raw table columns (FusedPlan::filters): they
-    // read the columns themselves, so the comparison / connective statements feeding them need not run for their sake
-    bool filter_on = !getenv("VDL_NO_FILTER_FUSION");
-    bool column_filter(const Node &n) const { return filter_on && n.op == Op::FoldSelect && p->fused.filters.count(n.id) != 0; }
-    // Gather statements that need not run: read only by `Gather(this, filter)`, or only by the filter idiom
-    // FoldSelect(RangeV 0 1 this, this) (the RangeV then only lends its length and an upper bound of the validity)
-    std::vector<char> lazy_gather_ok;
-
-    DVec densify(const DVec &v) {
-        if (v.kind == DVec::LAZYG) return gather_now(v.lg->src, v.lg->pos);
-        if (v.kind == DVec::EXPR) return expr_force(v);
-        if (v.kind == DVec::SPARSE) return sparse_to_dense(v);
-        if (v.kind != DVec::ONEHOT && v.kind != DVec::OHCONST) return v;
-        DVec src = v;
-        if (v.kind == DVec::OHCONST) {   // materialise the constant into a one-hot record first
-            BufP oh = dev_alloc(c, 3 * sizeof(int64_t));
-            HIP_CHECK(launch_onehot_const(B_MUL, (const int64_t *)v.data->p, 0, 0, (int64_t *)oh->p, s));
-            HIP_CHECK(launch_onehot_const(B_ADD, (const int64_t *)oh->p, v.from, 0, (int64_t *)oh->p, s));
-            src.data = oh;
-        }
-        DVec o;
-        o.kind = DVec::DENSE; o.n = v.n;
-        o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(v.n, 1));
-        o.valid = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(v.n), 1));
-        HIP_CHECK(launch_onehot_dense((const int64_t *)src.data->p, (int64_t *)o.data->p, (uint64_t *)o.valid->p, v.n, s));
-        return o;
-    }
-
-    bool descends(const SelP &x, const SelP &from) const {
-        for (SelP k = x; k; k = k->parent) if (k == from) return true;
-        return false;
-    }
-    // SPARSE op SPARSE (on one selection, or one selection filtered out of the other), or SPARSE op constant
-    // whose validity covers the selection
-    bool sparse_binary(const Node &n, const DVec &a0, const DVec &b0, DVec &o) {
-        DVec a = a0, b = b0;
-        if (a.kind == DVec::SPARSE && b.kind == DVec::SPARSE && a.sel != b.sel) {
-            DVec t;
-            if (descends(b.sel, a.sel) && sparse_narrow(a, b.sel, t)) a = t;
-            else if (descends(a.sel, b.sel) && sparse_narrow(b, a.sel, t)) b = t;
-            else return false;
-        }
-        const SelP sel = a.kind == DVec::SPARSE ? a.sel : b.sel;
-        auto as_const = [&](const DVec &k, Src &out) {
-            if (!(k.kind == DVec::RANGE && k.step == 0)) return false;
-            if (k.valid && !subset(bitmap_of(sel), k.valid)) return false;
-            out.kind = SRC_RANGE; out.from = k.from; out.step = 0;
-            return true;
-        };
-        Src sa, sb;
-        if (a.kind == DVec::SPARSE) sa = i64_src(a.data); else if (!as_const(a, sa)) return false;
-        if (b.kind == DVec::SPARSE) sb = i64_src(b.data); else if (!as_const(b, sb)) return false;
-        BufP data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(sel->m, 1));
-        HIP_CHECK(launch_binary(n.bin, sa, sb, (int64_t *)data->p, sel->m, s));
-        o = make_sparse(sel, data);
-        return true;
-    }
-
-    DVec binary(const Node &n, const DVec &a0, const DVec &b0) {
-        DVec a = a0, b = b0;
-        if (a.kind == DVec::SPARSE || b.kind == DVec::SPARSE) {
-            if (a.n != b.n)
-                throw Error(VDL_ERR_SHAPE, std::string(kBinNames[n.bin]) + " (Id " + std::to_string(n.id) + "): operand lengths differ (" +
-                                               std::to_string(a.n) + " vs " + std::to_string(b.n) + ")");
-            DVec o;
-            if (sparse_binary(n, a, b, o)) return o;
-            a = densify(a); b = densify(b);
-        }
-        {
-            DVec o;
-            if (expr_binary(n, a, b, o)) return o;
-            if (a.kind == DVec::EXPR) a = expr_force(a);
-            if (b.kind == DVec::EXPR) b = expr_force(b);
-        }
-        const bool a_oh = a.kind == DVec::ONEHOT || a.kind == DVec::OHCONST;
-        const bool b_oh = b.kind == DVec::ONEHOT || b.kind == DVec::OHCONST;
-        if (a.n != b.n)
-            throw Error(VDL_ERR_SHAPE, std::string(kBinNames[n.bin]) + " (Id " + std::to_string(n.id) + "): operand lengths differ (" +
-                                           std::to_string(a.n) + " vs " + std::to_string(b.n) + ")");
-        if (a_oh && b_oh) {
-            DVec o; o.n = a.n;
-            if (a.kind == DVec::OHCONST && b.kind == DVec::OHCONST) {
-                if (a.data != b.data) { a = densify(a); b = densify(b); }
-                else { o = a; o.from = apply_bin(n.bin, a.from, b.from); return o; }
-            } else {
-                o.kind = DVec::ONEHOT;
-                o.data = dev_alloc(c, 3 * sizeof(int64_t));
-                if (a.kind == DVec::ONEHOT && b.kind == DVec::ONEHOT)
-                    HIP_CHECK(launch_onehot_binary(n.bin, (const int64_t *)a.data->p, (const int64_t *)b.data->p, (int64_t *)o.data->p, s));
-                else if (a.kind == DVec::ONEHOT && a.data == b.data)
-                    HIP_CHECK(launch_onehot_const(n.bin, (const int64_t *)a.data->p, b.from, 0, (int64_t *)o.data->p, s));
-                else if (b.kind == DVec::ONEHOT && a.data == b.data)
-                    HIP_CHECK(launch_onehot_const(n.bin, (const int64_t *)b.data->p, a.from, 1, (int64_t *)o.data->p, s));
-                else { a = densify(a); b = densify(b); o.kind = DVec::NONE; }
-                if (o.kind == DVec::ONEHOT) return o;
-            }
-        } else if (a_oh || b_oh) {
-            a = densify(a); b = densify(b);
-        }
-        DVec o;
-        o.n = a.n;
-        if (a.kind == DVec::RANGE && b.kind == DVec::RANGE && a.step == 0 && b.step == 0) {   // constant folding
-            o.kind = DVec::RANGE; o.from = apply_bin(n.bin, a.from, b.from); o.step = 0;
-            o.valid = and_valid(a, b, o.n);
-            return o;
-        }
-        o.kind = DVec::DENSE;
-        o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(o.n, 1));
-        HIP_CHECK(launch_binary(n.bin, src_of(a), src_of(b), (int64_t *)o.data->p, o.n, s));
-        o.valid = and_valid(a, b, o.n);
-        return o;
-    }
-
-    // Result transfers of pinned outputs are queued on the context's copy stream behind the kernels that produced them
-    // and overlap the statements that follow; the run waits for them at its end.
-    std::vector<BufP> copies_in_flight;
-    void copy_out(Output &o, const BufP &dev, size_t count) {
-        if (p->device_outputs && count >= kBigOutput) {  // the caller reads it where it is
-            o.dev_keep = dev; o.dev = (const int64_t *)dev->p; o.big_n = count;
-            return;
-        }
-        int64_t *dst = host_out(o, count);
-        if (!o.big) {                                   // small / pageable: the plain blocking route
-            HIP_CHECK(hipMemcpyAsync(dst, dev->p, sizeof(int64_t) * count, hipMemcpyDeviceToHost, s));
-            HIP_CHECK(hipStreamSynchronize(s));
-            return;
-        }
-        if (!c->copy_stream) {
-            HIP_CHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-            HIP_CHECK(hipEventCreateWithFlags(&c->copy_ev, hipEventDisableTiming));
-        }
-        HIP_CHECK(hipEventRecord(c->copy_ev, s));
-        HIP_CHECK(hipStreamWaitEvent(c->copy_stream, c->copy_ev, 0));
-        HIP_CHECK(hipMemcpyAsync(dst, dev->p, sizeof(int64_t) * count, hipMemcpyDeviceToHost, c->copy_stream));
-        copies_in_flight.push_back(dev);                // the pool must not hand the buffer out again before the copy ran
-    }
-    void finish_copies() {
-        if (copies_in_flight.empty()) return;
-        HIP_CHECK(hipStreamSynchronize(c->copy_stream));
-        copies_in_flight.clear();
-    }
-
-    // where the values of an output go on the host: a pinned buffer of the plan when large
-    int64_t *host_out(Output &o, size_t count) {
-        if (count >= kBigOutput) {
-            int64_t *pin = p->pinned_out(p->outs.size(), count);
-            if (pin) { o.big = pin; o.big_n = count; return pin; }
-        }
-        o.vals.resize(count);
-        return o.vals.data();
-    }
-
-    void materialize(const Node &n, const DVec &v0) {
-        Output o;
-        o.node = n.id;
-        o.name = n.field;
-        o.tmp = "tmp" + std::to_string(n.id);
-        DVec v = v0;
-        if (v.kind == DVec::SPARSE) {                       // every entry holds a value: the output is the entries
-            if (v.sel->m > 0) copy_out(o, v.data, (size_t)v.sel->m);
-            p->outs.push_back(std::move(o));
-            return;
-        }
-        if (v.kind == DVec::OHCONST) v = densify(v);
-        if (v.kind == DVec::ONEHOT) {
-            int64_t h[3];
-            HIP_CHECK(hipMemcpyAsync(h, v.data->p, sizeof h, hipMemcpyDeviceToHost, s));
-            HIP_CHECK(hipStreamSynchronize(s));
-            if (h[2] > 0) o.vals.push_back(h[0]);
-        } else {
-            const int64_t nb = (v.n + compact_tile() - 1) / compact_tile();
-            if (nb > 0) {
-                BufP counts = dev_alloc(c, sizeof(int64_t) * (size_t)(nb + 1));
-                HIP_CHECK(launch_compact_count(vp(v), v.n, (int64_t *)counts->p, s));
-                HIP_CHECK(launch_compact_scan((int64_t *)counts->p, nb, s));
-                int64_t total = 0;
-                HIP_CHECK(hipMemcpyAsync(&total, (int64_t *)counts->p + nb, sizeof total, hipMemcpyDeviceToHost, s));
-                HIP_CHECK(hipStreamSynchronize(s));
-                if (total > 0) {
-                    BufP outb = dev_alloc(c, sizeof(int64_t) * (size_t)total);
-                    HIP_CHECK(launch_compact_write(src_of(v), vp(v), v.n, (const int64_t *)counts->p, (int64_t *)outb->p, s));
-                    copy_out(o, outb, (size_t)total);
-                }
-            }
-        }
-        p->outs.push_back(std::move(o));
-    }
-
-    // entries of a SPARSE vector on a selection filtered (possibly in several steps) out of its own
-    bool sparse_narrow(const DVec &src, const SelP &to, DVec &o) {
-        std::vector<SelP> chain;
-        for (SelP x = to; x && x != src.sel; x = x->parent) chain.push_back(x);
-        if (chain.empty() || chain.back()->parent != src.sel) return false;
-        BufP cur = src.data;
-        int64_t cur_m = src.sel->m;
-        for (size_t k = chain.size(); k-- > 0;) {
-            const SelP &step = chain[k];
-            BufP d = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(step->m, 1));
-            BufP junk = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(step->m), 1));
-            HIP_CHECK(launch_gather(i64_src(cur), nullptr, cur_m, i64_src(step->ppos), nullptr, step->m, (int64_t *)d->p, (uint64_t *)junk->p, s));
-            cur = d; cur_m = step->m;
-        }
-        o = make_sparse(to, cur);
-        o.ids = src.ids;
-        return true;
-    }
-
-    // Gather with a sparse side: the filter idiom Gather(x, FoldSelect(..)) producing or narrowing a SPARSE vector,
-    // and gathers through sparse positions (FK joins of filtered fact rows).  false = take the general route.
-    bool sparse_gather(const DVec &src, const DVec &pos, DVec &o) {
-        const bool identity = pos.kind == DVec::RANGE && pos.from == 0 && pos.step == 1 && pos.n == src.n;
-        if (identity) {
-            if (!pos.valid) return false;
-            if (src.kind == DVec::LAZYG) {
-                // Gather(Gather(x, p), filter): only the filter's rows of the inner gather are ever needed
-                const LazyGather &lg = *src.lg;
-                if (!subset(pos.valid, lg.pos.valid)) return false;
-                SelP sel = sel_for(pos.valid, src.n);
-                if (!sel->worth) return false;
-                DVec pe = sparse_take(lg.pos, sel);                                            // the inner positions on the selection
-                BufP data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(sel->m, 1));
-                BufP sub = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(sel->m), 1));
-                HIP_CHECK(launch_gather(src_of(lg.src), vp(lg.src), lg.src.n, i64_src(pe.data), nullptr, sel->m, (int64_t *)data->p, (uint64_t *)sub->p, s));
-                o = sparse_normalised(sel, data, sub);
-                return true;
-            }
-            if (src.kind == DVec::SPARSE) {
-                if (subset(bitmap_of(src.sel), pos.valid)) { o = src; return true; }             // the filter keeps every entry
-                auto it = sel_of_bitmap.find(pos.valid->p);
-                if (it != sel_of_bitmap.end() && sparse_narrow(src, it->second, o)) return true;
-                return false;
-            }
-            if (!(src.kind == DVec::DENSE || src.kind == DVec::COLUMN || src.kind == DVec::RANGE)) return false;
-            BufP both = src.valid ? and_bitmaps(src.valid, pos.valid, src.n) : pos.valid;
-            SelP sel = sel_for(both, src.n);
-            if (!sel->worth) return false;
-            if (src.kind == DVec::RANGE && src.step == 0) return false;                        // constants stay virtual
-            if (src.kind == DVec::RANGE && src.from == 0 && src.step == 1 && sel->idx) {        // row ids through a filter = the selection's slot list
-                o = make_sparse(sel, sel->idx);
-                o.ids = true;
-                return true;
-            }
-            o = sparse_take(src, sel);
-            return true;
-        }
-        if (pos.kind == DVec::SPARSE) {
-            DVec from = densify(src);
-            if (!(from.kind == DVec::DENSE || from.kind == DVec::COLUMN || from.kind == DVec::RANGE)) return false;
-            const SelP &sel = pos.sel;
-            BufP data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(sel->m, 1));
-            BufP sub = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(sel->m), 1));
-            HIP_CHECK(launch_gather(src_of(from), vp(from), from.n, i64_src(pos.data), nullptr, sel->m, (int64_t *)data->p, (uint64_t *)sub->p, s));
-            o = sparse_normalised(sel, data, sub);
-            return true;
-        }
-        return false;
-    }
-
-    // FoldSelect over general runs (oracle/vdl_oracle.c:op_fold F_SEL): inside every run of the control vector (EPS
-    // control slots skipped) the slot ids of the non-zero data are packed into the run's first member slots.
-    // On the m non-EPS control slots: run number by a prefix sum over the run heads; a stable Partition by
-    // (run, not selected) ranks the selected entries of a run first, in order, so rank = the member slot to write.
-    DVec fold_select_runs(const DVec &ctl, const DVec &d) {
-        const int64_t n = d.n;
-        DVec o; o.kind = DVec::DENSE; o.n = n;
-        o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(n, 1));
-        o.valid = zero_bitmap(n);
-        BufP offsets;
-        const int64_t m = popcount(ctl.valid, n, &offsets);
-        if (m == 0) return o;
-        BufP idx = compact_write(iota_src(), ctl.valid, n, offsets, m);             // member slots
-        auto at_members = [&](const DVec &v, BufP &vals, BufP &vbits) {
-            vals = dev_alloc(c, sizeof(int64_t) * (size_t)m);
-            vbits = dev_alloc(c, sizeof(uint64_t) * (size_t)nwords(m));
-            HIP_CHECK(launch_gather(src_of(v), vp(v), v.n, i64_src(idx), nullptr, m, (int64_t *)vals->p, (uint64_t *)vbits->p, s));
-        };
-        BufP ce, cv, de, dv;
-        at_members(ctl, ce, cv);
-        at_members(d, de, dv);
-        BufP flags = dev_alloc(c, sizeof(int64_t) * (size_t)m), excl = dev_alloc(c, sizeof(int64_t) * (size_t)m);
-        HIP_CHECK(launch_run_heads((const int64_t *)ce->p, m, (int64_t *)flags->p, (int64_t *)excl->p, s));
-        BufP sums = dev_alloc(c, sizeof(int64_t) * (size_t)(prefix_sum_blocks(m) + 2));
-        HIP_CHECK(launch_prefix_sum((int64_t *)excl->p, m, (int64_t *)sums->p, s));
-        BufP keys = dev_alloc(c, sizeof(int64_t) * (size_t)m);
-        BufP selected = dev_alloc(c, sizeof(uint64_t) * (size_t)nwords(m));
-        HIP_CHECK(launch_fsel_keys((const int64_t *)excl->p, (const int64_t *)flags->p, (const int64_t *)de->p, (const uint64_t *)dv->p, m,
-                                   (int64_t *)keys->p, (uint64_t *)selected->p, s));
-        int64_t last[2];
-        HIP_CHECK(hipMemcpyAsync(&last[0], (const int64_t *)excl->p + (m - 1), sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipMemcpyAsync(&last[1], (const int64_t *)flags->p + (m - 1), sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipStreamSynchronize(s));
-        const int64_t nruns = last[0] + last[1];
-        DVec kv; kv.kind = DVec::DENSE; kv.n = m; kv.data = keys;
-        DVec rank = partition_positions(kv, 0, 2 * nruns);
-        BufP target = dev_alloc(c, sizeof(int64_t) * (size_t)m), junk = dev_alloc(c, sizeof(uint64_t) * (size_t)nwords(m));
-        HIP_CHECK(launch_gather(i64_src(idx), nullptr, m, i64_src(rank.data), nullptr, m, (int64_t *)target->p, (uint64_t *)junk->p, s));
-        HIP_CHECK(launch_scatter(i64_src(idx), (const uint64_t *)selected->p, i64_src(target), nullptr, m, n, (int64_t *)o.data->p, (uint64_t *)o.valid->p, s));
-        return o;
-    }
-
-    // Partition positions of `data` over the pivots RangeC pmin pcount 1 (EPS in -> EPS out)
-    DVec partition_positions(const DVec &data, int64_t pmin, int64_t pcount) {
-        DVec o;
-        o.kind = DVec::DENSE; o.n = data.n; o.valid = data.valid;
-        o.perm = !data.valid;                                   // every slot gets a rank: a permutation of 0 .. n-1
-        o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(o.n, 1));
-        if (o.n > 0) {
-            const int passes = partition_passes(pcount);
-            const int64_t hn = 256 * partition_tiles(o.n);
-            BufP hist = dev_alloc(c, sizeof(int64_t) * (size_t)(hn + 1));
-            BufP scr = dev_alloc(c, sizeof(int64_t) * (size_t)(prefix_sum_blocks(hn) + 2));
-            BufP nvalid = dev_alloc(c, sizeof(int64_t));
-            BufP ka, sa, kb, sb;
-            if (passes > 1) {
-                ka = dev_alloc(c, sizeof(int64_t) * (size_t)o.n); sa = dev_alloc(c, sizeof(int64_t) * (size_t)o.n);
-                kb = dev_alloc(c, sizeof(int64_t) * (size_t)o.n); sb = dev_alloc(c, sizeof(int64_t) * (size_t)o.n);
-            }
-            HIP_CHECK(launch_partition(src_of(data), vp(data), o.n, pmin, pcount, (int64_t *)hist->p, (int64_t *)scr->p,
-                                       ka ? (uint64_t *)ka->p : nullptr, sa ? (int64_t *)sa->p : nullptr,
-                                       kb ? (uint64_t *)kb->p : nullptr, sb ? (int64_t *)sb->p : nullptr,
-                                       (int64_t *)nvalid->p, (int64_t *)o.data->p, s));
-        }
-        return o;
-    }
-
-    DVec exec(const Node &n) {
-        auto V = [&](int id) -> const DVec & { return vec[(size_t)id]; };
-        DVec o;
-        switch (n.op) {
-        case Op::Load: {
-            const Column &col = find_col(c, n.column);
-            o.kind = DVec::COLUMN; o.n = col.n; o.ptr = col.dev; o.width = col.width; o.keep = col.owned;
-            return o;
-        }
-        case Op::Project: case Op::Shuffle:
-            return V(n.a);
-        case Op::RangeV: {
-            const DVec &r = V(n.a);
-            if (r.kind == DVec::ONEHOT || r.kind == DVec::OHCONST) {
-                if (n.imm1 == 0) { o.kind = DVec::OHCONST; o.n = r.n; o.data = r.data; o.from = n.imm0; return o; }
-                DVec d = densify(r);
-                o.kind = DVec::RANGE; o.n = d.n; o.from = n.imm0; o.step = n.imm1; o.valid = d.valid;
-                return o;
-            }
-            if (r.kind == DVec::EXPR) {
-                o.kind = DVec::RANGE; o.n = r.n; o.from = n.imm0; o.step = n.imm1; o.valid = expr_valid(*r.ex, r.n);
-                return o;
-            }
-            if (r.kind == DVec::LAZYG) {          // only as the control of FoldSelect over the same gather (lazy_gather_ok): an upper bound will do
-                o.kind = DVec::RANGE; o.n = r.n; o.from = n.imm0; o.step = n.imm1; o.valid = r.lg->pos.valid;
-                return o;
-            }
-            if (r.kind == DVec::SPARSE) {
-                o.kind = DVec::RANGE; o.n = r.n; o.from = n.imm0; o.step = n.imm1; o.valid = bitmap_of(r.sel);
-                return o;
-            }
-            o.kind = DVec::RANGE; o.n = r.n; o.from = n.imm0; o.step = n.imm1; o.valid = r.valid;
-            return o;
-        }
-        case Op::RangeC:
-            o.kind = DVec::RANGE; o.n = n.imm1; o.from = n.imm0; o.step = n.imm2;
-            return o;
-        case Op::Binary:
-            return binary(n, V(n.a), V(n.b));
-        case Op::FoldSelect: {
-            if (column_filter(n)) {
-                const FilterSpec &fs = p->fused.filters.at(n.id);
-                FilterArgs fa;
-                fa.ncol = (int)fs.cols.size(); fa.never = fs.never ? 1 : 0;
-                int64_t rows = -1;
-                for (int k = 0; k < fa.ncol; k++) {
-                    const Column &col = find_col(c, fs.cols[(size_t)k].name);
-                    if (rows >= 0 && col.n != rows)
-                        throw Error(VDL_ERR_SHAPE, "columns of table '" + fs.table + "' have different lengths in the catalog");
-                    rows = col.n;
-                    fa.col[k].p = col.dev;
-                    fa.col[k].kind = col.width == 8 ? SRC_I64 : col.width == 4 ? SRC_I32 : col.width == 2 ? SRC_I16 : SRC_I8;
-                    fa.nint[k] = fs.cols[(size_t)k].n;
-                    for (int j = 0; j < fa.nint[k]; j++) { fa.lo[k][j] = fs.cols[(size_t)k].lo[j]; fa.hi[k][j] = fs.cols[(size_t)k].hi[j]; }
-                }
-                o.kind = DVec::RANGE; o.n = rows; o.from = 0; o.step = 1;
-                o.valid = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(rows), 1));
-                HIP_CHECK(launch_filter_columns(fa, (uint64_t *)o.valid->p, rows, s));
-                return o;
-            }
-            if (V(n.b).kind == DVec::SPARSE) {
-                // filter of a filtered vector: the new selection is carved out of the entries, not out of the n slots
-                const DVec &sd = V(n.b);
-                DVec ctl0 = densify(V(n.a));
-                if (ctl0.n == sd.n && ctl0.kind == DVec::RANGE && ctl0.step != 0 && subset(bitmap_of(sd.sel), ctl0.valid)) {
-                    const SelP &ps = sd.sel;
-                    BufP flags = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(ps->m), 1));
-                    HIP_CHECK(launch_select_bitmap(i64_src(sd.data), nullptr, nullptr, (uint64_t *)flags->p, ps->m, s));
-                    BufP offsets;
-                    const int64_t count = popcount(flags, ps->m, &offsets);
-                    SelP ch = child_selection(ps, flags, count, offsets);
-                    o.kind = DVec::RANGE; o.n = sd.n; o.from = 0; o.step = 1; o.valid = bitmap_of(ch);
-                    return o;
-                }
-            }
-            if (V(n.b).kind == DVec::LAZYG) {
-                DVec ctl0 = densify(V(n.a));
-                const LazyGather &lg = *V(n.b).lg;
-                if (ctl0.n == V(n.b).n && ctl0.kind == DVec::RANGE && ctl0.step != 0) {
-                    o.kind = DVec::RANGE; o.n = ctl0.n; o.from = 0; o.step = 1;
-                    o.valid = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(o.n), 1));
-                    HIP_CHECK(launch_select_gather(src_of(lg.src), vp(lg.src), lg.src.n, src_of(lg.pos), vp(lg.pos), vp(ctl0), (uint64_t *)o.valid->p, o.n, s));
-                    note_subset(o.valid, lg.pos.valid); note_subset(o.valid, ctl0.valid);
-                    return o;
-                }
-            }
-            DVec ctl = densify(V(n.a)), d = densify(V(n.b));
-            if (ctl.n != d.n) throw Error(VDL_ERR_SHAPE, "FoldSelect (Id " + std::to_string(n.id) + "): operand lengths differ");
-            if (!(ctl.kind == DVec::RANGE && ctl.step != 0)) return fold_select_runs(ctl, d);
-            o.kind = DVec::RANGE; o.n = d.n; o.from = 0; o.step = 1;
-            o.valid = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(d.n), 1));
-            HIP_CHECK(launch_select_bitmap(src_of(d), vp(d), vp(ctl), (uint64_t *)o.valid->p, d.n, s));
-            note_subset(o.valid, d.valid); note_subset(o.valid, ctl.valid);
-            return o;
-        }
-        case Op::Gather: {
-            if (sparse_on) {
-                DVec fast;
-                if (sparse_gather(V(n.a), V(n.b), fast)) return fast;
-            }
-            DVec src = densify(V(n.a)), pos = densify(V(n.b));
-            if (pos.kind == DVec::RANGE && pos.from == 0 && pos.step == 1 && pos.n == src.n) {
-                // positions are the slot ids themselves (a filter): a view, no data movement
-                o = src;
-                o.valid = and_valid(src, pos, src.n);
-                return o;
-            }
-            // a gather whose only reader is a filter (FoldSelect over it, or Gather of it through a filter) is not run:
-            // the reader evaluates it where it needs it
-            if (fuse_on && lazy_gather_ok[(size_t)n.id]) {
-                o.kind = DVec::LAZYG; o.n = pos.n;
-                o.lg = std::make_shared<LazyGather>();
-                o.lg->src = src; o.lg->pos = pos;
-                return o;
-            }
-            return gather_now(src, pos);
-        }
-        case Op::Scatter: {
-            {
-                // positions that are the slots' own ids (the dim side of a join scatters ones / row ids back by
-                // Gather(rowids, FoldSelect(..)), Vlite.hs:1268-1275): the result is the source restricted to those slots
-                const DVec &ps = V(n.c), &sv = V(n.a);
-                const int64_t nout = V(n.b).n;
-                BufP where;
-                bool identity = false;
-                if (ps.kind == DVec::RANGE && ps.from == 0 && ps.step == 1 && ps.n == nout) { identity = true; where = ps.valid; }
-                else if (sparse_on && ps.kind == DVec::SPARSE && ps.ids && ps.n == nout) { identity = true; where = bitmap_of(ps.sel); }
-                if (identity && sv.n == ps.n) {
-                    if (sv.kind == DVec::RANGE || sv.kind == DVec::DENSE || sv.kind == DVec::COLUMN) {
-                        o = sv;
-                        o.valid = sv.valid && where ? and_bitmaps(sv.valid, where, nout) : (sv.valid ? sv.valid : where);
-                        return o;
-                    }
-                    if (sv.kind == DVec::SPARSE && ps.kind == DVec::SPARSE && sv.sel == ps.sel) return sv;
-                }
-            }
-            if (sparse_on && V(n.c).kind == DVec::SPARSE) {
-                // positions known only on a selection: m writes instead of n
-                const DVec &sp = V(n.c);
-                DVec sv = V(n.a);
-                const int64_t nout = V(n.b).n;
-                bool ok = sv.n == sp.n;
-                if (ok && sv.kind == DVec::SPARSE && sv.sel != sp.sel) {
-                    DVec t;
-                    if (descends(sp.sel, sv.sel) && sparse_narrow(sv, sp.sel, t)) sv = t; else ok = false;
-                }
-                Src ssrc;
-                if (ok && sv.kind == DVec::SPARSE) ssrc = i64_src(sv.data);
-                else if (ok && sv.kind == DVec::RANGE && sv.step == 0 && subset(bitmap_of(sp.sel), sv.valid)) { ssrc.kind = SRC_RANGE; ssrc.from = sv.from; ssrc.step = 0; }
-                else if (ok && sv.kind == DVec::RANGE && sv.from == 0 && sv.step == 1 && subset(bitmap_of(sp.sel), sv.valid)) ssrc = idx_src(*sp.sel);   // row ids
-                else ok = false;
-                if (ok) {
-                    const int64_t m = sp.sel->m;
-                    if (sp.perm && m <= nout) {
-                        // the positions are a permutation of 0 .. m-1 (Partition): the result lives on the prefix selection
-                        SelP pre = prefix_selection(nout, m);
-                        BufP data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(m, 1));
-                        HIP_CHECK(launch_scatter(ssrc, nullptr, i64_src(sp.data), nullptr, m, m, (int64_t *)data->p, nullptr, s));
-                        return make_sparse(pre, data);
-                    }
-                    o.kind = DVec::DENSE; o.n = nout;
-                    o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(nout, 1));
-                    o.valid = zero_bitmap(nout);
-                    HIP_CHECK(launch_scatter(ssrc, nullptr, i64_src(sp.data), nullptr, m, nout, (int64_t *)o.data->p, (uint64_t *)o.valid->p, s));
-                    return o;
-                }
-            }
-            DVec src = densify(V(n.a)), pos = densify(V(n.c));
-            const DVec &fold = V(n.b);
-            if (src.n != pos.n) throw Error(VDL_ERR_SHAPE, "Scatter (Id " + std::to_string(n.id) + "): source and position lengths differ");
-            o.kind = DVec::DENSE; o.n = fold.n;
-            o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(o.n, 1));
-            if (pos.perm && !pos.valid && !src.valid && src.n == o.n) {      // a permutation of all slots: every slot is written
-                HIP_CHECK(launch_scatter(src_of(src), nullptr, src_of(pos), nullptr, src.n, o.n, (int64_t *)o.data->p, nullptr, s));
-                return o;
-            }
-            o.valid = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(o.n), 1));
-            HIP_CHECK(launch_fill_words((uint64_t *)o.valid->p, 0, nwords(o.n), s));
-            HIP_CHECK(launch_scatter(src_of(src), vp(src), src_of(pos), vp(pos), src.n, o.n, (int64_t *)o.data->p, (uint64_t *)o.valid->p, s));
-            return o;
-        }
-        case Op::FoldSum: case Op::FoldMin: case Op::FoldMax: case Op::FoldCount: case Op::FoldChoose: {
-            if (sparse_on && V(n.b).kind == DVec::SPARSE && V(n.a).kind == DVec::RANGE && V(n.a).step == 0 && V(n.a).n == V(n.b).n &&
-                V(n.b).sel->m > 0 && V(n.b).sel->idx && V(n.a).valid && V(n.a).valid == V(n.b).sel->bitmap) {
-                // one run over exactly the selected slots (the ungrouped aggregate of a filtered table, Vlite.hs:636-639):
-                // fold the entries; the result sits at the run's first slot = the selection's first slot
-                const DVec &sd = V(n.b);
-                const int kind = n.op == Op::FoldSum ? 0 : n.op == Op::FoldMin ? 1 : n.op == Op::FoldMax ? 2 : n.op == Op::FoldCount ? 3 : 4;
-                BufP scratch = dev_alloc(c, sizeof(int64_t) * 3 * (size_t)fold_scratch_blocks());
-                o.kind = DVec::ONEHOT; o.n = sd.n;
-                o.data = dev_alloc(c, 3 * sizeof(int64_t));
-                HIP_CHECK(launch_fold_global(kind, i64_src(sd.data), nullptr, nullptr, sd.sel->m, (int64_t *)scratch->p, (int64_t *)o.data->p, s));
-                HIP_CHECK(hipMemcpyAsync((int64_t *)o.data->p + 1, sd.sel->idx->p, sizeof(int64_t), hipMemcpyDeviceToDevice, s));
-                return o;
-            }
-            const bool data_on_sel = V(n.a).kind == DVec::SPARSE &&
-                                     ((V(n.b).kind == DVec::SPARSE && V(n.a).sel == V(n.b).sel) ||
-                                      (V(n.b).kind == DVec::RANGE && V(n.b).step == 0 && V(n.b).n == V(n.a).n && subset(bitmap_of(V(n.a).sel), V(n.b).valid)));
-            if (sparse_on && data_on_sel) {
-                // runs skip EPS slots, so folding the m entries gives the same runs; results sit at run-first entries
-                const DVec &sc = V(n.a), &sd = V(n.b);
-                const SelP &sel = sc.sel;
-                Src dsrc = sd.kind == DVec::SPARSE ? i64_src(sd.data) : src_of(sd);
-                const int64_t m = sel->m;
-                const int kind = n.op == Op::FoldSum ? 0 : n.op == Op::FoldMin ? 1 : n.op == Op::FoldMax ? 2 : n.op == Op::FoldCount ? 3 : 4;
-                // every entry holds a datum, so each run yields a result at its head: the run heads of this control
-                // vector -- and the selection they form -- are computed once and shared by all folds over it
-                // (a GROUP BY folds every aggregate over the same sorted key, Vlite.hs:1056-1060)
-                RunHeads &rh = heads_of[sc.data->p];
-                if (!rh.heads) {
-                    const size_t nw = (size_t)std::max<int64_t>(nwords(m), 1);
-                    rh.ctl = sc.data;
-                    rh.heads = dev_alloc(c, sizeof(uint64_t) * nw);
-                    rh.wordhd = dev_alloc(c, sizeof(int64_t) * (nw + (size_t)maxscan_blocks((int64_t)nw) + 1));
-                    HIP_CHECK(launch_fold_heads(i64_src(sc.data), nullptr, m, (uint64_t *)rh.heads->p, (int64_t *)rh.wordhd->p, s));
-                    rh.count = popcount(rh.heads, m, &rh.offsets);
-                    rh.child = child_selection(sel, rh.heads, rh.count, rh.offsets);
-                }
-                BufP data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(m, 1));
-                BufP vout = zero_bitmap(m);
-                HIP_CHECK(launch_fold_runs(kind, dsrc, nullptr, nullptr, (const uint64_t *)rh.heads->p, (const int64_t *)rh.wordhd->p, m,
-                                           (int64_t *)data->p, (uint64_t *)vout->p, s));
-                return make_sparse(rh.child, compact_write(i64_src(data), rh.heads, m, rh.offsets, rh.count));
-            }
-            DVec ctl = densify(V(n.a)), d = densify(V(n.b));
-            if (ctl.n != d.n) throw Error(VDL_ERR_SHAPE, std::string(op_name(n.op, -1)) + " (Id " + std::to_string(n.id) + "): operand lengths differ");
-            const int kind = n.op == Op::FoldSum ? 0 : n.op == Op::FoldMin ? 1 : n.op == Op::FoldMax ? 2 : n.op == Op::FoldCount ? 3 : 4;
-            if (!(ctl.kind == DVec::RANGE && ctl.step == 0)) {
-                // general control vector (grouped aggregates fold data scattered into key order)
-                const size_t nw = (size_t)std::max<int64_t>(nwords(d.n), 1);
-                BufP heads = dev_alloc(c, sizeof(uint64_t) * nw);
-                BufP wordhd = dev_alloc(c, sizeof(int64_t) * (nw + (size_t)maxscan_blocks((int64_t)nw) + 1));
-                o.kind = DVec::DENSE; o.n = d.n;
-                o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(d.n, 1));
-                o.valid = dev_alloc(c, sizeof(uint64_t) * nw);
-                HIP_CHECK(launch_fill_words((uint64_t *)o.valid->p, 0, nwords(d.n), s));
-                HIP_CHECK(launch_fold_segmented(kind, src_of(ctl), vp(ctl), src_of(d), vp(d), d.n, (uint64_t *)heads->p,
-                                                (int64_t *)wordhd->p, (int64_t *)o.data->p, (uint64_t *)o.valid->p, s));
-                return o;
-            }
-            BufP scratch = dev_alloc(c, sizeof(int64_t) * 3 * (size_t)fold_scratch_blocks());
-            o.kind = DVec::ONEHOT; o.n = d.n;
-            o.data = dev_alloc(c, 3 * sizeof(int64_t));
-            HIP_CHECK(launch_fold_global(kind, src_of(d), vp(d), vp(ctl), d.n, (int64_t *)scratch->p, (int64_t *)o.data->p, s));
-            return o;
-        }
-        case Op::Partition: {
-            if (sparse_on && V(n.a).kind == DVec::SPARSE) {
-                const DVec &sd = V(n.a);
-                const DVec &pv = V(n.b);
-                if (pv.kind == DVec::RANGE && pv.step == 1 && !pv.valid) {
-                    DVec pos = partition_positions(entries(sd), pv.from, pv.n);       // every entry holds a value: a permutation of 0 .. m-1
-                    DVec r = make_sparse(sd.sel, pos.data);
-                    r.perm = true;
-                    return r;
-                }
-            }
-            DVec data = densify(V(n.a));
-            const DVec &piv = V(n.b);
-            if (!(piv.kind == DVec::RANGE && piv.step == 1 && !piv.valid))
-                throw Error(VDL_ERR_UNSUPPORTED, "Partition (Id " + std::to_string(n.id) +
-                                                     "): pivots must be a RangeC with step 1 (what mplan2vdl emits, Vlite.hs:1088-1091)");
-            return partition_positions(data, piv.from, piv.n);
-        }
-        case Op::Semisort: {
-            // gather mask that sorts the non-EPS values (stable): positions over [min, max] of the data, inverted
-            DVec d = densify(V(n.a));
-            o.kind = DVec::DENSE; o.n = d.n;
-            o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(d.n, 1));
-            o.valid = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(d.n), 1));
-            HIP_CHECK(launch_fill_words((uint64_t *)o.valid->p, 0, nwords(d.n), s));
-            if (d.n == 0) return o;
-            BufP scratch = dev_alloc(c, sizeof(int64_t) * 3 * (size_t)fold_scratch_blocks());
-            BufP mm = dev_alloc(c, 6 * sizeof(int64_t));
-            HIP_CHECK(launch_fold_global(1, src_of(d), vp(d), nullptr, d.n, (int64_t *)scratch->p, (int64_t *)mm->p, s));
-            HIP_CHECK(launch_fold_global(2, src_of(d), vp(d), nullptr, d.n, (int64_t *)scratch->p, (int64_t *)mm->p + 3, s));
-            int64_t h[6];
-            HIP_CHECK(hipMemcpyAsync(h, mm->p, sizeof h, hipMemcpyDeviceToHost, s));
-            HIP_CHECK(hipStreamSynchronize(s));
-            if (h[2] == 0) return o;                                      // nothing but EPS
-            const uint64_t span = (uint64_t)h[3] - (uint64_t)h[0];
-            if (span >= ((uint64_t)1 << 62))
-                throw Error(VDL_ERR_UNSUPPORTED, "Semisort (Id " + std::to_string(n.id) + "): value range wider than 2^62");
-            DVec pos = partition_positions(d, h[0], (int64_t)span + 1);
-            Src iota; iota.kind = SRC_RANGE; iota.from = 0; iota.step = 1;
-            HIP_CHECK(launch_scatter(iota, vp(d), src_of(pos), vp(pos), d.n, d.n, (int64_t *)o.data->p, (uint64_t *)o.valid->p, s));
-            return o;
-        }
-        case Op::Materialize:
-            materialize(n, V(n.a));
-            return V(n.a);
-        case Op::Cross: {
-            const int64_t m = V(n.a).n, k = V(n.b).n;
-            if (k > 0 && m > ((int64_t)1 << 40) / k)
-                throw Error(VDL_ERR_NOMEM, "CrossProduct (Id " + std::to_string(n.id) + "): " + std::to_string(m) + " x " + std::to_string(k) + " slots");
-            o.kind = DVec::DENSE; o.n = m * k;
-            o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(o.n, 1));
-            HIP_CHECK(launch_cross(o.n, k, n.bin, (int64_t *)o.data->p, s));
-            return o;
-        }
-        case Op::Like: {
-            if (sparse_on && V(n.a).kind == DVec::SPARSE) {
-                const DVec &sd = V(n.a);
-                DVec heap = densify(V(n.b));
-                LikePattern pat{};
-                pat.len = (int)n.pattern.size();
-                memcpy(pat.p, n.pattern.data(), n.pattern.size());
-                BufP data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(sd.sel->m, 1));
-                HIP_CHECK(launch_like(i64_src(sd.data), nullptr, sd.sel->m, src_of(heap), vp(heap), heap.n, pat, (int64_t *)data->p, s));
-                return make_sparse(sd.sel, data);
-            }
-            DVec d = densify(V(n.a)), heap = densify(V(n.b));
-            LikePattern pat{};
-            pat.len = (int)n.pattern.size();
-            memcpy(pat.p, n.pattern.data(), n.pattern.size());
-            o.kind = DVec::DENSE; o.n = d.n; o.valid = d.valid;
-            o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(d.n, 1));
-            HIP_CHECK(launch_like(src_of(d), vp(d), d.n, src_of(heap), vp(heap), heap.n, pat, (int64_t *)o.data->p, s));
-            return o;
-        }
-        }
-        return o;
-    }
-
-    void run() { run_nodes(p->prog.outputs, nullptr); }
-
-    // Executes the statements `targets` depend on.  `overrides` supplies ready-made vectors for some
-    // statements (their own operands are then not evaluated): used by the sharded Partition exchange.
-    void run_nodes(const std::vector<int> &targets, const std::map<int, DVec> *overrides) {
-        const Program &P = p->prog;
-        std::vector<char> needed(P.nodes.size(), 0);
-        for (int id : targets) needed[(size_t)id] = 1;
-        for (auto it = P.order.rbegin(); it != P.order.rend(); ++it) {
-            const Node &n = P.at(*it);
-            if (!needed[(size_t)n.id]) continue;
-            if (overrides && overrides->count(n.id)) continue;
-            if (column_filter(n)) continue;
-            for (int opnd : {n.a, n.b, n.c}) if (opnd > 0) needed[(size_t)opnd] = 1;
-        }
-        for (size_t k = 0; k < P.order.size(); k++) {
-            const Node &n = P.at(P.order[k]);
-            if (!needed[(size_t)n.id] || (overrides && overrides->count(n.id)) || column_filter(n)) continue;
-            for (int opnd : {n.a, n.b, n.c}) if (opnd > 0) last_use[(size_t)opnd] = (int)k;
-        }
-        for (int id : targets) last_use[(size_t)id] = 1 << 30;      // targets stay alive for the caller
-        n_uses.assign(P.nodes.size(), 0);
-        read_by_binary_only.assign(P.nodes.size(), 1);
-        std::vector<std::vector<std::pair<int, int>>> readers(P.nodes.size());      // (reader id, operand slot)
-        for (size_t k = 0; k < P.order.size(); k++) {
-            const Node &n = P.at(P.order[k]);
-            if (!needed[(size_t)n.id] || (overrides && overrides->count(n.id)) || column_filter(n)) continue;
-            int slot = 0;
-            for (int opnd : {n.a, n.b, n.c}) {
-                if (opnd > 0) {
-                    n_uses[(size_t)opnd]++;
-                    if (n.op != Op::Binary) read_by_binary_only[(size_t)opnd] = 0;
-                    readers[(size_t)opnd].push_back({n.id, slot});
-                }
-                slot++;
-            }
-            if (n.op == Op::Binary && n.a == n.b && n.a > 0) n_uses[(size_t)n.a]--;       // x op x: both operands are one reader
-        }
-        for (int id : targets) n_uses[(size_t)id] += 2;
-        lazy_gather_ok.assign(P.nodes.size(), 0);
-        for (int id : P.order) {
-            const Node &g = P.at(id);
-            if (g.op != Op::Gather || !needed[(size_t)id] || n_uses[(size_t)id] != (int)readers[(size_t)id].size()) continue;   // targets excluded
-            const auto &rd = readers[(size_t)id];
-            if (rd.size() == 1 && P.at(rd[0].first).op == Op::Gather && rd[0].second == 0 && P.at(rd[0].first).b != id) lazy_gather_ok[(size_t)id] = 1;
-            if (rd.size() == 2) {
-                int rv = -1, fs = -1;
-                for (const auto &r : rd) {
-                    const Node &x = P.at(r.first);
-                    if (x.op == Op::RangeV && x.imm1 != 0 && r.second == 0) rv = r.first;
-                    if (x.op == Op::FoldSelect && r.second == 1 && x.b == id) fs = r.first;
-                }
-                if (rv >= 0 && fs >= 0 && P.at(fs).a == rv && readers[(size_t)rv].size() == 1 && n_uses[(size_t)rv] == 1) lazy_gather_ok[(size_t)id] = 1;
-            }
-        }
-        p->outs.clear();
-        p->timings.clear();
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (p->profiling) { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1)); }
-        for (size_t k = 0; k < P.order.size(); k++) {
-            const Node &n = P.at(P.order[k]);
-            if (!needed[(size_t)n.id]) continue;
-            if (overrides && overrides->count(n.id)) { vec[(size_t)n.id] = overrides->at(n.id); continue; }
-            if (p->profiling) HIP_CHECK(hipEventRecord(e0, s));
-            vec[(size_t)n.id] = exec(n);
-            if (trace_forms) {
-                const DVec &r = vec[(size_t)n.id];
-                static const char *const kn[] = {"none", "dense", "column", "range", "onehot", "ohconst", "sparse", "expr", "lazy"};
-                static_assert(sizeof kn / sizeof kn[0] == DVec::LAZYG + 1, "one name per vector form");
-                std::fprintf(stderr, "  Id %-4d %-18s -> %-7s n=%lld", n.id, op_name(n.op, n.bin), kn[r.kind], (long long)r.n);
-                if (r.kind == DVec::SPARSE) std::fprintf(stderr, " m=%lld%s%s", (long long)r.sel->m, r.sel->idx ? "" : " (prefix)", r.perm ? " perm" : "");
-                std::fprintf(stderr, "  scatters so far %d\n", densified);
-            }
-            if (p->profiling) {
-                HIP_CHECK(hipEventRecord(e1, s));
-                HIP_CHECK(hipEventSynchronize(e1));
-                float ms = 0;
-                HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-                p->timings.push_back({"timeInMicrosecondsForStatement" + std::to_string(n.id) + "_" + op_name(n.op, n.bin), (double)ms * 1e3});
-            }
-            for (int opnd : {n.a, n.b, n.c})
-                if (opnd > 0 && last_use[(size_t)opnd] == (int)k) vec[(size_t)opnd] = DVec{};
-        }
-        HIP_CHECK(hipStreamSynchronize(s));
-        finish_copies();
-        if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
-    }
-};
-
-// ------------------------------------------------------------------------------------------------
-// sharded Partition: exchange analysis (which vectors travel) -- see vdl_kernels.hip "Row exchange"
-// ------------------------------------------------------------------------------------------------
-struct ExchangeSpec {
-    bool ok = false;
-    std::string why;
-    int part = 0, key = 0;             // Partition statement, its (resolved) data operand
-    std::vector<int> sources;          // resolved source statements of the Scatters that use the partition; [0] = key
-    int64_t pmin = 0, pcount = 0;
-};
-
-int resolve_alias(const Program &P, int id) {
-    while (P.at(id).op == Op::Project || P.at(id).op == Op::Shuffle) id = P.at(id).a;
-    return id;
-}
-
-// `table`: name of the row-sharded table ("" = trust the caller).  With a table name the statements
-// below the scatters are checked to be row-local over that table: its columns may pass through
-// element-wise operators, constants and Gathers *from* replicated vectors only.
-ExchangeSpec analyse_exchange(const Program &P, const std::string &table = std::string()) {
-    ExchangeSpec x;
-    std::vector<char> needed(P.nodes.size(), 0);
-    for (int id : P.outputs) needed[(size_t)id] = 1;
-    for (auto it = P.order.rbegin(); it != P.order.rend(); ++it) {
-        const Node &n = P.at(*it);
-        if (!needed[(size_t)n.id]) continue;
-        for (int opnd : {n.a, n.b, n.c}) if (opnd > 0) needed[(size_t)opnd] = 1;
-    }
-    for (int id : P.order) {
-        if (!needed[(size_t)id] || P.at(id).op != Op::Partition) continue;
-        if (x.part) { x.why = "more than one Partition"; return x; }
-        x.part = id;
-    }
-    if (!x.part) { x.why = "no Partition in the program"; return x; }
-    const Node &pn = P.at(x.part);
-    const Node &piv = P.at(resolve_alias(P, pn.b));
-    if (piv.op != Op::RangeC || piv.imm2 != 1 || piv.imm1 <= 0) { x.why = "pivots are not a RangeC with step 1"; return x; }
-    x.pmin = piv.imm0; x.pcount = piv.imm1;
-    x.key = resolve_alias(P, pn.a);
-    x.sources.push_back(x.key);
-    std::vector<char> is_cut(P.nodes.size(), 0);
-    for (int id : P.order) {
-        const Node &n = P.at(id);
-        if (!needed[(size_t)id]) continue;
-        bool uses = false;
-        for (int opnd : {n.a, n.b, n.c}) uses |= opnd > 0 && resolve_alias(P, opnd) == x.part && !(n.op == Op::Project || n.op == Op::Shuffle);
-        if (!uses) continue;
-        if (n.op != Op::Scatter || resolve_alias(P, n.c) != x.part || resolve_alias(P, n.a) == x.part || resolve_alias(P, n.b) == x.part) {
-            x.why = "the Partition result is used other than as Scatter positions (statement " + std::to_string(id) + ")";
-            return x;
-        }
-        is_cut[(size_t)id] = 1;
-        const int src = resolve_alias(P, n.a);
-        if (std::find(x.sources.begin(), x.sources.end(), src) == x.sources.end()) x.sources.push_back(src);
-    }
-    if ((int)x.sources.size() - 1 > kMaxExSources) { x.why = "too many scattered vectors"; return x; }
-    // everything above the scatters must be derived from them alone
-    std::vector<char> seen(P.nodes.size(), 0);
-    std::vector<int> stack(P.outputs.begin(), P.outputs.end());
-    while (!stack.empty()) {
-        const int id = stack.back(); stack.pop_back();
-        if (seen[(size_t)id]) continue;
-        seen[(size_t)id] = 1;
-        const Node &n = P.at(id);
-        if (is_cut[(size_t)id]) continue;
-        if (n.op == Op::Load) { x.why = "output depends on column " + n.column + " other than through the partition"; return x; }
-        if (id == x.part) { x.why = "Partition reachable past the scatters"; return x; }
-        for (int opnd : {n.a, n.b, n.c}) if (opnd > 0) stack.push_back(opnd);
-    }
-    // size references of the scatters are evaluated after the exchange: they must hang off the travelling vectors
-    std::vector<char> is_src(P.nodes.size(), 0);
-    for (int id : x.sources) is_src[(size_t)id] = 1;
-    std::fill(seen.begin(), seen.end(), 0);
-    stack.clear();
-    for (int id : P.order) if (is_cut[(size_t)id]) stack.push_back(P.at(id).b);
-    while (!stack.empty()) {
-        const int id = stack.back(); stack.pop_back();
-        if (seen[(size_t)id] || is_src[(size_t)id]) continue;
-        seen[(size_t)id] = 1;
-        const Node &n = P.at(id);
-        if (n.op == Op::Load) { x.why = "a Scatter size reference depends on column " + n.column + " directly"; return x; }
-        for (int opnd : {n.a, n.b, n.c}) if (opnd > 0) stack.push_back(opnd);
-    }
-    if (!table.empty()) {
-        // class of every statement below the Partition: R = replicated (same on every rank), V = one value per
-        // row of the shard, N = (local) row numbers of the shard, as the filter idiom
-        // Gather(x, FoldSelect(RangeV 0 step 1, cond)) of Vlite.hs produces them
-        enum : char { R = 0, V = 1, N = 2 };
-        std::vector<char> below(P.nodes.size(), 0), cls(P.nodes.size(), R);
-        stack.assign(x.sources.begin(), x.sources.end());
-        while (!stack.empty()) {
-            const int id = stack.back(); stack.pop_back();
-            if (below[(size_t)id]) continue;
-            below[(size_t)id] = 1;
-            const Node &n = P.at(id);
-            for (int opnd : {n.a, n.b, n.c}) if (opnd > 0) stack.push_back(opnd);
-        }
-        for (int id : P.order) {
-            if (!below[(size_t)id]) continue;
-            const Node &n = P.at(id);
-            auto C = [&](int o) { return o > 0 ? cls[(size_t)o] : (char)R; };
-            const std::string at = " (statement " + std::to_string(id) + ")";
-            char &out = cls[(size_t)id];
-            switch (n.op) {
-            case Op::Load: out = n.column.compare(0, table.size() + 1, table + ".") == 0 ? V : R; break;
-            case Op::RangeC: break;
-            case Op::Project: case Op::Shuffle: case Op::Materialize: out = C(n.a); break;
-            case Op::Like:
-                if (C(n.b) != R) { x.why = "Like over a sharded string heap" + at; return x; }
-                if (C(n.a) == N) { x.why = "Like on row numbers" + at; return x; }
-                out = C(n.a);
-                break;
-            case Op::Binary:
-                if (C(n.a) == N || C(n.b) == N) { x.why = "arithmetic on row numbers of the sharded table, which are rank-local" + at; return x; }
-                out = (C(n.a) == V || C(n.b) == V) ? V : R;
-                break;
-            case Op::RangeV:
-                if (C(n.a) == R) break;
-                if (n.imm1 == 0) out = V;
-                else if (n.imm0 == 0 && n.imm1 == 1) out = N;
-                else { x.why = "a strided range over the sharded table is rank-local" + at; return x; }
-                break;
-            case Op::FoldSelect: {
-                if (C(n.a) == R && C(n.b) == R) break;
-                const Node &ctl = P.at(resolve_alias(P, n.a));
-                if (!(ctl.op == Op::RangeV && C(n.a) == N)) { x.why = "FoldSelect over runs of the sharded table" + at; return x; }
-                out = N;
-                break;
-            }
-            case Op::Gather:
-                if (C(n.a) == R && C(n.b) != N) out = C(n.b);                 // replicated data by FK / replicated positions
-                else if (C(n.a) != R && C(n.b) == N) out = C(n.a);            // shard data by shard row numbers
-                else { x.why = "Gather mixes replicated and rank-local positions" + at; return x; }
-                break;
-            default:
-                if (C(n.a) != R || C(n.b) != R || C(n.c) != R) { x.why = std::string(op_name(n.op, n.bin)) + " over the sharded table below the Partition" + at; return x; }
-            }
-        }
-        for (int id : x.sources) {
-            if (cls[(size_t)id] == N) { x.why = "statement " + std::to_string(id) + " feeds the Partition with rank-local row numbers"; return x; }
-            if (cls[(size_t)id] != V) { x.why = "statement " + std::to_string(id) + " feeds the Partition but does not depend on table " + table; return x; }
-        }
-    }
-    x.ok = true;
-    return x;
-}
+namespace vdl {
+namespace eng {
 
 std::string describe_plan(const vdl_plan *p) {
     std::ostringstream o;
@@ -1732,24 +298,9 @@ std::string describe_plan(const vdl_plan *p) {
     return o.str();
 }
 
-template <typename F>
-int guard(vdl_ctx *c, F &&f) {
-    try {
-        f();
-        return VDL_OK;
-    } catch (const Error &e) {
-        if (c) c->err = e.what();
-        return e.code;
-    } catch (const std::bad_alloc &) {
-        if (c) c->err = "out of host memory";
-        return VDL_ERR_NOMEM;
-    } catch (const std::exception &e) {
-        if (c) c->err = e.what();
-        return VDL_ERR_ARG;
-    }
-}
+}  // namespace eng
+}  // namespace vdl
 
-}  // namespace
 
 // ------------------------------------------------------------------------------------------------
 // C ABI
@@ -2043,127 +594,6 @@ int vdl_resolve_first(vdl_ctx *c, vdl_plan *p, void *dev_partials) {
             HIP_CHECK(launch_mscan_resolve_first(p->mcols[ns + g], p->mdesc[ns + g], (const MScanDesc *)p->mdev[ns + g]->p,
                                                  (int64_t *)dev_partials + p->gword_offset[g], c->stream));
         }
-    });
-}
-
-/* ---- sharded Partition: local phase -> row exchange (caller: RCCL all-to-all) -> local tail ---- */
-
-int vdl_exchange_spec(const vdl_plan *p, const char *sharded_table, int *n_columns) {
-    if (!p) return VDL_ERR_ARG;
-    ExchangeSpec x = analyse_exchange(p->prog, sharded_table ? sharded_table : "");
-    if (!x.ok) {
-        if (p->ctx) p->ctx->err = "no sharded-Partition structure: " + x.why;
-        return VDL_ERR_UNSUPPORTED;
-    }
-    if (n_columns) *n_columns = (int)x.sources.size() + 1;      // key, scattered vectors, validity mask
-    return VDL_OK;
-}
-
-int vdl_exchange_begin(vdl_ctx *c, vdl_plan *p, int world, int64_t *counts_host) {
-    if (!c || !p || !counts_host || world < 1 || world > kMaxExWorld) return VDL_ERR_ARG;
-    return guard(c, [&] {
-        need_device(c);
-        ExchangeSpec x = analyse_exchange(p->prog);
-        if (!x.ok) throw Error(VDL_ERR_UNSUPPORTED, "no sharded-Partition structure: " + x.why);
-        GenExec g(c, p);
-        g.run_nodes(x.sources, nullptr);
-        vdl_plan::ExState &ex = p->ex;
-        ex = vdl_plan::ExState{};
-        ex.world = world; ex.nodes = x.sources; ex.pmin = x.pmin; ex.pcount = x.pcount;
-        // sources that live on one sparse selection travel as their entries (m rows instead of n slots to route and pack)
-        bool all_sparse = !x.sources.empty();
-        for (int id : x.sources) {
-            const DVec &v = g.vec[(size_t)id];
-            all_sparse = all_sparse && v.kind == DVec::SPARSE && v.sel == g.vec[(size_t)x.sources[0]].sel;
-        }
-        for (int id : x.sources) ex.src.push_back(all_sparse ? g.entries(g.vec[(size_t)id]) : g.densify(g.vec[(size_t)id]));
-        const DVec &key = ex.src[0];
-        ex.n = key.n;
-        for (const DVec &v : ex.src)
-            if (v.n != ex.n) throw Error(VDL_ERR_SHAPE, "vectors scattered by one Partition have different lengths");
-        const size_t nw = (size_t)std::max<int64_t>(GenExec::nwords(ex.n), 1);
-        BufP dest = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(ex.n, 1));
-        ex.vdest = dev_alloc(c, sizeof(uint64_t) * nw);
-        ex.pos = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(ex.n, 1));
-        BufP counts = dev_alloc(c, sizeof(int64_t) * (size_t)(world + 1));
-        HIP_CHECK(hipMemsetAsync(counts->p, 0, sizeof(int64_t) * (size_t)(world + 1), c->stream));
-        HIP_CHECK(launch_ex_dest(g.src_of(key), g.vp(key), ex.n, ex.pmin, ex.pcount, world, (int64_t *)dest->p, (uint64_t *)ex.vdest->p,
-                                 (int64_t *)counts->p, (int64_t *)counts->p + world, c->stream));
-        if (ex.n > 0) {
-            // stable order inside each destination = one 8-bit Partition pass over the destination ranks
-            const int64_t hn = 256 * partition_tiles(ex.n);
-            BufP hist = dev_alloc(c, sizeof(int64_t) * (size_t)(hn + 1));
-            BufP scr = dev_alloc(c, sizeof(int64_t) * (size_t)(prefix_sum_blocks(hn) + 2));
-            BufP nvalid = dev_alloc(c, sizeof(int64_t));
-            Src d; d.p = dest->p; d.kind = SRC_I64;
-            HIP_CHECK(launch_partition(d, (const uint64_t *)ex.vdest->p, ex.n, 0, world, (int64_t *)hist->p, (int64_t *)scr->p, nullptr, nullptr,
-                                       nullptr, nullptr, (int64_t *)nvalid->p, (int64_t *)ex.pos->p, c->stream));
-        }
-        std::vector<int64_t> h((size_t)world + 1);
-        HIP_CHECK(hipMemcpyAsync(h.data(), counts->p, sizeof(int64_t) * (size_t)(world + 1), hipMemcpyDeviceToHost, c->stream));
-        HIP_CHECK(hipStreamSynchronize(c->stream));
-        if (h[(size_t)world] > 0)
-            throw Error(VDL_ERR_UNSUPPORTED, std::to_string(h[(size_t)world]) + " row(s) carry a partition key outside the pivots; run unsharded");
-        ex.n_send = 0;
-        for (int r = 0; r < world; r++) { counts_host[r] = h[(size_t)r]; ex.n_send += h[(size_t)r]; }
-        ex.active = true;
-    });
-}
-
-int vdl_exchange_pack(vdl_ctx *c, vdl_plan *p, void *dev_send) {
-    if (!c || !p) return VDL_ERR_ARG;
-    return guard(c, [&] {
-        need_device(c);
-        vdl_plan::ExState &ex = p->ex;
-        if (!ex.active) throw Error(VDL_ERR_ARG, "vdl_exchange_pack before vdl_exchange_begin");
-        if (ex.n_send == 0) return;
-        if (!dev_send) throw Error(VDL_ERR_ARG, "vdl_exchange_pack: null send buffer");
-        GenExec g(c, p);
-        int64_t *out = (int64_t *)dev_send;
-        ExValid ev;
-        for (size_t k = 0; k < ex.src.size(); k++) {
-            HIP_CHECK(launch_ex_pack(g.src_of(ex.src[k]), (const uint64_t *)ex.vdest->p, (const int64_t *)ex.pos->p, ex.n, out + (int64_t)k * ex.n_send, c->stream));
-            if (k > 0) ev.valid[ev.n++] = g.vp(ex.src[k]);
-        }
-        HIP_CHECK(launch_ex_mask(ev, (const uint64_t *)ex.vdest->p, (const int64_t *)ex.pos->p, ex.n, out + (int64_t)ex.src.size() * ex.n_send, c->stream));
-        HIP_CHECK(hipStreamSynchronize(c->stream));      // the buffer goes to the caller's collective, possibly on another stream
-    });
-}
-
-int vdl_exchange_finish(vdl_ctx *c, vdl_plan *p, const void *dev_recv, int64_t n_recv) {
-    if (!c || !p || (!dev_recv && n_recv > 0) || n_recv < 0) return VDL_ERR_ARG;
-    return guard(c, [&] {
-        need_device(c);
-        vdl_plan::ExState &ex = p->ex;
-        if (!ex.active) throw Error(VDL_ERR_ARG, "vdl_exchange_finish before vdl_exchange_begin");
-        const int64_t *in = (const int64_t *)dev_recv;
-        const size_t m = ex.src.size();
-        std::map<int, DVec> over;
-        // usually every travelling row holds a value in every vector (mask word = all ones): no bitmaps needed then
-        bool all_valid = n_recv == 0 || m <= 1;
-        if (!all_valid) {
-            BufP scratch = dev_alloc(c, sizeof(int64_t) * 3 * (size_t)fold_scratch_blocks());
-            BufP r = dev_alloc(c, 3 * sizeof(int64_t));
-            Src mk; mk.p = in + (int64_t)m * n_recv; mk.kind = SRC_I64;
-            HIP_CHECK(launch_fold_global(1 /* min */, mk, nullptr, nullptr, n_recv, (int64_t *)scratch->p, (int64_t *)r->p, c->stream));
-            int64_t h[3];
-            HIP_CHECK(hipMemcpyAsync(h, r->p, sizeof h, hipMemcpyDeviceToHost, c->stream));
-            HIP_CHECK(hipStreamSynchronize(c->stream));
-            all_valid = h[0] == (int64_t)(((uint64_t)1 << (m - 1)) - 1);
-        }
-        for (size_t k = 0; k < m; k++) {
-            DVec v;
-            v.kind = DVec::COLUMN; v.n = n_recv; v.ptr = in + (int64_t)k * n_recv; v.width = 8;
-            if (k > 0 && !all_valid) {      // source vectors had EPS rows: rebuild their bitmaps from the mask column
-                v.valid = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(GenExec::nwords(n_recv), 1));
-                HIP_CHECK(launch_ex_unmask(in + (int64_t)m * n_recv, n_recv, (int)k - 1, (uint64_t *)v.valid->p, c->stream));
-            }
-            over[ex.nodes[k]] = v;
-        }
-        ex.src.clear(); ex.vdest.reset(); ex.pos.reset();          // phase-A vectors are no longer needed
-        ex.active = false;
-        GenExec g(c, p);
-        g.run_nodes(p->prog.outputs, &over);
     });
 }
 

@@ -1,0 +1,298 @@
+// vdl_engine_internal.h -- what the translation units behind the C ABI share: the HBM pool, the column catalog,
+// the vector forms of the per-operator executor, and the definitions of vdl_ctx / vdl_plan.  Not installed;
+// include/vdl.h is the interface.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <set>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "vdl.h"
+#include "vdl_fuse.h"
+#include "vdl_ir.h"
+#include "vdl_kernels.h"
+
+
+namespace vdl {
+namespace eng {
+
+
+#define HIP_CHECK(expr)                                                                                         \
+    do {                                                                                                        \
+        hipError_t e_ = (expr);                                                                                 \
+        if (e_ != hipSuccess)                                                                                   \
+            throw Error(VDL_ERR_DEVICE, std::string(#expr) + " failed: " + hipGetErrorString(e_));              \
+    } while (0)
+
+// ---- HBM pool: size-class free lists; everything runs on one stream, so a buffer released on the
+// host can be handed to a later launch without extra synchronisation (stream order protects it).
+struct Pool {
+    std::multimap<size_t, void *> free_list;
+    size_t live_bytes = 0, peak_bytes = 0;
+    static size_t round_up(size_t b) {
+        size_t c = 256;
+        while (c < b) c <<= 1;
+        if (c > (size_t(1) << 26)) c = (b + (size_t(1) << 26) - 1) & ~((size_t(1) << 26) - 1);   // 64 MiB granules above 64 MiB
+        return c;
+    }
+    void *alloc(size_t bytes, size_t *cls) {
+        size_t c = round_up(bytes ? bytes : 1);
+        *cls = c;
+        auto it = free_list.find(c);
+        void *p = nullptr;
+        if (it != free_list.end()) { p = it->second; free_list.erase(it); }
+        else {
+            hipError_t e = hipMalloc(&p, c);
+            if (e != hipSuccess) {
+                trim();
+                e = hipMalloc(&p, c);
+                if (e != hipSuccess) throw Error(VDL_ERR_NOMEM, "hipMalloc of " + std::to_string(c) + " bytes failed");
+            }
+        }
+        live_bytes += c;
+        peak_bytes = std::max(peak_bytes, live_bytes);
+        return p;
+    }
+    void release(void *p, size_t cls) {
+        if (closed) { (void)hipFree(p); return; }        // the context is gone: give the memory back at once
+        free_list.emplace(cls, p);
+        live_bytes -= cls;
+    }
+    void trim() { for (auto &kv : free_list) (void)hipFree(kv.second); free_list.clear(); }
+    bool closed = false;
+    ~Pool() { trim(); }
+};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cls = 0;
+    std::shared_ptr<Pool> pool;       // buffers (held by plans) may outlive their context
+    ~DevBuf() { if (p && pool) pool->release(p, cls); }
+};
+using BufP = std::shared_ptr<DevBuf>;
+
+struct Column {
+    const void *dev = nullptr;
+    int width = 0;
+    int64_t n = 0;
+    BufP owned;
+};
+
+// device-side vector of the general path
+// A selection: m of n slots, ascending.  Vectors that hold values only on a sparse selection (after a selective
+// filter, Vlite.hs:721-730) are stored as SPARSE: the m values of the selected slots, so that everything
+// downstream of the filter touches m instead of n elements (GenExec: "sparse vectors").
+struct Sel {
+    int64_t n = 0, m = 0;
+    BufP idx;                       // the m slot ids; null = the prefix 0 .. m-1
+    BufP bitmap;                    // n bits with exactly the selected slots set (prefix selections: built on demand)
+    std::shared_ptr<Sel> parent;    // the selection this one was filtered from, and
+    BufP ppos;                      // for each of the m slots its entry number inside the parent
+    bool worth = true;              // false: too dense to be worth compacting (only m is known)
+};
+using SelP = std::shared_ptr<Sel>;
+
+struct ExprNode;
+struct LazyGather;
+
+struct DVec {
+    enum Kind { NONE, DENSE, COLUMN, RANGE, ONEHOT, OHCONST, SPARSE, EXPR, LAZYG } kind = NONE;
+    int64_t n = 0;
+    SelP sel;                   // SPARSE: data = the sel->m values; valid = bitmap over those m entries (null = all hold a value)
+    bool perm = false;          // SPARSE: the values are a permutation of 0 .. m-1 (Partition positions)
+    bool ids = false;           // SPARSE: every value is its own slot id (row ids gathered through a filter)
+    std::shared_ptr<LazyGather> lg; // LAZYG: Gather(src, pos) not run yet: its only reader is a filter that needs few (or none) of its values
+    std::shared_ptr<ExprNode> ex;   // EXPR: a not yet evaluated tree of element-wise operators (fused when somebody needs the values)
+    BufP data;                  // DENSE: n int64; ONEHOT/OHCONST: {value, slot, count}
+    const void *ptr = nullptr;  // COLUMN: borrowed catalog pointer
+    int width = 8;
+    int64_t from = 0, step = 0; // RANGE; OHCONST: from = the constant
+    BufP valid;                 // bitmap, null = every slot holds a value
+    BufP keep;                  // COLUMN: keeps an engine-owned column alive
+};
+
+// Element-wise operators whose only reader is another element-wise operator are not run one by one: they pile up
+// in a tree whose leaves are stored vectors, and the tree runs as one kernel (k_expr) when its root is needed.
+struct ExprNode {
+    int bin = -1;                          // -1: leaf
+    std::shared_ptr<ExprNode> l, r;
+    DVec leaf;                             // DENSE / COLUMN / RANGE
+    int leaves = 1, instrs = 1, depth = 1;
+};
+
+struct LazyGather { DVec src, pos; };        // both in dense form (DENSE / COLUMN / RANGE)
+
+constexpr size_t kBigOutput = 1u << 16;     // values; from here on results use pinned host memory (or stay on the device)
+struct Output {
+    int node = 0;
+    std::string name, tmp;
+    std::vector<int64_t> vals;
+    const int64_t *big = nullptr;      // large results land in a pinned buffer the plan keeps (pageable copies run at a few GB/s)
+    size_t big_n = 0;
+    std::shared_ptr<void> dev_keep;    // vdl_plan_set_device_outputs: large results stay in HBM, owned by the plan until its next run
+    const int64_t *dev = nullptr;
+    const int64_t *ptr() const { return dev ? nullptr : big ? big : vals.data(); }
+    size_t count() const { return (dev || big) ? big_n : vals.size(); }
+};
+struct Timing { std::string label; double usec; };
+
+
+}  // namespace eng
+}  // namespace vdl
+
+using namespace vdl;
+using namespace vdl::eng;
+
+
+struct vdl_ctx {
+    int device = -1;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t copy_stream = nullptr;     // result copies of the general path run here, behind an event, while later statements compute
+    hipEvent_t copy_ev = nullptr;
+    int num_cus = 256;
+    std::map<std::string, Column> cols;
+    uint64_t catalog_version = 1;      // bumped on every catalog change: plans re-bind only when it moved
+    std::shared_ptr<Pool> pool = std::make_shared<Pool>();
+    std::string err;
+};
+
+struct vdl_plan {
+    vdl_ctx *ctx = nullptr;          // only dereferenced inside calls that receive the live context
+    int device = -1;                 // copied at parse time: the plan may outlive its context
+    Program prog;
+    FusedPlan fused;
+    bool use_fusion = true;
+    bool profiling = false;
+    bool device_outputs = false;
+    std::string description;
+    std::vector<Output> outs;
+    std::vector<Timing> timings;
+    // fused state
+    std::vector<ScanArgs> sargs;
+    std::vector<ScanLaunch> scfg;
+    std::vector<BufP> block_partials;
+    std::vector<int32_t> reduce_ops;
+    std::vector<int64_t> word_offset;
+    std::vector<MScanCols> mcols;            // [scans..., gscans...] entries that run on k_mscan
+    std::vector<MScanDesc> mdesc;
+    std::vector<ScanLaunch> mcfg;
+    std::vector<BufP> mparts, mdev;
+    std::vector<int64_t> gword_offset;
+    int dominant = -1;
+    std::string dominant_kernel;
+    int64_t n_words = 0;
+    int64_t row_offset = 0;                  // global index of this rank's first row (sharded FoldChoose)
+    // sharded Partition exchange (vdl_exchange_*)
+    struct ExState {
+        bool active = false;
+        int world = 0;
+        int64_t n = 0, n_send = 0;
+        std::vector<DVec> src;             // [0] = key, then the other scattered vectors
+        BufP vdest, pos;
+        std::vector<int> nodes;
+        int64_t pmin = 0, pcount = 0;
+    } ex;
+    BufP words;
+    int64_t words_cap = 0;
+    std::string fallback_note;
+    bool bound = false;
+    uint64_t bound_version = 0;
+    // pipelined finalisation: two pinned host slots, one event each
+    int64_t *host_words[2] = {nullptr, nullptr};
+    int64_t host_cap = 0;
+    hipEvent_t slot_ev[2] = {nullptr, nullptr};
+    bool slot_pending[2] = {false, false};
+    int64_t scan_rows = 0, scan_bytes = 0;
+    double scan_usec = 0;
+    static constexpr int kEvRing = 4;   // runs in flight before their timing is read (pipelined callers: up to 3)
+    hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};   // profiling events, one pair per run, ring
+    bool ev_pending[kEvRing] = {}, ev_bound[kEvRing] = {};
+    uint64_t ev_seq[kEvRing] = {};
+    unsigned run_seq = 0;
+    int last_ev = 0;
+    const void *ev_buf[kEvRing] = {};   // partial-word buffer each event pair's run wrote (pipelined callers finalise out of order)
+    int slot_ev_idx[2] = {-1, -1};
+    // pinned result buffers of the general path, one per output ordinal, grown on demand
+    std::vector<std::pair<int64_t *, size_t>> out_pinned;
+    int64_t *pinned_out(size_t ordinal, size_t count) {
+        if (out_pinned.size() <= ordinal) out_pinned.resize(ordinal + 1, {nullptr, 0});
+        auto &b = out_pinned[ordinal];
+        if (b.second < count) {
+            if (b.first) (void)hipHostFree(b.first);
+            b.first = nullptr; b.second = 0;
+            if (hipHostMalloc((void **)&b.first, sizeof(int64_t) * count, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); b.first = nullptr; return nullptr; }
+            b.second = count;
+        }
+        return b.first;
+    }
+    ~vdl_plan() {
+        for (auto &b : out_pinned) if (b.first) (void)hipHostFree(b.first);
+        for (int k = 0; k < 2; k++) {
+            if (ev0[k]) (void)hipEventDestroy(ev0[k]);
+            if (ev1[k]) (void)hipEventDestroy(ev1[k]);
+            if (ev0[k + 2]) (void)hipEventDestroy(ev0[k + 2]);
+            if (ev1[k + 2]) (void)hipEventDestroy(ev1[k + 2]);
+            if (slot_ev[k]) (void)hipEventDestroy(slot_ev[k]);
+            if (host_words[k]) (void)hipHostFree(host_words[k]);
+        }
+    }
+};
+
+namespace vdl {
+namespace eng {
+
+
+inline BufP dev_alloc(vdl_ctx *c, size_t bytes) {
+    auto b = std::make_shared<DevBuf>();
+    b->pool = c->pool;
+    b->p = c->pool->alloc(bytes, &b->cls);
+    return b;
+}
+
+inline void need_device(vdl_ctx *c) {
+    if (c->device < 0) throw Error(VDL_ERR_DEVICE, "this context has no HIP device (opened with device < 0)");
+    HIP_CHECK(hipSetDevice(c->device));
+}
+
+inline uint64_t fnv1a(const std::string &s) {
+    uint64_t h = 0xCBF29CE484222325ULL;
+    for (unsigned char ch : s) { h ^= ch; h *= 0x100000001B3ULL; }
+    return h;
+}
+
+inline const Column &find_col(vdl_ctx *c, const std::string &name) {
+    auto it = c->cols.find(name);
+    if (it == c->cols.end()) throw Error(VDL_ERR_COLUMN, "Load: column '" + name + "' is not in the catalog");
+    return it->second;
+}
+
+std::string describe_plan(const vdl_plan *p);
+
+template <typename F>
+int guard(vdl_ctx *c, F &&f) {
+    try {
+        f();
+        return VDL_OK;
+    } catch (const Error &e) {
+        if (c) c->err = e.what();
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        if (c) c->err = "out of host memory";
+        return VDL_ERR_NOMEM;
+    } catch (const std::exception &e) {
+        if (c) c->err = e.what();
+        return VDL_ERR_ARG;
+    }
+}
+
+
+}  // namespace eng
+}  // namespace vdl

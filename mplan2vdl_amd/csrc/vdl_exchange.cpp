@@ -1,0 +1,279 @@
+// vdl_exchange.cpp -- sharded Partition: which vectors travel (analysis) and the three C-ABI calls around the
+// caller's all-to-all (vdl_exchange_begin / _pack / _finish); see vdl_kernels.hip "Row exchange".
+#include "vdl_genexec.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// sharded Partition: exchange analysis (which vectors travel) -- see vdl_kernels.hip "Row exchange"
+// ------------------------------------------------------------------------------------------------
+struct ExchangeSpec {
+    bool ok = false;
+    std::string why;
+    int part = 0, key = 0;             // Partition statement, its (resolved) data operand
+    std::vector<int> sources;          // resolved source statements of the Scatters that use the partition; [0] = key
+    int64_t pmin = 0, pcount = 0;
+};
+
+int resolve_alias(const Program &P, int id) {
+    while (P.at(id).op == Op::Project || P.at(id).op == Op::Shuffle) id = P.at(id).a;
+    return id;
+}
+
+// `table`: name of the row-sharded table ("" = trust the caller).  With a table name the statements
+// below the scatters are checked to be row-local over that table: its columns may pass through
+// element-wise operators, constants and Gathers *from* replicated vectors only.
+ExchangeSpec analyse_exchange(const Program &P, const std::string &table = std::string()) {
+    ExchangeSpec x;
+    std::vector<char> needed(P.nodes.size(), 0);
+    for (int id : P.outputs) needed[(size_t)id] = 1;
+    for (auto it = P.order.rbegin(); it != P.order.rend(); ++it) {
+        const Node &n = P.at(*it);
+        if (!needed[(size_t)n.id]) continue;
+        for (int opnd : {n.a, n.b, n.c}) if (opnd > 0) needed[(size_t)opnd] = 1;
+    }
+    for (int id : P.order) {
+        if (!needed[(size_t)id] || P.at(id).op != Op::Partition) continue;
+        if (x.part) { x.why = "more than one Partition"; return x; }
+        x.part = id;
+    }
+    if (!x.part) { x.why = "no Partition in the program"; return x; }
+    const Node &pn = P.at(x.part);
+    const Node &piv = P.at(resolve_alias(P, pn.b));
+    if (piv.op != Op::RangeC || piv.imm2 != 1 || piv.imm1 <= 0) { x.why = "pivots are not a RangeC with step 1"; return x; }
+    x.pmin = piv.imm0; x.pcount = piv.imm1;
+    x.key = resolve_alias(P, pn.a);
+    x.sources.push_back(x.key);
+    std::vector<char> is_cut(P.nodes.size(), 0);
+    for (int id : P.order) {
+        const Node &n = P.at(id);
+        if (!needed[(size_t)id]) continue;
+        bool uses = false;
+        for (int opnd : {n.a, n.b, n.c}) uses |= opnd > 0 && resolve_alias(P, opnd) == x.part && !(n.op == Op::Project || n.op == Op::Shuffle);
+        if (!uses) continue;
+        if (n.op != Op::Scatter || resolve_alias(P, n.c) != x.part || resolve_alias(P, n.a) == x.part || resolve_alias(P, n.b) == x.part) {
+            x.why = "the Partition result is used other than as Scatter positions (statement " + std::to_string(id) + ")";
+            return x;
+        }
+        is_cut[(size_t)id] = 1;
+        const int src = resolve_alias(P, n.a);
+        if (std::find(x.sources.begin(), x.sources.end(), src) == x.sources.end()) x.sources.push_back(src);
+    }
+    if ((int)x.sources.size() - 1 > kMaxExSources) { x.why = "too many scattered vectors"; return x; }
+    // everything above the scatters must be derived from them alone
+    std::vector<char> seen(P.nodes.size(), 0);
+    std::vector<int> stack(P.outputs.begin(), P.outputs.end());
+    while (!stack.empty()) {
+        const int id = stack.back(); stack.pop_back();
+        if (seen[(size_t)id]) continue;
+        seen[(size_t)id] = 1;
+        const Node &n = P.at(id);
+        if (is_cut[(size_t)id]) continue;
+        if (n.op == Op::Load) { x.why = "output depends on column " + n.column + " other than through the partition"; return x; }
+        if (id == x.part) { x.why = "Partition reachable past the scatters"; return x; }
+        for (int opnd : {n.a, n.b, n.c}) if (opnd > 0) stack.push_back(opnd);
+    }
+    // size references of the scatters are evaluated after the exchange: they must hang off the travelling vectors
+    std::vector<char> is_src(P.nodes.size(), 0);
+    for (int id : x.sources) is_src[(size_t)id] = 1;
+    std::fill(seen.begin(), seen.end(), 0);
+    stack.clear();
+    for (int id : P.order) if (is_cut[(size_t)id]) stack.push_back(P.at(id).b);
+    while (!stack.empty()) {
+        const int id = stack.back(); stack.pop_back();
+        if (seen[(size_t)id] || is_src[(size_t)id]) continue;
+        seen[(size_t)id] = 1;
+        const Node &n = P.at(id);
+        if (n.op == Op::Load) { x.why = "a Scatter size reference depends on column " + n.column + " directly"; return x; }
+        for (int opnd : {n.a, n.b, n.c}) if (opnd > 0) stack.push_back(opnd);
+    }
+    if (!table.empty()) {
+        // class of every statement below the Partition: R = replicated (same on every rank), V = one value per
+        // row of the shard, N = (local) row numbers of the shard, as the filter idiom
+        // Gather(x, FoldSelect(RangeV 0 step 1, cond)) of Vlite.hs produces them
+        enum : char { R = 0, V = 1, N = 2 };
+        std::vector<char> below(P.nodes.size(), 0), cls(P.nodes.size(), R);
+        stack.assign(x.sources.begin(), x.sources.end());
+        while (!stack.empty()) {
+            const int id = stack.back(); stack.pop_back();
+            if (below[(size_t)id]) continue;
+            below[(size_t)id] = 1;
+            const Node &n = P.at(id);
+            for (int opnd : {n.a, n.b, n.c}) if (opnd > 0) stack.push_back(opnd);
+        }
+        for (int id : P.order) {
+            if (!below[(size_t)id]) continue;
+            const Node &n = P.at(id);
+            auto C = [&](int o) { return o > 0 ? cls[(size_t)o] : (char)R; };
+            const std::string at = " (statement " + std::to_string(id) + ")";
+            char &out = cls[(size_t)id];
+            switch (n.op) {
+            case Op::Load: out = n.column.compare(0, table.size() + 1, table + ".") == 0 ? V : R; break;
+            case Op::RangeC: break;
+            case Op::Project: case Op::Shuffle: case Op::Materialize: out = C(n.a); break;
+            case Op::Like:
+                if (C(n.b) != R) { x.why = "Like over a sharded string heap" + at; return x; }
+                if (C(n.a) == N) { x.why = "Like on row numbers" + at; return x; }
+                out = C(n.a);
+                break;
+            case Op::Binary:
+                if (C(n.a) == N || C(n.b) == N) { x.why = "arithmetic on row numbers of the sharded table, which are rank-local" + at; return x; }
+                out = (C(n.a) == V || C(n.b) == V) ? V : R;
+                break;
+            case Op::RangeV:
+                if (C(n.a) == R) break;
+                if (n.imm1 == 0) out = V;
+                else if (n.imm0 == 0 && n.imm1 == 1) out = N;
+                else { x.why = "a strided range over the sharded table is rank-local" + at; return x; }
+                break;
+            case Op::FoldSelect: {
+                if (C(n.a) == R && C(n.b) == R) break;
+                const Node &ctl = P.at(resolve_alias(P, n.a));
+                if (!(ctl.op == Op::RangeV && C(n.a) == N)) { x.why = "FoldSelect over runs of the sharded table" + at; return x; }
+                out = N;
+                break;
+            }
+            case Op::Gather:
+                if (C(n.a) == R && C(n.b) != N) out = C(n.b);                 // replicated data by FK / replicated positions
+                else if (C(n.a) != R && C(n.b) == N) out = C(n.a);            // shard data by shard row numbers
+                else { x.why = "Gather mixes replicated and rank-local positions" + at; return x; }
+                break;
+            default:
+                if (C(n.a) != R || C(n.b) != R || C(n.c) != R) { x.why = std::string(op_name(n.op, n.bin)) + " over the sharded table below the Partition" + at; return x; }
+            }
+        }
+        for (int id : x.sources) {
+            if (cls[(size_t)id] == N) { x.why = "statement " + std::to_string(id) + " feeds the Partition with rank-local row numbers"; return x; }
+            if (cls[(size_t)id] != V) { x.why = "statement " + std::to_string(id) + " feeds the Partition but does not depend on table " + table; return x; }
+        }
+    }
+    x.ok = true;
+    return x;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* ---- sharded Partition: local phase -> row exchange (caller: RCCL all-to-all) -> local tail ---- */
+
+int vdl_exchange_spec(const vdl_plan *p, const char *sharded_table, int *n_columns) {
+    if (!p) return VDL_ERR_ARG;
+    ExchangeSpec x = analyse_exchange(p->prog, sharded_table ? sharded_table : "");
+    if (!x.ok) {
+        if (p->ctx) p->ctx->err = "no sharded-Partition structure: " + x.why;
+        return VDL_ERR_UNSUPPORTED;
+    }
+    if (n_columns) *n_columns = (int)x.sources.size() + 1;      // key, scattered vectors, validity mask
+    return VDL_OK;
+}
+
+int vdl_exchange_begin(vdl_ctx *c, vdl_plan *p, int world, int64_t *counts_host) {
+    if (!c || !p || !counts_host || world < 1 || world > kMaxExWorld) return VDL_ERR_ARG;
+    return guard(c, [&] {
+        need_device(c);
+        ExchangeSpec x = analyse_exchange(p->prog);
+        if (!x.ok) throw Error(VDL_ERR_UNSUPPORTED, "no sharded-Partition structure: " + x.why);
+        GenExec g(c, p);
+        g.run_nodes(x.sources, nullptr);
+        vdl_plan::ExState &ex = p->ex;
+        ex = vdl_plan::ExState{};
+        ex.world = world; ex.nodes = x.sources; ex.pmin = x.pmin; ex.pcount = x.pcount;
+        // sources that live on one sparse selection travel as their entries (m rows instead of n slots to route and pack)
+        bool all_sparse = !x.sources.empty();
+        for (int id : x.sources) {
+            const DVec &v = g.vec[(size_t)id];
+            all_sparse = all_sparse && v.kind == DVec::SPARSE && v.sel == g.vec[(size_t)x.sources[0]].sel;
+        }
+        for (int id : x.sources) ex.src.push_back(all_sparse ? g.entries(g.vec[(size_t)id]) : g.densify(g.vec[(size_t)id]));
+        const DVec &key = ex.src[0];
+        ex.n = key.n;
+        for (const DVec &v : ex.src)
+            if (v.n != ex.n) throw Error(VDL_ERR_SHAPE, "vectors scattered by one Partition have different lengths");
+        const size_t nw = (size_t)std::max<int64_t>(GenExec::nwords(ex.n), 1);
+        BufP dest = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(ex.n, 1));
+        ex.vdest = dev_alloc(c, sizeof(uint64_t) * nw);
+        ex.pos = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(ex.n, 1));
+        BufP counts = dev_alloc(c, sizeof(int64_t) * (size_t)(world + 1));
+        HIP_CHECK(hipMemsetAsync(counts->p, 0, sizeof(int64_t) * (size_t)(world + 1), c->stream));
+        HIP_CHECK(launch_ex_dest(g.src_of(key), g.vp(key), ex.n, ex.pmin, ex.pcount, world, (int64_t *)dest->p, (uint64_t *)ex.vdest->p,
+                                 (int64_t *)counts->p, (int64_t *)counts->p + world, c->stream));
+        if (ex.n > 0) {
+            // stable order inside each destination = one 8-bit Partition pass over the destination ranks
+            const int64_t hn = 256 * partition_tiles(ex.n);
+            BufP hist = dev_alloc(c, sizeof(int64_t) * (size_t)(hn + 1));
+            BufP scr = dev_alloc(c, sizeof(int64_t) * (size_t)(prefix_sum_blocks(hn) + 2));
+            BufP nvalid = dev_alloc(c, sizeof(int64_t));
+            Src d; d.p = dest->p; d.kind = SRC_I64;
+            HIP_CHECK(launch_partition(d, (const uint64_t *)ex.vdest->p, ex.n, 0, world, (int64_t *)hist->p, (int64_t *)scr->p, nullptr, nullptr,
+                                       nullptr, nullptr, (int64_t *)nvalid->p, (int64_t *)ex.pos->p, c->stream));
+        }
+        std::vector<int64_t> h((size_t)world + 1);
+        HIP_CHECK(hipMemcpyAsync(h.data(), counts->p, sizeof(int64_t) * (size_t)(world + 1), hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (h[(size_t)world] > 0)
+            throw Error(VDL_ERR_UNSUPPORTED, std::to_string(h[(size_t)world]) + " row(s) carry a partition key outside the pivots; run unsharded");
+        ex.n_send = 0;
+        for (int r = 0; r < world; r++) { counts_host[r] = h[(size_t)r]; ex.n_send += h[(size_t)r]; }
+        ex.active = true;
+    });
+}
+
+int vdl_exchange_pack(vdl_ctx *c, vdl_plan *p, void *dev_send) {
+    if (!c || !p) return VDL_ERR_ARG;
+    return guard(c, [&] {
+        need_device(c);
+        vdl_plan::ExState &ex = p->ex;
+        if (!ex.active) throw Error(VDL_ERR_ARG, "vdl_exchange_pack before vdl_exchange_begin");
+        if (ex.n_send == 0) return;
+        if (!dev_send) throw Error(VDL_ERR_ARG, "vdl_exchange_pack: null send buffer");
+        GenExec g(c, p);
+        int64_t *out = (int64_t *)dev_send;
+        ExValid ev;
+        for (size_t k = 0; k < ex.src.size(); k++) {
+            HIP_CHECK(launch_ex_pack(g.src_of(ex.src[k]), (const uint64_t *)ex.vdest->p, (const int64_t *)ex.pos->p, ex.n, out + (int64_t)k * ex.n_send, c->stream));
+            if (k > 0) ev.valid[ev.n++] = g.vp(ex.src[k]);
+        }
+        HIP_CHECK(launch_ex_mask(ev, (const uint64_t *)ex.vdest->p, (const int64_t *)ex.pos->p, ex.n, out + (int64_t)ex.src.size() * ex.n_send, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));      // the buffer goes to the caller's collective, possibly on another stream
+    });
+}
+
+int vdl_exchange_finish(vdl_ctx *c, vdl_plan *p, const void *dev_recv, int64_t n_recv) {
+    if (!c || !p || (!dev_recv && n_recv > 0) || n_recv < 0) return VDL_ERR_ARG;
+    return guard(c, [&] {
+        need_device(c);
+        vdl_plan::ExState &ex = p->ex;
+        if (!ex.active) throw Error(VDL_ERR_ARG, "vdl_exchange_finish before vdl_exchange_begin");
+        const int64_t *in = (const int64_t *)dev_recv;
+        const size_t m = ex.src.size();
+        std::map<int, DVec> over;
+        // usually every travelling row holds a value in every vector (mask word = all ones): no bitmaps needed then
+        bool all_valid = n_recv == 0 || m <= 1;
+        if (!all_valid) {
+            BufP scratch = dev_alloc(c, sizeof(int64_t) * 3 * (size_t)fold_scratch_blocks());
+            BufP r = dev_alloc(c, 3 * sizeof(int64_t));
+            Src mk; mk.p = in + (int64_t)m * n_recv; mk.kind = SRC_I64;
+            HIP_CHECK(launch_fold_global(1 /* min */, mk, nullptr, nullptr, n_recv, (int64_t *)scratch->p, (int64_t *)r->p, c->stream));
+            int64_t h[3];
+            HIP_CHECK(hipMemcpyAsync(h, r->p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            all_valid = h[0] == (int64_t)(((uint64_t)1 << (m - 1)) - 1);
+        }
+        for (size_t k = 0; k < m; k++) {
+            DVec v;
+            v.kind = DVec::COLUMN; v.n = n_recv; v.ptr = in + (int64_t)k * n_recv; v.width = 8;
+            if (k > 0 && !all_valid) {      // source vectors had EPS rows: rebuild their bitmaps from the mask column
+                v.valid = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(GenExec::nwords(n_recv), 1));
+                HIP_CHECK(launch_ex_unmask(in + (int64_t)m * n_recv, n_recv, (int)k - 1, (uint64_t *)v.valid->p, c->stream));
+            }
+            over[ex.nodes[k]] = v;
+        }
+        ex.src.clear(); ex.vdest.reset(); ex.pos.reset();          // phase-A vectors are no longer needed
+        ex.active = false;
+        GenExec g(c, p);
+        g.run_nodes(p->prog.outputs, &over);
+    });
+}
+
+}  // extern "C"
