@@ -1,11 +1,11 @@
 // vdl_exchange.cpp -- sharded Partition: which vectors travel (analysis) and the three C-ABI calls around the
-// caller's all-to-all (vdl_exchange_begin / _pack / _finish); see vdl_kernels.hip "Row exchange".
+// caller's all-to-all (vdl_exchange_begin / _pack / _finish); see vdl_partition.hip "Row exchange".
 #include "vdl_genexec.h"
 
 namespace {
 
 // ------------------------------------------------------------------------------------------------
-// sharded Partition: exchange analysis (which vectors travel) -- see vdl_kernels.hip "Row exchange"
+// sharded Partition: exchange analysis (which vectors travel) -- see vdl_partition.hip "Row exchange"
 // ------------------------------------------------------------------------------------------------
 struct ExchangeSpec {
     bool ok = false;

@@ -1,4 +1,5 @@
-// vdl_kernels.h -- launch wrappers for the HIP kernels in vdl_kernels.hip (gfx950).
+// vdl_kernels.h -- launch wrappers for the HIP kernels (gfx950): vdl_kernels.hip (fused scan, column generator),
+// vdl_mscan.hip (multi-aggregate / grouped scan), vdl_ops.hip (per-operator kernels), vdl_partition.hip.
 // All launchers are asynchronous on the given stream and return the hipError_t of the launch.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -153,7 +154,7 @@ hipError_t launch_fsel_keys(const int64_t *excl_heads, const int64_t *flags, con
 int64_t prefix_sum_blocks(int64_t n);
 hipError_t launch_prefix_sum(int64_t *x, int64_t n, int64_t *sums, hipStream_t s);
 
-// Partition with pivots RangeC pmin pcount 1 (bucket = clamp(data - pmin, 0, pcount)); see vdl_kernels.hip
+// Partition with pivots RangeC pmin pcount 1 (bucket = clamp(data - pmin, 0, pcount)); see vdl_partition.hip
 int64_t partition_tiles(int64_t n);
 int partition_passes(int64_t pcount);
 hipError_t launch_partition(Src data, const uint64_t *valid, int64_t n, int64_t pmin, int64_t pcount, int64_t *hist,
@@ -169,7 +170,7 @@ hipError_t launch_fold_runs(int kind, Src d, const uint64_t *vd, const uint64_t 
 hipError_t launch_fold_segmented(int kind, Src ctl, const uint64_t *vc, Src d, const uint64_t *vd, int64_t n, uint64_t *heads,
                                  int64_t *wordhd, int64_t *out, uint64_t *vout, hipStream_t s);
 
-// ---- row exchange for sharded Partition (see vdl_kernels.hip) -------------------------------------
+// ---- row exchange for sharded Partition (see vdl_partition.hip) ------------------------------------
 constexpr int kMaxExSources = 62;
 constexpr int kMaxExWorld = 128;          // ranks in one exchange (vdl_exchange_begin)
 struct ExValid { int n = 0; const uint64_t *valid[kMaxExSources] = {}; };

@@ -1,0 +1,397 @@
+// vdl_partition.hip -- device-wide prefix sum, Partition (stable LSD radix ranks) and the row exchange of a sharded
+// Partition.
+#include "vdl_device.h"
+
+namespace vdl {
+
+// ------------------------------------------------------------------------------------------
+// device-wide exclusive prefix sum over int64 (in place): block sums -> one-block scan of the
+// sums -> per-block scan with carry.  Tile = 1024 threads x 4 consecutive items.
+// ------------------------------------------------------------------------------------------
+constexpr int kPsBlock = 1024, kPsItems = 4, kPsTile = kPsBlock * kPsItems;
+int64_t prefix_sum_blocks(int64_t n) { return (n + kPsTile - 1) / kPsTile; }
+
+__global__ __launch_bounds__(kPsBlock) void k_ps_block_sums(const int64_t *x, int64_t n, int64_t *sums) {
+    __shared__ int64_t red[kPsBlock / kWave];
+    const int64_t base = (int64_t)blockIdx.x * kPsTile + (int64_t)threadIdx.x * kPsItems;
+    int64_t t = 0;
+#pragma unroll
+    for (int k = 0; k < kPsItems; k++) if (base + k < n) t += x[base + k];
+    t = wave_reduce(t, R_SUM);
+    if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) { int64_t a = 0; for (int w = 0; w < kPsBlock / kWave; w++) a += red[w]; sums[blockIdx.x] = a; }
+}
+
+__global__ __launch_bounds__(kPsBlock) void k_ps_apply(int64_t *x, int64_t n, const int64_t *block_excl) {
+    __shared__ int64_t wsum[kPsBlock / kWave];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const int64_t base = (int64_t)blockIdx.x * kPsTile + (int64_t)tid * kPsItems;
+    int64_t v[kPsItems], t = 0;
+#pragma unroll
+    for (int k = 0; k < kPsItems; k++) { v[k] = (base + k < n) ? x[base + k] : 0; t += v[k]; }
+    int64_t incl = t;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) { int64_t y = __shfl_up(incl, off, kWave); if (lane >= off) incl += y; }
+    if (lane == kWave - 1) wsum[wave] = incl;
+    __syncthreads();
+    int64_t run = block_excl[blockIdx.x] + incl - t;
+    for (int w = 0; w < wave; w++) run += wsum[w];
+#pragma unroll
+    for (int k = 0; k < kPsItems; k++) { if (base + k < n) x[base + k] = run; run += v[k]; }
+}
+
+// sums: prefix_sum_blocks(n) + 1 int64 of scratch; the grand total is left in sums[nblocks]
+hipError_t launch_prefix_sum(int64_t *x, int64_t n, int64_t *sums, hipStream_t s) {
+    (void)hipGetLastError();   // see launch_status()
+    const int64_t nb = prefix_sum_blocks(n);
+    if (nb <= 0) return hipSuccess;
+    k_ps_block_sums<<<(int)nb, kPsBlock, 0, s>>>(x, n, sums);
+    if (launch_compact_scan(sums, nb, s) != hipSuccess) return hipGetLastError();      // the one-block scan lives in vdl_ops.hip
+    k_ps_apply<<<(int)nb, kPsBlock, 0, s>>>(x, n, sums);
+    return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
+// Partition (/root/reference/src/Vdl.hs:130,266-269; Vlite.hs:358-366,508,1082-1098): positions
+// that stably group `data` by pivot bucket.  Pivots are the emitted RangeC min cnt 1, so
+// bucket = clamp(data - min, 0, cnt).  Implemented as an LSD radix sort of (bucket, slot) over the
+// non-EPS slots, 8 bits per pass; each pass = tile histogram (LDS atomics) -> device-wide prefix
+// sum in digit-major order -> stable scatter (see k_part_scatter).  The last pass writes out[slot] = rank instead of the sorted pair.
+// Dense group-by domains (Q1: 32 buckets) need one pass, Q3's 2^38 domain five.
+// ------------------------------------------------------------------------------------------
+constexpr int kPartBlock = 256, kPartSteps = 16, kPartTile = kPartBlock * kPartSteps, kRadix = 256;
+int64_t partition_tiles(int64_t n) { return (n + kPartTile - 1) / kPartTile; }
+
+struct PartIn {
+    Src data;                    // first pass: raw data column
+    const uint64_t *valid;       // first pass: validity of data
+    int64_t pmin, pcount;        // pivots = RangeC pmin pcount 1
+    const uint64_t *keys;        // later passes: bucket values of the previous pass
+    const int64_t *slots;        // later passes: originating slot
+    const int64_t *n_dev;        // later passes: number of elements (device scalar)
+    int64_t n;                   // first pass: number of slots; later: upper bound for the grid
+    int shift;
+};
+
+// A wave's share of a tile: kPartSteps x 64 consecutive slots starting at a multiple of 64, fetched with every load
+// issued before the first use (the validity word of a step is the same for all lanes).
+template <bool FIRST>
+__device__ __forceinline__ void part_fetch_share(const PartIn &in, int64_t n, int64_t share0 /* multiple of 64 */, int lane,
+                                                 uint64_t (&keys)[kPartSteps], int64_t (&slots)[kPartSteps], bool (&oks)[kPartSteps]) {
+    if (FIRST) {
+        by_kind(in.data.kind, [&](auto kd) {
+#pragma unroll
+            for (int st = 0; st < kPartSteps; st++) {
+                const int64_t i = share0 + st * kWave + lane;
+                oks[st] = i < n;
+                slots[st] = i;
+                keys[st] = (uint64_t)ldk<decltype(kd)::value>(in.data, oks[st] ? i : 0);
+            }
+        });
+        if (in.valid) {
+            const int64_t nw = (n + 63) >> 6;
+            uint64_t t[kPartSteps];
+#pragma unroll
+            for (int st = 0; st < kPartSteps; st++) { const int64_t w = (share0 >> 6) + st; t[st] = in.valid[w < nw ? w : nw - 1]; }
+#pragma unroll
+            for (int st = 0; st < kPartSteps; st++) oks[st] = oks[st] & (((t[st] >> lane) & 1ull) != 0);
+        }
+#pragma unroll
+        for (int st = 0; st < kPartSteps; st++) {                // bucket = clamp(data - min, 0, cnt)
+            const int64_t x = (int64_t)keys[st];
+            int64_t b = 0;
+            if (x > in.pmin) { b = (int64_t)((uint64_t)x - (uint64_t)in.pmin); if (b < 0 || b > in.pcount) b = in.pcount; }
+            keys[st] = (uint64_t)b;
+        }
+    } else {
+#pragma unroll
+        for (int st = 0; st < kPartSteps; st++) {
+            const int64_t i = share0 + st * kWave + lane;
+            oks[st] = i < n;
+            const int64_t ii = oks[st] ? i : 0;                  // n > 0 here
+            keys[st] = in.keys[ii]; slots[st] = in.slots[ii];
+        }
+    }
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(kPartBlock) void k_part_hist(PartIn in, int64_t ntiles, int64_t *hist /*[256][ntiles]*/) {
+    __shared__ unsigned int h[kRadix];
+    const int64_t n = FIRST ? in.n : *in.n_dev;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    h[tid] = 0;
+    __syncthreads();
+    if ((int64_t)blockIdx.x * kPartTile < n) {                   // (n = 0 leaves the key buffers unwritten)
+        uint64_t keys[kPartSteps];
+        int64_t slots[kPartSteps];
+        bool oks[kPartSteps];
+        part_fetch_share<FIRST>(in, n, (int64_t)blockIdx.x * kPartTile + (int64_t)wave * (kPartSteps * kWave), lane, keys, slots, oks);
+#pragma unroll
+        for (int st = 0; st < kPartSteps; st++)
+            if (oks[st]) atomicAdd(&h[(keys[st] >> in.shift) & (kRadix - 1)], 1u);
+    }
+    __syncthreads();
+    hist[(int64_t)tid * ntiles + blockIdx.x] = h[tid];
+}
+
+// Each wave owns a contiguous quarter of the tile (16 steps of 64 slots), so the stable order inside a tile is wave,
+// step, lane.  A wave ranks its slots on its own (peer masks from 8 ballots, its running digit counts in its row of
+// whist: LDS operations of one wave execute in order); one barrier later the rows are turned into per-wave offsets
+// and every slot knows its destination.  (A version that kept the block in step order needed three barriers per
+// step, 48 per tile, and was twice as slow.)
+template <bool FIRST, bool LAST>
+__global__ __launch_bounds__(kPartBlock) void k_part_scatter(PartIn in, int64_t ntiles, const int64_t *offsets,
+                                                              uint64_t *keys_out, int64_t *slots_out, int64_t *pos_out) {
+    constexpr int NW = kPartBlock / kWave;
+    __shared__ int64_t woff[NW][kRadix];
+    __shared__ unsigned int whist[NW][kRadix];
+    const int64_t n = FIRST ? in.n : *in.n_dev;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+#pragma unroll
+    for (int w = 0; w < NW; w++) whist[w][tid] = 0;
+    __syncthreads();
+    uint64_t keys[kPartSteps];
+    int64_t slots[kPartSteps];
+    bool oks[kPartSteps];
+#pragma unroll
+    for (int st = 0; st < kPartSteps; st++) { keys[st] = 0; slots[st] = 0; oks[st] = false; }
+    if ((int64_t)blockIdx.x * kPartTile < n)                    // the whole share is fetched up front
+        part_fetch_share<FIRST>(in, n, (int64_t)blockIdx.x * kPartTile + (int64_t)wave * (kPartSteps * kWave), lane, keys, slots, oks);
+    unsigned int local[kPartSteps];                             // rank among this wave's slots with the same digit
+    volatile unsigned int *mine = whist[wave];
+#pragma unroll
+    for (int st = 0; st < kPartSteps; st++) {
+        const unsigned d = (unsigned)((keys[st] >> in.shift) & (kRadix - 1));
+        uint64_t peers = __ballot(oks[st]);                     // lanes of this wave holding the same digit (and a value)
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const uint64_t m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const unsigned rank = (unsigned)__popcll(peers & ((1ull << lane) - 1));
+        const unsigned pre = oks[st] ? mine[d] : 0u;
+        if (oks[st] && rank == 0) mine[d] = pre + (unsigned)__popcll(peers);     // one leader per digit
+        local[st] = pre + rank;
+    }
+    __syncthreads();
+    if (LAST) {                                                 // ranks go to out[slot]: scattered whatever the order
+        {
+            int64_t run = offsets[(int64_t)tid * ntiles + blockIdx.x];          // where this tile's slots of digit `tid` start
+#pragma unroll
+            for (int w = 0; w < NW; w++) { woff[w][tid] = run; run += whist[w][tid]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < kPartSteps; st++) {
+            if (oks[st]) {
+                const unsigned d = (unsigned)((keys[st] >> in.shift) & (kRadix - 1));
+                pos_out[slots[st]] = woff[wave][d] + local[st];
+            }
+        }
+        return;
+    }
+    // The tile is put into digit order in LDS first (keys, then slots through the same buffer): a digit's slots of
+    // one tile are neighbours at the destination, so consecutive lanes then store consecutive words instead of 64
+    // scattered ones.
+    __shared__ uint64_t stage[kPartTile];
+    __shared__ unsigned int wtot[NW];
+    __shared__ int64_t gdelta[kRadix];                          // destination of sorted index idx with digit d = gdelta[d] + idx
+    unsigned total;
+    {
+        unsigned cnt = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) cnt += whist[w][tid];
+        unsigned incl = cnt;                                    // exclusive scan of the tile's digit counts over the block
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) { const unsigned y = __shfl_up(incl, off, kWave); if (lane >= off) incl += y; }
+        if (lane == kWave - 1) wtot[wave] = incl;
+        __syncthreads();
+        unsigned pre = 0;
+        for (int w = 0; w < wave; w++) pre += wtot[w];
+        total = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) total += wtot[w];
+        const unsigned tstart = pre + incl - cnt;               // where digit `tid` starts inside the sorted tile
+        unsigned run = tstart;
+#pragma unroll
+        for (int w = 0; w < NW; w++) { woff[w][tid] = run; run += whist[w][tid]; }                            // tile-local
+        gdelta[tid] = offsets[(int64_t)tid * ntiles + blockIdx.x] - (int64_t)tstart;
+        __syncthreads();
+    }
+    unsigned lpos[kPartSteps];
+#pragma unroll
+    for (int st = 0; st < kPartSteps; st++) {
+        const unsigned d = (unsigned)((keys[st] >> in.shift) & (kRadix - 1));
+        lpos[st] = (unsigned)woff[wave][d] + local[st];
+        if (oks[st]) stage[lpos[st]] = keys[st];
+    }
+    __syncthreads();
+    int64_t dest[kPartSteps];
+#pragma unroll
+    for (int k = 0; k < kPartSteps; k++) {
+        const unsigned idx = (unsigned)k * kPartBlock + tid;
+        dest[k] = -1;
+        if (idx < total) {
+            const uint64_t key = stage[idx];
+            dest[k] = gdelta[(key >> in.shift) & (kRadix - 1)] + idx;
+            keys_out[dest[k]] = key;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < kPartSteps; st++)
+        if (oks[st]) stage[lpos[st]] = (uint64_t)slots[st];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kPartSteps; k++)
+        if (dest[k] >= 0) slots_out[dest[k]] = (int64_t)stage[(unsigned)k * kPartBlock + tid];
+}
+
+// scratch layout is owned by the caller (vdl_engine.cpp); see launch_partition's arguments.
+hipError_t launch_partition(Src data, const uint64_t *valid, int64_t n, int64_t pmin, int64_t pcount,
+                            int64_t *hist /* 256*ntiles + 1 */, int64_t *scan_scratch /* prefix_sum_blocks(256*ntiles)+1 */,
+                            uint64_t *keys_a, int64_t *slots_a, uint64_t *keys_b, int64_t *slots_b /* n each, or null if one pass */,
+                            int64_t *n_valid_dev /* 1 word */, int64_t *pos_out, hipStream_t s) {
+    (void)hipGetLastError();   // see launch_status()
+    if (n <= 0) return hipSuccess;
+    int bits = 0;
+    while (bits < 63 && ((uint64_t)pcount >> bits) != 0) bits++;       // buckets 0..pcount
+    const int passes = bits <= 8 ? 1 : (bits + 7) / 8;
+    const int64_t ntiles = partition_tiles(n);
+    const int64_t hn = (int64_t)kRadix * ntiles;
+    PartIn in{};
+    in.data = data; in.valid = valid; in.pmin = pmin; in.pcount = pcount; in.n = n; in.n_dev = n_valid_dev;
+    uint64_t *kin = nullptr, *kout = keys_a; int64_t *sin = nullptr, *sout = slots_a;
+    for (int p = 0; p < passes; p++) {
+        in.shift = 8 * p; in.keys = kin; in.slots = sin;
+        const bool first = p == 0, last = p == passes - 1;
+        if (first) k_part_hist<true><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist);
+        else k_part_hist<false><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist);
+        hipError_t e = launch_prefix_sum(hist, hn, scan_scratch, s);
+        if (e != hipSuccess) return e;
+        if (first) {   // number of non-EPS slots = grand total of the first histogram
+            e = hipMemcpyAsync(n_valid_dev, scan_scratch + prefix_sum_blocks(hn), sizeof(int64_t), hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) return e;
+        }
+        if (first && last) k_part_scatter<true, true><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist, nullptr, nullptr, pos_out);
+        else if (first) k_part_scatter<true, false><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist, kout, sout, nullptr);
+        else if (last) k_part_scatter<false, true><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist, nullptr, nullptr, pos_out);
+        else k_part_scatter<false, false><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist, kout, sout, nullptr);
+        kin = kout; sin = sout;
+        kout = (kout == keys_a) ? keys_b : keys_a;
+        sout = (sout == slots_a) ? slots_b : slots_a;
+    }
+    return launch_status();
+}
+int partition_passes(int64_t pcount) {
+    int bits = 0;
+    while (bits < 63 && ((uint64_t)pcount >> bits) != 0) bits++;
+    return bits <= 8 ? 1 : (bits + 7) / 8;
+}
+
+// ------------------------------------------------------------------------------------------
+// Row exchange for sharded Partition (Partition / join redistribution over
+// xGMI).  Each rank sends every row of the partition key and of the vectors scattered by it to the
+// rank that owns the row's key range; afterwards Partition / Scatter / Fold run locally on the
+// received rows and the outputs of the ranks concatenate in rank order (keys ascend across ranks).
+//   k_ex_dest   : destination rank of each row = (key - pmin) * world / pcount, EPS for rows that do
+//                 not take part; per-destination row counts by 64-bit atomics (world <= 256)
+//   (stable order inside each destination: launch_partition over the destination vector)
+//   k_ex_pack   : scatter a column into send order; k_ex_mask: validity word of the source vectors
+//   k_ex_unmask : received validity words -> one bitmap per source vector
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ex_dest(Src key, const uint64_t *vkey, int64_t n, int64_t pmin, int64_t pcount, int world,
+                                                 int64_t *dest, uint64_t *vdest, int64_t *counts, int64_t *oob) {
+    __shared__ unsigned long long cnt[kMaxExWorld + 1];       // per-block row counts per destination (+ out-of-range keys)
+    for (int i = threadIdx.x; i <= kMaxExWorld; i += blockDim.x) cnt[i] = 0;
+    __syncthreads();
+    const int64_t nw = (n + 63) >> 6;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave);
+    for (int64_t w = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; w < nw; w += wstride) {
+        const int64_t i = (w << 6) + lane;
+        bool ok = i < n && bit(vkey, i);
+        bool out_of_range = false;
+        int64_t d = 0;
+        if (ok) {
+            const int64_t b = (int64_t)((uint64_t)ld(key, i) - (uint64_t)pmin);
+            if (b < 0 || b >= pcount) { out_of_range = true; ok = false; }
+            else d = (int64_t)(((unsigned __int128)(uint64_t)b * (uint64_t)world) / (uint64_t)pcount);
+        }
+        if (i < n) dest[i] = d;
+        const uint64_t m = __ballot(ok);
+        if (lane == 0) vdest[w] = m;
+        const uint64_t bad = __ballot(out_of_range);
+        if (bad && lane == 0) atomicAdd(&cnt[kMaxExWorld], (unsigned long long)__popcll(bad));
+        // one LDS atomic per (wave, destination present in the wave)
+        uint64_t todo = m;
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int64_t dl = __shfl(d, leader, kWave);
+            const uint64_t same = __ballot(ok && d == dl) & todo;
+            if (lane == leader) atomicAdd(&cnt[dl], (unsigned long long)__popcll(same));
+            todo &= ~same;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= kMaxExWorld; i += blockDim.x) {
+        const unsigned long long c = cnt[i];
+        if (c) atomicAdd((unsigned long long *)(i == kMaxExWorld ? oob : &counts[i]), c);
+    }
+}
+hipError_t launch_ex_dest(Src key, const uint64_t *vkey, int64_t n, int64_t pmin, int64_t pcount, int world, int64_t *dest,
+                          uint64_t *vdest, int64_t *counts, int64_t *oob, hipStream_t s) {
+    (void)hipGetLastError();
+    if (n <= 0) return hipSuccess;
+    k_ex_dest<<<grid_for(n, 256, 4), 256, 0, s>>>(key, vkey, n, pmin, pcount, world, dest, vdest, counts, oob);
+    return launch_status();
+}
+
+__global__ __launch_bounds__(256) void k_ex_pack(Src src, const uint64_t *vdest, const int64_t *pos, int64_t n, int64_t *out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        if (bit(vdest, i)) out[pos[i]] = ld(src, i);
+}
+hipError_t launch_ex_pack(Src src, const uint64_t *vdest, const int64_t *pos, int64_t n, int64_t *out, hipStream_t s) {
+    (void)hipGetLastError();
+    if (n <= 0) return hipSuccess;
+    k_ex_pack<<<grid_for(n, 256, 4), 256, 0, s>>>(src, vdest, pos, n, out);
+    return launch_status();
+}
+
+// mask word per row: bit j = source vector j holds a value in that row (j < 63)
+__global__ __launch_bounds__(256) void k_ex_mask(ExValid v, const uint64_t *vdest, const int64_t *pos, int64_t n, int64_t *out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (!bit(vdest, i)) continue;
+        uint64_t m = 0;
+        for (int j = 0; j < v.n; j++) m |= (uint64_t)bit(v.valid[j], i) << j;
+        out[pos[i]] = (int64_t)m;
+    }
+}
+hipError_t launch_ex_mask(const ExValid &v, const uint64_t *vdest, const int64_t *pos, int64_t n, int64_t *out, hipStream_t s) {
+    (void)hipGetLastError();
+    if (n <= 0) return hipSuccess;
+    k_ex_mask<<<grid_for(n, 256, 4), 256, 0, s>>>(v, vdest, pos, n, out);
+    return launch_status();
+}
+
+__global__ __launch_bounds__(256) void k_ex_unmask(const int64_t *mask, int64_t n, int j, uint64_t *valid) {
+    const int64_t nw = (n + 63) >> 6;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave);
+    for (int64_t w = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; w < nw; w += wstride) {
+        const int64_t i = (w << 6) + lane;
+        const uint64_t m = __ballot(i < n && (((uint64_t)mask[i < n ? i : 0] >> j) & 1ull));
+        if (lane == 0) valid[w] = m;
+    }
+}
+hipError_t launch_ex_unmask(const int64_t *mask, int64_t n, int j, uint64_t *valid, hipStream_t s) {
+    (void)hipGetLastError();
+    if (n <= 0) return hipSuccess;
+    k_ex_unmask<<<grid_for(n, 256, 4), 256, 0, s>>>(mask, n, j, valid);
+    return launch_status();
+}
+
+}  // namespace vdl
