@@ -66,6 +66,15 @@ template <int K> __device__ __forceinline__ int64_t ldk(const Src &s, int64_t i)
     if (K == SRC_I8) return ((const int8_t *)s.p)[i];
     return (int64_t)((uint64_t)s.from + (uint64_t)i * (uint64_t)s.step);
 }
+// the same for data that is read once (streams through a fold): non-temporal, so that it does not displace what the
+// following statements reuse
+template <int K> __device__ __forceinline__ int64_t ldk_stream(const Src &s, int64_t i) {
+    if (K == SRC_I64) return __builtin_nontemporal_load((const int64_t *)s.p + i);
+    if (K == SRC_I32) return __builtin_nontemporal_load((const int32_t *)s.p + i);
+    if (K == SRC_I16) return __builtin_nontemporal_load((const int16_t *)s.p + i);
+    if (K == SRC_I8) return __builtin_nontemporal_load((const int8_t *)s.p + i);
+    return (int64_t)((uint64_t)s.from + (uint64_t)i * (uint64_t)s.step);
+}
 template <class F> __device__ __forceinline__ void by_kind(int kind, F f) {
     switch (kind) {
     case SRC_I64: f(std::integral_constant<int, SRC_I64>{}); break;
@@ -74,6 +83,11 @@ template <class F> __device__ __forceinline__ void by_kind(int kind, F f) {
     case SRC_I8: f(std::integral_constant<int, SRC_I8>{}); break;
     default: f(std::integral_constant<int, SRC_RANGE>{}); break;
     }
+}
+template <class F> __device__ __forceinline__ void by_reduction(int rk, F f) {        // same for R_SUM / R_MIN / R_MAX
+    if (rk == R_SUM) f(std::integral_constant<int, R_SUM>{});
+    else if (rk == R_MIN) f(std::integral_constant<int, R_MIN>{});
+    else f(std::integral_constant<int, R_MAX>{});
 }
 constexpr int kGatherUnroll = 4;      // bitmap words (64 positions each) a wave has in flight
 

@@ -207,7 +207,7 @@ int fold_scratch_blocks() { return kFoldBlocks; }
 
 __global__ __launch_bounds__(256) void k_fold_global(int kind, Src d, const uint64_t *vd, const uint64_t *vc, int64_t n,
                                                      int64_t *scratch) {
-    constexpr int U = kGatherUnroll;
+    constexpr int U = 8;                                        // 4 KB of data per wave in flight: a cold stream needs it
     const int rk = kind == 1 ? R_MIN : kind == 2 ? R_MAX : R_SUM;
     const int ak = kind == 4 ? R_MIN : rk;
     const int64_t nw = (n + 63) >> 6;
@@ -217,7 +217,8 @@ __global__ __launch_bounds__(256) void k_fold_global(int kind, Src d, const uint
     // slots, and for count / choose the result itself -- all three come from the bitmap words, not from the rows
     int64_t acc = r_identity(rk);
     int64_t first = INT64_MAX, cnt = 0, chosen = INT64_MAX;
-    by_kind(d.kind, [&](auto kd) {
+    by_kind(d.kind, [&](auto kd) { by_reduction(rk, [&](auto rc) {
+        constexpr int RK = decltype(rc)::value;
         for (int64_t w0 = wave_index() * U; w0 < nw; w0 += wstride) {
             int64_t x[U];
             uint64_t mc[U], md[U];
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256) void k_fold_global(int kind, Src d, const uint
             for (int u = 0; u < U; u++) {
                 const int64_t w = w0 + u < nw ? w0 + u : nw - 1;
                 const int64_t i = (w << 6) + lane;
-                x[u] = kind < 3 ? ldk<decltype(kd)::value>(d, i < n ? i : 0) : 0;     // wave-uniform test; masked lanes read slot 0
+                x[u] = kind < 3 ? ldk_stream<decltype(kd)::value>(d, i < n ? i : 0) : 0;     // wave-uniform test; masked lanes read slot 0
                 const int64_t rem = n - (w << 6);
                 mc[u] = w0 + u < nw ? (rem < 64 ? (1ull << rem) - 1 : ~0ull) : 0ull;
             }
@@ -251,10 +252,10 @@ __global__ __launch_bounds__(256) void k_fold_global(int kind, Src d, const uint
                 if (mc[u] && first == INT64_MAX) first = wbase + __ffsll((long long)mc[u]) - 1;      // words come in ascending order per wave
                 if (md[u] && chosen == INT64_MAX) chosen = wbase + __ffsll((long long)md[u]) - 1;
                 cnt += __popcll(md[u]);
-                if ((md[u] >> lane) & 1ull) acc = r_combine(rk, acc, x[u]);
+                if ((md[u] >> lane) & 1ull) acc = r_combine(RK, acc, x[u]);
             }
         }
-    });
+    }); });
     if (kind == 3) acc = lane == 0 ? cnt : 0;
     else if (kind == 4) acc = lane == 0 ? chosen : INT64_MAX;
     if (lane != 0) { first = INT64_MAX; cnt = 0; }
@@ -772,77 +773,112 @@ __device__ __forceinline__ void atomic_combine(int rk, int64_t *addr, int64_t v)
 // (dense GROUP BY domains) the per-word atomics all landed on the same handful of addresses and serialised.
 __global__ __launch_bounds__(256) void k_seg_fold(int kind, Src d, const uint64_t *vd, const uint64_t *vc, const uint64_t *heads,
                                                   const int64_t *wordhd, int64_t n, int64_t *out, uint64_t *vout) {
-    const int rk = (kind == 1 || kind == 4) ? R_MIN : kind == 2 ? R_MAX : R_SUM;
+    constexpr int U = kGatherUnroll;
+    const int rk_rt = (kind == 1 || kind == 4) ? R_MIN : kind == 2 ? R_MAX : R_SUM;
     const int64_t nw = (n + 63) >> 6;
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / kWave);
-    const int64_t g = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    const int64_t g = wave_index();
     const int64_t per = (nw + nwaves - 1) / nwaves;
     const int64_t w_end = (g + 1) * per < nw ? (g + 1) * per : nw;
-    int64_t carry_h = -1, carry_x = r_identity(rk);           // wave-uniform: the run still open after the previous word
-    for (int64_t w = g * per; w < w_end; w++) {
-        const int64_t i = (w << 6) + lane;
-        const uint64_t hm = heads[w] & (lane == 63 ? ~0ull : ((2ull << lane) - 1));   // heads at or before this lane
-        int64_t h = hm ? (w << 6) + 63 - __clzll((long long)hm) : (w > 0 ? wordhd[w - 1] : -1);
-        const bool ok = i < n && bit(vc, i) && bit(vd, i) && h >= 0;
-        int64_t x = r_identity(rk);
-        if (ok) x = kind == 3 ? 1 : kind == 4 ? i : ld(d, i);
-        // lane segments = maximal stretches of consecutive active lanes with one head; an EPS slot
-        // inside a run splits it into several segments, each adds its part to the same out[h]
-        const int64_t hp = __shfl_up(h, 1, kWave);
-        const bool okp = __shfl_up((int)ok, 1, kWave) != 0;
-        const bool starts = lane == 0 || !ok || !okp || hp != h;
-        const uint64_t sm = __ballot(starts) & (lane == 63 ? ~0ull : ((2ull << lane) - 1));
-        const int seg0 = 63 - __clzll((long long)sm);   // first lane of my segment (bit 0 is always set)
+    const uint64_t upto = lane == 63 ? ~0ull : ((2ull << lane) - 1);        // lanes at or before mine
+    by_kind(d.kind, [&](auto kd) { by_reduction(rk_rt, [&](auto rc) {
+        constexpr int rk = decltype(rc)::value;
+        int64_t carry_h = -1, carry_x = r_identity(rk);       // wave-uniform: the run still open after the previous word
+        for (int64_t w0 = g * per; w0 < w_end; w0 += U) {
+            // operands of U words first (the words of a wave are processed in order: the carried run links them)
+            uint64_t hw_[U], okw_[U];
+            int64_t x_[U], prev_[U];
 #pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-            const int64_t y = __shfl_up(x, off, kWave);
-            if (lane - off >= seg0) x = r_combine(rk, x, y);
-        }
-        const int64_t hn = __shfl_down(h, 1, kWave);
-        const bool okn = __shfl_down((int)ok, 1, kWave) != 0;
-        const bool tail = ok && (lane == kWave - 1 || !okn || hn != h);
-        // runs that begin and end inside this word with every slot taking part are one segment nobody else adds to:
-        // a plain store and one validity update per word (a sparse GROUP BY has ~30 such runs per word, and their
-        // atomics on out[] and on the same word of vout[] were most of the kernel)
-        const uint64_t hw = heads[w], okm = __ballot(ok);
-        bool whole = false;
-        if ((hw >> lane) & 1) {
-            const uint64_t later = lane == kWave - 1 ? 0 : hw >> (lane + 1);
-            if (later) {
-                const int q = lane + __ffsll((long long)later);           // lane of the next head (<= 63)
-                const uint64_t range = (1ull << q) - (1ull << lane);
-                whole = (okm & range) == range;
+            for (int u = 0; u < U; u++) {
+                const int64_t w = w0 + u < w_end ? w0 + u : w_end - 1;
+                const int64_t i = (w << 6) + lane;
+                hw_[u] = heads[w];
+                prev_[u] = w > 0 ? wordhd[w - 1] : -1;
+                const int64_t rem = n - (w << 6);
+                okw_[u] = rem < 64 ? (1ull << rem) - 1 : ~0ull;
+                x_[u] = kind < 3 ? ldk<decltype(kd)::value>(d, i < n ? i : 0) : (kind == 3 ? 1 : i);
+            }
+            if (vc) {
+                uint64_t t[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) t[u] = vc[w0 + u < w_end ? w0 + u : w_end - 1];
+#pragma unroll
+                for (int u = 0; u < U; u++) okw_[u] &= t[u];
+            }
+            if (vd) {
+                uint64_t t[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) t[u] = vd[w0 + u < w_end ? w0 + u : w_end - 1];
+#pragma unroll
+                for (int u = 0; u < U; u++) okw_[u] &= t[u];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (w0 + u >= w_end) break;                    // wave-uniform
+                const int64_t w = w0 + u;
+                const uint64_t hw = hw_[u];
+                const uint64_t hm = hw & upto;                 // heads at or before this lane
+                const int64_t h = hm ? (w << 6) + 63 - __clzll((long long)hm) : prev_[u];
+                const bool ok = ((okw_[u] >> lane) & 1ull) != 0 && h >= 0;
+                int64_t x = ok ? x_[u] : r_identity(rk);
+                // lane segments = maximal stretches of consecutive active lanes with one head; an EPS slot
+                // inside a run splits it into several segments, each adds its part to the same out[h]
+                const int64_t hp = __shfl_up(h, 1, kWave);
+                const uint64_t okm = __ballot(ok);
+                const bool okp = lane > 0 && ((okm >> (lane - 1)) & 1ull);
+                const bool starts = lane == 0 || !ok || !okp || hp != h;
+                const uint64_t sm = __ballot(starts) & upto;
+                const int seg0 = 63 - __clzll((long long)sm);  // first lane of my segment (bit 0 is always set)
+#pragma unroll
+                for (int off = 1; off < kWave; off <<= 1) {
+                    const int64_t y = __shfl_up(x, off, kWave);
+                    if (lane - off >= seg0) x = r_combine(rk, x, y);
+                }
+                const int64_t hn = __shfl_down(h, 1, kWave);
+                const bool okn = lane < kWave - 1 && ((okm >> (lane + 1)) & 1ull);
+                const bool tail = ok && (lane == kWave - 1 || !okn || hn != h);
+                // runs that begin and end inside this word with every slot taking part are one segment nobody else adds
+                // to: a plain store and one validity update per word (a sparse GROUP BY has ~30 such runs per word,
+                // and their atomics on out[] and on the same word of vout[] were most of the kernel)
+                bool whole = false;
+                if ((hw >> lane) & 1) {
+                    const uint64_t later = lane == kWave - 1 ? 0 : hw >> (lane + 1);
+                    if (later) {
+                        const int q = lane + __ffsll((long long)later);       // lane of the next head (<= 63)
+                        const uint64_t range = (1ull << q) - (1ull << lane);
+                        whole = (okm & range) == range;
+                    }
+                }
+                const uint64_t wholem = __ballot(whole);
+                const bool mine = tail && ((wholem >> seg0) & 1);              // my segment is such a run
+                // the run carried over from the previous word: continue it in this word's first segment, or write it out
+                if (carry_h >= 0) {
+                    const bool ok0 = (okm & 1ull) != 0;
+                    const int64_t h0 = __shfl(h, 0, kWave);
+                    if (ok0 && h0 == carry_h) {
+                        if (tail && seg0 == 0) x = r_combine(rk, x, carry_x);
+                    } else if (lane == 0) {
+                        atomic_combine(rk, &out[carry_h], carry_x);
+                        atomicOr((unsigned long long *)&vout[carry_h >> 6], 1ull << (carry_h & 63));
+                    }
+                    carry_h = -1;
+                }
+                if ((okm >> (kWave - 1)) & 1ull) { carry_h = __shfl(h, kWave - 1, kWave); carry_x = __shfl(x, kWave - 1, kWave); }   // lane 63 is that segment's tail
+                if (mine) {
+                    out[h] = x;
+                } else if (tail && lane != kWave - 1) {
+                    atomic_combine(rk, &out[h], x);
+                    atomicOr((unsigned long long *)&vout[h >> 6], 1ull << (h & 63));
+                }
+                if (lane == 0 && wholem) atomicOr((unsigned long long *)&vout[w], wholem);   // runs from other words may set bits here too
             }
         }
-        const uint64_t wholem = __ballot(whole);
-        const bool mine = tail && ((wholem >> seg0) & 1);                  // my segment is such a run
-        // the run carried over from the previous word: continue it in this word's first segment, or write it out
-        if (carry_h >= 0) {
-            const bool ok0 = __shfl((int)ok, 0, kWave) != 0;
-            const int64_t h0 = __shfl(h, 0, kWave);
-            if (ok0 && h0 == carry_h) {
-                if (tail && seg0 == 0) x = r_combine(rk, x, carry_x);
-            } else if (lane == 0) {
-                atomic_combine(rk, &out[carry_h], carry_x);
-                atomicOr((unsigned long long *)&vout[carry_h >> 6], 1ull << (carry_h & 63));
-            }
-            carry_h = -1;
+        if (carry_h >= 0 && lane == 0) {
+            atomic_combine(rk, &out[carry_h], carry_x);
+            atomicOr((unsigned long long *)&vout[carry_h >> 6], 1ull << (carry_h & 63));
         }
-        const bool ok63 = __shfl((int)ok, kWave - 1, kWave) != 0;
-        if (ok63) { carry_h = __shfl(h, kWave - 1, kWave); carry_x = __shfl(x, kWave - 1, kWave); }   // lane 63 is that segment's tail
-        if (mine) {
-            out[h] = x;
-        } else if (tail && lane != kWave - 1) {
-            atomic_combine(rk, &out[h], x);
-            atomicOr((unsigned long long *)&vout[h >> 6], 1ull << (h & 63));
-        }
-        if (lane == 0 && wholem) atomicOr((unsigned long long *)&vout[w], wholem);   // runs from other words may set bits here too
-    }
-    if (carry_h >= 0 && lane == 0) {
-        atomic_combine(rk, &out[carry_h], carry_x);
-        atomicOr((unsigned long long *)&vout[carry_h >> 6], 1ull << (carry_h & 63));
-    }
+    }); });
 }
 
 __global__ void k_seg_fill(int64_t *out, int64_t v, int64_t n) {
