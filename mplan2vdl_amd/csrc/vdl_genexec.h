@@ -254,7 +254,22 @@ struct GenExec {
         expr_emit(*e.r, prog);
         prog.code[prog.n_instr++] = (signed char)e.bin;
     }
+    static bool expr_fits(const ExprNode &e) { return e.leaves <= kExprLeaves && e.instrs <= kExprInstrs && e.depth <= kExprDepth; }
     DVec expr_force(const DVec &v) {
+        if (!expr_fits(*v.ex)) {            // a predicate tree larger than k_expr takes (kept for k_pred) has to produce values after all
+            auto side = [&](const std::shared_ptr<ExprNode> &x) {
+                if (x->bin < 0) return x;
+                DVec t; t.kind = DVec::EXPR; t.n = v.n; t.ex = x;
+                auto leaf = std::make_shared<ExprNode>();
+                leaf->leaf = expr_force(t);
+                return leaf;
+            };
+            auto top = std::make_shared<ExprNode>();
+            top->bin = v.ex->bin; top->l = side(v.ex->l); top->r = side(v.ex->r);
+            top->leaves = 2; top->instrs = 3; top->depth = 2;
+            DVec t; t.kind = DVec::EXPR; t.n = v.n; t.ex = top;
+            return expr_force(t);
+        }
         const ExprNode &e = *v.ex;
         DVec o; o.kind = DVec::DENSE; o.n = v.n;
         o.valid = expr_valid(e, v.n);
@@ -264,13 +279,54 @@ struct GenExec {
         HIP_CHECK(launch_expr(prog, (int64_t *)o.data->p, v.n, s));
         return o;
     }
+    // A tree that is a filter predicate -- LogicalAnd / LogicalOr over comparisons of stored vectors -- as a program on
+    // 64-row masks (k_pred): no 0/1 vector is ever written.  false: not of that shape (arithmetic inside, too large).
+    bool pred_on = !getenv("VDL_NO_PRED_FUSION");
+    std::vector<char> lazy_pred_ok;          // Binary statements read only by the filter idiom FoldSelect(RangeV 0 1 this, this)
+    bool pred_cmp(PredProg &P, int op, const DVec &a, const DVec &b) {
+        if (P.n_cmp >= kPredCmps || P.n_instr >= kPredInstrs || a.n != b.n) return false;
+        P.a[P.n_cmp] = src_of(a); P.b[P.n_cmp] = src_of(b); P.op[P.n_cmp] = (signed char)op;
+        P.code[P.n_instr++] = (signed char)P.n_cmp++;
+        return true;
+    }
+    bool pred_emit(const ExprNode &e, PredProg &P, int depth) {
+        if (depth >= kPredDepth) return false;
+        auto is_leaf = [](const ExprNode &x) { return x.bin < 0; };
+        auto same_leaf = [&](const ExprNode &x, const ExprNode &y) {
+            if (x.bin >= 0 || y.bin >= 0) return false;
+            const Src p = src_of(x.leaf), q = src_of(y.leaf);
+            return p.p == q.p && p.kind == q.kind && p.from == q.from && p.step == q.step && x.leaf.n == y.leaf.n;
+        };
+        if (is_leaf(e)) {                                        // a stored value read as a truth value
+            DVec zero; zero.kind = DVec::RANGE; zero.n = e.leaf.n; zero.from = 0; zero.step = 0;
+            return pred_cmp(P, P_NE, e.leaf, zero);
+        }
+        if ((e.bin == B_GT || e.bin == B_EQ) && is_leaf(*e.l) && is_leaf(*e.r))
+            return pred_cmp(P, e.bin == B_GT ? P_GT : P_EQ, e.l->leaf, e.r->leaf);
+        if (e.bin == B_LOR && e.l->bin == B_GT && e.r->bin == B_EQ) {        // a >= b as the emitter prints it (Vdl.hs:143)
+            const ExprNode &g = *e.l, &q = *e.r;
+            if ((same_leaf(*g.l, *q.r) && same_leaf(*g.r, *q.l)) || (same_leaf(*g.l, *q.l) && same_leaf(*g.r, *q.r)))
+                return pred_cmp(P, P_GE, g.l->leaf, g.r->leaf);
+        }
+        if (e.bin == B_SUB && is_leaf(*e.l) && e.l->leaf.kind == DVec::RANGE && e.l->leaf.step == 0 && e.l->leaf.from == 1 &&
+            e.r->bin == B_EQ && is_leaf(*e.r->l) && is_leaf(*e.r->r))            // a != b = 1 - (a == b) (Vdl.hs:152)
+            return pred_cmp(P, P_NE, e.r->l->leaf, e.r->r->leaf);
+        if (e.bin == B_LAND || e.bin == B_LOR) {
+            if (!pred_emit(*e.l, P, depth) || !pred_emit(*e.r, P, depth + 1)) return false;
+            if (P.n_instr >= kPredInstrs) return false;
+            P.code[P.n_instr++] = (signed char)(e.bin == B_LAND ? P_AND : P_OR);
+            return true;
+        }
+        return false;
+    }
+
     // Binary over stored vectors / pending trees: extend the tree; run it unless the only reader is another Binary
     bool expr_binary(const Node &n, const DVec &a, const DVec &b, DVec &o) {
         if (!fuse_on || n.bin == B_DIV || n.bin == B_MOD) return false;      // division stays in k_binary (code size, see k_expr)
         const bool ta = a.kind == DVec::EXPR, tb = b.kind == DVec::EXPR;
         if (!(ta || leafable(a)) || !(tb || leafable(b)) || a.n != b.n) return false;
         if (!ta && !tb && a.kind == DVec::RANGE && b.kind == DVec::RANGE && a.step == 0 && b.step == 0) return false;   // constant folding stays
-        const bool lazy = n_uses[(size_t)n.id] == 1 && read_by_binary_only[(size_t)n.id];
+        const bool lazy = (n_uses[(size_t)n.id] == 1 && read_by_binary_only[(size_t)n.id]) || (pred_on && lazy_pred_ok[(size_t)n.id]);
         if (!lazy && !ta && !tb) return false;                   // a lone operator: the plain kernel
         DVec x = a, y = b;
         for (;;) {
@@ -280,7 +336,12 @@ struct GenExec {
             t->leaves = el->leaves + er->leaves;
             t->instrs = el->instrs + er->instrs + 1;
             t->depth = std::max(el->depth, er->depth + 1);
-            if (t->leaves <= kExprLeaves && t->instrs <= kExprInstrs && t->depth <= kExprDepth) {
+            bool fits = expr_fits(*t);
+            if (!fits && pred_on && (n.bin == B_LAND || n.bin == B_LOR)) {      // predicates have limits of their own (k_pred)
+                PredProg probe;
+                fits = pred_emit(*t, probe, 0);
+            }
+            if (fits) {
                 o = DVec{};
                 o.kind = DVec::EXPR; o.n = a.n; o.ex = t;
                 if (!lazy) o = expr_force(o);
@@ -701,6 +762,19 @@ struct GenExec {
                     return o;
                 }
             }
+            if (V(n.b).kind == DVec::EXPR && pred_on) {
+                DVec ctl0 = densify(V(n.a));
+                PredProg prog;
+                if (ctl0.n == V(n.b).n && ctl0.kind == DVec::RANGE && ctl0.step != 0 && pred_emit(*V(n.b).ex, prog, 0)) {
+                    BufP ok = expr_valid(*V(n.b).ex, ctl0.n);
+                    if (ctl0.valid && ctl0.valid != ok) ok = ok ? and_bitmaps(ok, ctl0.valid, ctl0.n) : ctl0.valid;
+                    o.kind = DVec::RANGE; o.n = ctl0.n; o.from = 0; o.step = 1;
+                    o.valid = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(o.n), 1));
+                    HIP_CHECK(launch_pred(prog, ok ? (const uint64_t *)ok->p : nullptr, (uint64_t *)o.valid->p, o.n, s));
+                    note_subset(o.valid, ok);
+                    return o;
+                }
+            }
             if (V(n.b).kind == DVec::LAZYG) {
                 DVec ctl0 = densify(V(n.a));
                 const LazyGather &lg = *V(n.b).lg;
@@ -1004,6 +1078,20 @@ struct GenExec {
                 }
                 if (rv >= 0 && fs >= 0 && P.at(fs).a == rv && readers[(size_t)rv].size() == 1 && n_uses[(size_t)rv] == 1) lazy_gather_ok[(size_t)id] = 1;
             }
+        }
+        lazy_pred_ok.assign(P.nodes.size(), 0);
+        for (int id : P.order) {
+            const Node &b = P.at(id);
+            if (b.op != Op::Binary || !needed[(size_t)id] || n_uses[(size_t)id] != (int)readers[(size_t)id].size()) continue;   // targets excluded
+            const auto &rd = readers[(size_t)id];
+            if (rd.size() != 2) continue;
+            int rv = -1, fs = -1;
+            for (const auto &r : rd) {
+                const Node &x = P.at(r.first);
+                if (x.op == Op::RangeV && x.imm1 != 0 && r.second == 0) rv = r.first;
+                if (x.op == Op::FoldSelect && r.second == 1 && x.b == id) fs = r.first;
+            }
+            if (rv >= 0 && fs >= 0 && P.at(fs).a == rv && readers[(size_t)rv].size() == 1 && n_uses[(size_t)rv] == 1) lazy_pred_ok[(size_t)id] = 1;
         }
         p->outs.clear();
         p->timings.clear();

@@ -102,6 +102,19 @@ struct ExprProg {
 };
 hipError_t launch_expr(const ExprProg &prog, int64_t *out, int64_t n, hipStream_t s);
 hipError_t launch_and_words(const uint64_t *a, const uint64_t *b, uint64_t *out, int64_t nwords, hipStream_t s);
+// A filter predicate -- comparisons between stored vectors joined by LogicalAnd / LogicalOr -- evaluated straight into
+// the selection bitmap: a comparison of 64 rows is one 64-bit mask (v_cmp writes it), the connectives work on masks.
+// Postfix: code >= 0 pushes comparison #code, P_AND / P_OR combine the two topmost masks.
+constexpr int kPredCmps = 16, kPredInstrs = 32, kPredDepth = 8;
+enum : int { P_GT = 0, P_EQ = 1, P_GE = 2, P_NE = 3, P_AND = -1, P_OR = -2 };
+struct PredProg {
+    int n_instr = 0, n_cmp = 0;
+    Src a[kPredCmps], b[kPredCmps];
+    signed char op[kPredCmps] = {};
+    signed char code[kPredInstrs] = {};
+};
+// out bit i = predicate(i) & valid bit i (valid null = every slot)
+hipError_t launch_pred(const PredProg &prog, const uint64_t *valid, uint64_t *out, int64_t n, hipStream_t s);
 // A first-level filter evaluated straight off its columns: bit i = every column's value lies in one of its intervals
 struct FilterArgs {
     int ncol = 0, never = 0;

@@ -155,6 +155,73 @@ hipError_t launch_filter_columns(const FilterArgs &a0, uint64_t *out, int64_t n,
     return launch_status();
 }
 
+// Filter predicates on masks (PredProg, vdl_kernels.h).  A wave takes U bitmap words per trip.  Its mask stack lives
+// across the lanes of one 64-bit register: lane depth*U + u holds the mask of word u at that stack depth, so pushing is
+// a lane-id compare, a connective is one shuffle by U lanes, and nothing is indexed dynamically.
+constexpr int kPredWords = 4;
+static_assert(kPredDepth * kPredWords <= kWave, "the mask stack fits the lanes of a wave");
+__global__ __launch_bounds__(256) void k_pred(const PredProg P, const uint64_t *valid, uint64_t *out, int64_t n) {
+    constexpr int U = kPredWords;
+    const int64_t nw = (n + 63) >> 6;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave) * U;
+    for (int64_t w0 = wave_index() * U; w0 < nw; w0 += wstride) {
+        int64_t row[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { const int64_t i = ((w0 + u) << 6) + lane; row[u] = i < n ? i : 0; }    // bits past n are cut below
+        uint64_t stk = 0;
+        int sp = 0;
+        for (int k = 0; k < P.n_instr; k++) {
+            const int code = P.code[k];                          // wave-uniform
+            if (code >= 0) {
+                const Src A = P.a[code], B = P.b[code];
+                const int op = P.op[code];
+                uint64_t m[U];
+                by_kind(A.kind, [&](auto ka) { by_kind(B.kind, [&](auto kb) {
+                    int64_t x[U], y[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++) { x[u] = ldk<decltype(ka)::value>(A, row[u]); y[u] = ldk<decltype(kb)::value>(B, row[u]); }
+                    if (op == P_GT) {
+#pragma unroll
+                        for (int u = 0; u < U; u++) m[u] = __ballot(x[u] > y[u]);
+                    } else if (op == P_EQ) {
+#pragma unroll
+                        for (int u = 0; u < U; u++) m[u] = __ballot(x[u] == y[u]);
+                    } else if (op == P_GE) {
+#pragma unroll
+                        for (int u = 0; u < U; u++) m[u] = __ballot(x[u] >= y[u]);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < U; u++) m[u] = __ballot(x[u] != y[u]);
+                    }
+                }); });
+#pragma unroll
+                for (int u = 0; u < U; u++) if (lane == sp * U + u) stk = m[u];
+                sp++;
+            } else {
+                const uint64_t above = __shfl_down(stk, U, kWave);      // the same word one level up
+                if (lane / U == sp - 2) stk = code == P_AND ? (stk & above) : (stk | above);
+                sp--;
+            }
+        }
+        // lanes 0 .. U-1 hold the result words
+        if (lane < U && w0 + lane < nw) {
+            const int64_t w = w0 + lane;
+            const int64_t rem = n - (w << 6);
+            uint64_t keep = rem < 64 ? (1ull << rem) - 1 : ~0ull;
+            if (valid) keep &= valid[w];
+            out[w] = stk & keep;
+        }
+    }
+}
+hipError_t launch_pred(const PredProg &prog, const uint64_t *valid, uint64_t *out, int64_t n, hipStream_t s) {
+    (void)hipGetLastError();
+    if (n <= 0) return hipSuccess;
+    if (prog.n_instr <= 0 || prog.n_cmp <= 0 || prog.n_cmp > kPredCmps || prog.n_instr > kPredInstrs) return hipErrorInvalidValue;
+    k_pred<<<grid_for((n + 63) >> 6, 4, kPredWords), 256, 0, s>>>(prog, valid, out, n);
+    return launch_status();
+}
+
 __global__ void k_and_words(const uint64_t *a, const uint64_t *b, uint64_t *out, int64_t nw) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += stride) out[i] = a[i] & b[i];

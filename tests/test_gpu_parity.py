@@ -648,6 +648,60 @@ def test_results_as_numpy_arrays_and_execute_collect(q6_text):
     e.close()
 
 
+def _random_predicate(rng, k, vals, depth):
+    """VDL lines for a random boolean tree over the value statements `vals`; returns (lines, id of the root, next free id).
+    Leaves: a > b, a == b, a >= b and a != b as the emitter prints them (Vdl.hs:139-152), or a bare value as a truth value."""
+    if depth == 0 or rng.random() < 0.25:
+        a, b = (int(x) for x in rng.choice(vals, 2))
+        kind = rng.integers(0, 5)
+        if kind == 0:
+            return ["%d,Greater,val,Id %d,val,Id %d,val" % (k, a, b)], k, k + 1
+        if kind == 1:
+            return ["%d,Equals,val,Id %d,val,Id %d,val" % (k, a, b)], k, k + 1
+        if kind == 2:       # a >= b
+            return ["%d,Greater,val,Id %d,val,Id %d,val" % (k, a, b), "%d,Equals,val,Id %d,val,Id %d,val" % (k + 1, b, a),
+                    "%d,LogicalOr,val,Id %d,val,Id %d,val" % (k + 2, k, k + 1)], k + 2, k + 3
+        if kind == 3:       # a != b
+            return ["%d,Equals,val,Id %d,val,Id %d,val" % (k, a, b), "%d,RangeV,val,1,Id %d,0" % (k + 1, k),
+                    "%d,Subtract,val,Id %d,val,Id %d,val" % (k + 2, k + 1, k)], k + 2, k + 3
+        return [], a, k     # the value itself
+    l1, r1, k = _random_predicate(rng, k, vals, depth - 1)
+    l2, r2, k = _random_predicate(rng, k, vals, depth - 1)
+    op = "LogicalAnd" if rng.random() < 0.5 else "LogicalOr"
+    return l1 + l2 + ["%d,%s,val,Id %d,val,Id %d,val" % (k, op, r1, r2)], k, k + 1
+
+
+def test_filter_predicates_evaluated_on_masks(monkeypatch):
+    """Select over a boolean tree of comparisons between stored vectors (columns of several widths, constants, a
+    vector with EPS slots): the tree runs as one kernel on 64-row masks.  Same result as the oracle and as the
+    operator-by-operator route (VDL_NO_PRED_FUSION), for trees of every size up to more comparisons than one kernel takes."""
+    rng = np.random.default_rng(2024)
+    n = 70001
+    cols = {"t.a": rng.integers(0, 6, n).astype(np.int8), "t.b": rng.integers(0, 6, n).astype(np.int16),
+            "t.c": rng.integers(-3, 4, n).astype(np.int32), "t.d": rng.integers(0, 6, n).astype(np.int64)}
+    head = ["1,Load,t.a", "2,Project,val,Id 1,a", "3,Load,t.b", "4,Project,val,Id 3,b", "5,Load,t.c", "6,Project,val,Id 5,c",
+            "7,Load,t.d", "8,Project,val,Id 7,d", "9,RangeV,val,3,Id 2,0", "10,RangeV,val,0,Id 2,0",
+            # a vector with EPS slots: d gathered through the filter c > 0
+            "11,Greater,val,Id 6,val,Id 10,val", "12,RangeV,val,0,Id 11,1", "13,FoldSelect,val,Id 12,val,Id 11,val", "14,Gather,Id 8,Id 13,val"]
+    vals = [2, 4, 6, 8, 9, 10, 14]
+    e = engine_with(cols)
+    for depth in (0, 1, 2, 3, 4, 5):
+        for rep in range(4):
+            lines, root, k = _random_predicate(rng, 15, vals, depth)
+            if root < 15:
+                continue            # a bare value: nothing to fuse
+            body = lines + ["%d,RangeV,val,0,Id %d,1" % (k, root), "%d,FoldSelect,val,Id %d,val,Id %d,val" % (k + 1, k, root),
+                            "%d,Gather,Id 4,Id %d,val" % (k + 2, k + 1), "%d,MaterializeCompact,Id %d" % (k + 3, k + 2)]
+            text = prog(*(head + body))
+            want = oracle_run(text, cols)
+            monkeypatch.delenv("VDL_NO_PRED_FUSION", raising=False)
+            got = e.run_vdl(text)["results"]
+            assert got == want, (depth, rep, text)
+            monkeypatch.setenv("VDL_NO_PRED_FUSION", "1")
+            assert e.run_vdl(text)["results"] == want, (depth, rep)
+    e.close()
+
+
 def test_large_outputs_can_stay_on_the_device():
     """vdl_plan_set_device_outputs: outputs of >= 65536 values are handed out as device pointers, smaller ones stay
     host-side; the values are those of the host route."""
