@@ -179,7 +179,9 @@ int  vdl_finalize_end(vdl_ctx *ctx, vdl_plan *plan, int slot);
  * runs on that stream, vdl_set_stream).
  * vdl_exchange_spec checks the structure; with sharded_table != NULL ("lineitem") it also verifies
  * that everything below the Partition is row-local over that table (element-wise operators,
- * constants, Gathers out of replicated vectors) and returns VDL_ERR_UNSUPPORTED with the reason
+ * constants, Gathers out of replicated vectors), lets the statements above the Partition read the
+ * replicated tables' columns (the plan remembers the placement for vdl_exchange_begin), and returns
+ * VDL_ERR_UNSUPPORTED with the reason
  * otherwise.  world <= 128. */
 int  vdl_exchange_spec(const vdl_plan *plan, const char *sharded_table, int *n_columns);
 int  vdl_exchange_begin(vdl_ctx *ctx, vdl_plan *plan, int world, int64_t *counts_host /* world */);

@@ -200,6 +200,7 @@ struct vdl_plan {
         std::vector<int> nodes;
         int64_t pmin = 0, pcount = 0;
     } ex;
+    std::string sharded_table;             // placement named in the last vdl_exchange_spec ("" = not stated)
     BufP words;
     int64_t words_cap = 0;
     std::string fallback_note;

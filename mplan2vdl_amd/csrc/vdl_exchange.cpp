@@ -69,7 +69,13 @@ ExchangeSpec analyse_exchange(const Program &P, const std::string &table = std::
         seen[(size_t)id] = 1;
         const Node &n = P.at(id);
         if (is_cut[(size_t)id]) continue;
-        if (n.op == Op::Load) { x.why = "output depends on column " + n.column + " other than through the partition"; return x; }
+        if (n.op == Op::Load) {
+            // columns of the other (replicated) tables are there on every rank: the tail may gather from them by values
+            // that travelled (Q10 prints customer columns through the group's FK value)
+            if (!table.empty() && n.column.compare(0, table.size() + 1, table + ".") != 0) continue;
+            x.why = "output depends on column " + n.column + " other than through the partition";
+            return x;
+        }
         if (id == x.part) { x.why = "Partition reachable past the scatters"; return x; }
         for (int opnd : {n.a, n.b, n.c}) if (opnd > 0) stack.push_back(opnd);
     }
@@ -165,6 +171,7 @@ int vdl_exchange_spec(const vdl_plan *p, const char *sharded_table, int *n_colum
         return VDL_ERR_UNSUPPORTED;
     }
     if (n_columns) *n_columns = (int)x.sources.size() + 1;      // key, scattered vectors, validity mask
+    const_cast<vdl_plan *>(p)->sharded_table = sharded_table ? sharded_table : "";     // vdl_exchange_begin analyses for the same placement
     return VDL_OK;
 }
 
@@ -172,7 +179,7 @@ int vdl_exchange_begin(vdl_ctx *c, vdl_plan *p, int world, int64_t *counts_host)
     if (!c || !p || !counts_host || world < 1 || world > kMaxExWorld) return VDL_ERR_ARG;
     return guard(c, [&] {
         need_device(c);
-        ExchangeSpec x = analyse_exchange(p->prog);
+        ExchangeSpec x = analyse_exchange(p->prog, p->sharded_table);
         if (!x.ok) throw Error(VDL_ERR_UNSUPPORTED, "no sharded-Partition structure: " + x.why);
         GenExec g(c, p);
         g.run_nodes(x.sources, nullptr);

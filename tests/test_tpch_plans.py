@@ -180,3 +180,24 @@ def test_sparse_vector_routes_agree(cfg, monkeypatch, mode):
         got = e.run_vdl(text)["results"]
         e.close()
         assert got == want, (mode, "hierarchical", n)
+
+
+def test_which_plans_have_a_sharded_route(cfg):
+    """Host-only: the plans vdl_exchange_spec accepts for a row-sharded lineitem, and the reasons the others get."""
+    import mplan2vdl_amd as m
+
+    e = m.Engine(device=None)
+    verdict = {}
+    for n in PLANS:
+        p = e.parse(frontend.compile_plan(open(os.path.join(META, "%02d.sql.mplan" % n)).read(), cfg))
+        if p.is_fused:
+            verdict[n] = "fused"
+            continue
+        try:
+            p.exchange_columns("lineitem")
+            verdict[n] = "exchange"
+        except m.VdlError as ex:
+            verdict[n] = str(ex)
+    assert sorted(n for n, v in verdict.items() if v == "fused") == [1, 6]
+    assert sorted(n for n, v in verdict.items() if v == "exchange") == [3, 5, 9, 10, 12, 20]
+    assert "more than one Partition" in verdict[18] and "no Partition" in verdict[14] and "below the Partition" in verdict[4]
