@@ -147,6 +147,12 @@ int  vdl_plan_partial_spec(const vdl_plan *plan, int64_t *n_words, const int32_t
 int  vdl_run_local(vdl_ctx *ctx, vdl_plan *plan, void *dev_partials);
 /* After the merge: produce the outputs from the (merged) words; synchronises. */
 int  vdl_finalize(vdl_ctx *ctx, vdl_plan *plan, const void *dev_partials);
+/* Placement for plans that do not fuse: `table` is split by rows over the ranks, every other table is replicated.
+ * With it, vdl_plan_partial_spec / vdl_run_local / vdl_finalize also serve general plans whose outputs hang off
+ * GLOBAL folds over that table (a join followed by an ungrouped aggregate: TPC-H Q14, Q19): three words per fold
+ * {value, first slot, count}, everything below the folds checked to be row-local, the statements above them run on
+ * the merged scalars.  VDL_ERR_UNSUPPORTED with the reason otherwise.  Also what vdl_exchange_spec records. */
+int  vdl_plan_set_sharded_table(vdl_plan *plan, const char *table);
 /* Global index of this rank's first row (default 0); row ids in VDL_REDUCE_FIRST words are global. */
 int  vdl_plan_set_row_offset(vdl_plan *plan, int64_t row0);
 /* Second merge phase of VDL_REDUCE_FIRST words (see the enum); asynchronous on the context stream. */

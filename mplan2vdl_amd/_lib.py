@@ -60,6 +60,7 @@ def load():
         "vdl_run_local": (i32, [vp, vp, vp]),
         "vdl_finalize": (i32, [vp, vp, vp]),
         "vdl_plan_set_row_offset": (i32, [vp, i64]),
+        "vdl_plan_set_sharded_table": (i32, [vp, ctypes.c_char_p]),
         "vdl_resolve_first": (i32, [vp, vp, vp]),
         "vdl_exchange_spec": (i32, [vp, ctypes.c_char_p, P(i32)]),
         "vdl_exchange_begin": (i32, [vp, vp, i32, P(i64)]),
@@ -81,6 +82,6 @@ ABI_SYMBOLS = [
     "vdl_upload_column", "vdl_generate_column", "vdl_drop_column", "vdl_column_info", "vdl_download_column",
     "vdl_parse", "vdl_plan_free", "vdl_plan_describe", "vdl_plan_is_fused", "vdl_plan_set_fusion",
     "vdl_plan_set_profiling", "vdl_run", "vdl_n_outputs", "vdl_output", "vdl_plan_set_device_outputs", "vdl_output_device", "vdl_n_timings", "vdl_timing",
-    "vdl_plan_scan_stats", "vdl_plan_partial_spec", "vdl_run_local", "vdl_finalize", "vdl_finalize_begin", "vdl_finalize_end", "vdl_plan_set_row_offset", "vdl_resolve_first", "vdl_exchange_spec", "vdl_exchange_begin", "vdl_exchange_pack",
+    "vdl_plan_scan_stats", "vdl_plan_partial_spec", "vdl_run_local", "vdl_finalize", "vdl_finalize_begin", "vdl_finalize_end", "vdl_plan_set_row_offset", "vdl_plan_set_sharded_table", "vdl_resolve_first", "vdl_exchange_spec", "vdl_exchange_begin", "vdl_exchange_pack",
     "vdl_exchange_finish",
 ]

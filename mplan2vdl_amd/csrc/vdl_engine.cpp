@@ -542,11 +542,19 @@ int vdl_plan_scan_stats(const vdl_plan *p, int64_t *rows, int64_t *algo_bytes, d
 
 int vdl_plan_partial_spec(const vdl_plan *p, int64_t *n_words, const int32_t **reduce_ops) {
     if (!p) return VDL_ERR_ARG;
-    if (!(p->use_fusion && p->fused.ok)) {
-        if (p->ctx) p->ctx->err = "sharded execution needs a fused plan (outputs = global or dense-domain grouped folds)";
-        return VDL_ERR_UNSUPPORTED;
-    }
     vdl_plan *q = const_cast<vdl_plan *>(p);
+    if (!(p->use_fusion && p->fused.ok)) {
+        // not fused: the plan can still be sharded by rows if its outputs hang off global folds (vdl_plan_set_sharded_table)
+        std::string why;
+        if (!general_partial_spec(p, q->reduce_ops, why)) {
+            if (p->ctx) p->ctx->err = "sharded execution needs a fused plan (outputs = global or dense-domain grouped folds) or global folds over the "
+                                      "row-sharded table: " + why;
+            return VDL_ERR_UNSUPPORTED;
+        }
+        if (n_words) *n_words = (int64_t)q->reduce_ops.size();
+        if (reduce_ops) *reduce_ops = q->reduce_ops.data();
+        return VDL_OK;
+    }
     q->reduce_ops.clear();
     bool shardable = true;
     const int64_t off = plan_words(p, &q->reduce_ops, &shardable);
@@ -559,7 +567,7 @@ int vdl_run_local(vdl_ctx *c, vdl_plan *p, void *dev_partials) {
     if (!c || !p || !dev_partials) return VDL_ERR_ARG;
     return guard(c, [&] {
         need_device(c);
-        if (!(p->use_fusion && p->fused.ok)) throw Error(VDL_ERR_UNSUPPORTED, "sharded execution needs a fused plan");
+        if (!(p->use_fusion && p->fused.ok)) { general_run_local(c, p, (int64_t *)dev_partials); return; }
         run_fused_local(c, p, (int64_t *)dev_partials, false);
     });
 }
@@ -568,12 +576,17 @@ int vdl_finalize(vdl_ctx *c, vdl_plan *p, const void *dev_partials) {
     if (!c || !p || !dev_partials) return VDL_ERR_ARG;
     return guard(c, [&] {
         need_device(c);
-        if (!(p->use_fusion && p->fused.ok)) throw Error(VDL_ERR_UNSUPPORTED, "sharded execution needs a fused plan");
+        if (!(p->use_fusion && p->fused.ok)) { general_finalize(c, p, (const int64_t *)dev_partials); return; }
         finalize_begin(c, p, (const int64_t *)dev_partials, 0);
         finalize_end(c, p, 0);
     });
 }
 
+int vdl_plan_set_sharded_table(vdl_plan *p, const char *table) {
+    if (!p) return VDL_ERR_ARG;
+    p->sharded_table = table ? table : "";
+    return VDL_OK;
+}
 int vdl_plan_set_row_offset(vdl_plan *p, int64_t row0) {
     if (!p) return VDL_ERR_ARG;
     p->row_offset = row0;
@@ -601,7 +614,7 @@ int vdl_finalize_begin(vdl_ctx *c, vdl_plan *p, const void *dev_partials, int sl
     if (!c || !p || !dev_partials) return VDL_ERR_ARG;
     return guard(c, [&] {
         need_device(c);
-        if (!(p->use_fusion && p->fused.ok)) throw Error(VDL_ERR_UNSUPPORTED, "sharded execution needs a fused plan");
+        if (!(p->use_fusion && p->fused.ok)) { general_finalize(c, p, (const int64_t *)dev_partials); return; }   // nothing left for _end
         finalize_begin(c, p, (const int64_t *)dev_partials, slot);
     });
 }
@@ -610,6 +623,7 @@ int vdl_finalize_end(vdl_ctx *c, vdl_plan *p, int slot) {
     if (!c || !p) return VDL_ERR_ARG;
     return guard(c, [&] {
         need_device(c);
+        if (!(p->use_fusion && p->fused.ok)) return;
         finalize_end(c, p, slot);
     });
 }

@@ -201,6 +201,8 @@ struct vdl_plan {
         int64_t pmin = 0, pcount = 0;
     } ex;
     std::string sharded_table;             // placement named in the last vdl_exchange_spec ("" = not stated)
+    std::vector<int> cut_folds;            // general plan sharded through its global folds: the folds of the last vdl_run_local
+    std::vector<int64_t> cut_n;            // and the lengths of their operands on this rank
     BufP words;
     int64_t words_cap = 0;
     std::string fallback_note;
@@ -276,6 +278,10 @@ inline const Column &find_col(vdl_ctx *c, const std::string &name) {
 }
 
 std::string describe_plan(const vdl_plan *p);
+// general (not fused) plans sharded by rows through their global folds, vdl_exchange.cpp
+bool general_partial_spec(const vdl_plan *p, std::vector<int32_t> &ops, std::string &why);
+void general_run_local(vdl_ctx *c, vdl_plan *p, int64_t *dev_words);
+void general_finalize(vdl_ctx *c, vdl_plan *p, const int64_t *dev_words);
 
 template <typename F>
 int guard(vdl_ctx *c, F &&f) {

@@ -20,6 +20,66 @@ int resolve_alias(const Program &P, int id) {
     return id;
 }
 
+// Class of every statement below `roots` when `table` is split by rows over the ranks: R = replicated (same on every
+// rank), V = one value per row of the shard, N = (local) row numbers of the shard, as the filter idiom
+// Gather(x, FoldSelect(RangeV 0 step 1, cond)) of Vlite.hs produces them.  false + why: something is not row-local.
+enum : char { R = 0, V = 1, N = 2 };
+bool classify_rows(const Program &P, const std::vector<int> &roots, const std::string &table, const char *boundary,
+                   std::vector<char> &cls, std::string &why) {
+    std::vector<char> below(P.nodes.size(), 0);
+    cls.assign(P.nodes.size(), R);
+    std::vector<int> stack(roots.begin(), roots.end());
+    while (!stack.empty()) {
+        const int id = stack.back(); stack.pop_back();
+        if (below[(size_t)id]) continue;
+        below[(size_t)id] = 1;
+        const Node &n = P.at(id);
+        for (int opnd : {n.a, n.b, n.c}) if (opnd > 0) stack.push_back(opnd);
+    }
+    for (int id : P.order) {
+        if (!below[(size_t)id]) continue;
+        const Node &n = P.at(id);
+        auto C = [&](int o) { return o > 0 ? cls[(size_t)o] : (char)R; };
+        const std::string at = " (statement " + std::to_string(id) + ")";
+        char &out = cls[(size_t)id];
+        switch (n.op) {
+        case Op::Load: out = n.column.compare(0, table.size() + 1, table + ".") == 0 ? V : R; break;
+        case Op::RangeC: break;
+        case Op::Project: case Op::Shuffle: case Op::Materialize: out = C(n.a); break;
+        case Op::Like:
+            if (C(n.b) != R) { why = "Like over a sharded string heap" + at; return false; }
+            if (C(n.a) == N) { why = "Like on row numbers" + at; return false; }
+            out = C(n.a);
+            break;
+        case Op::Binary:
+            if (C(n.a) == N || C(n.b) == N) { why = "arithmetic on row numbers of the sharded table, which are rank-local" + at; return false; }
+            out = (C(n.a) == V || C(n.b) == V) ? V : R;
+            break;
+        case Op::RangeV:
+            if (C(n.a) == R) break;
+            if (n.imm1 == 0) out = V;
+            else if (n.imm0 == 0 && n.imm1 == 1) out = N;
+            else { why = "a strided range over the sharded table is rank-local" + at; return false; }
+            break;
+        case Op::FoldSelect: {
+            if (C(n.a) == R && C(n.b) == R) break;
+            const Node &ctl = P.at(resolve_alias(P, n.a));
+            if (!(ctl.op == Op::RangeV && C(n.a) == N)) { why = "FoldSelect over runs of the sharded table" + at; return false; }
+            out = N;
+            break;
+        }
+        case Op::Gather:
+            if (C(n.a) == R && C(n.b) != N) out = C(n.b);                 // replicated data by FK / replicated positions
+            else if (C(n.a) != R && C(n.b) == N) out = C(n.a);            // shard data by shard row numbers
+            else { why = "Gather mixes replicated and rank-local positions" + at; return false; }
+            break;
+        default:
+            if (C(n.a) != R || C(n.b) != R || C(n.c) != R) { why = std::string(op_name(n.op, n.bin)) + " over the sharded table below " + boundary + at; return false; }
+        }
+    }
+    return true;
+}
+
 // `table`: name of the row-sharded table ("" = trust the caller).  With a table name the statements
 // below the scatters are checked to be row-local over that table: its columns may pass through
 // element-wise operators, constants and Gathers *from* replicated vectors only.
@@ -94,60 +154,8 @@ ExchangeSpec analyse_exchange(const Program &P, const std::string &table = std::
         for (int opnd : {n.a, n.b, n.c}) if (opnd > 0) stack.push_back(opnd);
     }
     if (!table.empty()) {
-        // class of every statement below the Partition: R = replicated (same on every rank), V = one value per
-        // row of the shard, N = (local) row numbers of the shard, as the filter idiom
-        // Gather(x, FoldSelect(RangeV 0 step 1, cond)) of Vlite.hs produces them
-        enum : char { R = 0, V = 1, N = 2 };
-        std::vector<char> below(P.nodes.size(), 0), cls(P.nodes.size(), R);
-        stack.assign(x.sources.begin(), x.sources.end());
-        while (!stack.empty()) {
-            const int id = stack.back(); stack.pop_back();
-            if (below[(size_t)id]) continue;
-            below[(size_t)id] = 1;
-            const Node &n = P.at(id);
-            for (int opnd : {n.a, n.b, n.c}) if (opnd > 0) stack.push_back(opnd);
-        }
-        for (int id : P.order) {
-            if (!below[(size_t)id]) continue;
-            const Node &n = P.at(id);
-            auto C = [&](int o) { return o > 0 ? cls[(size_t)o] : (char)R; };
-            const std::string at = " (statement " + std::to_string(id) + ")";
-            char &out = cls[(size_t)id];
-            switch (n.op) {
-            case Op::Load: out = n.column.compare(0, table.size() + 1, table + ".") == 0 ? V : R; break;
-            case Op::RangeC: break;
-            case Op::Project: case Op::Shuffle: case Op::Materialize: out = C(n.a); break;
-            case Op::Like:
-                if (C(n.b) != R) { x.why = "Like over a sharded string heap" + at; return x; }
-                if (C(n.a) == N) { x.why = "Like on row numbers" + at; return x; }
-                out = C(n.a);
-                break;
-            case Op::Binary:
-                if (C(n.a) == N || C(n.b) == N) { x.why = "arithmetic on row numbers of the sharded table, which are rank-local" + at; return x; }
-                out = (C(n.a) == V || C(n.b) == V) ? V : R;
-                break;
-            case Op::RangeV:
-                if (C(n.a) == R) break;
-                if (n.imm1 == 0) out = V;
-                else if (n.imm0 == 0 && n.imm1 == 1) out = N;
-                else { x.why = "a strided range over the sharded table is rank-local" + at; return x; }
-                break;
-            case Op::FoldSelect: {
-                if (C(n.a) == R && C(n.b) == R) break;
-                const Node &ctl = P.at(resolve_alias(P, n.a));
-                if (!(ctl.op == Op::RangeV && C(n.a) == N)) { x.why = "FoldSelect over runs of the sharded table" + at; return x; }
-                out = N;
-                break;
-            }
-            case Op::Gather:
-                if (C(n.a) == R && C(n.b) != N) out = C(n.b);                 // replicated data by FK / replicated positions
-                else if (C(n.a) != R && C(n.b) == N) out = C(n.a);            // shard data by shard row numbers
-                else { x.why = "Gather mixes replicated and rank-local positions" + at; return x; }
-                break;
-            default:
-                if (C(n.a) != R || C(n.b) != R || C(n.c) != R) { x.why = std::string(op_name(n.op, n.bin)) + " over the sharded table below the Partition" + at; return x; }
-            }
-        }
+        std::vector<char> cls;
+        if (!classify_rows(P, x.sources, table, "the Partition", cls, x.why)) return x;
         for (int id : x.sources) {
             if (cls[(size_t)id] == N) { x.why = "statement " + std::to_string(id) + " feeds the Partition with rank-local row numbers"; return x; }
             if (cls[(size_t)id] != V) { x.why = "statement " + std::to_string(id) + " feeds the Partition but does not depend on table " + table; return x; }
@@ -157,7 +165,128 @@ ExchangeSpec analyse_exchange(const Program &P, const std::string &table = std::
     return x;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// General plans whose outputs hang off GLOBAL folds over the sharded table (join + ungrouped aggregate: Q14, Q19):
+// each rank folds its rows, the fold results travel as mergeable words (vdl_plan_partial_spec / vdl_run_local), and the
+// statements above the folds run on the merged scalars (vdl_finalize).  Same three calls as for fused plans.
+// ------------------------------------------------------------------------------------------------
+struct FoldCut {
+    bool ok = false;
+    std::string why;
+    std::vector<int> folds;            // global Fold{Sum,Min,Max,Count} statements over row-local data, program order
+};
+
+FoldCut analyse_folds(const Program &P, const std::string &table) {
+    FoldCut x;
+    if (table.empty()) { x.why = "no row-sharded table named (vdl_plan_set_sharded_table)"; return x; }
+    std::vector<char> needed(P.nodes.size(), 0);
+    for (int id : P.outputs) needed[(size_t)id] = 1;
+    for (auto it = P.order.rbegin(); it != P.order.rend(); ++it) {
+        const Node &n = P.at(*it);
+        if (!needed[(size_t)n.id]) continue;
+        for (int opnd : {n.a, n.b, n.c}) if (opnd > 0) needed[(size_t)opnd] = 1;
+    }
+    // dep: reads the sharded table not through a cut; via: derived from a cut (a merged scalar)
+    std::vector<char> dep(P.nodes.size(), 0), via(P.nodes.size(), 0);
+    for (int id : P.order) {
+        if (!needed[(size_t)id]) continue;
+        const Node &n = P.at(id);
+        const std::string at = " (statement " + std::to_string(id) + ")";
+        if (n.op == Op::Load) { dep[(size_t)id] = n.column.compare(0, table.size() + 1, table + ".") == 0; continue; }
+        bool d = false, v = false;
+        for (int opnd : {n.a, n.b, n.c}) if (opnd > 0) { d |= dep[(size_t)opnd] != 0; v |= via[(size_t)opnd] != 0; }
+        const bool fold = n.op == Op::FoldSum || n.op == Op::FoldMin || n.op == Op::FoldMax || n.op == Op::FoldCount;
+        if (fold && d && !v) {
+            const Node &ctl = P.at(resolve_alias(P, n.a));
+            if (ctl.op == Op::RangeV && ctl.imm1 == 0) {          // one run over everything: a global fold
+                x.folds.push_back(id);
+                via[(size_t)id] = 1;
+                continue;
+            }
+        }
+        if (v) {
+            // above the folds only scalars: element-wise operators with constants or other merged scalars
+            if (d) { x.why = std::string(op_name(n.op, n.bin)) + " combines a global fold result with rows of " + table + at; return x; }
+            const bool scalar_op = n.op == Op::Binary || n.op == Op::RangeV || n.op == Op::Project || n.op == Op::Shuffle || n.op == Op::Materialize;
+            if (!scalar_op) { x.why = std::string(op_name(n.op, n.bin)) + " uses a global fold result as a vector" + at; return x; }
+            if (n.op == Op::Binary)
+                for (int opnd : {n.a, n.b})
+                    if (!via[(size_t)opnd]) {
+                        const Op o = P.at(resolve_alias(P, opnd)).op;
+                        if (o != Op::RangeV && o != Op::RangeC) { x.why = "a global fold result meets a stored vector" + at; return x; }
+                    }
+            via[(size_t)id] = 1;
+            continue;
+        }
+        dep[(size_t)id] = d;
+    }
+    if (x.folds.empty()) { x.why = "no global fold over table " + table; return x; }
+    for (int id : P.outputs)
+        if (dep[(size_t)id]) { x.why = "output " + std::to_string(id) + " depends on rows of " + table + " other than through a global fold"; return x; }
+    std::vector<int> roots;
+    for (int id : x.folds) { roots.push_back(P.at(id).a); roots.push_back(P.at(id).b); }
+    std::vector<char> cls;
+    if (!classify_rows(P, roots, table, "the global folds", cls, x.why)) return x;
+    for (int id : x.folds)
+        if (cls[(size_t)P.at(id).b] == N) { x.why = "statement " + std::to_string(id) + " folds rank-local row numbers"; return x; }
+    x.ok = true;
+    return x;
+}
+
+int fold_reduce_kind(Op op) { return op == Op::FoldMin ? 1 : op == Op::FoldMax ? 2 : 0; }       // count merges as a sum
+
 }  // namespace
+
+namespace vdl {
+namespace eng {
+
+bool general_partial_spec(const vdl_plan *p, std::vector<int32_t> &ops, std::string &why) {
+    FoldCut x = analyse_folds(p->prog, p->sharded_table);
+    if (!x.ok) { why = x.why; return false; }
+    ops.clear();
+    for (int id : x.folds) {
+        const int k = fold_reduce_kind(p->prog.at(id).op);
+        ops.push_back(k == 1 ? VDL_REDUCE_MIN : k == 2 ? VDL_REDUCE_MAX : VDL_REDUCE_SUM);
+        ops.push_back(VDL_REDUCE_MIN);          // first control slot (global row id)
+        ops.push_back(VDL_REDUCE_SUM);          // number of data folded
+    }
+    return true;
+}
+
+void general_run_local(vdl_ctx *c, vdl_plan *p, int64_t *dev_words) {
+    FoldCut x = analyse_folds(p->prog, p->sharded_table);
+    if (!x.ok) throw Error(VDL_ERR_UNSUPPORTED, "no sharded route for this plan: " + x.why);
+    GenExec g(c, p);
+    g.run_nodes(x.folds, nullptr);
+    p->cut_folds = x.folds;
+    p->cut_n.clear();
+    for (size_t k = 0; k < x.folds.size(); k++) {
+        const DVec &v = g.vec[(size_t)x.folds[k]];
+        if (v.kind != DVec::ONEHOT) throw Error(VDL_ERR_UNSUPPORTED, "global fold " + std::to_string(x.folds[k]) + " did not yield a scalar record");
+        p->cut_n.push_back(v.n);
+        HIP_CHECK(launch_fold_words((const int64_t *)v.data->p, fold_reduce_kind(p->prog.at(x.folds[k]).op), p->row_offset,
+                                    dev_words + 3 * (int64_t)k, c->stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(c->stream));            // the records die with the executor
+}
+
+void general_finalize(vdl_ctx *c, vdl_plan *p, const int64_t *dev_words) {
+    if (p->cut_folds.empty()) throw Error(VDL_ERR_ARG, "vdl_finalize before vdl_run_local");
+    std::map<int, DVec> over;
+    for (size_t k = 0; k < p->cut_folds.size(); k++) {
+        DVec v;
+        v.kind = DVec::ONEHOT; v.n = p->cut_n[k];
+        v.data = dev_alloc(c, 3 * sizeof(int64_t));
+        HIP_CHECK(launch_fold_record(dev_words + 3 * (int64_t)k, (int64_t *)v.data->p, c->stream));
+        over[p->cut_folds[k]] = v;
+    }
+    GenExec g(c, p);
+    g.run_nodes(p->prog.outputs, &over);
+}
+
+}  // namespace eng
+}  // namespace vdl
 
 extern "C" {
 

@@ -115,6 +115,9 @@ struct PredProg {
 };
 // out bit i = predicate(i) & valid bit i (valid null = every slot)
 hipError_t launch_pred(const PredProg &prog, const uint64_t *valid, uint64_t *out, int64_t n, hipStream_t s);
+// global fold record {value, first slot, count} <-> three words that merge across shards (reduce: 0 sum, 1 min, 2 max)
+hipError_t launch_fold_words(const int64_t *rec, int reduce, int64_t row0, int64_t *out, hipStream_t s);
+hipError_t launch_fold_record(const int64_t *words, int64_t *rec, hipStream_t s);
 // A first-level filter evaluated straight off its columns: bit i = every column's value lies in one of its intervals
 struct FilterArgs {
     int ncol = 0, never = 0;

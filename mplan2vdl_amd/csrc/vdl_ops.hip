@@ -398,6 +398,28 @@ hipError_t launch_onehot_const(int op, const int64_t *a, int64_t k, int const_le
     k_onehot_const<<<1, 1, 0, s>>>(op, a, k, const_left, out);
     return launch_status();
 }
+// A global fold result {value, first control slot, count} of one shard as three mergeable words (value by the fold's
+// own reduction with its identity when nothing was folded, first slot as a global row id by MIN, count by SUM), and back.
+__global__ void k_fold_words(const int64_t *rec, int rk, int64_t row0, int64_t *out) {
+    out[0] = rec[2] > 0 ? rec[0] : r_identity(rk);
+    out[1] = rec[1] >= 0 ? rec[1] + row0 : INT64_MAX;
+    out[2] = rec[2];
+}
+__global__ void k_fold_record(const int64_t *words, int64_t *rec) {
+    rec[0] = words[2] > 0 ? words[0] : 0;
+    rec[1] = words[1] == INT64_MAX ? -1 : words[1];
+    rec[2] = words[2];
+}
+hipError_t launch_fold_words(const int64_t *rec, int reduce, int64_t row0, int64_t *out, hipStream_t s) {
+    (void)hipGetLastError();
+    k_fold_words<<<1, 1, 0, s>>>(rec, reduce == 1 ? R_MIN : reduce == 2 ? R_MAX : R_SUM, row0, out);
+    return launch_status();
+}
+hipError_t launch_fold_record(const int64_t *words, int64_t *rec, hipStream_t s) {
+    (void)hipGetLastError();
+    k_fold_record<<<1, 1, 0, s>>>(words, rec);
+    return launch_status();
+}
 __global__ void k_onehot_dense(const int64_t *oh, int64_t *out, uint64_t *valid, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t slot = oh[2] > 0 ? oh[1] : -1;

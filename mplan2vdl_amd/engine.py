@@ -120,6 +120,11 @@ class Plan:
         self._e._check(self._e._L.vdl_finalize(self._e._c, self._h, ctypes.c_void_p(dev_ptr)))
         return self._collect()
 
+    def set_sharded_table(self, table):
+        """Placement for plans that do not fuse: `table` is split by rows over the ranks, the others are replicated
+        (then partial_spec / run_local / finalize also serve general plans whose outputs hang off global folds)."""
+        self._e._check(self._e._L.vdl_plan_set_sharded_table(self._h, table.encode() if table else None))
+
     def set_row_offset(self, row0):
         self._e._check(self._e._L.vdl_plan_set_row_offset(self._h, int(row0)))
 

@@ -571,6 +571,116 @@ def test_tpch_plans_with_a_sharded_route_match_the_oracle(plan_no, world):
     assert sum(sum(c) for c in counts) > 0
 
 
+def _emulated_fold_merge(text, shards, row0s, table):
+    """Ranks emulated with one context each on one GPU: local phase per rank, the all-reduce of the partial words done
+    in numpy by their VDL_REDUCE_* tags, finalisation on every rank (all must print the same answer)."""
+    import torch
+    from mplan2vdl_amd import _lib
+
+    engines = [engine_with(cols) for cols in shards]
+    plans = [e.parse(text) for e in engines]
+    for p, r0 in zip(plans, row0s):
+        p.set_sharded_table(table)
+        p.set_row_offset(r0)
+    nw, ops = plans[0].partial_spec()
+    bufs = [torch.zeros(nw, dtype=torch.int64, device="cuda") for _ in plans]
+    for p, b in zip(plans, bufs):
+        assert p.partial_spec() == (nw, ops)
+        p.run_local(b.data_ptr())
+    torch.cuda.synchronize()
+    words = np.stack([b.cpu().numpy() for b in bufs])
+    merged = np.array([{_lib.REDUCE_SUM: np.sum, _lib.REDUCE_MIN: np.min, _lib.REDUCE_MAX: np.max}[op](words[:, k]) for k, op in enumerate(ops)], dtype=np.int64)
+    results = []
+    for p, b in zip(plans, bufs):
+        b.copy_(torch.from_numpy(merged))
+        torch.cuda.synchronize()
+        results.append(p.finalize(b.data_ptr())["results"])
+    for e in engines:
+        e.close()
+    assert all(r == results[0] for r in results)
+    return results[0]
+
+
+@pytest.mark.parametrize("plan_no", [14, 19])
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_join_plus_global_aggregate_plans_shard_through_their_folds(plan_no, world):
+    """TPC-H Q14 and Q19 do not fuse (a join) and have no Partition: with lineitem split by rows, each rank folds its rows
+    and the fold records merge like the partial words of a fused scan (vdl_plan_set_sharded_table)."""
+    import os
+    from conftest import ROOT
+    from mplan2vdl_amd import catalog, frontend, shard_rows
+
+    meta = os.path.join(ROOT, "tests", "golden", "tpch10noorder")
+    cfg = frontend.load_metadata(meta)
+    text = frontend.compile_plan(open(os.path.join(meta, "%02d.sql.mplan" % plan_no)).read(), cfg)
+    cols = catalog.synth_columns(meta, cfg, text, scale=2e-3)
+    want = oracle_run(text, cols)
+    assert any(len(v) for d in want.values() for v in d.values())
+    n_li = len(next(v for k, v in cols.items() if k.startswith("lineitem.") and not k.endswith(".heap")))
+    shards, row0s = [], []
+    for r in range(world):
+        r0, r1 = shard_rows(n_li, r, world)
+        row0s.append(r0)
+        shards.append({k: (v[r0:r1] if k.startswith("lineitem.") and not k.endswith(".heap") else v) for k, v in cols.items()})
+    assert _emulated_fold_merge(text, shards, row0s, "lineitem") == want
+    if world == 1:              # the driver class the fused plans use (no process group: merge is a no-op), pipelined too
+        import torch
+        import mplan2vdl_amd as m
+
+        e = engine_with(cols)
+        plan = e.parse(text)
+        plan.set_sharded_table("lineitem")
+        bufs = [torch.zeros(16, dtype=torch.int64, device="cuda") for _ in range(2)]
+        q = m.ShardedQuery(plan, bufs[0])
+        assert q.step()["results"] == want
+        seen = []
+        assert q.run_pipelined(3, bufs, on_result=lambda r: seen.append(r["results"]))["results"] == want
+        assert seen == [want] * 3
+        e.close()
+
+
+def test_global_folds_of_every_kind_merge_across_shards():
+    """Sum / min / max / count over a filtered, gathered vector with EPS rows, a rank whose rows all fail the filter, the
+    scalar tail (a quotient of two folds) evaluated after the merge; and the shapes that are refused."""
+    import mplan2vdl_amd as m
+    from mplan2vdl_amd import shard_rows
+
+    rng = np.random.default_rng(4)
+    n = 40000
+    cols = {"t.a": rng.integers(-50, 50, n).astype(np.int64), "t.f": (np.arange(n) >= n // 3).astype(np.int64) * rng.integers(0, 2, n),
+            "t.k": rng.integers(0, 100, n).astype(np.int32), "d.w": np.arange(100, dtype=np.int64) * 3 - 7}
+    head = ["1,Load,t.a", "2,Project,val,Id 1,a", "3,Load,t.f", "4,Project,val,Id 3,f", "5,Load,t.k", "6,Project,val,Id 5,k",
+            "7,Load,d.w", "8,Project,val,Id 7,w",
+            "9,RangeV,val,0,Id 4,1", "10,FoldSelect,val,Id 9,val,Id 4,val",          # rows with f != 0 (none in the first third)
+            "11,Gather,Id 2,Id 10,val", "12,Gather,Id 6,Id 10,val", "13,Gather,Id 8,Id 12,val",   # a, and w[k] through the FK
+            "14,Multiply,val,Id 11,val,Id 13,val", "15,RangeV,val,0,Id 14,0"]
+    body = ["16,FoldSum,val,Id 15,val,Id 14,val", "17,FoldMin,val,Id 15,val,Id 14,val", "18,FoldMax,val,Id 15,val,Id 14,val",
+            "19,FoldCount,val,Id 15,val,Id 14,val", "20,Divide,val,Id 16,val,Id 19,val",
+            "21,MaterializeCompact,Id 16", "22,MaterializeCompact,Id 17", "23,MaterializeCompact,Id 18", "24,MaterializeCompact,Id 19",
+            "25,MaterializeCompact,Id 20"]
+    text = prog(*(head + body))
+    want = oracle_run(text, cols)
+    for world in (1, 2, 3, 5):
+        shards, row0s = [], []
+        for r in range(world):
+            r0, r1 = shard_rows(n, r, world)
+            row0s.append(r0)
+            shards.append({k: (v[r0:r1] if k.startswith("t.") else v) for k, v in cols.items()})
+        assert _emulated_fold_merge(text, shards, row0s, "t") == want, world
+    e = m.Engine(device=None)
+    bad = e.parse(prog(*(head + ["16,FoldSum,val,Id 15,val,Id 14,val", "17,Multiply,val,Id 16,val,Id 11,val", "18,MaterializeCompact,Id 17"])))
+    bad.set_sharded_table("t")
+    with pytest.raises(m.VdlError, match="with rows of t"):
+        bad.partial_spec()
+    rows = e.parse(prog(*(head + ["16,FoldSum,val,Id 15,val,Id 10,val", "17,MaterializeCompact,Id 16"])))      # folds the row numbers themselves
+    rows.set_sharded_table("t")
+    with pytest.raises(m.VdlError, match="rank-local row numbers"):
+        rows.partial_spec()
+    none = e.parse(text)
+    with pytest.raises(m.VdlError, match="no row-sharded table named"):
+        none.partial_spec()
+
+
 def test_exchange_run_helper_single_rank_and_errors(q6_text):
     import mplan2vdl_amd as m
     from conftest import golden

@@ -201,3 +201,13 @@ def test_which_plans_have_a_sharded_route(cfg):
     assert sorted(n for n, v in verdict.items() if v == "fused") == [1, 6]
     assert sorted(n for n, v in verdict.items() if v == "exchange") == [3, 5, 9, 10, 12, 20]
     assert "more than one Partition" in verdict[18] and "no Partition" in verdict[14] and "below the Partition" in verdict[4]
+    # the two join + ungrouped-aggregate plans shard through their global folds instead
+    for n, folds in ((14, 2), (19, 1)):
+        p = e.parse(frontend.compile_plan(open(os.path.join(META, "%02d.sql.mplan" % n)).read(), cfg))
+        p.set_sharded_table("lineitem")
+        nw, ops = p.partial_spec()
+        assert nw == 3 * folds and ops == [m._lib.REDUCE_SUM, m._lib.REDUCE_MIN, m._lib.REDUCE_SUM] * folds
+    p = e.parse(frontend.compile_plan(open(os.path.join(META, "18.sql.mplan")).read(), cfg))
+    p.set_sharded_table("lineitem")
+    with pytest.raises(m.VdlError, match="no global fold over table lineitem"):
+        p.partial_spec()
