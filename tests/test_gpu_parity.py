@@ -667,6 +667,13 @@ def test_global_folds_of_every_kind_merge_across_shards():
             row0s.append(r0)
             shards.append({k: (v[r0:r1] if k.startswith("t.") else v) for k, v in cols.items()})
         assert _emulated_fold_merge(text, shards, row0s, "t") == want, world
+    # more ranks than rows: some shards are empty
+    tiny = {"t.a": np.array([5, -2, 9], dtype=np.int64), "t.f": np.array([1, 0, 1], dtype=np.int64)}
+    ttext = prog("1,Load,t.a", "2,Project,val,Id 1,a", "3,Load,t.f", "4,Project,val,Id 3,f", "5,RangeV,val,0,Id 4,1", "6,FoldSelect,val,Id 5,val,Id 4,val",
+                 "7,Gather,Id 2,Id 6,val", "8,RangeV,val,0,Id 7,0", "9,FoldSum,val,Id 8,val,Id 7,val", "10,FoldMax,val,Id 8,val,Id 7,val",
+                 "11,MaterializeCompact,Id 9", "12,MaterializeCompact,Id 10")
+    bounds = [shard_rows(3, r, 5) for r in range(5)]
+    assert _emulated_fold_merge(ttext, [{k: v[r0:r1] for k, v in tiny.items()} for r0, r1 in bounds], [r0 for r0, _ in bounds], "t") == oracle_run(ttext, tiny)
     e = m.Engine(device=None)
     bad = e.parse(prog(*(head + ["16,FoldSum,val,Id 15,val,Id 14,val", "17,Multiply,val,Id 16,val,Id 11,val", "18,MaterializeCompact,Id 17"])))
     bad.set_sharded_table("t")
