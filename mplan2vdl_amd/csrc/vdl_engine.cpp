@@ -59,6 +59,7 @@ int64_t bind_mscan(vdl_ctx *c, const PlanT &sp, MScanCols &cols, MScanDesc &d, i
         cols.ptr[k] = col.dev; cols.width[k] = col.width;
         cols.lo[k] = sp.cols[(size_t)k].lo; cols.hi[k] = sp.cols[(size_t)k].hi;
         cols.filtered[k] = (cols.lo[k] != INT64_MIN || cols.hi[k] != INT64_MAX) ? 1 : 0;
+        d.flo[k] = cols.lo[k]; d.fhi[k] = cols.hi[k];
         *bytes_per_row += col.width;
     }
     cols.n = n;

@@ -69,6 +69,7 @@ struct MScanDesc {                           // lives in device memory, read wit
     int nagg = 0, nkey = 0, replicas = 1, pad = 0;
     int64_t pmin = 0, pcount = 0;            // grouped: bucket = key - pmin in [0, pcount)
     int64_t *block_partials = nullptr;       // global: [grid][1 + nagg]; grouped: [grid][pcount * (1 + nagg) + 1]
+    int64_t flo[kMaxScanCols] = {}, fhi[kMaxScanCols] = {};      // range filter per column (read only for filtered columns)
     MAggDesc agg[kMaxGroupAggs];
     KeyStep key[kMaxKeySteps];
 };

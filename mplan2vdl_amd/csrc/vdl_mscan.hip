@@ -124,14 +124,37 @@ __device__ __forceinline__ void key_combine(int op, int swap, int64_t (&acc)[RW]
     }
 }
 
+// What the scan kernels take by value: column bases (kept in the global address space), the widths and the
+// filtered-column set packed into one word each.  (MScanCols itself held 64 SGPRs live across the tile loop -- widths,
+// flags and sixteen 64-bit bounds -- and the grouped kernel spilled hundreds of scalar values into VGPR lanes; the
+// bounds now sit in the device descriptor and are read where a column is actually filtered.)
+struct MsArgs {
+    int ncol = 0;
+    uint32_t widths = 0;                     // 4 bits per column: bytes
+    uint32_t filtered = 0;                   // bit c: column c has a range filter (MScanDesc::flo / fhi)
+    int64_t n = 0, row0 = 0;
+    const void *ptr[kMaxScanCols] = {};
+    __host__ __device__ int width(int c) const { return (int)((widths >> (4 * c)) & 15u); }
+};
+static MsArgs ms_args(const MScanCols &cols) {
+    MsArgs a;
+    a.ncol = cols.ncol; a.n = cols.n; a.row0 = cols.row0;
+    for (int c = 0; c < cols.ncol; c++) {
+        a.ptr[c] = cols.ptr[c];
+        a.widths |= (uint32_t)cols.width[c] << (4 * c);
+        if (cols.filtered[c]) a.filtered |= 1u << c;
+    }
+    return a;
+}
+
 template <int NC, int U, bool VEC, bool NT>
-__device__ __forceinline__ void load_tile(const MScanCols &C, int64_t base, int64_t (&v)[NC][2 * U]) {
+__device__ __forceinline__ void load_tile(const MsArgs &C, int64_t base, int64_t (&v)[NC][2 * U]) {
     constexpr int BS = kMsBlock;
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         if (c < C.ncol) {                                  // wave-uniform
             const char *p = (const char *)C.ptr[c];
-            const int w = C.width[c];
+            const int w = C.width(c);
             if (!VEC) {
 #pragma unroll
                 for (int u = 0; u < U; u++) {
@@ -156,13 +179,13 @@ __device__ __forceinline__ void load_tile(const MScanCols &C, int64_t base, int6
 }
 
 template <int NC, int RW>
-__device__ __forceinline__ void eval_pass(const MScanCols &C, const int64_t (&v)[NC][RW], bool (&pass)[RW]) {
+__device__ __forceinline__ void eval_pass(const MsArgs &C, const MScanDesc &D, const int64_t (&v)[NC][RW], bool (&pass)[RW]) {
 #pragma unroll
     for (int r = 0; r < RW; r++) pass[r] = true;
 #pragma unroll
     for (int c = 0; c < NC; c++) {
-        if (c < C.ncol && C.filtered[c]) {
-            const int64_t lo = C.lo[c], hi = C.hi[c];
+        if ((C.filtered >> c) & 1u) {                      // wave-uniform (bits only below ncol)
+            const int64_t lo = D.flo[c], hi = D.fhi[c];
 #pragma unroll
             for (int r = 0; r < RW; r++) pass[r] = pass[r] & (v[c][r] >= lo) & (v[c][r] <= hi);
         }
@@ -219,7 +242,7 @@ __device__ __forceinline__ void eval_term(const MAggDesc &d, const int64_t (&v)[
 
 // LDS use: global form (1 + nagg) * 256 lane slots; grouped form replicas * (pcount * (1 + nagg) | 1) + 256 + nagg + 1 trash words
 template <int NC, int U, bool VEC, bool NT, bool GROUPED>
-__global__ __launch_bounds__(kMsBlock) void k_mscan(const MScanCols C, const MScanDesc *__restrict__ Dp) {
+__global__ __launch_bounds__(kMsBlock) void k_mscan(const MsArgs C, const MScanDesc *__restrict__ Dp) {
     extern __shared__ int64_t lds[];
     const MScanDesc &D = *Dp;
     constexpr int BS = kMsBlock, TILE = BS * 2 * U, ROWS = 2 * U;
@@ -254,7 +277,7 @@ __global__ __launch_bounds__(kMsBlock) void k_mscan(const MScanCols C, const MSc
     auto process = [&](auto rows_tag, const int64_t (&v)[NC][decltype(rows_tag)::value], const int64_t (&rowid)[decltype(rows_tag)::value]) {
         constexpr int RW = decltype(rows_tag)::value;
         bool pass[RW];
-        eval_pass<NC, RW>(C, v, pass);
+        eval_pass<NC, RW>(C, D, v, pass);
         int off[RW];
         if (GROUPED) {
             // group key: two-accumulator program (vdl_fuse.h KeyStep)
@@ -349,7 +372,7 @@ __global__ __launch_bounds__(kMsBlock) void k_mscan(const MScanCols C, const MSc
             rid[0] = C.row0 + i;
 #pragma unroll
             for (int c = 0; c < NC; c++)
-                if (c < C.ncol) v1[c][0] = load_scalar(C.ptr[c], C.width[c], i);
+                if (c < C.ncol) v1[c][0] = load_scalar(C.ptr[c], C.width(c), i);
             process(std::integral_constant<int, 1>{}, v1, rid);
         }
     }
@@ -409,7 +432,7 @@ __global__ __launch_bounds__(256) void k_mscan_finish(const MScanDesc *__restric
 // FoldChoose per group: replace the group's smallest (global) row id by that row's column value.
 // owned_only (sharded execution, after the MIN all-reduce of the row ids): only the rank that holds the
 // row writes the value, every other rank writes 0, and a SUM all-reduce then spreads it.
-__global__ void k_mscan_first(const MScanCols C, const MScanDesc *__restrict__ Dp, int owned_only, int64_t *table) {
+__global__ void k_mscan_first(const MsArgs C, const MScanDesc *__restrict__ Dp, int owned_only, int64_t *table) {
     const MScanDesc &D = *Dp;
     const int W = D.nagg + 1;
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -421,12 +444,12 @@ __global__ void k_mscan_first(const MScanCols C, const MScanDesc *__restrict__ D
         for (int k = 0; k < kMaxScanCols; k++) if ((D.agg[j].used >> k) & 1u) c = k;
         const int64_t r = table[b * W + 1 + j] - C.row0;
         const bool mine = live && r >= 0 && r < C.n;
-        if (mine) table[b * W + 1 + j] = load_scalar(C.ptr[c], C.width[c], r);
+        if (mine) table[b * W + 1 + j] = load_scalar(C.ptr[c], C.width(c), r);
         else if (owned_only || !live) table[b * W + 1 + j] = 0;
     }
 }
 
-typedef void (*mscan_fn)(const MScanCols, const MScanDesc *);
+typedef void (*mscan_fn)(const MsArgs, const MScanDesc *);
 struct MsVariant { int nc, u; bool vec, grouped; mscan_fn fn; const char *name; };
 #define VDL_MS(NC, U, VEC, NT, GR) {NC, U, VEC, GR, k_mscan<NC, U, VEC, NT, GR>, "k_mscan<" #NC "," #U "," #VEC "," #NT "," #GR ">"}
 const MsVariant kMsVariants[] = {
@@ -497,18 +520,18 @@ hipError_t launch_mscan(const MScanCols &cols, const MScanDesc &d, const MScanDe
     if (cfg.variant < 0 || cfg.variant >= kNumMsVariants) return hipErrorInvalidValue;
     int nblocks = 0;
     if (!never && cols.n > 0) {
-        hipLaunchKernelGGL(kMsVariants[cfg.variant].fn, dim3(cfg.grid), dim3(cfg.block), ms_lds_bytes(d, grouped), s, cols, dev_desc);
+        hipLaunchKernelGGL(kMsVariants[cfg.variant].fn, dim3(cfg.grid), dim3(cfg.block), ms_lds_bytes(d, grouped), s, ms_args(cols), dev_desc);
         nblocks = cfg.grid;
     }
     const int64_t words = grouped ? d.pcount * (d.nagg + 1) + 1 : d.nagg + 1;
     k_mscan_finish<<<(int)((words + 3) / 4), 256, 0, s>>>(dev_desc, nblocks, grouped ? 1 : 0, out);
-    if (grouped && resolve_first) k_mscan_first<<<(int)((d.pcount + 255) / 256), 256, 0, s>>>(cols, dev_desc, 0, out);
+    if (grouped && resolve_first) k_mscan_first<<<(int)((d.pcount + 255) / 256), 256, 0, s>>>(ms_args(cols), dev_desc, 0, out);
     return hipGetLastError();
 }
 
 hipError_t launch_mscan_resolve_first(const MScanCols &cols, const MScanDesc &d, const MScanDesc *dev_desc, int64_t *table, hipStream_t s) {
     (void)hipGetLastError();
-    k_mscan_first<<<(int)((d.pcount + 255) / 256), 256, 0, s>>>(cols, dev_desc, 1, table);
+    k_mscan_first<<<(int)((d.pcount + 255) / 256), 256, 0, s>>>(ms_args(cols), dev_desc, 1, table);
     return hipGetLastError();
 }
 
