@@ -284,7 +284,40 @@ __global__ __launch_bounds__(kMsBlock) void k_mscan(const MsArgs C, const MScanD
             int64_t acc[RW], tmp[RW];
 #pragma unroll
             for (int r = 0; r < RW; r++) { acc[r] = 0; tmp[r] = 0; }
+            const int ncomp = D.ncomp;
+            if (ncomp > 0) {
+                // the composite key in straight-line code: no step records, no operator dispatch (interpreting Q1's nine
+                // steps was a quarter of the kernel)
+#pragma unroll
+                for (int k = 0; k < kMaxKeyComps; k++) {
+                    if (k < ncomp) {                           // wave-uniform
+                        const KeyComp kc = D.comp[k];
+                        int64_t x[RW];
+#pragma unroll
+                        for (int r = 0; r < RW; r++) x[r] = 0;
+#pragma unroll
+                        for (int c = 0; c < NC; c++) {
+                            if (c == kc.col) {
+#pragma unroll
+                                for (int r = 0; r < RW; r++) x[r] = v[c][r];
+                            }
+                        }
+#pragma unroll
+                        for (int r = 0; r < RW; r++)
+                            acc[r] |= (int64_t)(((uint64_t)(x[r] >> kc.rsh) - (uint64_t)kc.sub) << kc.lsh);
+                    }
+                }
+                if (D.key_masked) {
+                    const int64_t mk = D.key_mask;
+#pragma unroll
+                    for (int r = 0; r < RW; r++) acc[r] &= mk;
+                }
+            } else
+#ifdef VDL_MS_NOKEY           // timing experiment only (results are wrong): what does the interpreted key program cost?
+            for (int s = 0; s < 0; s++) {
+#else
             for (int s = 0; s < D.nkey; s++) {
+#endif
                 const KeyStep st = D.key[s];               // wave-uniform
                 if (st.kind == KeyStep::LOAD) {
 #pragma unroll
@@ -320,7 +353,11 @@ __global__ __launch_bounds__(kMsBlock) void k_mscan(const MsArgs C, const MScanD
 #pragma unroll
             for (int r = 0; r < RW; r++) cnt += pass[r] ? 1 : 0;
         }
+#ifdef VDL_MS_NOAGG          // timing experiment only (results are wrong): what do the aggregates cost?
+        for (int j = 0; j < 0; j++) {
+#else
         for (int j = 0; j < nagg; j++) {                   // runtime loop: descriptors by scalar loads
+#endif
             const MAggDesc d = D.agg[j];                   // whole descriptor into SGPRs: one scalar-load wait per aggregate
             const int rk = rk_of(d.kind);
             int64_t t[RW];
@@ -469,6 +506,55 @@ size_t ms_lds_bytes(const MScanDesc &d, bool grouped) {
 
 }  // namespace
 
+// KeyStep program -> canonical components, when it has that shape (see KeyComp).  Symbolic run: each accumulator is a
+// list of components; a right shift / subtract applies to a lone unshifted component, a left shift to all of them.
+static void canonical_key(MScanDesc &d) {
+    d.ncomp = 0; d.key_masked = 0; d.key_mask = 0;
+    if (getenv("VDL_NO_CANON_KEY") || d.nkey <= 0) return;
+    struct Form { KeyComp c[kMaxKeyComps]; int n = 0; bool shifted[kMaxKeyComps] = {}, subbed[kMaxKeyComps] = {}; };
+    Form f[2];
+    bool masked = false;
+    int64_t mask = 0;
+    for (int s = 0; s < d.nkey; s++) {
+        const KeyStep &st = d.key[s];
+        if (masked) return;                                            // the mask must be the last step
+        if (st.kind == KeyStep::LOAD) {
+            if (st.target < 0 || st.target > 1 || st.col < 0) return;
+            Form &t = f[st.target];
+            t = Form{};
+            t.n = 1; t.c[0].col = st.col;
+        } else if (st.kind == KeyStep::OPK) {
+            if (st.target < 0 || st.target > 1) return;
+            Form &t = f[st.target];
+            if (t.n < 1 || st.const_left) return;
+            if (st.bin == B_SHIFT && st.k >= 0) {                      // right shift: first thing done to a loaded column
+                if (t.n != 1 || t.shifted[0] || t.subbed[0] || t.c[0].lsh != 0 || st.k > 63) return;
+                t.c[0].rsh = (int)st.k; t.shifted[0] = true;
+            } else if (st.bin == B_SHIFT) {                            // left shift: distributes over the OR of components
+                if (st.k < -63) return;
+                for (int k = 0; k < t.n; k++) { t.c[k].lsh += (int)(-st.k); if (t.c[k].lsh > 63) return; }
+            } else if (st.bin == B_SUB || st.bin == B_ADD) {
+                if (t.n != 1 || t.c[0].lsh != 0) return;
+                t.c[0].sub = (int64_t)((uint64_t)t.c[0].sub + (st.bin == B_SUB ? (uint64_t)st.k : (uint64_t)0 - (uint64_t)st.k));
+                t.subbed[0] = true;
+            } else if (st.bin == B_BAND && st.target == 0) {
+                masked = true; mask = st.k;
+            } else {
+                return;
+            }
+        } else {                                                       // COMBINE: acc = acc | tmp
+            if (st.bin != B_BOR || f[0].n < 1 || f[1].n < 1 || f[0].n + f[1].n > kMaxKeyComps) return;
+            for (int k = 0; k < f[1].n; k++) { f[0].c[f[0].n] = f[1].c[k]; f[0].n++; }
+            f[1] = Form{};
+        }
+    }
+    if (f[0].n < 1) return;
+    d.ncomp = f[0].n;
+    for (int k = 0; k < f[0].n; k++) d.comp[k] = f[0].c[k];
+    d.key_masked = masked ? 1 : 0;
+    d.key_mask = mask;
+}
+
 ScanLaunch mscan_launch_config(const MScanCols &cols, MScanDesc &d, bool grouped, int num_cus) {
     bool vec = true;
     for (int c = 0; c < cols.ncol; c++)
@@ -487,6 +573,7 @@ ScanLaunch mscan_launch_config(const MScanCols &cols, MScanDesc &d, bool grouped
     if (cfg.variant < 0) return cfg;
     d.replicas = 1;
     if (grouped) {
+        canonical_key(d);
         const int64_t words = d.pcount * (d.nagg + 1);
         int r = 8;
         while (r > 1 && words * r > 2304) r >>= 1;         // replicas <= 18 KiB (+ 2 KiB of trash rows): LDS never caps the occupancy
