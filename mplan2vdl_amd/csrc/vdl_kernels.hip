@@ -65,7 +65,6 @@ hipError_t launch_gen_column(void *out, int elem_bytes, int64_t row0, int64_t n,
 // Per-lane accumulators -> 64-lane shuffle reduction -> LDS across the 4 waves -> one partial
 // row per block; k_scan_finish folds the partial rows (deterministic order, no atomics).
 // ------------------------------------------------------------------------------------------
-constexpr int kScanBlock = 256;
 
 template <int NC, int NA, int ROWS>
 __device__ __forceinline__ void scan_accumulate(const ScanArgs &A, const int64_t (&v)[NC][ROWS], int64_t (&acc)[NA],
