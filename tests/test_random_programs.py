@@ -2,6 +2,8 @@
 Partition + Scatter + Fold group-bys, global folds, element-wise chains) through the oracle and the GPU engine:
 the statement-by-statement executor rewrites vector forms aggressively (sparse selections, fused expression trees,
 view scatters), and this is the net under it.  Each program also runs with those rewrites forced on / off."""
+import os
+
 import numpy as np
 import pytest
 
@@ -17,7 +19,10 @@ class Gen:
         self.lines, self.nid = [], 0
         self.pool = {}                                   # table -> statement ids of vectors of that table's length
         self.cols = {}
+        big = int(os.environ.get("VDL_FUZZ_ROWS", "0"))     # tools/fuzz_general_path.py: tables of many tiles / blocks
         self.n = {"t": int(self.rng.integers(1, 4000)), "u": int(self.rng.integers(1, 300))}
+        if big:
+            self.n = {"t": int(self.rng.integers(big // 2, big)), "u": int(self.rng.integers(1, max(big // 50, 2)))}
         if seed % 17 == 0:
             self.n["t"] = 1 + seed % 3                       # degenerate tables now and then
         if seed % 23 == 0:
