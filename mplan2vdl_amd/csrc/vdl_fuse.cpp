@@ -11,6 +11,7 @@
 #include "vdl.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <sstream>
 
 namespace vdl {
@@ -546,6 +547,56 @@ static void show_scalar(const Scalar &s, std::ostringstream &o) {
     }
 }
 
+// Symbolic run over the key steps: each accumulator is a list of components; a right shift / subtract applies to a
+// lone unshifted component, a left shift to all of them (it distributes over the OR), a final mask is kept aside.
+int composite_key(const KeyStep *steps, int n, KeyComp *comps, int *masked_out, int64_t *mask_out) {
+    if (masked_out) *masked_out = 0;
+    if (mask_out) *mask_out = 0;
+    if (getenv("VDL_NO_CANON_KEY") || n <= 0) return 0;
+    struct Form { KeyComp c[kMaxKeyComps]; int n = 0; bool shifted[kMaxKeyComps] = {}, subbed[kMaxKeyComps] = {}; };
+    Form f[2];
+    bool masked = false;
+    int64_t mask = 0;
+    for (int s = 0; s < n; s++) {
+        const KeyStep &st = steps[s];
+        if (masked) return 0;                                          // the mask must be the last step
+        if (st.kind == KeyStep::LOAD) {
+            if (st.target < 0 || st.target > 1 || st.col < 0) return 0;
+            Form &t = f[st.target];
+            t = Form{};
+            t.n = 1; t.c[0].col = st.col;
+        } else if (st.kind == KeyStep::OPK) {
+            if (st.target < 0 || st.target > 1) return 0;
+            Form &t = f[st.target];
+            if (t.n < 1 || st.const_left) return 0;
+            if (st.bin == B_SHIFT && st.k >= 0) {                      // right shift: first thing done to a loaded column
+                if (t.n != 1 || t.shifted[0] || t.subbed[0] || t.c[0].lsh != 0 || st.k > 63) return 0;
+                t.c[0].rsh = (int)st.k; t.shifted[0] = true;
+            } else if (st.bin == B_SHIFT) {                            // left shift: distributes over the OR of components
+                if (st.k < -63) return 0;
+                for (int k = 0; k < t.n; k++) { t.c[k].lsh += (int)(-st.k); if (t.c[k].lsh > 63) return 0; }
+            } else if (st.bin == B_SUB || st.bin == B_ADD) {
+                if (t.n != 1 || t.c[0].lsh != 0) return 0;
+                t.c[0].sub = (int64_t)((uint64_t)t.c[0].sub + (st.bin == B_SUB ? (uint64_t)st.k : (uint64_t)0 - (uint64_t)st.k));
+                t.subbed[0] = true;
+            } else if (st.bin == B_BAND && st.target == 0) {
+                masked = true; mask = st.k;
+            } else {
+                return 0;
+            }
+        } else {                                                       // COMBINE: acc = acc | tmp
+            if (st.bin != B_BOR || f[0].n < 1 || f[1].n < 1 || f[0].n + f[1].n > kMaxKeyComps) return 0;
+            for (int k = 0; k < f[1].n; k++) { f[0].c[f[0].n] = f[1].c[k]; f[0].n++; }
+            f[1] = Form{};
+        }
+    }
+    if (f[0].n < 1) return 0;
+    for (int k = 0; k < f[0].n; k++) comps[k] = f[0].c[k];
+    if (masked_out) *masked_out = masked ? 1 : 0;
+    if (mask_out) *mask_out = mask;
+    return f[0].n;
+}
+
 std::string describe_fused(const FusedPlan &F) {
     std::ostringstream o;
     if (!F.ok) { o << "not fused: " << F.why_not << "\n"; return o.str(); }
@@ -597,6 +648,20 @@ std::string describe_fused(const FusedPlan &F) {
             else o << (k.const_left ? " acc=" : " acc=") << kBinNames[k.bin] << (k.const_left ? "(tmp,acc);" : "(acc,tmp);");
         }
         o << "\n";
+        {
+            KeyComp kc[kMaxKeyComps];
+            int masked = 0;
+            int64_t mask = 0;
+            const int nc = composite_key(gp.key.data(), (int)gp.key.size(), kc, &masked, &mask);
+            if (nc > 0) {
+                o << "  key form: composite,";
+                for (int k = 0; k < nc; k++) o << (k ? " |" : "") << " ((col" << kc[k].col << " >> " << kc[k].rsh << ") - " << kc[k].sub << ") << " << kc[k].lsh;
+                if (masked) o << ", & " << mask;
+                o << " (straight-line code)\n";
+            } else {
+                o << "  key form: general (interpreted step by step)\n";
+            }
+        }
         for (size_t a = 0; a < gp.aggs.size(); a++) {
             const ScanAgg &ag = gp.aggs[a];
             o << "  agg" << a << " " << (ag.kind == AGG_SUM ? "sum" : ag.kind == AGG_MIN ? "min" : ag.kind == AGG_MAX ? "max" : "first") << " ";

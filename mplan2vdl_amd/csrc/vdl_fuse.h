@@ -70,6 +70,15 @@ struct KeyStep {
     int64_t k = 0;
 };
 
+// A group key of the shape makeCompositeKey emits (Vlite.hs:1123-1170): OR over components ((col >> rsh) - sub) << lsh,
+// optionally ANDed with a mask.  The grouped scan evaluates this form in straight-line code; any other key program is
+// interpreted step by step (KeyStep).
+constexpr int kMaxKeyComps = 4;
+struct KeyComp { int col = 0, rsh = 0, lsh = 0, pad = 0; int64_t sub = 0; };
+// KeyStep program -> components, when it has that shape: returns their number (0 = not of the shape; the mask, if
+// any, in *masked / *mask).  VDL_NO_CANON_KEY in the environment makes it answer 0.
+int composite_key(const KeyStep *steps, int n, KeyComp *comps, int *masked, int64_t *mask);
+
 struct GroupScanPlan {
     std::string table;
     std::vector<ScanColumn> cols;

@@ -65,11 +65,6 @@ struct MAggDesc {
     int64_t constant = 0;                    // datum when there is no column factor
     int64_t fa[kMaxScanCols] = {}, fs[kMaxScanCols] = {};
 };
-// A group key of the shape makeCompositeKey emits (Vlite.hs:1123-1170): OR over components ((col >> rsh) - sub) << lsh,
-// optionally ANDed with a mask.  The grouped scan evaluates this form in straight-line code; any other key program is
-// interpreted step by step (KeyStep).
-constexpr int kMaxKeyComps = 4;
-struct KeyComp { int col = 0, rsh = 0, lsh = 0, pad = 0; int64_t sub = 0; };
 struct MScanDesc {                           // lives in device memory, read with scalar loads
     int nagg = 0, nkey = 0, replicas = 1, pad = 0;
     int64_t pmin = 0, pcount = 0;            // grouped: bucket = key - pmin in [0, pcount)

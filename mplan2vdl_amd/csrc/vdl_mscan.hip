@@ -506,55 +506,6 @@ size_t ms_lds_bytes(const MScanDesc &d, bool grouped) {
 
 }  // namespace
 
-// KeyStep program -> canonical components, when it has that shape (see KeyComp).  Symbolic run: each accumulator is a
-// list of components; a right shift / subtract applies to a lone unshifted component, a left shift to all of them.
-static void canonical_key(MScanDesc &d) {
-    d.ncomp = 0; d.key_masked = 0; d.key_mask = 0;
-    if (getenv("VDL_NO_CANON_KEY") || d.nkey <= 0) return;
-    struct Form { KeyComp c[kMaxKeyComps]; int n = 0; bool shifted[kMaxKeyComps] = {}, subbed[kMaxKeyComps] = {}; };
-    Form f[2];
-    bool masked = false;
-    int64_t mask = 0;
-    for (int s = 0; s < d.nkey; s++) {
-        const KeyStep &st = d.key[s];
-        if (masked) return;                                            // the mask must be the last step
-        if (st.kind == KeyStep::LOAD) {
-            if (st.target < 0 || st.target > 1 || st.col < 0) return;
-            Form &t = f[st.target];
-            t = Form{};
-            t.n = 1; t.c[0].col = st.col;
-        } else if (st.kind == KeyStep::OPK) {
-            if (st.target < 0 || st.target > 1) return;
-            Form &t = f[st.target];
-            if (t.n < 1 || st.const_left) return;
-            if (st.bin == B_SHIFT && st.k >= 0) {                      // right shift: first thing done to a loaded column
-                if (t.n != 1 || t.shifted[0] || t.subbed[0] || t.c[0].lsh != 0 || st.k > 63) return;
-                t.c[0].rsh = (int)st.k; t.shifted[0] = true;
-            } else if (st.bin == B_SHIFT) {                            // left shift: distributes over the OR of components
-                if (st.k < -63) return;
-                for (int k = 0; k < t.n; k++) { t.c[k].lsh += (int)(-st.k); if (t.c[k].lsh > 63) return; }
-            } else if (st.bin == B_SUB || st.bin == B_ADD) {
-                if (t.n != 1 || t.c[0].lsh != 0) return;
-                t.c[0].sub = (int64_t)((uint64_t)t.c[0].sub + (st.bin == B_SUB ? (uint64_t)st.k : (uint64_t)0 - (uint64_t)st.k));
-                t.subbed[0] = true;
-            } else if (st.bin == B_BAND && st.target == 0) {
-                masked = true; mask = st.k;
-            } else {
-                return;
-            }
-        } else {                                                       // COMBINE: acc = acc | tmp
-            if (st.bin != B_BOR || f[0].n < 1 || f[1].n < 1 || f[0].n + f[1].n > kMaxKeyComps) return;
-            for (int k = 0; k < f[1].n; k++) { f[0].c[f[0].n] = f[1].c[k]; f[0].n++; }
-            f[1] = Form{};
-        }
-    }
-    if (f[0].n < 1) return;
-    d.ncomp = f[0].n;
-    for (int k = 0; k < f[0].n; k++) d.comp[k] = f[0].c[k];
-    d.key_masked = masked ? 1 : 0;
-    d.key_mask = mask;
-}
-
 ScanLaunch mscan_launch_config(const MScanCols &cols, MScanDesc &d, bool grouped, int num_cus) {
     bool vec = true;
     for (int c = 0; c < cols.ncol; c++)
@@ -573,7 +524,7 @@ ScanLaunch mscan_launch_config(const MScanCols &cols, MScanDesc &d, bool grouped
     if (cfg.variant < 0) return cfg;
     d.replicas = 1;
     if (grouped) {
-        canonical_key(d);
+        d.ncomp = composite_key(d.key, d.nkey, d.comp, &d.key_masked, &d.key_mask);
         const int64_t words = d.pcount * (d.nagg + 1);
         int r = 8;
         while (r > 1 && words * r > 2304) r >>= 1;         // replicas <= 18 KiB (+ 2 KiB of trash rows): LDS never caps the occupancy

@@ -52,6 +52,7 @@ def test_q1_fuses_into_one_grouped_scan(q1_text):
     assert "group-scan 0 table=lineitem buckets=[0,31]" in d                 # RangeC 0 32 1 pivots
     assert "lineitem.l_shipdate in [-inf,729999]" in d
     assert "acc=BitwiseAnd(acc,31)" in d                                     # size hint evaluated, Vlite.hs:1111-1115
+    assert "key form: composite, ((col1 >> 3) - 2) << 2 | ((col2 >> 3) - 2) << 0, & 31" in d      # makeCompositeKey's shape: no interpreter
     assert d.count(" sum ") == 5 and d.count(" first ") == 2                 # duplicate FoldSums shared, count(*) = the row-count word
     assert "Divide(agg2,count)" in d                                         # avg = sum / count, Vlite.hs:1038-1041
     nw, ops = p.partial_spec()                                               # 32 buckets x (count + 7 aggregates) + out-of-domain count

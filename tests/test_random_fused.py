@@ -71,7 +71,20 @@ class Gen:
         if grouped:
             g = lambda v: self.emit("Gather,Id %d,Id %d,val" % (v, sel))
             kb, kd = g(self.c[1]), g(self.c[3])
-            key = self.bin("BitwiseOr", self.bin("BitShift", kb, self.bin("Subtract", self.const(0, kb), self.const(3, kb))), kd)   # b << 3 | d
+            shl = lambda v, k: self.bin("BitShift", v, self.bin("Subtract", self.const(0, v), self.const(k, v)))
+            shape = int(r.integers(0, 5))
+            if shape == 0:          # b << 3 | d
+                key = self.bin("BitwiseOr", shl(kb, 3), kd)
+            elif shape == 1:        # ((b >> 1) - 1) << 3 | (d - 2): right shifts and offsets per component (makeCompositeKey, Vlite.hs:1123-1170)
+                kb1 = self.bin("Subtract", self.bin("BitShift", kb, self.const(1, kb)), self.const(1, kb))
+                key = self.bin("BitwiseOr", shl(kb1, 3), self.bin("Subtract", kd, self.const(2, kd)))
+            elif shape == 2:        # three components: ((b << 2) | (d >> 1)) << 2 | (d & ... no: | b) -- nested shifts distribute
+                inner = self.bin("BitwiseOr", shl(kb, 2), self.bin("BitShift", kd, self.const(1, kd)))
+                key = self.bin("BitwiseOr", shl(inner, 2), self.bin("BitShift", kb, self.const(2, kb)))
+            elif shape == 3:        # not of the composite shape (an Add joins the parts): the step interpreter
+                key = self.bin("Add", shl(kb, 3), kd)
+            else:                   # not of the composite shape either: an offset after the shift-left
+                key = self.bin("BitwiseOr", self.bin("Add", shl(kb, 3), self.const(8, kb)), kd)
             if r.random() < 0.5:
                 key = self.bin("BitwiseAnd", key, self.const(255, key))
             dom = int(r.choice([256, 64]))           # 64: keys outside the pivots -> the engine must notice and fall back
@@ -96,13 +109,17 @@ class Gen:
 
 
 def test_generator_is_accepted_by_oracle_and_planner():
-    fused = 0
+    fused = composite = interpreted = 0
     e = m.Engine(device=None)
     for seed in range(60):
         text, cols = Gen(seed).build()
         assert oracle_run(text, cols) is not None
-        fused += e.parse(text).is_fused
+        p = e.parse(text)
+        fused += p.is_fused
+        composite += "key form: composite" in p.describe()
+        interpreted += "key form: general" in p.describe()
     assert fused >= 20                                # a good share of them really exercises the fused scans
+    assert composite >= 5 and interpreted >= 3        # both ways of evaluating a group key
 
 
 @pytest.mark.gpu
