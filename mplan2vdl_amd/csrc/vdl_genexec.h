@@ -918,6 +918,9 @@ struct GenExec {
                     rh.count = popcount(rh.heads, m, &rh.offsets);
                     rh.child = child_selection(sel, rh.heads, rh.count, rh.offsets);
                 }
+                // FoldChoose takes a run's first element, and here every entry holds one: the values at the run heads, i.e. one
+                // compaction by the head bitmap (every output column of a GROUP BY is such a fold, Vlite.hs:1056-1060)
+                if (kind == 4) return make_sparse(rh.child, compact_write(dsrc, rh.heads, m, rh.offsets, rh.count));
                 BufP data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(m, 1));
                 BufP vout = zero_bitmap(m);
                 HIP_CHECK(launch_fold_runs(kind, dsrc, nullptr, nullptr, (const uint64_t *)rh.heads->p, (const int64_t *)rh.wordhd->p, m,
