@@ -177,6 +177,8 @@ hipError_t launch_prefix_sum(int64_t *x, int64_t n, int64_t *sums, hipStream_t s
 // Partition with pivots RangeC pmin pcount 1 (bucket = clamp(data - pmin, 0, pcount)); see vdl_partition.hip
 int64_t partition_tiles(int64_t n);
 int partition_passes(int64_t pcount);
+// flag[0] (pre-zeroed by the caller) becomes 1 when d[i] > d[i+1] somewhere: the data is not in non-decreasing order
+hipError_t launch_sorted_check(Src d, int64_t n, int64_t *flag, hipStream_t s);
 hipError_t launch_partition(Src data, const uint64_t *valid, int64_t n, int64_t pmin, int64_t pcount, int64_t *hist,
                             int64_t *scan_scratch, uint64_t *keys_a, int64_t *slots_a, uint64_t *keys_b, int64_t *slots_b,
                             int64_t *n_valid_dev, int64_t *pos_out, hipStream_t s);

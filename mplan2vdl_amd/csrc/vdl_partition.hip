@@ -248,6 +248,25 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(PartIn in, int64_t 
         if (dest[k] >= 0) slots_out[dest[k]] = (int64_t)stage[(unsigned)k * kPartBlock + tid];
 }
 
+// Is the (fully valid) data already in non-decreasing order?  Then its stable partition ranks are 0, 1, 2, ... and none of
+// the radix passes is needed: TPC-H lineitems are clustered by order key, so the composite group keys of Q3 / Q18 arrive
+// sorted.  flag[0] (pre-zeroed) is set when a descent is found.
+__global__ __launch_bounds__(256) void k_sorted_check(Src d, int64_t n, int64_t *flag) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    by_kind(d.kind, [&](auto kd) {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i + 1 < n; i += stride)
+            bad |= ldk<decltype(kd)::value>(d, i) > ldk<decltype(kd)::value>(d, i + 1);
+    });
+    if (__ballot(bad) != 0 && (threadIdx.x & (kWave - 1)) == 0) flag[0] = 1;
+}
+hipError_t launch_sorted_check(Src d, int64_t n, int64_t *flag, hipStream_t s) {
+    (void)hipGetLastError();
+    if (n <= 1) return hipSuccess;
+    k_sorted_check<<<grid_for(n, 256, 8), 256, 0, s>>>(d, n, flag);
+    return launch_status();
+}
+
 // scratch layout is owned by the caller (vdl_engine.cpp); see launch_partition's arguments.
 hipError_t launch_partition(Src data, const uint64_t *valid, int64_t n, int64_t pmin, int64_t pcount,
                             int64_t *hist /* 256*ntiles + 1 */, int64_t *scan_scratch /* prefix_sum_blocks(256*ntiles)+1 */,

@@ -844,6 +844,45 @@ def test_filter_predicates_evaluated_on_masks(monkeypatch):
     e.close()
 
 
+@pytest.mark.parametrize("case", ["sorted", "one descent at the end", "one descent at the start", "shuffled", "sorted with EPS rows"])
+def test_partition_of_data_that_is_already_in_order(case, monkeypatch):
+    """A multi-pass Partition first checks whether its input is already in non-decreasing order (clustered fact tables:
+    the group keys of Q3 / Q18) and then hands out the identity ranks without a radix pass; a single descent anywhere
+    sends it down the sort.  Same answers with the check switched off."""
+    rng = np.random.default_rng(8)
+    n = 150000
+    keys = np.sort(rng.integers(0, 1 << 30, n)).astype(np.int64)
+    if case == "one descent at the end":
+        keys[-1] = keys[-2] - 1
+    elif case == "one descent at the start":
+        keys[0] = keys[1] + 1
+    elif case == "shuffled":
+        rng.shuffle(keys)
+    cols = {"t.k": keys, "t.v": rng.integers(-100, 100, n).astype(np.int64), "t.f": np.ones(n, dtype=np.int64)}
+    if case == "sorted with EPS rows":
+        cols["t.f"][::7] = 0
+    text = prog("1,Load,t.k", "2,Project,val,Id 1,k", "3,Load,t.v", "4,Project,val,Id 3,v", "5,Load,t.f", "6,Project,val,Id 5,f",
+                "7,RangeV,val,0,Id 6,1", "8,FoldSelect,val,Id 7,val,Id 6,val", "9,Gather,Id 2,Id 8,val", "10,Gather,Id 4,Id 8,val",
+                "11,RangeC,val,0,%d,1" % (1 << 30), "12,Partition,val,Id 9,val,Id 11,val",
+                "13,RangeV,val,0,Id 9,1", "14,Scatter,Id 9,Id 13,val,Id 12,val", "15,Scatter,Id 10,Id 13,val,Id 12,val",
+                "16,FoldSum,val,Id 14,val,Id 15,val", "17,FoldChoose,val,Id 14,val,Id 14,val", "18,FoldMax,val,Id 14,val,Id 15,val",
+                "19,MaterializeCompact,Id 16", "20,MaterializeCompact,Id 17", "21,MaterializeCompact,Id 18", "22,MaterializeCompact,Id 12")
+    want = oracle_run(text, cols)
+    e = engine_with(cols)
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("VDL_NO_SORTED_SHORTCUT", "1")
+        else:
+            monkeypatch.delenv("VDL_NO_SORTED_SHORTCUT", raising=False)
+        for mode in (None, "VDL_SPARSE_ALWAYS", "VDL_NO_SPARSE"):
+            for k in ("VDL_SPARSE_ALWAYS", "VDL_NO_SPARSE"):
+                monkeypatch.delenv(k, raising=False)
+            if mode:
+                monkeypatch.setenv(mode, "1")
+            assert e.run_vdl(text)["results"] == want, (case, off, mode)
+    e.close()
+
+
 def test_large_outputs_can_stay_on_the_device():
     """vdl_plan_set_device_outputs: outputs of >= 65536 values are handed out as device pointers, smaller ones stay
     host-side; the values are those of the host route."""
