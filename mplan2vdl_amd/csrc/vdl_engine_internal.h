@@ -97,6 +97,7 @@ struct Sel {
     std::shared_ptr<Sel> parent;    // the selection this one was filtered from, and
     BufP ppos;                      // for each of the m slots its entry number inside the parent
     bool worth = true;              // false: too dense to be worth compacting (only m is known)
+    BufP wrank;                     // selected slots before each bitmap word (built when something gathers out of a vector on this selection)
 };
 using SelP = std::shared_ptr<Sel>;
 

@@ -607,6 +607,26 @@ struct GenExec {
             o = sparse_take(src, sel);
             return true;
         }
+        if (pos.kind == DVec::SPARSE && src.kind == DVec::SPARSE && src.sel->idx && src.sel->m > 0 && !getenv("VDL_NO_RANKED_GATHER")) {
+            // both sides sparse (a join reading a filtered dimension column through the fact side's surviving keys): the
+            // entry of a source slot is found by rank in the source selection's bitmap; no dense copy of the source
+            const SelP &ss = src.sel;
+            const BufP &bits = bitmap_of(ss);
+            if (!ss->wrank) {
+                const int64_t nw = nwords(ss->n);
+                ss->wrank = dev_alloc(c, sizeof(int64_t) * (size_t)(nw + 1));
+                BufP sums = dev_alloc(c, sizeof(int64_t) * (size_t)(prefix_sum_blocks(nw) + 2));
+                HIP_CHECK(launch_word_counts((const uint64_t *)bits->p, nw, (int64_t *)ss->wrank->p, s));
+                HIP_CHECK(launch_prefix_sum((int64_t *)ss->wrank->p, nw, (int64_t *)sums->p, s));
+            }
+            const SelP &sel = pos.sel;
+            BufP data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(sel->m, 1));
+            BufP sub = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(sel->m), 1));
+            HIP_CHECK(launch_gather_ranked((const int64_t *)src.data->p, (const uint64_t *)bits->p, (const int64_t *)ss->wrank->p, src.n,
+                                           i64_src(pos.data), nullptr, sel->m, (int64_t *)data->p, (uint64_t *)sub->p, s));
+            o = sparse_normalised(sel, data, sub);
+            return true;
+        }
         if (pos.kind == DVec::SPARSE) {
             DVec from = densify(src);
             if (!(from.kind == DVec::DENSE || from.kind == DVec::COLUMN || from.kind == DVec::RANGE)) return false;

@@ -122,6 +122,11 @@ hipError_t launch_pred(const PredProg &prog, const uint64_t *valid, uint64_t *ou
 // global fold record {value, first slot, count} <-> three words that merge across shards (reduce: 0 sum, 1 min, 2 max)
 hipError_t launch_fold_words(const int64_t *rec, int reduce, int64_t row0, int64_t *out, hipStream_t s);
 hipError_t launch_fold_record(const int64_t *words, int64_t *rec, hipStream_t s);
+// Gather out of a sparse vector without densifying it: counts[w] = popcount of bitmap word w (the caller turns them into
+// exclusive prefix sums = wrank), then out[i] = entries[wrank[p/64] + popcount(word below bit p)] for p = pos[i] selected.
+hipError_t launch_word_counts(const uint64_t *bitmap, int64_t nwords, int64_t *counts, hipStream_t s);
+hipError_t launch_gather_ranked(const int64_t *entries, const uint64_t *bitmap, const int64_t *wrank, int64_t nsrc, Src pos, const uint64_t *vpos,
+                                int64_t n, int64_t *out, uint64_t *vout, hipStream_t s);
 // A first-level filter evaluated straight off its columns: bit i = every column's value lies in one of its intervals
 struct FilterArgs {
     int ncol = 0, never = 0;

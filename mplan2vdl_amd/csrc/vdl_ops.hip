@@ -682,6 +682,63 @@ __global__ __launch_bounds__(256) void k_gather(Src src, const uint64_t *vsrc, i
         });
     });
 }
+// Gather out of a SPARSE vector (values only on a selection: `entries` in selection order, `bitmap` over the n slots,
+// wrank[w] = selected slots before bitmap word w): the entry of slot p is wrank[p / 64] + popcount(bits of word below p).
+// No dense copy of the source is made (a join reads a filtered dimension column this way).
+__global__ __launch_bounds__(256) void k_word_ranks(const uint64_t *bitmap, int64_t nw, int64_t *counts) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nw; w += stride) counts[w] = __popcll(bitmap[w]);
+}
+hipError_t launch_word_counts(const uint64_t *bitmap, int64_t nw, int64_t *counts, hipStream_t s) {
+    (void)hipGetLastError();
+    if (nw <= 0) return hipSuccess;
+    k_word_ranks<<<grid_for(nw, 256, 4), 256, 0, s>>>(bitmap, nw, counts);
+    return launch_status();
+}
+__global__ __launch_bounds__(256) void k_gather_ranked(const int64_t *entries, const uint64_t *bitmap, const int64_t *wrank, int64_t nsrc,
+                                                       Src pos, const uint64_t *vpos, int64_t n, int64_t *out, uint64_t *vout) {
+    constexpr int U = kGatherUnroll;
+    const int64_t nw = (n + 63) >> 6;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave) * U;
+    by_kind(pos.kind, [&](auto kp) {
+        for (int64_t w0 = wave_index() * U; w0 < nw; w0 += wstride) {
+            int64_t pc[U];
+            bool ok[U];
+            gather_slots<decltype(kp)::value, false>(pos, vpos, nullptr, nullptr, nsrc, n, nw, w0, lane, pc, ok);
+            uint64_t word[U];
+            int64_t before[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) { word[u] = bitmap[pc[u] >> 6]; before[u] = wrank[pc[u] >> 6]; }
+            int64_t e[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int b = (int)(pc[u] & 63);
+                ok[u] = ok[u] & (((word[u] >> b) & 1ull) != 0);
+                e[u] = ok[u] ? before[u] + __popcll(word[u] & ((1ull << b) - 1)) : 0;
+            }
+            int64_t x[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) x[u] = entries[e[u]];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int64_t i = ((w0 + u) << 6) + lane;
+                if (i < n) out[i] = ok[u] ? x[u] : 0;
+                const uint64_t m = __ballot(ok[u]);
+                if (lane == 0 && w0 + u < nw) vout[w0 + u] = m;
+            }
+        }
+    });
+}
+hipError_t launch_gather_ranked(const int64_t *entries, const uint64_t *bitmap, const int64_t *wrank, int64_t nsrc, Src pos, const uint64_t *vpos,
+                                int64_t n, int64_t *out, uint64_t *vout, hipStream_t s) {
+    (void)hipGetLastError();
+    if (n <= 0) return hipSuccess;
+    if (nsrc <= 0) return hipErrorInvalidValue;              // the caller handles empty sources
+    k_gather_ranked<<<grid_for(n, 256, 4), 256, 0, s>>>(entries, bitmap, wrank, nsrc, pos, vpos, n, out, vout);
+    return launch_status();
+}
+
 hipError_t launch_gather(Src src, const uint64_t *vsrc, int64_t nsrc, Src pos, const uint64_t *vpos, int64_t n, int64_t *out,
                          uint64_t *vout, hipStream_t s) {
     (void)hipGetLastError();   // see launch_status()
