@@ -500,7 +500,6 @@ hipError_t launch_compact_scan(int64_t *counts, int64_t nb, hipStream_t s) {
 }
 
 __global__ __launch_bounds__(256) void k_compact_write(Src v, const uint64_t *valid, int64_t n, const int64_t *offsets, int64_t *out) {
-    __shared__ int wcount[kCompactWords];
     __shared__ int wprefix[kCompactWords];
     __shared__ uint64_t wmask[kCompactWords];
     const int64_t nw = (n + 63) >> 6;
@@ -515,10 +514,15 @@ __global__ __launch_bounds__(256) void k_compact_write(Src v, const uint64_t *va
             if (rem < 64) m &= (1ull << rem) - 1;
         }
         wmask[tid] = m;
-        wcount[tid] = __popcll(m);
+        // exclusive prefix of the 64 word counts inside the first wave (a loop on one thread cost 3 us per tile: a fifth of a
+        // second per billion rows at any density)
+        static_assert(kCompactWords == kWave, "one lane per word of the tile");
+        const int cnt = __popcll(m);
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) { const int y = __shfl_up(incl, off, kWave); if (lane >= off) incl += y; }
+        wprefix[tid] = incl - cnt;
     }
-    __syncthreads();
-    if (tid == 0) { int run = 0; for (int k = 0; k < kCompactWords; k++) { wprefix[k] = run; run += wcount[k]; } }
     __syncthreads();
     const int64_t base = offsets[blockIdx.x];
     constexpr int U = 4, NW = 256 / kWave;
