@@ -883,6 +883,26 @@ def test_partition_of_data_that_is_already_in_order(case, monkeypatch):
     e.close()
 
 
+@pytest.mark.parametrize("n", [4096, 4097, 4351, 4352 + 63, 100000])
+def test_single_int32_column_filter_with_wide_loads(n, monkeypatch):
+    """One 4-byte column against one interval takes 16-byte loads, four rows per lane (256-row groups, the last rows one
+    per lane): every group / tail split, against the oracle and against the one-row-per-lane kernel."""
+    rng = np.random.default_rng(n)
+    cols = {"t.d": rng.integers(0, 1000, n).astype(np.int32), "t.v": rng.integers(-9, 10, n).astype(np.int64)}
+    text = prog("1,Load,t.d", "2,Project,val,Id 1,d", "3,Load,t.v", "4,Project,val,Id 3,v",
+                "5,RangeV,val,300,Id 2,0", "6,Greater,val,Id 2,val,Id 5,val", "7,RangeV,val,0,Id 6,1", "8,FoldSelect,val,Id 7,val,Id 6,val",
+                "9,Gather,Id 4,Id 8,val", "10,MaterializeCompact,Id 9", "11,Gather,Id 2,Id 8,val", "12,MaterializeCompact,Id 11",
+                "13,MaterializeCompact,Id 8")
+    want = oracle_run(text, cols)
+    e = engine_with(cols)
+    p = e.parse(text)
+    p.set_fusion(False)
+    assert p.run()["results"] == want
+    monkeypatch.setenv("VDL_NO_WIDE_FILTER", "1")
+    assert p.run()["results"] == want
+    e.close()
+
+
 def test_large_outputs_can_stay_on_the_device():
     """vdl_plan_set_device_outputs: outputs of >= 65536 values are handed out as device pointers, smaller ones stay
     host-side; the values are those of the host route."""
