@@ -663,10 +663,73 @@ __global__ __launch_bounds__(256) void k_select_gather(Src src, const uint64_t *
         });
     });
 }
+// The join filter as the compiler emits it: the fact side's 4-byte FK column against the dimension side's mask, which
+// after the view scatter is a constant with a validity bitmap -- bit i of the result = row i takes part (vc) and the bit
+// of dimension row fk[i] is set.  Four consecutive rows per lane (one 16-byte load of the FK column), a wave covers 256
+// rows = four result words, put together by an OR over each group of 16 lanes (as in k_filter_i32_wide).
+constexpr int kFkGroups = 2;                             // 256-row groups a wave has in flight in the join filter (16 lookups per lane and group)
+template <typename T>
+__global__ __launch_bounds__(256) void k_select_fk_bitmap(const T *fk, const uint64_t *vfk, const uint64_t *dim_bits, int64_t ndim,
+                                                          const uint64_t *vc, uint64_t *out, int64_t ngroups) {
+    typedef T tx2 __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t gstride = (int64_t)gridDim.x * (blockDim.x / kWave) * kFkGroups;
+    for (int64_t g0 = wave_index() * kFkGroups; g0 < ngroups; g0 += gstride) {
+        tx2 pa[kFkGroups], pb[kFkGroups];                   // rows 4l, 4l+1 and 4l+2, 4l+3 of the group
+        uint64_t take[kFkGroups];
+#pragma unroll
+        for (int u = 0; u < kFkGroups; u++) {
+            const int64_t g = g0 + u < ngroups ? g0 + u : ngroups - 1;
+            const tx2 *base = (const tx2 *)(fk + g * 256) + 2 * lane;
+            pa[u] = __builtin_nontemporal_load(base);
+            pb[u] = __builtin_nontemporal_load(base + 1);
+            take[u] = vc ? vc[g * 4 + (lane >> 4)] : ~0ull;          // the word of my 16-lane group
+            if (vfk) take[u] &= vfk[g * 4 + (lane >> 4)];
+        }
+        uint64_t w[kFkGroups][4];
+        bool in[kFkGroups][4];
+#pragma unroll
+        for (int u = 0; u < kFkGroups; u++) {
+            const int64_t q[4] = {(int64_t)pa[u].x, (int64_t)pa[u].y, (int64_t)pb[u].x, (int64_t)pb[u].y};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                in[u][j] = q[j] >= 0 && q[j] < ndim;
+                w[u][j] = dim_bits[in[u][j] ? (q[j] >> 6) : 0];       // the dimension bitmap is small and stays in cache
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kFkGroups; u++) {
+            const int64_t q[4] = {(int64_t)pa[u].x, (int64_t)pa[u].y, (int64_t)pb[u].x, (int64_t)pb[u].y};
+            unsigned nib = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) nib |= (in[u][j] && ((w[u][j] >> (q[j] & 63)) & 1ull)) ? (1u << j) : 0u;
+            nib &= (unsigned)((take[u] >> (4 * (lane & 15))) & 15ull);
+            uint64_t part = (uint64_t)nib << (4 * (lane & 15));
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) part |= __shfl_xor(part, off, kWave);
+            if ((lane & 15) == 0 && g0 + u < ngroups) out[(g0 + u) * 4 + (lane >> 4)] = part;
+        }
+    }
+}
+
 hipError_t launch_select_gather(Src src, const uint64_t *vsrc, int64_t nsrc, Src pos, const uint64_t *vpos, const uint64_t *vc, uint64_t *out,
                                 int64_t n, hipStream_t s) {
     (void)hipGetLastError();
     if (n <= 0) return hipSuccess;
+    if ((pos.kind == SRC_I32 || pos.kind == SRC_I64) && src.kind == SRC_RANGE && src.step == 0 && src.from != 0 && vsrc && nsrc > 0 && n >= 4096 &&
+        ((uintptr_t)pos.p & 15) == 0 && !getenv("VDL_NO_WIDE_FILTER")) {
+        const int64_t ngroups = n / 256;
+        const int grid = grid_for(ngroups, 4, kFkGroups);
+        if (pos.kind == SRC_I32) k_select_fk_bitmap<int32_t><<<grid, 256, 0, s>>>((const int32_t *)pos.p, vpos, vsrc, nsrc, vc, out, ngroups);
+        else k_select_fk_bitmap<int64_t><<<grid, 256, 0, s>>>((const int64_t *)pos.p, vpos, vsrc, nsrc, vc, out, ngroups);
+        const int64_t done = ngroups * 256;
+        if (done == n) return launch_status();
+        pos.p = (const char *)pos.p + done * (pos.kind == SRC_I32 ? 4 : 8);          // the last rows (fewer than 256) one per lane
+        if (vc) vc += done / 64;
+        if (vpos) vpos += done / 64;
+        out += done / 64;
+        n -= done;
+    }
     k_select_gather<<<grid_for(n, 256, 4), 256, 0, s>>>(src, vsrc, nsrc, pos, vpos, vc, out, n);
     return launch_status();
 }
