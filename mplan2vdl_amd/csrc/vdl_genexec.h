@@ -372,6 +372,7 @@ struct GenExec {
 
     DVec densify(const DVec &v) {
         if (v.kind == DVec::LAZYG) return gather_now(v.lg->src, v.lg->pos);
+        if (v.kind == DVec::EXPR && v.sel) return sparse_to_dense(sx_force(v));       // (never reached: only binary() reads such vectors)
         if (v.kind == DVec::EXPR) return expr_force(v);
         if (v.kind == DVec::SPARSE) return sparse_to_dense(v);
         if (v.kind != DVec::ONEHOT && v.kind != DVec::OHCONST) return v;
@@ -420,8 +421,64 @@ struct GenExec {
         return true;
     }
 
+    // ---- element-wise chains over the entries of one selection ---------------------------------------------------
+    // The same laziness as expr_binary, for SPARSE operands: a Binary whose only reader is another Binary is kept as a
+    // tree over the entry buffers (DVec kind EXPR with `sel` set) and runs as one k_expr over the m entries when the chain
+    // ends (Q3's composite key is ten such operators).  Only binary() ever sees such a vector (that is what "only reader is
+    // a Binary" guarantees); anything it cannot extend forces it into a plain SPARSE vector first.
+    static bool is_sx(const DVec &v) { return v.kind == DVec::EXPR && v.sel; }
+    DVec sx_force(const DVec &v) {
+        const int64_t m = v.sel->m;
+        BufP data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(m, 1));
+        if (m > 0) {
+            ExprProg prog;
+            expr_emit(*v.ex, prog);
+            HIP_CHECK(launch_expr(prog, (int64_t *)data->p, m, s));
+        }
+        return make_sparse(v.sel, data);
+    }
+    bool sparse_expr_binary(const Node &n, const DVec &a, const DVec &b, DVec &o) {
+        if (!fuse_on || n.bin == B_DIV || n.bin == B_MOD || getenv("VDL_NO_SPARSE_EXPR")) return false;
+        SelP sel;
+        for (const DVec *v : {&a, &b})
+            if (v->kind == DVec::SPARSE || is_sx(*v)) { if (sel && v->sel != sel) return false; sel = v->sel; }
+        if (!sel || sel->m <= 0) return false;
+        auto node_of = [&](const DVec &v, std::shared_ptr<ExprNode> &out) {
+            if (is_sx(v)) { out = v.ex; return true; }
+            auto e = std::make_shared<ExprNode>();
+            if (v.kind == DVec::SPARSE) { e->leaf = entries(v); out = e; return true; }
+            if (v.kind == DVec::RANGE && v.step == 0 && (!v.valid || subset(bitmap_of(sel), v.valid))) {
+                e->leaf = DVec{}; e->leaf.kind = DVec::RANGE; e->leaf.n = sel->m; e->leaf.from = v.from; e->leaf.step = 0;
+                out = e; return true;
+            }
+            return false;
+        };
+        std::shared_ptr<ExprNode> el, er;
+        if (!node_of(a, el) || !node_of(b, er)) return false;
+        const bool lazy = n_uses[(size_t)n.id] == 1 && read_by_binary_only[(size_t)n.id];
+        if (!lazy && el->bin < 0 && er->bin < 0) return false;                // a lone operator: the plain kernel
+        auto t = std::make_shared<ExprNode>();
+        t->bin = n.bin; t->l = el; t->r = er;
+        t->leaves = el->leaves + er->leaves;
+        t->instrs = el->instrs + er->instrs + 1;
+        t->depth = std::max(el->depth, er->depth + 1);
+        if (!expr_fits(*t)) return false;                                      // the caller forces the pending sides and goes operator by operator
+        o = DVec{};
+        o.kind = DVec::EXPR; o.n = sel->n; o.sel = sel; o.ex = t;
+        if (!lazy) o = sx_force(o);
+        return true;
+    }
+
     DVec binary(const Node &n, const DVec &a0, const DVec &b0) {
         DVec a = a0, b = b0;
+        if (a.kind == DVec::SPARSE || b.kind == DVec::SPARSE || is_sx(a) || is_sx(b)) {
+            if (a.n == b.n) {
+                DVec o;
+                if (sparse_expr_binary(n, a, b, o)) return o;
+            }
+            if (is_sx(a)) a = sx_force(a);
+            if (is_sx(b)) b = sx_force(b);
+        }
         if (a.kind == DVec::SPARSE || b.kind == DVec::SPARSE) {
             if (a.n != b.n)
                 throw Error(VDL_ERR_SHAPE, std::string(kBinNames[n.bin]) + " (Id " + std::to_string(n.id) + "): operand lengths differ (" +
