@@ -43,7 +43,9 @@ hipError_t launch_binary(int op, Src a, Src b, int64_t *out, int64_t n, hipStrea
 // registers with compile-time indices: every instruction switches (scalar branches) on the stack height it runs
 // at and on its operator.  Each lane evaluates kExprRows rows at once to amortise the scalar work.
 constexpr int kExprRows = 4;
-#define VDL_EX_PUSH(K) case K: _Pragma("unroll") for (int r = 0; r < kExprRows; r++) st[K][r] = row[r] < n ? ld(lf, row[r]) : 0; break;
+// (the leaf's representation is resolved once per push and its loads are unconditional -- rows past n read slot 0 and are
+// never stored -- so the four loads of a push go out together)
+#define VDL_EX_PUSH(K) case K: by_kind(lf.kind, [&](auto kk) { _Pragma("unroll") for (int r = 0; r < kExprRows; r++) st[K][r] = ldk<decltype(kk)::value>(lf, row[r] < n ? row[r] : 0); }); break;
 // a (x) b for the lane's rows; the operator switch is wave-uniform and sits outside the row loop
 #define VDL_EX_OP(OP) case OP: _Pragma("unroll") for (int r = 0; r < kExprRows; r++) a[r] = apply_bin(OP, a[r], b[r]); break;
 __device__ __forceinline__ void expr_rows(int op, int64_t (&a)[kExprRows], const int64_t (&b)[kExprRows]) {
