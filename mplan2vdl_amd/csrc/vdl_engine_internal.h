@@ -259,6 +259,10 @@ inline BufP dev_alloc(vdl_ctx *c, size_t bytes) {
     auto b = std::make_shared<DevBuf>();
     b->pool = c->pool;
     b->p = c->pool->alloc(bytes, &b->cls);
+    // debugging aid: VDL_POISON=<byte> fills every buffer handed out, so that a kernel reading what nobody wrote fails the
+    // same way every time instead of depending on what the memory held before
+    static const char *poison = getenv("VDL_POISON");
+    if (poison && b->p) (void)hipMemsetAsync(b->p, atoi(poison) & 255, b->cls, c->stream);
     return b;
 }
 
