@@ -110,6 +110,7 @@ struct DVec {
     SelP sel;                   // SPARSE: data = the sel->m values; valid = bitmap over those m entries (null = all hold a value)
     bool perm = false;          // SPARSE: the values are a permutation of 0 .. m-1 (Partition positions)
     bool iota = false;          // ... and that permutation is the identity (the partitioned data was already in order)
+    bool ranks = false;         // DENSE Partition positions: the values of the valid slots are exactly 0 .. m-1 (m = number of valid slots)
     bool ids = false;           // SPARSE: every value is its own slot id (row ids gathered through a filter)
     std::shared_ptr<LazyGather> lg; // LAZYG: Gather(src, pos) not run yet: its only reader is a filter that needs few (or none) of its values
     std::shared_ptr<ExprNode> ex;   // EXPR: a not yet evaluated tree of element-wise operators (fused when somebody needs the values)

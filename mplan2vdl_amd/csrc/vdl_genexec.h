@@ -744,6 +744,7 @@ struct GenExec {
         DVec o;
         o.kind = DVec::DENSE; o.n = data.n; o.valid = data.valid;
         o.perm = !data.valid;                                   // every slot gets a rank: a permutation of 0 .. n-1
+        o.ranks = true;                                         // in any case the valid slots get the ranks 0 .. m-1
         o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(o.n, 1));
         if (o.n > 1 && !data.valid && partition_passes(pcount) > 1 && !getenv("VDL_NO_SORTED_SHORTCUT")) {
             // data already in order (lineitems are clustered by order key: the group keys of Q3 / Q18 arrive sorted)?
@@ -969,6 +970,17 @@ struct GenExec {
             if (pos.perm && !pos.valid && !src.valid && src.n == o.n) {      // a permutation of all slots: every slot is written
                 HIP_CHECK(launch_scatter(src_of(src), nullptr, src_of(pos), nullptr, src.n, o.n, (int64_t *)o.data->p, nullptr, s));
                 return o;
+            }
+            if (pos.ranks && pos.valid && subset(pos.valid, src.valid) && !getenv("VDL_NO_RANK_SCATTER")) {
+                // Partition ranks of a filtered vector (a filter too dense to go sparse: Q1 keeps 98 % of lineitem): the slots
+                // written are exactly 0 .. m-1, so the validity of the result is a prefix -- no atomic per element (59 M
+                // atomics into 0.9 M bitmap words were 85 % of this kernel)
+                const int64_t m = sel_for(pos.valid, pos.n)->m;
+                if (m <= o.n) {
+                    o.valid = bitmap_of(prefix_selection(o.n, m));
+                    HIP_CHECK(launch_scatter(src_of(src), nullptr, src_of(pos), vp(pos), src.n, o.n, (int64_t *)o.data->p, nullptr, s));
+                    return o;
+                }
             }
             o.valid = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(o.n), 1));
             HIP_CHECK(launch_fill_words((uint64_t *)o.valid->p, 0, nwords(o.n), s));
