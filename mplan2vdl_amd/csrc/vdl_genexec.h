@@ -145,6 +145,8 @@ struct GenExec {
     }
     struct RunHeads { BufP ctl, heads, wordhd, offsets; int64_t count = 0; SelP child; };
     std::map<const void *, RunHeads> heads_of;                  // control entries buffer -> its run heads (kept alive by .ctl)
+    struct DenseHeads { BufP ctl, ctlv, heads, wordhd; };
+    std::map<std::pair<const void *, const void *>, DenseHeads> dense_heads;    // (control data, its validity) of a stored control vector -> run heads
     SelP prefix_selection(int64_t n, int64_t m) {
         for (const SelP &x : prefixes) if (x->n == n && x->m == m) return x;
         SelP x = std::make_shared<Sel>();
@@ -1039,12 +1041,26 @@ struct GenExec {
             if (!(ctl.kind == DVec::RANGE && ctl.step == 0)) {
                 // general control vector (grouped aggregates fold data scattered into key order)
                 const size_t nw = (size_t)std::max<int64_t>(nwords(d.n), 1);
-                BufP heads = dev_alloc(c, sizeof(uint64_t) * nw);
-                BufP wordhd = dev_alloc(c, sizeof(int64_t) * (nw + (size_t)maxscan_blocks((int64_t)nw) + 1));
                 o.kind = DVec::DENSE; o.n = d.n;
                 o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(d.n, 1));
                 o.valid = dev_alloc(c, sizeof(uint64_t) * nw);
                 HIP_CHECK(launch_fill_words((uint64_t *)o.valid->p, 0, nwords(d.n), s));
+                // the folds of one GROUP BY all run over the same sorted key: its run heads are computed once
+                const void *kd = ctl.kind == DVec::DENSE && ctl.data ? ctl.data->p : nullptr;
+                if (kd) {
+                    DenseHeads &dh = dense_heads[std::make_pair(kd, (const void *)(ctl.valid ? ctl.valid->p : nullptr))];
+                    if (!dh.heads) {
+                        dh.ctl = ctl.data; dh.ctlv = ctl.valid;                 // keep the key's addresses from being reused
+                        dh.heads = dev_alloc(c, sizeof(uint64_t) * nw);
+                        dh.wordhd = dev_alloc(c, sizeof(int64_t) * (nw + (size_t)maxscan_blocks((int64_t)nw) + 1));
+                        HIP_CHECK(launch_fold_heads(src_of(ctl), vp(ctl), d.n, (uint64_t *)dh.heads->p, (int64_t *)dh.wordhd->p, s));
+                    }
+                    HIP_CHECK(launch_fold_runs(kind, src_of(d), vp(d), vp(ctl), (const uint64_t *)dh.heads->p, (const int64_t *)dh.wordhd->p, d.n,
+                                               (int64_t *)o.data->p, (uint64_t *)o.valid->p, s));
+                    return o;
+                }
+                BufP heads = dev_alloc(c, sizeof(uint64_t) * nw);
+                BufP wordhd = dev_alloc(c, sizeof(int64_t) * (nw + (size_t)maxscan_blocks((int64_t)nw) + 1));
                 HIP_CHECK(launch_fold_segmented(kind, src_of(ctl), vp(ctl), src_of(d), vp(d), d.n, (uint64_t *)heads->p,
                                                 (int64_t *)wordhd->p, (int64_t *)o.data->p, (uint64_t *)o.valid->p, s));
                 return o;
