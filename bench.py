@@ -72,6 +72,57 @@ def secondary_measurements(eng, rows):
     return also
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` started bare (no torchrun environment): start the N ranks ourselves, one process per
+    GPU, from this parent -- which has not touched HIP -- and hand their exit code back.  Same command line the driver
+    uses: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def dry_run(args, world, rank):
+    """--dry-run: the launcher, the rendezvous, the row-range sharding and the merge of the partial words, WITHOUT a GPU
+    (CPU boxes, tests/test_bench_launch.py): every rank evaluates Q6 over its shard of a small table with the CPU
+    checker, the partials are all-reduced over gloo, and the merged answer must equal the unsharded one.  The line it
+    prints carries "dry_run": true and no throughput: it is a plumbing check, never a measurement."""
+    import torch
+    import torch.distributed as dist
+
+    import mplan2vdl_amd as m
+    import oracle
+    from mplan2vdl_amd import datagen
+
+    if world > 1:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    total_rows = args.rows or datagen.LINEITEM_ROWS["sf0.01"]
+    lo, hi = m.shard_rows(total_rows, rank, world)
+    specs = [(datagen.SEED, datagen.col_id(c), datagen.LINEITEM[c].lo, datagen.LINEITEM[c].hi,
+              datagen.LINEITEM[c].mul, datagen.LINEITEM[c].add) for c in datagen.Q6_COLUMNS]
+    rev, cnt = oracle.sql_q6_generated(specs, lo, hi - lo, threads=1)
+    words = torch.tensor([cnt, rev], dtype=torch.int64)
+    if world > 1:
+        m.merge_partials(words, [m._lib.REDUCE_SUM, m._lib.REDUCE_SUM], dist)
+    whole = oracle.sql_q6_generated(specs, 0, total_rows, threads=1)
+    ok = (int(words[1]), int(words[0])) == whole
+    n_ranks = dist.get_world_size() if world > 1 else 1
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no GPU): launcher + sharding + merge only", "value": None, "unit": "rows/s", "n_gpus": n_ranks,
+                          "steps": 0, "warmup": 0, "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                          "dtype": "int64", "data": "synthetic", "dry_run": True, "config": {"workload": "tpch_q6_rows%d" % total_rows},
+                          "revenue": int(words[1]), "verified_bit_exact_vs_cpu": ok}))
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,7 +136,17 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--query", default="q6", choices=["q6", "q1"],
                     help="q6 (default, BASELINE.json's metric) or q1 (grouped fused scan; secondary measurement)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: check launcher / sharding / merge plumbing only (see dry_run)")
+    ap.add_argument("--latency-steps", type=int, default=10, help="queries run one at a time after the timed region to report per-query latency")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))         # nothing below runs in the parent: it never touches HIP
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        print("bench.py: --gpus %d but the launcher started %s rank(s)" % (args.gpus, os.environ.get("WORLD_SIZE", "1")), file=sys.stderr)
+        sys.exit(2)
+    if args.dry_run:
+        sys.exit(dry_run(args, int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))))
 
     import torch
     import torch.distributed as dist
@@ -111,6 +172,10 @@ def main():
                                     device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            print("bench.py: the communicator has %d rank(s), --gpus asked for %d" % (dist.get_world_size(), args.gpus), file=sys.stderr)
+            sys.exit(2)
+    n_ranks = dist.get_world_size() if world > 1 else 1      # what the JSON line reports: the communicator's size, not the flag
 
     total_rows = args.rows or datagen.LINEITEM_ROWS[args.sf]
     lo, hi = m.shard_rows(total_rows, rank, world)
@@ -166,6 +231,22 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # per-query latency: the same query run one at a time (local phase, merge, finalisation, answer on the host before
+    # the next one starts) -- `value` above is pipelined throughput, this is what a single request waits for
+    latency_ms = None
+    if args.latency_steps > 0:
+        lat = []
+        for _ in range(args.latency_steps):
+            sync_all()
+            t1 = time.perf_counter()
+            query.step()
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t1)
+        lt = torch.tensor([sum(lat[1:]) / max(len(lat) - 1, 1) if len(lat) > 1 else lat[0]], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(lt, op=dist.ReduceOp.MAX)
+        latency_ms = float(lt.item()) * 1e3
 
     revenue = result["results"]["tmp42"][".revenue"] if args.query == "q6" else None
     kernel_label = next((k.replace("timeInMicrosecondsForFusedScan_", "") for k in result["timings"] if "FusedScan" in k), "k_scan")
@@ -236,8 +317,8 @@ def main():
                 traffic = None
         out = {
             "metric": "rows/s, TPC-H %s %s (fused VDL scan), + achieved HBM GB/s in roofline" % (args.query.upper(), args.sf.upper()),
-            "value": rows_per_s, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "value": rows_per_s, "unit": "rows/s", "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "latency_ms_per_query": latency_ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int64", "data": "synthetic",
             "config": {"workload": "tpch_%s_%s" % (args.query, args.sf if not args.rows else "rows%d" % args.rows),
                        "rows_total": total_rows, "rows_per_gpu": my_rows, "bytes_per_row": q_bytes,

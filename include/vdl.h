@@ -69,7 +69,8 @@ const char *vdl_version(void);
 /* Run on the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream).  The handle is
  * used as given: 0 / NULL means the legacy default stream (what torch uses unless told otherwise),
  * so that collectives and tensor ops issued by the caller order against the engine's kernels.
- * vdl_use_own_stream() goes back to the engine's private non-blocking stream. */
+ * vdl_use_own_stream() goes back to the engine's private non-blocking stream.  Both drain the stream being left
+ * first (the engine's buffers are protected by stream order), so switch streams between queries, not inside one. */
 int  vdl_set_stream(vdl_ctx *ctx, void *hip_stream);
 int  vdl_use_own_stream(vdl_ctx *ctx);
 
@@ -128,6 +129,17 @@ int  vdl_plan_set_device_outputs(vdl_plan *plan, int enabled);
 int  vdl_output_device(const vdl_plan *plan, int k, const int64_t **dev_vals, size_t *n);
 int  vdl_n_timings(const vdl_plan *plan);
 int  vdl_timing(const vdl_plan *plan, int k, const char **label, double *usec);
+
+/* Debugging aid for parity work.  With tracing on, a vdl_run that goes statement by statement (plan not fused, or
+ * vdl_plan_set_fusion(plan, 0)) keeps a host copy of every statement's vector as it stood right after the statement:
+ * n slots, vals[i] and ok[i] (1 = the slot holds a value, 0 = EPS; vals is 0 there).  `form` names the engine's
+ * internal representation ("dense", "sparse", "range", "onehot", ...).  vals / ok are NULL for statements whose
+ * evaluation was deferred at that point (fused expression trees, lazy gathers) and for vectors of more than 2^22
+ * slots.  Entries are in execution order and stay valid until the plan runs again or is freed. */
+int  vdl_plan_set_trace(vdl_plan *plan, int enabled);
+int  vdl_n_traced(const vdl_plan *plan);
+int  vdl_traced(const vdl_plan *plan, int k, int *node_id, const char **form, int64_t *n,
+                const int64_t **vals, const uint8_t **ok);
 
 /* Per-kernel device time of the last vdl_run()/vdl_run_local(), measured with HIP events
  * on the stream the kernels were launched on; enabled with vdl_plan_set_profiling(). */

@@ -357,6 +357,12 @@ int vdl_set_stream(vdl_ctx *c, void *hip_stream) {
     if (!c) return VDL_ERR_ARG;
     return guard(c, [&] {
         need_device(c);
+        // pool buffers and plan-owned scratch are protected by stream order alone: drain the stream being left (and the
+        // copy stream) so that nothing queued there can still touch memory a launch on the new stream is handed
+        if (c->stream != (hipStream_t)hip_stream) {
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            if (c->copy_stream) HIP_CHECK(hipStreamSynchronize(c->copy_stream));
+        }
         c->stream = (hipStream_t)hip_stream;      // 0 is a real choice: the legacy default stream
     });
 }
@@ -365,6 +371,10 @@ int vdl_use_own_stream(vdl_ctx *c) {
     if (!c) return VDL_ERR_ARG;
     return guard(c, [&] {
         need_device(c);
+        if (c->stream != c->own_stream) {
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            if (c->copy_stream) HIP_CHECK(hipStreamSynchronize(c->copy_stream));
+        }
         c->stream = c->own_stream;
     });
 }
@@ -486,6 +496,23 @@ int vdl_output_device(const vdl_plan *p, int k, const int64_t **dev_vals, size_t
     const Output &o = p->outs[(size_t)k];
     if (dev_vals) *dev_vals = o.dev;
     if (n) *n = o.count();
+    return VDL_OK;
+}
+int vdl_plan_set_trace(vdl_plan *p, int enabled) {
+    if (!p) return VDL_ERR_ARG;
+    p->tracing = enabled != 0;
+    if (!p->tracing) p->traced.clear();
+    return VDL_OK;
+}
+int vdl_n_traced(const vdl_plan *p) { return p ? (int)p->traced.size() : 0; }
+int vdl_traced(const vdl_plan *p, int k, int *node_id, const char **form, int64_t *n, const int64_t **vals, const uint8_t **ok) {
+    if (!p || k < 0 || k >= (int)p->traced.size()) return VDL_ERR_ARG;
+    const Traced &t = p->traced[(size_t)k];
+    if (node_id) *node_id = t.node;
+    if (form) *form = t.form;
+    if (n) *n = t.n;
+    if (vals) *vals = t.have ? t.vals.data() : nullptr;
+    if (ok) *ok = t.have ? t.ok.data() : nullptr;
     return VDL_OK;
 }
 int vdl_plan_set_profiling(vdl_plan *p, int enabled) {

@@ -146,6 +146,11 @@ struct Output {
     size_t count() const { return (dev || big) ? big_n : vals.size(); }
 };
 struct Timing { std::string label; double usec; };
+// vdl_plan_set_trace: a host copy of a statement's vector in semantic form (n slots: value + "holds a value"), taken
+// right after the statement ran on the per-operator executor.  `have` is false when the vector was not evaluated at
+// that point (pending expression tree / lazy gather) or is longer than kTraceMaxSlots.
+constexpr int64_t kTraceMaxSlots = (int64_t)1 << 22;
+struct Traced { int node = 0; const char *form = ""; int64_t n = 0; bool have = false; std::vector<int64_t> vals; std::vector<uint8_t> ok; };
 
 
 }  // namespace eng
@@ -174,6 +179,9 @@ struct vdl_plan {
     FusedPlan fused;
     bool use_fusion = true;
     bool profiling = false;
+    bool tracing = false;
+    std::vector<Traced> traced;
+    hipEvent_t stmt_ev[2] = {nullptr, nullptr};   // per-statement profiling of the per-operator executor (created on first use)
     bool device_outputs = false;
     std::string description;
     std::vector<Output> outs;
@@ -241,6 +249,7 @@ struct vdl_plan {
     }
     ~vdl_plan() {
         for (auto &b : out_pinned) if (b.first) (void)hipHostFree(b.first);
+        for (hipEvent_t e : stmt_ev) if (e) (void)hipEventDestroy(e);
         for (int k = 0; k < 2; k++) {
             if (ev0[k]) (void)hipEventDestroy(ev0[k]);
             if (ev1[k]) (void)hipEventDestroy(ev1[k]);
@@ -261,9 +270,15 @@ inline BufP dev_alloc(vdl_ctx *c, size_t bytes) {
     b->pool = c->pool;
     b->p = c->pool->alloc(bytes, &b->cls);
     // debugging aid: VDL_POISON=<byte> fills every buffer handed out, so that a kernel reading what nobody wrote fails the
-    // same way every time instead of depending on what the memory held before
+    // same way every time instead of depending on what the memory held before; VDL_POISON=rand[<seed>] fills it with
+    // plausible garbage instead (k_poison), a different mix per buffer
     static const char *poison = getenv("VDL_POISON");
-    if (poison && b->p) (void)hipMemsetAsync(b->p, atoi(poison) & 255, b->cls, c->stream);
+    if (poison && b->p) {
+        if (!std::strncmp(poison, "rand", 4)) {
+            static uint64_t counter = 0;
+            (void)launch_poison(b->p, b->cls, (uint64_t)std::strtoull(poison + 4, nullptr, 10) * 1000003ull + 8 * (++counter), c->stream);
+        } else (void)hipMemsetAsync(b->p, atoi(poison) & 255, b->cls, c->stream);
+    }
     return b;
 }
 

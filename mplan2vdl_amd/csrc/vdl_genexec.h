@@ -143,8 +143,8 @@ struct GenExec {
         }
         return sel->bitmap;
     }
-    struct RunHeads { BufP ctl, heads, wordhd, offsets; int64_t count = 0; SelP child; };
-    std::map<const void *, RunHeads> heads_of;                  // control entries buffer -> its run heads (kept alive by .ctl)
+    struct RunHeads { BufP ctl, heads, wordhd, offsets; int64_t count = 0; SelP sel, child; };
+    std::map<std::pair<const void *, const void *>, RunHeads> heads_of;   // (control entries buffer, its selection) -> run heads (both kept alive by the entry)
     struct DenseHeads { BufP ctl, ctlv, heads, wordhd; };
     std::map<std::pair<const void *, const void *>, DenseHeads> dense_heads;    // (control data, its validity) of a stored control vector -> run heads
     SelP prefix_selection(int64_t n, int64_t m) {
@@ -901,6 +901,7 @@ struct GenExec {
                 // positions are the slot ids themselves (a filter): a view, no data movement
                 o = src;
                 o.valid = and_valid(src, pos, src.n);
+                if (o.valid != src.valid) o.perm = o.ranks = o.iota = false;     // fewer slots hold a value: no longer "the ranks 0 .. m-1"
                 return o;
             }
             // a gather whose only reader is a filter (FoldSelect over it, or Gather of it through a filter) is not run:
@@ -927,6 +928,7 @@ struct GenExec {
                     if (sv.kind == DVec::RANGE || sv.kind == DVec::DENSE || sv.kind == DVec::COLUMN) {
                         o = sv;
                         o.valid = sv.valid && where ? and_bitmaps(sv.valid, where, nout) : (sv.valid ? sv.valid : where);
+                        if (o.valid != sv.valid) o.perm = o.ranks = o.iota = false;
                         return o;
                     }
                     if (sv.kind == DVec::SPARSE && ps.kind == DVec::SPARSE && sv.sel == ps.sel) return sv;
@@ -1016,10 +1018,10 @@ struct GenExec {
                 // every entry holds a datum, so each run yields a result at its head: the run heads of this control
                 // vector -- and the selection they form -- are computed once and shared by all folds over it
                 // (a GROUP BY folds every aggregate over the same sorted key, Vlite.hs:1056-1060)
-                RunHeads &rh = heads_of[sc.data->p];
+                RunHeads &rh = heads_of[std::make_pair((const void *)sc.data->p, (const void *)sel.get())];
                 if (!rh.heads) {
                     const size_t nw = (size_t)std::max<int64_t>(nwords(m), 1);
-                    rh.ctl = sc.data;
+                    rh.ctl = sc.data; rh.sel = sel;
                     rh.heads = dev_alloc(c, sizeof(uint64_t) * nw);
                     rh.wordhd = dev_alloc(c, sizeof(int64_t) * (nw + (size_t)maxscan_blocks((int64_t)nw) + 1));
                     HIP_CHECK(launch_fold_heads(i64_src(sc.data), nullptr, m, (uint64_t *)rh.heads->p, (int64_t *)rh.wordhd->p, s));
@@ -1150,6 +1152,62 @@ struct GenExec {
         return o;
     }
 
+    // vdl_plan_set_trace: host copy of what the statement's vector MEANS (n slots, value + holds-a-value), whatever form
+    // it is stored in.  Reads the stored buffers only: no cache of the executor is touched (no bitmap_of / sel_for /
+    // densify), so a traced run takes the same decisions as an untraced one.
+    static const char *form_name(const DVec &r) {
+        static const char *const kn[] = {"none", "dense", "column", "range", "onehot", "ohconst", "sparse", "expr", "lazy"};
+        static_assert(sizeof kn / sizeof kn[0] == DVec::LAZYG + 1, "one name per vector form");
+        return kn[r.kind];
+    }
+    template <typename T> std::vector<T> fetch(const void *dev, size_t count) {
+        std::vector<T> h(count);
+        if (count) HIP_CHECK(hipMemcpyAsync(h.data(), dev, sizeof(T) * count, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        return h;
+    }
+    void snapshot(const Node &n, const DVec &v) {
+        Traced t;
+        t.node = n.id; t.form = form_name(v); t.n = v.n;
+        const bool stored = v.kind == DVec::DENSE || v.kind == DVec::COLUMN || v.kind == DVec::RANGE;
+        if (v.n < 0 || v.n > kTraceMaxSlots || v.kind == DVec::NONE || v.kind == DVec::EXPR || v.kind == DVec::LAZYG) { p->traced.push_back(std::move(t)); return; }
+        const size_t ns = (size_t)v.n;
+        t.have = true;
+        t.vals.assign(ns, 0); t.ok.assign(ns, 0);
+        if (stored) {
+            if (ns) {
+                BufP tmp = dev_alloc(c, sizeof(int64_t) * ns);
+                Src zero; zero.kind = SRC_RANGE; zero.from = 0; zero.step = 0;
+                HIP_CHECK(launch_binary(B_ADD, src_of(v), zero, (int64_t *)tmp->p, v.n, s));
+                t.vals = fetch<int64_t>(tmp->p, ns);
+            }
+            if (v.valid) {
+                const std::vector<uint64_t> w = fetch<uint64_t>(v.valid->p, (size_t)nwords(v.n));
+                for (size_t i = 0; i < ns; i++) t.ok[i] = (uint8_t)((w[i >> 6] >> (i & 63)) & 1u);
+            } else t.ok.assign(ns, 1);
+            for (size_t i = 0; i < ns; i++) if (!t.ok[i]) t.vals[i] = 0;
+        } else if (v.kind == DVec::SPARSE) {
+            const size_t m = (size_t)v.sel->m;
+            const std::vector<int64_t> data = fetch<int64_t>(v.data->p, m);
+            std::vector<int64_t> idx(m);
+            if (v.sel->idx) idx = fetch<int64_t>(v.sel->idx->p, m); else for (size_t k = 0; k < m; k++) idx[k] = (int64_t)k;
+            std::vector<uint64_t> held;
+            if (v.valid) held = fetch<uint64_t>(v.valid->p, (size_t)nwords((int64_t)m));
+            for (size_t k = 0; k < m; k++) {
+                if (v.valid && !((held[k >> 6] >> (k & 63)) & 1u)) continue;
+                if (idx[k] < 0 || idx[k] >= v.n || t.ok[(size_t)idx[k]]) { t.form = "sparse(BROKEN SELECTION)"; continue; }   // slot ids must be distinct and in range
+                t.vals[(size_t)idx[k]] = data[k]; t.ok[(size_t)idx[k]] = 1;
+            }
+        } else {                                                  // ONEHOT / OHCONST: {value, slot, count} of a global fold
+            const std::vector<int64_t> rec = fetch<int64_t>(v.data->p, 3);
+            if (rec[2] > 0 && rec[1] >= 0 && rec[1] < v.n) {
+                t.vals[(size_t)rec[1]] = v.kind == DVec::OHCONST ? v.from : rec[0];
+                t.ok[(size_t)rec[1]] = 1;
+            }
+        }
+        p->traced.push_back(std::move(t));
+    }
+
     void run() { run_nodes(p->prog.outputs, nullptr); }
 
     // Executes the statements `targets` depend on.  `overrides` supplies ready-made vectors for some
@@ -1221,19 +1279,19 @@ struct GenExec {
         }
         p->outs.clear();
         p->timings.clear();
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (p->profiling) { HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1)); }
+        if (p->profiling && !p->stmt_ev[1]) { HIP_CHECK(hipEventCreate(&p->stmt_ev[0])); HIP_CHECK(hipEventCreate(&p->stmt_ev[1])); }
+        const hipEvent_t e0 = p->stmt_ev[0], e1 = p->stmt_ev[1];      // owned by the plan: an error exit leaks nothing
+        p->traced.clear();
         for (size_t k = 0; k < P.order.size(); k++) {
             const Node &n = P.at(P.order[k]);
             if (!needed[(size_t)n.id]) continue;
             if (overrides && overrides->count(n.id)) { vec[(size_t)n.id] = overrides->at(n.id); continue; }
             if (p->profiling) HIP_CHECK(hipEventRecord(e0, s));
             vec[(size_t)n.id] = exec(n);
+            if (p->tracing) snapshot(n, vec[(size_t)n.id]);
             if (trace_forms) {
                 const DVec &r = vec[(size_t)n.id];
-                static const char *const kn[] = {"none", "dense", "column", "range", "onehot", "ohconst", "sparse", "expr", "lazy"};
-                static_assert(sizeof kn / sizeof kn[0] == DVec::LAZYG + 1, "one name per vector form");
-                std::fprintf(stderr, "  Id %-4d %-18s -> %-7s n=%lld", n.id, op_name(n.op, n.bin), kn[r.kind], (long long)r.n);
+                std::fprintf(stderr, "  Id %-4d %-18s -> %-7s n=%lld", n.id, op_name(n.op, n.bin), form_name(r), (long long)r.n);
                 if (r.kind == DVec::SPARSE) std::fprintf(stderr, " m=%lld%s%s", (long long)r.sel->m, r.sel->idx ? "" : " (prefix)", r.perm ? " perm" : "");
                 std::fprintf(stderr, "  scatters so far %d\n", densified);
             }
@@ -1249,7 +1307,6 @@ struct GenExec {
         }
         HIP_CHECK(hipStreamSynchronize(s));
         finish_copies();
-        if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
     }
 };
 

@@ -105,6 +105,7 @@ struct ExprProg {
     signed char code[kExprInstrs] = {};      // >= 0: apply BinOp code to the two topmost values; < 0: push leaf (-code - 1)
 };
 hipError_t launch_expr(const ExprProg &prog, int64_t *out, int64_t n, hipStream_t s);
+hipError_t launch_poison(void *p, size_t bytes, uint64_t seed, hipStream_t s);     // VDL_POISON=rand (debugging)
 hipError_t launch_and_words(const uint64_t *a, const uint64_t *b, uint64_t *out, int64_t nwords, hipStream_t s);
 // A filter predicate -- comparisons between stored vectors joined by LogicalAnd / LogicalOr -- evaluated straight into
 // the selection bitmap: a comparison of 64 rows is one 64-bit mask (v_cmp writes it), the connectives work on masks.

@@ -265,6 +265,37 @@ hipError_t launch_pred(const PredProg &prog, const uint64_t *valid, uint64_t *ou
     return launch_status();
 }
 
+// VDL_POISON=rand: every buffer the pool hands out is filled with plausible garbage -- small non-negative integers
+// (in-range slot ids / positions), dense bit patterns, -1, large values, zeros -- a different mix per buffer.  Stale
+// memory in a long-running process looks like that (old bitmaps, old positions), unlike a constant fill byte, which as
+// an index is always out of range and as a bitmap always the same: a read of memory nobody wrote then shows as a
+// wrong result instead of depending on what ran before.
+__global__ void k_poison(uint64_t *p, int64_t nw, uint64_t seed) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += stride) {
+        uint64_t x = seed + 0x9E3779B97F4A7C15ULL * (uint64_t)(i + 1);
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL; x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL; x ^= x >> 31;
+        uint64_t v;
+        switch ((seed >> 3) % 5 == 4 ? x & 7 : (seed >> 3) % 5) {       // four pure kinds of buffer, one mixed
+        case 0: v = x % 4096; break;                                  // small ids
+        case 1: v = x; break;                                         // dense bits / huge values
+        case 2: v = ~0ull; break;
+        case 3: v = x % 64; break;                                    // tiny ids: collide a lot
+        case 5: v = 0; break;
+        case 6: v = (x & 1) ? x % 300 : ~0ull; break;
+        default: v = x % 20000; break;
+        }
+        p[i] = v;
+    }
+}
+hipError_t launch_poison(void *p, size_t bytes, uint64_t seed, hipStream_t s) {
+    (void)hipGetLastError();
+    const int64_t nw = (int64_t)(bytes / 8);
+    if (nw <= 0) return hipSuccess;
+    k_poison<<<grid_for(nw, 256, 4), 256, 0, s>>>((uint64_t *)p, nw, seed);
+    return launch_status();
+}
+
 __global__ void k_and_words(const uint64_t *a, const uint64_t *b, uint64_t *out, int64_t nw) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += stride) out[i] = a[i] & b[i];

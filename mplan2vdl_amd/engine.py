@@ -64,6 +64,25 @@ class Plan:
     def set_profiling(self, enabled):
         self._e._check(self._e._L.vdl_plan_set_profiling(self._h, int(bool(enabled))))
 
+    def set_trace(self, enabled):
+        """Keep a host copy of every statement's vector (statement-by-statement runs only): see `traced()`."""
+        self._e._check(self._e._L.vdl_plan_set_trace(self._h, int(bool(enabled))))
+
+    def traced(self):
+        """[(statement id, form, n, values or None, holds_value or None)] of the last traced run, in execution order."""
+        L, out = self._e._L, []
+        for k in range(L.vdl_n_traced(self._h)):
+            node, form, n = ctypes.c_int(), ctypes.c_char_p(), ctypes.c_int64()
+            vals, ok = ctypes.POINTER(ctypes.c_int64)(), ctypes.POINTER(ctypes.c_uint8)()
+            L.vdl_traced(self._h, k, ctypes.byref(node), ctypes.byref(form), ctypes.byref(n), ctypes.byref(vals), ctypes.byref(ok))
+            if ok or n.value == 0:      # null pointers = not evaluated at that point (an empty vector has nothing to point at either)
+                v = np.ctypeslib.as_array(vals, shape=(n.value,)).copy() if n.value else np.zeros(0, np.int64)
+                o = np.ctypeslib.as_array(ok, shape=(n.value,)).astype(bool) if n.value else np.zeros(0, bool)
+            else:
+                v = o = None
+            out.append((node.value, form.value.decode(), n.value, v, o))
+        return out
+
     def set_device_outputs(self, enabled):
         """Large outputs (>= 65536 values) stay in HBM: `collect()` returns them as `DeviceValues` (device pointer +
         length, `__cuda_array_interface__`: `torch.as_tensor(v, device=...)` wraps them without a copy).  They belong

@@ -62,6 +62,12 @@ class ShardedQuery:
         self.n_words, self.ops = runner.partial_spec()
         if buf.numel() < self.n_words:
             raise ValueError("partials buffer too small")
+        # The collectives run behind torch's current stream; the engine must launch on that same stream, or the
+        # all-reduce could read the partial words before the scan wrote them (and finalisation copy them before the
+        # reduction landed).  Made part of the API instead of a thing callers have to remember.
+        eng = getattr(runner, "_e", None)
+        if eng is not None and getattr(buf, "is_cuda", False):
+            eng.use_torch_stream()
 
     def _merge(self, buf):
         has_first = _lib.REDUCE_FIRST in self.ops

@@ -65,6 +65,10 @@ def lib():
         L.orc_sql_q1_generated.argtypes = [ctypes.POINTER(ColSpec), ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
                                            ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
         L.orc_max_threads.restype = ctypes.c_int
+        L.orc_keep_vectors.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.orc_vector.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int64),
+                                 ctypes.POINTER(ctypes.POINTER(ctypes.c_int64)), ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8)),
+                                 ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
         _lib = L
     return _lib
 
@@ -122,6 +126,25 @@ class Oracle:
         secs = self._L.orc_last_run_seconds(self._c)
         return {"results": results,
                 "timings": {"timeInMicrosecondsForCpuOracle": int(secs * 1e6)}}
+
+    def keep_vectors(self, keep=True):
+        """Keep every statement's vector readable after run() (statement-by-statement comparison with the engine)."""
+        self._L.orc_keep_vectors(self._c, int(bool(keep)))
+
+    def vector(self, node_id):
+        """(values, holds_value) of statement `node_id` after a run with keep_vectors: two arrays over the n slots
+        (int64 / bool), or None if the statement made no vector."""
+        n, frm, step = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        vals, ok = ctypes.POINTER(ctypes.c_int64)(), ctypes.POINTER(ctypes.c_uint8)()
+        if self._L.orc_vector(self._c, int(node_id), ctypes.byref(n), ctypes.byref(vals), ctypes.byref(ok), ctypes.byref(frm), ctypes.byref(step)):
+            return None
+        k = n.value
+        if vals:
+            v = np.ctypeslib.as_array(vals, shape=(k,)).copy() if k else np.zeros(0, np.int64)
+        else:
+            v = (np.uint64(frm.value & (2**64 - 1)) + np.arange(k, dtype=np.uint64) * np.uint64(step.value & (2**64 - 1))).astype(np.int64)
+        o = np.ctypeslib.as_array(ok, shape=(k,)).astype(bool) if (ok and k) else np.ones(k, bool)
+        return v, o
 
     @property
     def last_seconds(self):

@@ -81,6 +81,7 @@ typedef struct orc_ctx {
     char    err[512];
     double  last_seconds;
     int64_t ops_executed;
+    int     keep_vectors;     /* orc_keep_vectors: intermediates survive orc_run (statement-by-statement comparison in tests) */
 } orc_ctx;
 
 static double now_s(void) {
@@ -720,9 +721,22 @@ int orc_run(orc_ctx *c, const char *text, size_t len) {
     c->last_seconds = now_s() - t0;
     free(buf);
     /* intermediates are not needed after the run; outputs are kept */
-    for (int i = 0; i < c->nvecs; i++) free_vec(&c->vecs[i]);
-    free(c->vecs); c->vecs = NULL; c->nvecs = 0;
+    if (!c->keep_vectors) {
+        for (int i = 0; i < c->nvecs; i++) free_vec(&c->vecs[i]);
+        free(c->vecs); c->vecs = NULL; c->nvecs = 0;
+    }
     return rc;
+}
+
+/* Tracing for the parity tests: with keep != 0 the vector of every statement stays readable after orc_run (until the
+ * next run / orc_close), so that a mismatching program can be compared with the engine statement by statement.
+ * orc_vector: *vals == NULL for a virtual range (value_i = from + i*step), *ok == NULL when every slot holds a value. */
+void orc_keep_vectors(orc_ctx *c, int keep) { c->keep_vectors = keep; }
+int orc_vector(const orc_ctx *c, int id, int64_t *n, const int64_t **vals, const uint8_t **ok, int64_t *from, int64_t *step) {
+    if (id <= 0 || id >= c->nvecs || !c->vecs[id].defined) return -1;
+    const ovec *v = &c->vecs[id];
+    *n = v->n; *vals = v->is_range ? NULL : v->val; *ok = v->ok; *from = v->from; *step = v->step;
+    return 0;
 }
 
 int orc_n_outputs(const orc_ctx *c) { return c->nouts; }

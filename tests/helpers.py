@@ -82,3 +82,115 @@ def sql_like(s, pattern):
 
     rx = "".join(".*" if ch == "%" else "." if ch == "_" else re.escape(ch) for ch in pattern)
     return 1 if re.fullmatch(rx, s, flags=re.S) else 0
+
+
+# ---- statement-by-statement comparison (engine trace vs oracle vectors) -------------------------------------------
+def _statement_lines(text):
+    out = {}
+    for ln in text.splitlines():
+        head = ln.split(",", 1)[0].strip()
+        if head.isdigit():
+            out[int(head)] = ln.strip()
+    return out
+
+
+def compare_traced(plan, orc, text):
+    """First statement of the last traced run whose vector differs from the oracle's (orc ran `text` with
+    keep_vectors): None if every evaluated statement agrees, else a dict describing the divergence.
+    One deliberate difference is tolerated: a RangeV over a gather that the engine never runs (its only reader is the
+    filter idiom FoldSelect(RangeV 0 1 g, g)) lends its length and an UPPER BOUND of its validity
+    (vdl_genexec.h, `lazy_gather_ok`)."""
+    import numpy as np
+
+    lines = _statement_lines(text)
+    compared = 0
+    for node, form, n, vals, ok in plan.traced():
+        if vals is None:
+            continue
+        ref = orc.vector(node)
+        if ref is None:
+            continue
+        rv, ro = ref
+        line = lines.get(node, "?")
+        if len(rv) != n:
+            return {"statement": node, "line": line, "form": form, "why": "length %d, oracle %d" % (n, len(rv))}
+        compared += 1
+        bad_ok = np.nonzero(ok != ro)[0]
+        if len(bad_ok) and ",RangeV," in line and not np.any(ro & ~ok):
+            bad_ok = bad_ok[:0]
+            ok = ro
+        both = ok & ro
+        bad_val = np.nonzero(both & (vals != rv))[0]
+        if len(bad_ok) or len(bad_val):
+            return {"statement": node, "line": line, "form": form,
+                    "validity_differs_at": [int(i) for i in bad_ok[:8]], "n_validity_diffs": int(len(bad_ok)),
+                    "engine_holds": [bool(ok[i]) for i in bad_ok[:8]],
+                    "value_differs_at": [int(i) for i in bad_val[:8]], "n_value_diffs": int(len(bad_val)),
+                    "engine": [int(vals[i]) for i in bad_val[:8]], "oracle": [int(rv[i]) for i in bad_val[:8]]}
+    return None if compared else {"why": "nothing was traced"}
+
+
+def explain_mismatch(tag, seed, text, cols, got, want, reruns=3):
+    """A result differed from the oracle: write everything needed to study it to gpurun_out/mismatch/<tag>_<seed>.txt --
+    the switches in force, the program, both result dicts -- then run the program again statement by statement with
+    tracing on (`reruns` times: the failure may not show every time) and name the first statement whose vector
+    differs from the oracle's.  Returns the path of the report."""
+    import json
+    import os
+    import sys
+    import tempfile
+
+    import oracle
+
+    root = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "gpurun_out", "mismatch")
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, "%s_seed%s.txt" % (tag, seed))
+    with open(path, "w") as f:
+        f.write("tag %s  seed %s\nswitches: %s\n" % (tag, seed, {k: v for k, v in os.environ.items() if k.startswith("VDL_")}))
+        f.write("columns: %s\n" % {k: (str(v.dtype), len(v)) for k, v in cols.items()})
+        f.write("---- program\n%s\n---- engine\n%s\n---- oracle\n%s\n" % (text, json.dumps(got, sort_keys=True), json.dumps(want, sort_keys=True)))
+        for k in sorted(set(got) | set(want)):
+            if got.get(k) != want.get(k):
+                f.write("differs: %s\n  engine %s\n  oracle %s\n" % (k, got.get(k), want.get(k)))
+        orc = oracle.Oracle()
+        orc.keep_vectors(True)
+        for k, v in cols.items():
+            orc.add_column(k, v)
+        orc.run(text)
+        for attempt in range(reruns):
+            e = engine_with(cols)
+            p = e.parse(text)
+            p.set_fusion(False)
+            p.set_trace(True)
+            forms = ""
+            try:
+                # the engine's own account of the forms it chose (VDL_TRACE_FORMS goes to the C stderr): captured at fd level
+                sys.stderr.flush()
+                with tempfile.TemporaryFile() as cap:
+                    saved = os.dup(2)
+                    os.environ["VDL_TRACE_FORMS"] = "1"
+                    os.dup2(cap.fileno(), 2)
+                    try:
+                        again = p.run()["results"]
+                    finally:
+                        os.dup2(saved, 2)
+                        os.close(saved)
+                        os.environ.pop("VDL_TRACE_FORMS", None)
+                    cap.seek(0)
+                    forms = cap.read().decode(errors="replace")
+                first = compare_traced(p, orc, text)
+                f.write("---- traced rerun %d (statement by statement): results %s the oracle; first diverging statement: %s\n"
+                        % (attempt, "EQUAL" if again == want else "DIFFER FROM", json.dumps(first)))
+                if again != want or first is not None or attempt == 0:
+                    f.write(forms)
+            finally:
+                e.close()
+        orc.close()
+    return path
+
+
+def check_against_oracle(tag, seed, text, cols, got, want):
+    if got != want:
+        path = explain_mismatch(tag, seed, text, cols, got, want)
+        raise AssertionError("%s seed %s: engine and oracle differ; report in %s\n%s" % (tag, seed, path, open(path).read()[-6000:]))

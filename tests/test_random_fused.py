@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import mplan2vdl_amd as m
-from helpers import engine_with, oracle_run, prog
+from helpers import check_against_oracle, engine_with, oracle_run, prog
 
 
 class Gen:
@@ -135,6 +135,6 @@ def test_random_filter_aggregate_programs_match_the_oracle():
         p.set_fusion(False)
         unfused = p.run()["results"]
         e.close()
-        assert got == want, "seed %d (fused=%s)\n%s" % (seed, p.is_fused, text)
-        assert unfused == want, "seed %d (statement by statement)\n%s" % (seed, text)
+        check_against_oracle("random_fused_as_planned", seed, text, cols, got, want)
+        check_against_oracle("random_fused_statement_by_statement", seed, text, cols, unfused, want)
     assert fused >= 80

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import engine_with, oracle_run, prog
+from helpers import check_against_oracle, compare_traced, engine_with, oracle_run, prog
 
 BINOPS = ["Add", "Subtract", "Multiply", "Greater", "Equals", "LogicalAnd", "LogicalOr", "BitwiseAnd", "BitwiseOr", "Divide", "Modulo", "BitShift"]
 FOLDS = ["FoldSum", "FoldMin", "FoldMax", "FoldChoose", "FoldCount"]
@@ -107,13 +107,13 @@ class Gen:
         return prog(*self.lines), self.cols
 
 
-def check(seed, steps):
+def check(seed, steps, tag="random_programs"):
     text, cols = Gen(seed).build(steps)
     want = oracle_run(text, cols)
     e = engine_with(cols)
     got = e.run_vdl(text)["results"]
     e.close()
-    assert got == want, "seed %d\n%s" % (seed, text)
+    check_against_oracle(tag, seed, text, cols, got, want)      # on a mismatch: report file + traced reruns (helpers.explain_mismatch)
 
 
 def test_generator_produces_programs_the_oracle_accepts():
@@ -128,4 +128,32 @@ def test_random_programs_match_the_oracle(monkeypatch, mode):
     if mode:
         monkeypatch.setenv(mode, "1")
     for seed in range(120):
-        check(seed, 10 + seed % 30)
+        check(seed, 10 + seed % 30, "random_programs_%s" % (mode or "default"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [None, "VDL_SPARSE_ALWAYS", "VDL_NO_SPARSE"])
+def test_every_statement_of_random_programs_matches_the_oracle(monkeypatch, mode):
+    """Not only the outputs: with tracing on, the vector of every statement the executor evaluated (whatever form it
+    keeps it in) must equal the oracle's vector of that statement, slot by slot."""
+    import oracle
+
+    if mode:
+        monkeypatch.setenv(mode, "1")
+    for seed in range(200, 260):
+        text, cols = Gen(seed).build(10 + seed % 30)
+        orc = oracle.Oracle()
+        orc.keep_vectors(True)
+        for k, v in cols.items():
+            orc.add_column(k, v)
+        want = orc.run(text)["results"]
+        e = engine_with(cols)
+        p = e.parse(text)
+        p.set_fusion(False)
+        p.set_trace(True)
+        got = p.run()["results"]
+        first = compare_traced(p, orc, text)
+        e.close()
+        orc.close()
+        assert first is None, "seed %d (%s): %s\n%s" % (seed, mode, first, text)
+        check_against_oracle("traced_%s" % (mode or "default"), seed, text, cols, got, want)
