@@ -25,6 +25,31 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+Q1_SQL_ORDER = ["lineitem.l_shipdate", "lineitem.l_returnflag", "lineitem.l_linestatus", "lineitem.l_quantity",
+                "lineitem.l_extendedprice", "lineitem.l_discount", "lineitem.l_tax"]
+Q1_OUTPUTS = ["l_returnflag__lineitem__l_returnflag", "l_linestatus__lineitem__l_linestatus", "sum_qty", "sum_base_price",
+              "sum_disc_price", "sum_charge", "avg_qty", "avg_price", "avg_disc", "count_order"]
+
+
+def q1_matches_sql(results, total_rows, threads, report=None):
+    """Bit-exact check of a full-size Q1 answer: the SQL-semantics loop (oracle/vdl_oracle.c:orc_sql_q1_generated) over
+    the regenerated rows on the host cores.  Test infrastructure, always outside any timed region."""
+    import oracle
+    from mplan2vdl_amd import datagen
+
+    specs = [(datagen.SEED, datagen.col_id(c), datagen.LINEITEM[c].lo, datagen.LINEITEM[c].hi,
+              datagen.LINEITEM[c].mul, datagen.LINEITEM[c].add) for c in Q1_SQL_ORDER]
+    tab = oracle.sql_q1_generated(specs, 0, total_rows, threads=threads)
+    flat = {list(v.keys())[0][1:]: list(v.values())[0] for v in results.values()}
+    ok = True
+    for j, nm in enumerate(Q1_OUTPUTS):
+        if flat.get(nm) != [int(x) for x in tab[:, j]]:
+            ok = False
+            if report:
+                report("  %s: gpu %r\n  %s: cpu %r" % (nm, flat.get(nm), nm, [int(x) for x in tab[:, j]]))
+    return ok
+
+
 def secondary_measurements(eng, rows):
     """Not the headline metric: the other two single-GPU configurations of BASELINE.json on the same box, measured
     after the timed region (Q1 grouped fused scan over the same lineitem rows; Q3 at SF10 through the statement-by-
@@ -48,7 +73,8 @@ def secondary_measurements(eng, rows):
         also["tpch_q1_same_rows"] = {"rows": rows, "ms_per_query": 1e3 * sum(wall[2:]) / len(wall[2:]), "rows_per_s": rows / (sum(wall[2:]) / len(wall[2:])),
                                      "kernel_us": k_us, "bytes_per_row": datagen.Q1_BYTES_PER_ROW,
                                      "roofline_frac": rows * datagen.Q1_BYTES_PER_ROW / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                                     "groups": len(r["results"]["tmp101"][".count_order"])}
+                                     "groups": len(r["results"]["tmp101"][".count_order"]),
+                                     "verified_bit_exact_vs_cpu": q1_matches_sql(r["results"], rows, max(1, min(os.cpu_count() or 1, 64)))}
         q1.close()
         for name in datagen.Q1_COLUMNS:
             eng.drop(name)
@@ -264,20 +290,9 @@ def main():
         # torchrun exports OMP_NUM_THREADS=1; the checker may use the host's cores (capped)
         host_threads = max(1, min(os.cpu_count() or 1, 64))
         if not args.no_verify and args.query == "q1":
-            order = ["lineitem.l_shipdate", "lineitem.l_returnflag", "lineitem.l_linestatus", "lineitem.l_quantity",
-                     "lineitem.l_extendedprice", "lineitem.l_discount", "lineitem.l_tax"]
-            specs = [(datagen.SEED, datagen.col_id(c), datagen.LINEITEM[c].lo, datagen.LINEITEM[c].hi,
-                      datagen.LINEITEM[c].mul, datagen.LINEITEM[c].add) for c in order]
-            tab = oracle.sql_q1_generated(specs, 0, total_rows, threads=host_threads)
-            names = ["l_returnflag__lineitem__l_returnflag", "l_linestatus__lineitem__l_linestatus", "sum_qty", "sum_base_price",
-                     "sum_disc_price", "sum_charge", "avg_qty", "avg_price", "avg_disc", "count_order"]
-            flat = {list(v.keys())[0][1:]: list(v.values())[0] for v in result["results"].values()}
-            verified = all(flat[nm] == [int(x) for x in tab[:, j]] for j, nm in enumerate(names))
+            verified = q1_matches_sql(result["results"], total_rows, host_threads, lambda msg: print(msg, file=sys.stderr))
             if not verified:
                 print("VERIFICATION FAILED (q1)", file=sys.stderr)
-                for j, nm in enumerate(names):
-                    if flat[nm] != [int(x) for x in tab[:, j]]:
-                        print("  %s: gpu %r\n  %s: cpu %r" % (nm, flat[nm], nm, [int(x) for x in tab[:, j]]), file=sys.stderr)
         if not args.no_verify and args.query == "q6":
             # bit-exact check of the full-size answer: the SQL-semantics loop over regenerated rows
             # on all host cores (test infrastructure; outside the timed region)
@@ -306,13 +321,17 @@ def main():
                             "fused_sql_loop_rows_per_s_1core": n_s / f1,
                             "fused_sql_loop_rows_per_s_allcores": n_s / fn, "allcores": nt,
                             "interpreter_matches_sql_loop": ok}
-        traffic = None
+        # HBM bytes per launch from the PMC counters cannot be collected from inside this process: the figure is the one
+        # of the committed rocprofv3 --pmc FETCH_SIZE pass of this same command (tools/profile_bench.sh ->
+        # profiles/traffic.json), used only when it was taken for the same kernel over the same number of rows
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath))
-                if tj.get("rows") == my_rows and args.query == "q6":
+                tj = json.load(open(tpath)).get(args.query, {})
+                if tj.get("rows") == my_rows:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_source = "committed profile, not measured in this run: " + tj.get("source", "profiles/traffic.json")
             except Exception:
                 traffic = None
         out = {
@@ -327,7 +346,7 @@ def main():
                                     "" if os.environ.get("VDL_BENCH_SYNC_MERGE") == "1" or args.query != "q6" else ", overlapped with the next query's scan"))
                        if world > 1 else "local"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel_label, "kernel_us": kern_us,
                          "algorithmic_bytes_per_launch": my_rows * q_bytes},
             "cpu_baseline": cpu_baseline,

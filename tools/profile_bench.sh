@@ -1,24 +1,45 @@
 #!/bin/bash
-# rocprofv3 summaries of the headline bench (Q6 SF100) and of Q1 SF100, copied under profiles/ by hand afterwards
+# rocprofv3 evidence for bench.py's roofline objects: kernel-trace stats of the headline run (Q6 SF100) and of Q1 over the
+# same rows, plus separate --pmc FETCH_SIZE / WRITE_SIZE passes (never combined with other trace domains).  Leaves
+#   gpurun_out/profile_bench/{q6,q1}_kernel_stats.csv, {q6,q1}_bench.json, traffic.json
+# which are copied under profiles/rNN/ (and traffic.json to profiles/) by hand afterwards.
 set -e
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/profile_bench
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/q6 -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/q6.json 2> $OUT/q6.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/q1 -- python3 $ROOT/bench.py --query q1 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/q1.json 2> $OUT/q1.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/q6_fetch -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify > $OUT/q6_fetch.json 2> $OUT/q6_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/q6_write -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify > $OUT/q6_write.json 2> $OUT/q6_write.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/q6 -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > $OUT/q6_bench.json 2> $OUT/q6.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/q1 -- python3 $ROOT/bench.py --query q1 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/q1_bench.json 2> $OUT/q1.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/q6_fetch -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-secondary --latency-steps 0 > $OUT/q6_fetch.json 2> $OUT/q6_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/q6_write -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-secondary --latency-steps 0 > $OUT/q6_write.json 2> $OUT/q6_write.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/q1_fetch -- python3 $ROOT/bench.py --query q1 --steps 3 --warmup 1 --no-cpu-baseline --no-verify --latency-steps 0 > $OUT/q1_fetch.json 2> $OUT/q1_fetch.err
 for q in q6 q1; do
-  f=$(ls $OUT/$q/*/*kernel_stats.csv | head -n 1); echo "== $q"; head -n 6 $f | cut -c1-160; tail -n 1 $OUT/$q.json | cut -c1-300
+  f=$(ls $OUT/$q/*/*kernel_stats.csv | head -n 1); cp $f $OUT/${q}_kernel_stats.csv
+  echo "== $q"; head -n 6 $f | cut -c1-160; tail -n 1 $OUT/${q}_bench.json | cut -c1-300
 done
 python3 - $OUT <<'PY'
-import csv, glob, sys
-for tag in ("q6_fetch", "q6_write"):
-    f = glob.glob(sys.argv[1] + "/%s/*/*counter_collection.csv" % tag)[0]
-    tot, cnt = 0.0, set()
+import csv, glob, json, sys
+out = sys.argv[1]
+def per_dispatch(tag, needle):
+    f = glob.glob(out + "/%s/*/*counter_collection.csv" % tag)[0]
+    tot, ids, name = 0.0, set(), None
     for r in csv.DictReader(open(f)):
-        if "k_scan<" in r["Kernel_Name"]:
-            tot += float(r["Counter_Value"]); cnt.add(r["Dispatch_Id"])
-    print(tag, "k_scan dispatches", len(cnt), "counter per dispatch %.0f (KB units per the guide)" % (tot / max(len(cnt), 1)))
+        if needle in r["Kernel_Name"]:
+            tot += float(r["Counter_Value"]); ids.add(r["Dispatch_Id"]); name = r["Kernel_Name"]
+    return tot / max(len(ids), 1), len(ids), name
+# unit calibration on the generator: WRITE_SIZE of k_gen_column<long> against the bytes it is known to write (KiB per count?)
+res = {}
+for q, needle, rows_key in (("q6", "k_scan<", "q6_fetch"), ("q1", "k_mscan<", "q1_fetch")):
+    fetch, n, name = per_dispatch(rows_key, needle)
+    bench = json.loads(open(out + "/%s_fetch.json" % q).read().strip().splitlines()[-1])
+    rows = bench["config"]["rows_per_gpu"]
+    algo = bench["roofline"]["algorithmic_bytes_per_launch"]
+    res[q] = {"rows": rows, "kernel": name, "FETCH_SIZE_KiB_mean": fetch, "dispatches": n,
+              "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for wide coalesced streaming reads -> x2 (MI355X_MICROARCH.md, HBM section); unit = KiB",
+              "hbm_bytes_per_launch": int(fetch * 1024 * 2), "algorithmic_bytes_per_launch": algo,
+              "source": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 bench.py %s--steps 3 --warmup 1 (tools/profile_bench.sh)" % ("--query q1 " if q == "q1" else "")}
+    print(q, name, "FETCH_SIZE/dispatch %.0f KiB -> %.4g B (x2), algorithmic %.4g B, ratio %.5f" % (fetch, fetch * 2048, algo, fetch * 2048 / algo))
+w, n, name = per_dispatch("q6_write", "k_scan<")
+print("q6 WRITE_SIZE/dispatch %.1f KiB over %d dispatches" % (w, n))
+json.dump(res, open(out + "/traffic.json", "w"), indent=1)
 PY
