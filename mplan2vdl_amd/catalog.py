@@ -11,6 +11,12 @@ end to end:
   them (so equality predicates on string literals select something);
 * primary-key reference vectors (`table.<pk constraint>`, Vlite.hs:734-741): zeros, length only;
 * foreign-key join indices (`table.<fk constraint>`, Vlite.hs:1250-1258): row numbers of the scaled dim table;
+* the database is COHERENT: primary-key value columns are unique (ascending, spread over the catalog's range), every
+  foreign-key value column holds the key of the row its join index points at (l_orderkey = o_orderkey[lineitem_orders]),
+  lineitem's part / supplier indices go through its partsupp index, and (ps_partkey, ps_suppkey) pairs are unique --
+  so plans that join on VALUES (Q15's view, Q18's IN-subquery, Q20's correlated subquery) select the same rows as
+  plans that join through the indices, and the SQL text of a query can be evaluated over the columns directly
+  (tests/sql_eval.py);
 * string heaps (`table.col.heap`, Vdl.hs:246): NUL-terminated strings at 8-byte aligned offsets; the
   vocabulary contains a match and a near-miss for every LIKE pattern the program applies to that heap.
 """
@@ -105,8 +111,18 @@ def _build_heap(placed, free, base, limit=None):
     return np.frombuffer(bytes(buf), dtype=np.int8).copy(), where
 
 
-def synth_columns(meta_dir, cfg, vdl_text, scale=2e-4, seed=1):
-    """{column key path: numpy array} for every Load of `vdl_text`."""
+def _fk_graph(cfg):
+    """{(fact table, index column): (dim table, [(fact value column, dim key column), ...])} from the catalog's foreign keys."""
+    out = {}
+    for fk in cfg.fkrefs.values():
+        if fk.fkjoinorder != "FactDim" or fk.cols[0][1][1] == "%TID%":
+            continue
+        out[(fk.fact[0], fk.idxname[1])] = (fk.dim[0], [(a[1], b[1]) for a, b in fk.cols])
+    return out
+
+
+def synth_columns(meta_dir, cfg, vdl_text, scale=2e-4, seed=1, extra=()):
+    """{column key path: numpy array} for every Load of `vdl_text` (and every path in `extra`)."""
     codes = _per_column_codes(meta_dir)
     patterns = _like_patterns(vdl_text)
     info = {name: ci for name, ci in cfg.colinfo.to_list()}
@@ -116,7 +132,54 @@ def synth_columns(meta_dir, cfg, vdl_text, scale=2e-4, seed=1):
     fk_dim = {fk.idxname: fk.dim[0] for fk in cfg.fkrefs.values()}
     pk_names = set(cfg.table_pkeys.values())
     wanted = [ln.split(",")[2].split(";;")[0].strip() for ln in vdl_text.splitlines() if len(ln.split(",")) >= 3 and ln.split(",")[1] == "Load"]
+    wanted += list(extra)
     heaps, out = {}, {}
+    fks = _fk_graph(cfg)
+    single = {k: v for k, v in fks.items() if len(v[1]) == 1}
+    composite = {k: v for k, v in fks.items() if len(v[1]) > 1}
+    pk_value = set()                               # (table, column): single-column primary keys some foreign key refers to
+    fk_value = {}                                  # (fact table, value column) -> (index column, dim table, dim key column)
+    for (fact, idx), (dim, pairs) in single.items():
+        pk_value.add((dim, pairs[0][1]))
+        fk_value[(fact, pairs[0][0])] = (idx, dim, pairs[0][1])
+    # a fact table with a composite foreign key (lineitem -> partsupp on (partkey, suppkey)) reaches part / supplier THROUGH
+    # that row: {(fact, single index): (composite index, middle table, the middle table's own index to the same dim)}
+    via = {}
+    pair_tables = set()                            # tables whose rows are unique pairs of two foreign keys (partsupp)
+    for (fact, cidx), (mid, pairs) in composite.items():
+        pair_tables.add(mid)
+        for fcol, mcol in pairs:
+            for (f2, i2), (d2, p2) in single.items():
+                if f2 == fact and p2[0][0] == fcol:
+                    hop = [i3 for (f3, i3), (d3, p3) in single.items() if f3 == mid and p3[0][0] == mcol and d3 == d2]
+                    if hop:
+                        via[(fact, i2)] = (cidx, mid, hop[0])
+    memo = {}
+
+    def join_index(table, idx):
+        key = (table, idx)
+        if key in memo:
+            return memo[key]
+        n = rows[table]
+        dim = fks[key][0]
+        if key in via:                                                  # lineitem_part = partsupp_part[lineitem_partsupp]
+            cidx, mid, hop = via[key]
+            v = join_index(mid, hop)[join_index(table, cidx)]
+        elif table in pair_tables and key in single:                    # unique (part, supplier) pairs
+            mine = sorted(i for (f, i) in single if f == table)
+            i = np.arange(n, dtype=np.int64)
+            n0, n1 = rows[single[(table, mine[0])][0]], rows[single[(table, mine[1])][0]]
+            a = i % n0
+            v = a if idx == mine[0] else (i // n0 + a * 7) % n1
+        else:
+            v = _rng(seed, "%s.%s" % key).integers(0, rows[dim], n)
+        memo[key] = np.asarray(v, dtype=np.int64)
+        return memo[key]
+
+    def key_values(table, col):
+        ci = info[(table, col)]
+        lo, hi, n = int(ci.bounds[0]), int(ci.bounds[1]), rows[table]
+        return lo + np.arange(n, dtype=np.int64) * max((hi - lo) // max(n, 1), 1)
 
     def string_column(table, col):
         key = (table, col)
@@ -146,16 +209,26 @@ def synth_columns(meta_dir, cfg, vdl_text, scale=2e-4, seed=1):
             out[path] = np.zeros(n, np.int64)
             continue
         if key in fk_dim:
-            out[path] = _rng(seed, path).integers(0, rows[fk_dim[key]], n).astype(np.int64)
+            out[path] = join_index(table, parts[1])
             continue
         if key not in info:
             raise FrontendError("no column %s in the catalog" % path)
         ci = info[key]
         rng = _rng(seed, path)
+        if key in fk_value:                                              # the key of the row the join index points at
+            idx, dim, dcol = fk_value[key]
+            out[path] = key_values(dim, dcol)[join_index(table, idx)].astype(np.int32 if ci.stype == ("SInt32",) else np.int64)
+            continue
+        if key in pk_value:
+            out[path] = key_values(table, parts[1]).astype(np.int32 if ci.stype == ("SInt32",) else np.int64)
+            continue
         if ci.dtype[0][0] == "DString":
             _, where = string_column(table, parts[1])
             offs = np.array(sorted(where.values()), dtype=np.int64)
-            out[path] = offs[rng.integers(0, len(offs), n)]
+            if n <= len(offs) and codes.get(key):                        # nation / region: every name once, as in the real tables
+                out[path] = offs[rng.permutation(len(offs))[:n]]
+            else:
+                out[path] = offs[rng.integers(0, len(offs), n)]
             continue
         lo, hi, tz = int(ci.bounds[0]), int(ci.bounds[1]), int(ci.trailing_zeros)
         if tz >= 63 or hi < lo:

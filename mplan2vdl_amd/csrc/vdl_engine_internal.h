@@ -98,6 +98,7 @@ struct Sel {
     BufP ppos;                      // for each of the m slots its entry number inside the parent
     bool worth = true;              // false: too dense to be worth compacting (only m is known)
     BufP wrank;                     // selected slots before each bitmap word (built when something gathers out of a vector on this selection)
+    int64_t first_slot = -1;        // the first selected slot once somebody asked (GenExec::first_slot_of); prefix selections: 0
 };
 using SelP = std::shared_ptr<Sel>;
 

@@ -143,6 +143,14 @@ struct GenExec {
         }
         return sel->bitmap;
     }
+    int64_t first_slot_of(const SelP &sel) {
+        if (!sel->idx || sel->m <= 0) return 0;
+        if (sel->first_slot < 0) {
+            HIP_CHECK(hipMemcpyAsync(&sel->first_slot, sel->idx->p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+        }
+        return sel->first_slot;
+    }
     struct RunHeads { BufP ctl, heads, wordhd, offsets; int64_t count = 0; SelP sel, child; };
     std::map<std::pair<const void *, const void *>, RunHeads> heads_of;   // (control entries buffer, its selection) -> run heads (both kept alive by the entry)
     struct DenseHeads { BufP ctl, ctlv, heads, wordhd; };
@@ -1001,14 +1009,16 @@ struct GenExec {
                 BufP scratch = dev_alloc(c, sizeof(int64_t) * 3 * (size_t)fold_scratch_blocks());
                 o.kind = DVec::ONEHOT; o.n = sd.n;
                 o.data = dev_alloc(c, 3 * sizeof(int64_t));
+                // (the record's slot is 0: the run starts at slot 0 of the vector, not at the selection's first slot)
                 HIP_CHECK(launch_fold_global(kind, i64_src(sd.data), nullptr, nullptr, sd.sel->m, (int64_t *)scratch->p, (int64_t *)o.data->p, s));
-                HIP_CHECK(hipMemcpyAsync((int64_t *)o.data->p + 1, sd.sel->idx->p, sizeof(int64_t), hipMemcpyDeviceToDevice, s));
                 return o;
             }
             const bool data_on_sel = V(n.a).kind == DVec::SPARSE &&
                                      ((V(n.b).kind == DVec::SPARSE && V(n.a).sel == V(n.b).sel) ||
                                       (V(n.b).kind == DVec::RANGE && V(n.b).step == 0 && V(n.b).n == V(n.a).n && subset(bitmap_of(V(n.a).sel), V(n.b).valid)));
-            if (sparse_on && data_on_sel) {
+            // (the first run's result belongs in slot 0 of the vector: on the entries that is only the case when the selection
+            // starts at slot 0 -- always so for the prefix selections GROUP BY folds over; anything else takes the dense route)
+            if (sparse_on && data_on_sel && first_slot_of(V(n.a).sel) == 0) {
                 // runs skip EPS slots, so folding the m entries gives the same runs; results sit at run-first entries
                 const DVec &sc = V(n.a), &sd = V(n.b);
                 const SelP &sel = sc.sel;

@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void k_fold_global_finish(int kind, Src d, con
         }
         if (kind == 4) acc = cnt > 0 ? ld(d, acc) : 0;     // FoldChoose: the first datum of the run
         result[0] = acc;
-        result[1] = first == INT64_MAX ? -1 : first;
+        result[1] = first == INT64_MAX ? -1 : 0;     // the first (here: only) run of a vector starts at slot 0, whatever EPS slots precede its first member
         result[2] = cnt;
     }
 }
@@ -481,7 +481,7 @@ __global__ void k_fold_words(const int64_t *rec, int rk, int64_t row0, int64_t *
 }
 __global__ void k_fold_record(const int64_t *words, int64_t *rec) {
     rec[0] = words[2] > 0 ? words[0] : 0;
-    rec[1] = words[1] == INT64_MAX ? -1 : words[1];
+    rec[1] = words[1] == INT64_MAX ? -1 : 0;         // merged over all shards: the run starts at global slot 0
     rec[2] = words[2];
 }
 hipError_t launch_fold_words(const int64_t *rec, int reduce, int64_t row0, int64_t *out, hipStream_t s) {
@@ -969,6 +969,24 @@ __global__ __launch_bounds__(256) void k_seg_heads(Src ctl, const uint64_t *vc, 
     }
 }
 
+// The first run of a vector starts at slot 0 (EPS control slots ahead of its first member belong to it: an ungrouped
+// aggregate is read back at position 0, Vlite.hs:693-712).  k_seg_heads marks the first member; this moves that one mark
+// to slot 0.  One wave; the first non-empty word is almost always word 0 (vectors scattered into key order are dense).
+__global__ __launch_bounds__(64) void k_seg_first_head(uint64_t *heads, int64_t nw) {
+    const int lane = threadIdx.x;
+    for (int64_t w0 = 0; w0 < nw; w0 += kWave) {
+        const int64_t w = w0 + lane;
+        const uint64_t m = w < nw ? heads[w] : 0ull;
+        const uint64_t any = __ballot(m != 0);
+        if (!any) continue;
+        const int first_lane = __ffsll((long long)any) - 1;
+        if (lane == first_lane) heads[w] = m & (m - 1);                    // clear the lowest mark ...
+        __threadfence_block();
+        if (lane == first_lane) heads[0] |= 1ull;                          // ... and set it at slot 0 (same lane: ordered stores, even when w == 0)
+        return;
+    }
+}
+
 __global__ void k_seg_wordhd(const uint64_t *heads, int64_t nw, int64_t *wordhd) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nw; w += stride) {
@@ -1194,6 +1212,7 @@ hipError_t launch_fold_heads(Src ctl, const uint64_t *vc, int64_t n, uint64_t *h
     if (n <= 0) return hipSuccess;
     const int64_t nw = (n + 63) >> 6;
     k_seg_heads<<<grid_for(n, 256, 4), 256, 0, s>>>(ctl, vc, n, heads);
+    if (vc) k_seg_first_head<<<1, kWave, 0, s>>>(heads, nw);               // (without EPS slots the first member is slot 0 already)
     k_seg_wordhd<<<grid_for(nw, 256, 1), 256, 0, s>>>(heads, nw, wordhd);
     if (launch_maxscan(wordhd, nw, wordhd + nw, s) != hipSuccess) return hipGetLastError();
     return launch_status();

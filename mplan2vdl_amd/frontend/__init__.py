@@ -22,10 +22,16 @@ def load_metadata(directory, **flags):
                        j(directory, "dictionary.csv"), **flags)
 
 
-def compile_plan(plan_text, config, apply_passes=True, push_joins=False):
+def compile_plan(plan_text, config, apply_passes=True, push_joins=False, distinct_rangec=False):
+    """`distinct_rangec` switches off one reference bug (see vlite.DISTINCT_RANGEC); the default is bug-compatible."""
     tree = _parse.parse_mplan(_parse.filter_comments(plan_text))
     rel = _mplan.solve(config, tree)
     if push_joins:
         rel = _mplan.fuse_selects(_mplan.push_fk_joins(rel))
-    vexps = _vlite.vexps_from_mplan(rel, config, apply_passes=apply_passes)
-    return _vdl.vdl_from_vexps(vexps, config)
+    saved = _vlite.DISTINCT_RANGEC
+    _vlite.DISTINCT_RANGEC = bool(distinct_rangec)
+    try:
+        vexps = _vlite.vexps_from_mplan(rel, config, apply_passes=apply_passes)
+        return _vdl.vdl_from_vexps(vexps, config)
+    finally:
+        _vlite.DISTINCT_RANGEC = saved

@@ -29,13 +29,18 @@ class Vexp:
 #             ("Shuffle", "Gather"|"Scatter", source, pos) ("Fold", op, groups, data) ("Partition", pivots, data)
 #             ("VShuffle", arg) ("Like", data, pattern, col) ("CrossProduct", l, r, variant) ("Semisort", data)
 _INTERN = {}
+# compile_plan(distinct_rangec=True): give every RangeC its own identity.  NOT the reference's behaviour -- there all
+# RangeC hash alike (Vlite.hs:72-75,121), so a program with two GROUP BYs partitions the second key over the FIRST key's
+# pivots (TPC-H Q16, Q18: groups fall apart).  The tests use it to show that this is the only thing standing between
+# the compiled programs of those two plans and their SQL (tests/test_sql_pins.py).
+DISTINCT_RANGEC = False
 
 
 def vx_key(vx):
     """Structural identity as a small integer (hash-consing): the operator with its operands replaced by
     THEIR identities.  Nested tuples would re-expand shared sub-DAGs into trees on every hash."""
     k = vx[0]
-    flat = ("RangeC",) if k == "RangeC" else tuple(x.key if isinstance(x, Vexp) else x for x in vx)
+    flat = ("RangeC",) if k == "RangeC" and not DISTINCT_RANGEC else tuple(x.key if isinstance(x, Vexp) else x for x in vx)
     return _INTERN.setdefault(flat, len(_INTERN))
 
 
@@ -273,8 +278,10 @@ def sc(env, e):
     if k == "Identity":
         return pos_(env.list[0])
     if k == "Unary" and e[1] == "Year":
-        d = sc(env, e[2])                                 # ((days)*1000 + 1100) / 365243, Vlite.hs:988-994
-        return binop("Add", binop("Mul", d, const_(1000, d)), binop("Div", const_(1100, d), const_(365243, d)))
+        # ((days * 1000) + 1100) / 365243, Vlite.hs:988-994.  The source line reads `(d *. 1000) +. 1100 /. v365243`
+        # and the module declares no fixities, so all three operators are infixl 9: the sum is divided, not the 1100
+        d = sc(env, e[2])
+        return binop("Div", binop("Add", binop("Mul", d, const_(1000, d)), const_(1100, d)), const_(365243, d))
     if k == "IfThenElse":
         c, t, el = e[1], e[2], e[3]
         if c[0] == "Unary" and c[1] == "IsNull" and t[0] == "Literal" and t[2] == 0 and c[2] == el:

@@ -291,7 +291,13 @@ static int op_fold(orc_ctx *c, ovec *out, int kind, const ovec *ctl, const ovec 
         int64_t k = slot_val(ctl, i);
         if (!have_run || k != run_key) {
             if (have_run && kind != F_SEL && acc_ok) { out->val[run_first] = acc; out->ok[run_first] = 1; }
-            have_run = 1; run_key = k; run_first = i; acc = 0; acc_ok = 0; sel_write = i;
+            /* The first run of a value fold starts at slot 0: EPS control slots ahead of it belong to it.  The compiler
+             * relies on it -- the result of an ungrouped aggregate is a one-row relation (count = 1) that it broadcasts
+             * with Gather(result, zeros_ other), i.e. reads at position 0 (/root/reference/src/Vlite.hs:693-712, `@@ zeros_`;
+             * TPC-H Q11's HAVING threshold) -- while the aggregate's input is a FILTERED vector whose slot 0 is EPS
+             * unless row 0 happens to pass the filter.  FoldSelect keeps the slot of the member itself. */
+            run_first = (!have_run && kind != F_SEL) ? 0 : i;
+            have_run = 1; run_key = k; acc = 0; acc_ok = 0; sel_write = i;
         }
         if (!slot_ok(d, i)) continue;
         int64_t x = slot_val(d, i);

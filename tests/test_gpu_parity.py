@@ -196,6 +196,53 @@ def test_full_size_sf10_linearity_and_generated_check(q6_text):
     e.close()
 
 
+def test_full_size_sf10_q1_generated_check_and_shard_additivity(q1_text):
+    """BASELINE config 3 (Q1 at SF10, 59 986 052 rows) at full size, through size-independent properties: (1) every one
+    of the ten output columns equals the SQL-semantics loop over regenerated rows on all host cores; (2) the sums and
+    the counts are additive over row-range shards (group by group), and avg = sum / count holds on the whole."""
+    import mplan2vdl_amd as m
+    import oracle
+
+    names = ["l_returnflag__lineitem__l_returnflag", "l_linestatus__lineitem__l_linestatus", "sum_qty", "sum_base_price",
+             "sum_disc_price", "sum_charge", "avg_qty", "avg_price", "avg_disc", "count_order"]
+    order = ["lineitem.l_shipdate", "lineitem.l_returnflag", "lineitem.l_linestatus", "lineitem.l_quantity",
+             "lineitem.l_extendedprice", "lineitem.l_discount", "lineitem.l_tax"]
+    n = datagen.LINEITEM_ROWS["sf10"]
+    e = m.Engine(device=0)
+
+    def run(lo, cnt):
+        for name in datagen.Q1_COLUMNS:
+            e.generate(datagen.LINEITEM[name], lo, cnt)
+        p = e.parse(q1_text)
+        assert p.is_fused
+        r = p.run()["results"]
+        p.close()
+        return {list(v.keys())[0][1:]: list(v.values())[0] for v in r.values()}
+
+    full = run(0, n)
+    specs = [(datagen.SEED, datagen.col_id(c), datagen.LINEITEM[c].lo, datagen.LINEITEM[c].hi, datagen.LINEITEM[c].mul,
+              datagen.LINEITEM[c].add) for c in order]
+    tab = oracle.sql_q1_generated(specs, 0, n, threads=oracle.max_threads())
+    assert len(tab) == 6
+    for j, nm in enumerate(names):
+        assert full[nm] == [int(x) for x in tab[:, j]], nm
+    groups = list(zip(full[names[0]], full[names[1]]))
+    additive = ["sum_qty", "sum_base_price", "sum_disc_price", "sum_charge", "count_order"]
+    acc = {nm: [0] * len(groups) for nm in additive}
+    for k in range(3):
+        lo, hi = m.shard_rows(n, k, 3)
+        part = run(lo, hi - lo)
+        pg = list(zip(part[names[0]], part[names[1]]))
+        for nm in additive:
+            for g, v in zip(pg, part[nm]):
+                acc[nm][groups.index(g)] += v
+    for nm in additive:
+        assert acc[nm] == full[nm], nm
+    # avg = sum / count: the compiler's integer quotients (Vlite.hs:1033-1046), C truncation
+    assert full["avg_qty"] == [s // c for s, c in zip(full["sum_qty"], full["count_order"])]
+    e.close()
+
+
 def test_sharded_query_single_rank_path(q6_text):
     """run_local -> (no merge at world size 1) -> finalize through a torch-owned partials buffer."""
     import torch

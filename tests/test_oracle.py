@@ -93,6 +93,25 @@ def test_global_fold_result_sits_in_first_slot_and_skips_eps():
     assert out(lines) == [[23], [0], [9], [5]]
 
 
+def test_ungrouped_aggregate_over_a_filter_that_drops_row_0_is_read_back_at_position_0():
+    """The compiler broadcasts a one-row relation with Gather(result, zeros_ other) (Vlite.hs:693-712; Q11's HAVING
+    threshold): the result of an ungrouped aggregate must sit at slot 0 even when the filter dropped row 0 -- the first
+    run of a vector starts at slot 0, EPS control slots ahead of its first member belong to it."""
+    b = np.array([0, 1, 0, 1, 1, 0, 0, 1], dtype=np.int64)                   # filter keeps slots 1, 3, 4, 7: row 0 is gone
+    lines = HEAD + SEL + ["7,Gather,Id 2,Id 6,val", "8,RangeV,val,0,Id 7,0", "9,FoldSum,val,Id 8,val,Id 7,val",
+                          "10,RangeV,val,0,Id 2,0",                            # positions 0,0,0,... over the unfiltered table
+                          "11,Gather,Id 9,Id 10,val", "12,MaterializeCompact,Id 11",
+                          "13,Greater,val,Id 2,val,Id 11,val", "14,MaterializeCompact,Id 13"]
+    total = int(A[b != 0].sum())
+    assert out(lines, {"t.a": A, "t.b": b}) == [[total] * 8, [int(x > total) for x in A]]
+    # a second run keeps its own first member slot; only the FIRST run is pulled to slot 0
+    ctl = np.array([4, 4, 4, 6, 6, 6, 6, 6], dtype=np.int64)
+    lines = HEAD + SEL + ["7,Gather,Id 2,Id 6,val", "20,Load,t.k", "21,Project,val,Id 20,k", "22,Gather,Id 21,Id 6,val",
+                          "23,FoldSum,val,Id 22,val,Id 7,val", "24,RangeV,val,0,Id 23,1", "25,FoldSelect,val,Id 24,val,Id 24,val",
+                          "26,MaterializeCompact,Id 23"]
+    assert out(lines, {"t.a": A, "t.b": b, "t.k": ctl}) == [[int(A[1]), int(A[3] + A[4] + A[7])]]
+
+
 def test_fold_runs_follow_control_values():
     ctl = np.array([1, 1, 2, 2, 2, 1, 3, 3], dtype=np.int64)
     lines = ["1,Load,t.k", "2,Project,val,Id 1,k", "3,Load,t.a", "4,Project,val,Id 3,a",

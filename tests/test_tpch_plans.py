@@ -56,13 +56,13 @@ def test_oracle_runs_every_compiled_plan(cfg, n):
     assert len(sizes) == 1                                                      # all output columns of a query align
 
 
-def test_most_plans_select_something(cfg):
-    nonempty = 0
+def test_every_plan_selects_something(cfg):
+    """No vacuous parity: over the coherent catalog every one of the 15 plans returns rows (Q18's IN-subquery and Q15's
+    view join on VALUES, which the catalog keeps consistent with the join indices)."""
     for n in PLANS:
-        text, cols = program_and_columns(cfg, n, 2e-4)
+        text, cols = program_and_columns(cfg, n, 5e-4, seed=3)
         res = oracle_run(text, cols)
-        nonempty += any(len(list(v.values())[0]) > 0 for v in res.values())
-    assert nonempty >= 12
+        assert all(len(list(v.values())[0]) > 0 for v in res.values()), n
 
 
 @pytest.mark.gpu
@@ -79,10 +79,10 @@ def test_engine_matches_oracle_on_every_compiled_plan(cfg, n, scale, seed):
 
 def test_cross_product_lowering_agrees_with_join_index_lowering(cfg):
     """--crossproduct (Vlite.hs:671-680) and the FK join-index lowering are two programs for the same SQL;
-    where the join is over an FK index they must select the same rows (Q15 joins on values, which the
-    synthetic catalog does not keep consistent with the indices, and is left out)."""
+    they must select the same rows -- also Q15, which joins its view on VALUES (the catalog keeps key values
+    consistent with the join indices)."""
     xcfg = frontend.load_metadata(META, cross_product=True)
-    for n in (3, 11, 12, 14, 16, 19, 20):
+    for n in (3, 11, 12, 14, 15, 16, 19, 20):
         a_text, a_cols = program_and_columns(xcfg, n, 1e-5)
         b_text, b_cols = program_and_columns(cfg, n, 1e-5)
         assert "CrossProductOuter" in a_text and "CrossProduct" not in b_text

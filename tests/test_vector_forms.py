@@ -79,3 +79,34 @@ def test_unscattered_and_scattered_keys_sharing_one_buffer_get_their_own_run_hea
         "18,Add,val,Id 16,val,Id 17,val",
         "19,MaterializeCompact,Id 18", "20,MaterializeCompact,Id 16", "21,MaterializeCompact,Id 17")
     run_all_statements("shared_key_buffer_%s_%d" % (mode, n), text, cols)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("n,first_kept", [(8, 3), (700, 65), (5000, 4999), (5000, 0)])
+def test_the_first_run_of_a_fold_starts_at_slot_0(monkeypatch, mode, n, first_kept):
+    """An ungrouped aggregate over a filter that drops the leading rows is read back at position 0 (the compiler broadcasts
+    one-row relations with Gather(result, zeros_ other), Vlite.hs:693-712; TPC-H Q11), and so is the first run of a fold
+    over a general control vector that starts with EPS slots; later runs keep their own first member slot."""
+    if mode:
+        monkeypatch.setenv(mode, "1")
+    rng = np.random.default_rng(n + first_kept)
+    keep = (rng.random(n) < 0.3).astype(np.int64)
+    keep[:first_kept] = 0
+    keep[first_kept] = 1
+    cols = {"t.a": rng.integers(-50, 50, n).astype(np.int64), "t.b": keep, "t.k": np.sort(rng.integers(0, 6, n)).astype(np.int64)}
+    text = prog(
+        "1,Load,t.a", "2,Project,val,Id 1,a", "3,Load,t.b", "4,Project,val,Id 3,b", "5,Load,t.k", "6,Project,val,Id 5,k",
+        "7,RangeV,val,0,Id 4,1", "8,FoldSelect,val,Id 7,val,Id 4,val",
+        "9,Gather,Id 2,Id 8,val", "10,Gather,Id 6,Id 8,val",
+        "11,RangeV,val,0,Id 9,0",
+        "12,FoldSum,val,Id 11,val,Id 9,val", "13,FoldMax,val,Id 11,val,Id 9,val", "14,FoldChoose,val,Id 11,val,Id 9,val",
+        "15,RangeV,val,0,Id 2,0", "16,Gather,Id 12,Id 15,val", "17,Greater,val,Id 2,val,Id 16,val",
+        "18,MaterializeCompact,Id 16", "19,MaterializeCompact,Id 17",
+        "20,Subtract,val,Id 13,val,Id 14,val", "21,MaterializeCompact,Id 20",
+        "22,FoldSum,val,Id 10,val,Id 9,val", "23,FoldCount,val,Id 10,val,Id 9,val", "24,FoldChoose,val,Id 10,val,Id 9,val",
+        "25,Gather,Id 22,Id 15,val", "26,MaterializeCompact,Id 25",
+        "27,MaterializeCompact,Id 22", "28,MaterializeCompact,Id 23", "29,MaterializeCompact,Id 24",
+        "30,Add,val,Id 22,val,Id 12,val", "31,MaterializeCompact,Id 30")
+    got = run_all_statements("first_run_slot0_%s_%d_%d" % (mode, n, first_kept), text, cols)
+    total = int(cols["t.a"][keep != 0].sum())
+    assert got["tmp18"][".val"] == [total] * n                       # every row reads the aggregate at position 0
