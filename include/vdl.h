@@ -16,7 +16,7 @@
  * A Haskell host binds these with `foreign import ccall` (stub in INTEGRATION.md); the
  * CLI `vdlrun` and the Python package `mplan2vdl_amd` are the callers exercised here.
  *
- * Conventions: plain C types only, no callbacks; every call returns VDL_OK (0) or a
+ * Conventions: plain C types only, no callbacks (except the optional host transport of vdl_comm_init_host); every call returns VDL_OK (0) or a
  * VDL_ERR_* code and leaves a message for vdl_last_error(); pointers returned by
  * vdl_output()/vdl_timing()/vdl_plan_describe() are borrowed and stay valid until the
  * plan is run again or freed.  One context per process and GPU; calls on one context
@@ -205,6 +205,49 @@ int  vdl_exchange_spec(const vdl_plan *plan, const char *sharded_table, int *n_c
 int  vdl_exchange_begin(vdl_ctx *ctx, vdl_plan *plan, int world, int64_t *counts_host /* world */);
 int  vdl_exchange_pack(vdl_ctx *ctx, vdl_plan *plan, void *dev_send);
 int  vdl_exchange_finish(vdl_ctx *ctx, vdl_plan *plan, const void *dev_recv, int64_t n_recv);
+
+/* ---- multi-GPU behind this boundary: one process per GPU, the context owns the communicator --------------
+ * (SURVEY.md section 8(b),(e).)  A Haskell host -- or vdlrun --gpus N, or bench.py -- starts one process per GPU; each opens
+ * its context on its device, holds its row range of the sharded table (and the replicated tables in full), joins the
+ * communicator and calls vdl_run_sharded(); the collectives happen inside.
+ *
+ *   vdl_comm_unique_id : any one rank makes the 128-byte id (ncclGetUniqueId) and the host hands the bytes to the others
+ *                        (a file, a pipe, an environment variable, MPI, a torch store: any channel);
+ *   vdl_comm_init      : RCCL communicator over xGMI on the context's device (librccl is opened here, not at load time);
+ *   vdl_comm_init_host : instead of RCCL, collectives supplied by the caller over HOST memory (hosts that already have
+ *                        MPI / gloo; the tests' in-process stand-in).  The engine stages through pinned buffers.  These two
+ *                        callbacks are the only ones in this interface; both are called by every rank, in the same order.
+ *
+ * vdl_run_sharded picks the route from the plan:
+ *   outputs = global / dense-domain grouped folds (vdl_plan_partial_spec succeeds: fused plans, or general plans after
+ *   vdl_plan_set_sharded_table): local phase -> ONE all-gather of the partial words -> merge kernel -> finalise; every rank
+ *   ends with the full result.  FoldChoose words travel as (global row id, value) pairs: no second round.
+ *   plans with a Partition (vdl_plan_set_sharded_table names the row-sharded table): local phase -> ONE all-gather of
+ *   {status, rows per destination} -> ONE grouped send / receive of all columns -> local tail; rank r ends with the
+ *   groups of key range r, and the ranks' outputs concatenate in rank order to the unsharded result.
+ * vdl_run_sharded_begin / _end split the fold route for pipelined callers (slots 0 / 1): `begin` queues the scan on the
+ * engine stream and merge + copy-out behind it on the communication stream and returns; `end` waits for that slot's copy
+ * only, so the collective of query k hides behind the scan of query k+1. */
+#define VDL_COMM_ID_BYTES 128
+typedef struct vdl_comm_host {
+    void *user;
+    /* every rank contributes `bytes` from `send`; `recv` (world * bytes) gets rank r's block at r * bytes.  0 = ok. */
+    int (*all_gather)(void *user, const void *send, void *recv, size_t bytes);
+    /* rank-major blocks: send_bytes[r] bytes go to rank r, recv_bytes[r] bytes arrive from rank r.  0 = ok. */
+    int (*all_to_all)(void *user, const void *send, const size_t *send_bytes, void *recv, const size_t *recv_bytes);
+} vdl_comm_host;
+int  vdl_comm_unique_id(void *id_out /* VDL_COMM_ID_BYTES */);
+int  vdl_comm_init(vdl_ctx *ctx, int rank, int world, const void *id /* VDL_COMM_ID_BYTES */);
+int  vdl_comm_init_host(vdl_ctx *ctx, int rank, int world, const vdl_comm_host *transport);
+int  vdl_comm_info(const vdl_ctx *ctx, int *rank, int *world, const char **transport /* "rccl" | "host" */);
+void vdl_comm_free(vdl_ctx *ctx);                       /* also done by vdl_close */
+int  vdl_run_sharded(vdl_ctx *ctx, vdl_plan *plan);     /* results through vdl_output as after vdl_run */
+int  vdl_run_sharded_begin(vdl_ctx *ctx, vdl_plan *plan, int slot);
+int  vdl_run_sharded_end(vdl_ctx *ctx, vdl_plan *plan, int slot);
+/* The merge rule of the gathered partial words on the host (what the device kernel computes): `gathered` holds, per rank,
+ * n_words words followed by the same words with VDL_REDUCE_FIRST entries resolved to values.  For hosts / tests that want to
+ * check a transport without a GPU. */
+int  vdl_comm_merge_host(int world, int64_t n_words, const int32_t *ops, const int64_t *gathered, int64_t *out);
 
 #ifdef __cplusplus
 }

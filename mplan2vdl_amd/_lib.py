@@ -10,6 +10,14 @@ VDL_OK, VDL_ERR_PARSE, VDL_ERR_COLUMN, VDL_ERR_UNSUPPORTED, VDL_ERR_DEVICE, VDL_
 REDUCE_NONE, REDUCE_SUM, REDUCE_MIN, REDUCE_MAX, REDUCE_FIRST = range(5)
 
 _lib = None
+COMM_ID_BYTES = 128
+ALL_GATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+ALL_TO_ALL_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p,
+                                 ctypes.POINTER(ctypes.c_size_t))
+
+
+class CommHost(ctypes.Structure):          # vdl_comm_host (include/vdl.h)
+    _fields_ = [("user", ctypes.c_void_p), ("all_gather", ALL_GATHER_FN), ("all_to_all", ALL_TO_ALL_FN)]
 
 
 def load():
@@ -72,6 +80,17 @@ def load():
         "vdl_finalize_begin": (i32, [vp, vp, vp, i32]),
         "vdl_finalize_end": (i32, [vp, vp, i32]),
     }
+    sig.update({
+        "vdl_comm_unique_id": (i32, [vp]),
+        "vdl_comm_init": (i32, [vp, i32, i32, vp]),
+        "vdl_comm_init_host": (i32, [vp, i32, i32, P(CommHost)]),
+        "vdl_comm_info": (i32, [vp, P(i32), P(i32), P(cp)]),
+        "vdl_comm_free": (None, [vp]),
+        "vdl_run_sharded": (i32, [vp, vp]),
+        "vdl_run_sharded_begin": (i32, [vp, vp, i32]),
+        "vdl_run_sharded_end": (i32, [vp, vp, i32]),
+        "vdl_comm_merge_host": (i32, [i32, i64, P(ctypes.c_int32), P(i64), P(i64)]),
+    })
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError here = the library does not export the ABI
         fn.restype = res
@@ -86,5 +105,6 @@ ABI_SYMBOLS = [
     "vdl_parse", "vdl_plan_free", "vdl_plan_describe", "vdl_plan_is_fused", "vdl_plan_set_fusion",
     "vdl_plan_set_profiling", "vdl_plan_set_trace", "vdl_n_traced", "vdl_traced", "vdl_run", "vdl_n_outputs", "vdl_output", "vdl_plan_set_device_outputs", "vdl_output_device", "vdl_n_timings", "vdl_timing",
     "vdl_plan_scan_stats", "vdl_plan_partial_spec", "vdl_run_local", "vdl_finalize", "vdl_finalize_begin", "vdl_finalize_end", "vdl_plan_set_row_offset", "vdl_plan_set_sharded_table", "vdl_resolve_first", "vdl_exchange_spec", "vdl_exchange_begin", "vdl_exchange_pack",
-    "vdl_exchange_finish",
+    "vdl_exchange_finish", "vdl_comm_unique_id", "vdl_comm_init", "vdl_comm_init_host", "vdl_comm_info", "vdl_comm_free", "vdl_run_sharded",
+    "vdl_run_sharded_begin", "vdl_run_sharded_end", "vdl_comm_merge_host",
 ]

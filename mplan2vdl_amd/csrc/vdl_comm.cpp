@@ -1,0 +1,394 @@
+// vdl_comm.cpp -- the multi-GPU path behind the C ABI (SURVEY.md section 8(b),(e)): one process per GPU, a context owns its
+// communicator, vdl_run_sharded() runs a plan over this rank's rows and performs the collectives itself.
+//
+//   transport RCCL : librccl is opened at vdl_comm_init (dlopen: single-GPU users and CPU boxes need no RCCL); collectives are
+//                    queued on a communication stream of the context, ordered against the engine stream with events, so the
+//                    merge of query k overlaps the scan of query k+1 (vdl_run_sharded_begin / _end).
+//   transport HOST : the caller supplies all-gather / all-to-all over HOST memory (vdl_comm_init_host: MPI or gloo hosts,
+//                    and the in-process stand-in of the tests); the engine stages through pinned buffers.
+//
+// Collectives per query -- what bounds 8-GPU scaling of a 0.3 ms scan is their count and latency, not their size:
+//   plans whose outputs are global / dense-domain grouped folds (Q6, Q1; Q14, Q19 through their fold records):
+//       ONE all-gather of the partial words (Q6: 2 words, Q1: 289) + a local merge kernel that applies each word's
+//       VDL_REDUCE_* operator over the ranks.  FoldChoose words travel as (global row id, value) pairs, so the
+//       MIN -> resolve -> SUM double round of the all-reduce formulation is gone.
+//   plans with a Partition (Q3, Q5, Q9, Q10, Q12, Q20):
+//       ONE all-gather of {status, rows per destination} (the only host synchronisation: receive sizes depend on it), then
+//       ONE grouped send/receive (ncclGroupStart .. ncclGroupEnd) that moves every column's piece for every peer.
+#include <dlfcn.h>
+
+#include "vdl_engine_internal.h"
+
+namespace vdl {
+namespace eng {
+
+// ---- the slice of the RCCL API this file uses (types as in rccl.h; the library is bound at run time) ----
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+static_assert(sizeof(ncclUniqueId) == VDL_COMM_ID_BYTES, "vdl.h promises the size of ncclUniqueId");
+enum { kNcclSuccess = 0, kNcclInt64 = 4 };          // ncclResult_t / ncclDataType_t values (nccl.h: ncclInt64 = 4)
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*CommCount)(const ncclComm_t, int *) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+
+static Rccl &rccl() {
+    static Rccl r;
+    if (r.lib) return r;
+    const char *names[] = {getenv("VDL_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    std::string tried;
+    for (const char *n : names) {
+        if (!n || !*n) continue;
+        r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (r.lib) break;
+        tried += std::string(" ") + n + " (" + dlerror() + ")";
+    }
+    if (!r.lib) throw Error(VDL_ERR_DEVICE, "cannot load RCCL:" + tried);
+    auto sym = [&](const char *name) {
+        void *p = dlsym(r.lib, name);
+        if (!p) { std::string m = std::string("RCCL library lacks ") + name; dlclose(r.lib); r.lib = nullptr; throw Error(VDL_ERR_DEVICE, m); }
+        return p;
+    };
+    r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.CommCount = (decltype(r.CommCount))sym("ncclCommCount");
+    r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+    r.Send = (decltype(r.Send))sym("ncclSend");
+    r.Recv = (decltype(r.Recv))sym("ncclRecv");
+    r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    return r;
+}
+#define RCCL_CHECK(expr)                                                                                               \
+    do {                                                                                                               \
+        int e_ = (expr);                                                                                               \
+        if (e_ != kNcclSuccess) throw Error(VDL_ERR_DEVICE, std::string(#expr) + " failed: " + rccl().GetErrorString(e_)); \
+    } while (0)
+
+struct CommState {
+    enum Kind { RCCL, HOST } kind = HOST;
+    int rank = 0, world = 1;
+    ncclComm_t comm = nullptr;
+    vdl_comm_host host{};
+    hipStream_t stream = nullptr;               // communication stream (RCCL transport)
+    hipEvent_t ev_local[2] = {nullptr, nullptr};    // engine stream -> communication stream: the partial words of slot k are written
+    hipEvent_t ev_merged[2] = {nullptr, nullptr};   // communication stream: the send buffer of slot k has been consumed
+    char *stage = nullptr;                      // pinned staging for the HOST transport
+    size_t stage_cap = 0;
+    ~CommState() {
+        if (comm) (void)rccl().CommDestroy(comm);
+        for (int k = 0; k < 2; k++) {
+            if (ev_local[k]) (void)hipEventDestroy(ev_local[k]);
+            if (ev_merged[k]) (void)hipEventDestroy(ev_merged[k]);
+        }
+        if (stream) (void)hipStreamDestroy(stream);
+        if (stage) (void)hipHostFree(stage);
+    }
+    char *staging(size_t bytes) {
+        if (stage_cap < bytes) {
+            if (stage) (void)hipHostFree(stage);
+            stage = nullptr; stage_cap = 0;
+            HIP_CHECK(hipHostMalloc((void **)&stage, bytes, hipHostMallocDefault));
+            stage_cap = bytes;
+        }
+        return stage;
+    }
+};
+
+// per-plan buffers of the sharded fold route (two slots: pipelined callers)
+struct ShardState {
+    int64_t n_words = 0;
+    bool any_first = false;
+    BufP ops;                    // int32 per word on the device
+    BufP send[2], recv[2], merged[2];
+};
+
+static CommState &comm_of(vdl_ctx *c) {
+    if (!c->comm) throw Error(VDL_ERR_ARG, "no communicator on this context: call vdl_comm_init / vdl_comm_init_host first");
+    return *c->comm;
+}
+
+// all ranks contribute `bytes` (a multiple of 8) from dev_send; dev_recv receives world * bytes, rank r's block at r * bytes
+static void all_gather(vdl_ctx *c, const void *dev_send, void *dev_recv, size_t bytes, hipStream_t s) {
+    CommState &m = comm_of(c);
+    if (m.kind == CommState::RCCL) {
+        RCCL_CHECK(rccl().AllGather(dev_send, dev_recv, bytes / 8, kNcclInt64, m.comm, s));
+        return;
+    }
+    char *h = m.staging(bytes * (size_t)(m.world + 1));
+    HIP_CHECK(hipMemcpyAsync(h, dev_send, bytes, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (m.host.all_gather(m.host.user, h, h + bytes, bytes)) throw Error(VDL_ERR_DEVICE, "the host transport's all_gather failed");
+    HIP_CHECK(hipMemcpyAsync(dev_recv, h + bytes, bytes * (size_t)m.world, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));          // the staging buffer is reused by the next call
+}
+
+// every column c of `ncols`: rows [soff[d], soff[d] + scnt[d]) of send + c * n_send go to rank d, which receives them at
+// rows [roff[me-th source]..) of recv + c * n_recv, pieces in source-rank order
+static void all_to_all_columns(vdl_ctx *c, const int64_t *dev_send, int64_t n_send, const std::vector<int64_t> &scnt, int64_t *dev_recv,
+                               int64_t n_recv, const std::vector<int64_t> &rcnt, int ncols, hipStream_t s) {
+    CommState &m = comm_of(c);
+    std::vector<int64_t> soff((size_t)m.world + 1, 0), roff((size_t)m.world + 1, 0);
+    for (int r = 0; r < m.world; r++) { soff[(size_t)r + 1] = soff[(size_t)r] + scnt[(size_t)r]; roff[(size_t)r + 1] = roff[(size_t)r] + rcnt[(size_t)r]; }
+    if (m.kind == CommState::RCCL) {
+        RCCL_CHECK(rccl().GroupStart());
+        for (int r = 0; r < m.world; r++)
+            for (int col = 0; col < ncols; col++) {
+                if (scnt[(size_t)r] > 0)
+                    RCCL_CHECK(rccl().Send(dev_send + (int64_t)col * n_send + soff[(size_t)r], (size_t)scnt[(size_t)r], kNcclInt64, r, m.comm, s));
+                if (rcnt[(size_t)r] > 0)
+                    RCCL_CHECK(rccl().Recv(dev_recv + (int64_t)col * n_recv + roff[(size_t)r], (size_t)rcnt[(size_t)r], kNcclInt64, r, m.comm, s));
+            }
+        RCCL_CHECK(rccl().GroupEnd());
+        return;
+    }
+    // HOST transport: one all_to_all per call over a peer-major staging layout (block of peer r = its piece of every column)
+    const size_t sb = sizeof(int64_t) * (size_t)ncols * (size_t)n_send, rb = sizeof(int64_t) * (size_t)ncols * (size_t)n_recv;
+    char *h = m.staging(2 * (sb + rb) + 64);
+    int64_t *hs = (int64_t *)h, *hsp = hs + (size_t)ncols * (size_t)n_send, *hrp = hsp + (size_t)ncols * (size_t)n_send, *hr = hrp + (size_t)ncols * (size_t)n_recv;
+    if (sb) HIP_CHECK(hipMemcpyAsync(hs, dev_send, sb, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<size_t> sbytes((size_t)m.world), rbytes((size_t)m.world);
+    int64_t at = 0;
+    for (int r = 0; r < m.world; r++) {
+        for (int col = 0; col < ncols; col++) {
+            std::memcpy(hsp + at, hs + (int64_t)col * n_send + soff[(size_t)r], sizeof(int64_t) * (size_t)scnt[(size_t)r]);
+            at += scnt[(size_t)r];
+        }
+        sbytes[(size_t)r] = sizeof(int64_t) * (size_t)ncols * (size_t)scnt[(size_t)r];
+        rbytes[(size_t)r] = sizeof(int64_t) * (size_t)ncols * (size_t)rcnt[(size_t)r];
+    }
+    if (m.host.all_to_all(m.host.user, hsp, sbytes.data(), hrp, rbytes.data())) throw Error(VDL_ERR_DEVICE, "the host transport's all_to_all failed");
+    at = 0;
+    for (int r = 0; r < m.world; r++)
+        for (int col = 0; col < ncols; col++) {
+            std::memcpy(hr + (int64_t)col * n_recv + roff[(size_t)r], hrp + at, sizeof(int64_t) * (size_t)rcnt[(size_t)r]);
+            at += rcnt[(size_t)r];
+        }
+    if (rb) HIP_CHECK(hipMemcpyAsync(dev_recv, hr, rb, hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+}
+
+// the engine's launches go to `to` for the lifetime of this object (internal: no drain, the caller orders the streams with events)
+struct StreamSwap {
+    vdl_ctx *c;
+    hipStream_t saved;
+    StreamSwap(vdl_ctx *ctx, hipStream_t to) : c(ctx), saved(ctx->stream) { c->stream = to; }
+    ~StreamSwap() { c->stream = saved; }
+};
+
+static ShardState &shard_state(vdl_ctx *c, vdl_plan *p, const CommState &m) {
+    int64_t nw = 0;
+    const int32_t *ops = nullptr;
+    if (vdl_plan_partial_spec(p, &nw, &ops) != VDL_OK) throw Error(VDL_ERR_UNSUPPORTED, c->err);
+    if (!p->shard) p->shard = std::make_shared<ShardState>();
+    ShardState &st = *p->shard;
+    const size_t words = (size_t)std::max<int64_t>(nw, 1);
+    if (st.n_words != nw || !st.ops || !st.recv[0] || st.recv[0]->cls < sizeof(int64_t) * 2 * words * (size_t)m.world) {
+        st.n_words = nw;
+        st.any_first = false;
+        for (int64_t i = 0; i < nw; i++) st.any_first |= ops[i] == VDL_REDUCE_FIRST;
+        st.ops = dev_alloc(c, sizeof(int32_t) * words);
+        if (nw) HIP_CHECK(hipMemcpyAsync(st.ops->p, ops, sizeof(int32_t) * (size_t)nw, hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));                    // `ops` belongs to the plan and may be rewritten by the next spec call
+        for (int k = 0; k < 2; k++) {
+            st.send[k] = dev_alloc(c, sizeof(int64_t) * 2 * words);
+            st.recv[k] = dev_alloc(c, sizeof(int64_t) * 2 * words * (size_t)m.world);
+            st.merged[k] = dev_alloc(c, sizeof(int64_t) * words);
+        }
+    }
+    return st;
+}
+
+static void sharded_begin(vdl_ctx *c, vdl_plan *p, int slot) {
+    need_device(c);
+    if (slot < 0 || slot > 1) throw Error(VDL_ERR_ARG, "slot must be 0 or 1");
+    CommState &m = comm_of(c);
+    ShardState &st = shard_state(c, p, m);
+    const int64_t nw = st.n_words;
+    int64_t *send = (int64_t *)st.send[slot]->p;
+    const bool overlap = m.kind == CommState::RCCL;
+    hipStream_t cs = overlap ? m.stream : c->stream;
+    if (overlap && m.ev_merged[slot]) HIP_CHECK(hipStreamWaitEvent(c->stream, m.ev_merged[slot], 0));    // the previous query of this slot has left the send buffer
+    if (vdl_run_local(c, p, send) != VDL_OK) throw Error(VDL_ERR_DEVICE, c->err);
+    if (overlap) {
+        if (!m.ev_local[slot]) {
+            HIP_CHECK(hipEventCreateWithFlags(&m.ev_local[slot], hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&m.ev_merged[slot], hipEventDisableTiming));
+        }
+        HIP_CHECK(hipEventRecord(m.ev_local[slot], c->stream));
+        HIP_CHECK(hipStreamWaitEvent(cs, m.ev_local[slot], 0));
+    }
+    StreamSwap on_comm(c, cs);
+    // second half of the send buffer: the words again, FoldChoose words resolved to the value at this rank's own row id
+    if (nw) HIP_CHECK(hipMemcpyAsync(send + nw, send, sizeof(int64_t) * (size_t)nw, hipMemcpyDeviceToDevice, cs));
+    if (st.any_first && vdl_resolve_first(c, p, send + nw) != VDL_OK) throw Error(VDL_ERR_DEVICE, c->err);
+    int64_t *merged = (int64_t *)st.merged[slot]->p;
+    if (m.world > 1) {
+        all_gather(c, send, st.recv[slot]->p, sizeof(int64_t) * 2 * (size_t)nw, cs);
+        HIP_CHECK(launch_merge_words((const int64_t *)st.recv[slot]->p, m.world, nw, (const int32_t *)st.ops->p, merged, cs));
+    } else if (nw) {
+        HIP_CHECK(launch_merge_words(send, 1, nw, (const int32_t *)st.ops->p, merged, cs));
+    }
+    if (overlap) HIP_CHECK(hipEventRecord(m.ev_merged[slot], cs));
+    if (vdl_finalize_begin(c, p, merged, slot) != VDL_OK) throw Error(VDL_ERR_DEVICE, c->err);
+}
+
+static void sharded_exchange(vdl_ctx *c, vdl_plan *p) {
+    need_device(c);
+    CommState &m = comm_of(c);
+    int ncols = 0;
+    const std::string table = p->sharded_table;
+    if (table.empty()) throw Error(VDL_ERR_ARG, "vdl_run_sharded: name the row-sharded table first (vdl_plan_set_sharded_table)");
+    if (vdl_exchange_spec(p, table.c_str(), &ncols) != VDL_OK) throw Error(VDL_ERR_UNSUPPORTED, c->err);
+    // local phase; its outcome travels with the counts so that no rank is left waiting in a collective after a failure elsewhere
+    std::vector<int64_t> mine((size_t)m.world + 1, 0);
+    std::string local_error;
+    const int rc = vdl_exchange_begin(c, p, m.world, mine.data() + 1);
+    if (rc != VDL_OK) { local_error = c->err; mine.assign((size_t)m.world + 1, 0); }
+    mine[0] = rc;
+    const size_t row = (size_t)m.world + 1;
+    BufP dsend = dev_alloc(c, sizeof(int64_t) * row), drecv = dev_alloc(c, sizeof(int64_t) * row * (size_t)m.world);
+    HIP_CHECK(hipMemcpyAsync(dsend->p, mine.data(), sizeof(int64_t) * row, hipMemcpyHostToDevice, c->stream));
+    std::vector<int64_t> all(row * (size_t)m.world);
+    if (m.world > 1) {
+        all_gather(c, dsend->p, drecv->p, sizeof(int64_t) * row, c->stream);
+        HIP_CHECK(hipMemcpyAsync(all.data(), drecv->p, sizeof(int64_t) * all.size(), hipMemcpyDeviceToHost, c->stream));
+    } else {
+        all = mine;
+    }
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (int r = 0; r < m.world; r++)
+        if (all[(size_t)r * row] != VDL_OK) {
+            if (rc != VDL_OK) throw Error(rc, local_error);
+            throw Error(VDL_ERR_UNSUPPORTED, "sharded Partition exchange failed on rank " + std::to_string(r));
+        }
+    std::vector<int64_t> scnt(mine.begin() + 1, mine.end()), rcnt((size_t)m.world);
+    int64_t n_send = 0, n_recv = 0;
+    for (int r = 0; r < m.world; r++) {
+        rcnt[(size_t)r] = all[(size_t)r * row + 1 + (size_t)m.rank];
+        n_send += scnt[(size_t)r]; n_recv += rcnt[(size_t)r];
+    }
+    BufP send = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(n_send * ncols, 1));
+    if (vdl_exchange_pack(c, p, send->p) != VDL_OK) throw Error(VDL_ERR_DEVICE, c->err);
+    BufP recv = send;
+    if (m.world > 1) {
+        recv = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(n_recv * ncols, 1));
+        all_to_all_columns(c, (const int64_t *)send->p, n_send, scnt, (int64_t *)recv->p, n_recv, rcnt, ncols, c->stream);
+    }
+    p->shard_keep = recv;                                     // the tail reads the received columns in place
+    if (vdl_exchange_finish(c, p, recv->p, n_recv) != VDL_OK) throw Error(VDL_ERR_DEVICE, c->err);
+    p->shard_keep.reset();
+}
+
+static bool fold_route(vdl_ctx *c, vdl_plan *p) {
+    int64_t nw = 0;
+    const int32_t *ops = nullptr;
+    const std::string keep = c->err;
+    const bool ok = vdl_plan_partial_spec(p, &nw, &ops) == VDL_OK;
+    if (!ok) c->err = keep;
+    return ok;
+}
+
+}  // namespace eng
+}  // namespace vdl
+
+extern "C" {
+
+int vdl_comm_unique_id(void *id_out) {
+    if (!id_out) return VDL_ERR_ARG;
+    try {
+        ncclUniqueId id;
+        if (rccl().GetUniqueId(&id) != kNcclSuccess) return VDL_ERR_DEVICE;
+        std::memcpy(id_out, &id, sizeof id);
+        return VDL_OK;
+    } catch (const Error &e) {
+        std::fprintf(stderr, "vdl_comm_unique_id: %s\n", e.what());
+        return e.code;
+    }
+}
+
+int vdl_comm_init(vdl_ctx *c, int rank, int world, const void *id) {
+    if (!c || !id || world < 1 || rank < 0 || rank >= world || world > kMaxExWorld) return VDL_ERR_ARG;
+    return guard(c, [&] {
+        need_device(c);
+        auto m = std::make_shared<CommState>();
+        m->kind = CommState::RCCL; m->rank = rank; m->world = world;
+        ncclUniqueId uid;
+        std::memcpy(&uid, id, sizeof uid);
+        RCCL_CHECK(rccl().CommInitRank(&m->comm, world, uid, rank));
+        int count = 0;
+        RCCL_CHECK(rccl().CommCount(m->comm, &count));
+        if (count != world) throw Error(VDL_ERR_DEVICE, "the RCCL communicator has " + std::to_string(count) + " rank(s), " + std::to_string(world) + " expected");
+        HIP_CHECK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+        c->comm = m;
+    });
+}
+
+int vdl_comm_init_host(vdl_ctx *c, int rank, int world, const vdl_comm_host *transport) {
+    if (!c || !transport || !transport->all_gather || !transport->all_to_all || world < 1 || rank < 0 || rank >= world || world > kMaxExWorld) return VDL_ERR_ARG;
+    return guard(c, [&] {
+        auto m = std::make_shared<CommState>();
+        m->kind = CommState::HOST; m->rank = rank; m->world = world; m->host = *transport;
+        c->comm = m;
+    });
+}
+
+int vdl_comm_info(const vdl_ctx *c, int *rank, int *world, const char **transport) {
+    if (!c || !c->comm) return VDL_ERR_ARG;
+    if (rank) *rank = c->comm->rank;
+    if (world) *world = c->comm->world;
+    if (transport) *transport = c->comm->kind == CommState::RCCL ? "rccl" : "host";
+    return VDL_OK;
+}
+
+void vdl_comm_free(vdl_ctx *c) {
+    if (!c || !c->comm) return;
+    if (c->device >= 0) { (void)hipSetDevice(c->device); (void)hipDeviceSynchronize(); }
+    c->comm.reset();
+}
+
+int vdl_run_sharded_begin(vdl_ctx *c, vdl_plan *p, int slot) {
+    if (!c || !p) return VDL_ERR_ARG;
+    return guard(c, [&] {
+        if (!fold_route(c, p)) throw Error(VDL_ERR_UNSUPPORTED, "vdl_run_sharded_begin serves plans whose outputs are folds (partial words); plans with a "
+                                                               "Partition exchange rows and run through vdl_run_sharded");
+        sharded_begin(c, p, slot);
+    });
+}
+
+int vdl_run_sharded_end(vdl_ctx *c, vdl_plan *p, int slot) {
+    if (!c || !p) return VDL_ERR_ARG;
+    return vdl_finalize_end(c, p, slot);
+}
+
+int vdl_run_sharded(vdl_ctx *c, vdl_plan *p) {
+    if (!c || !p) return VDL_ERR_ARG;
+    int rc = guard(c, [&] {
+        if (fold_route(c, p)) sharded_begin(c, p, 0);
+        else sharded_exchange(c, p);
+    });
+    if (rc != VDL_OK) return rc;
+    return fold_route(c, p) ? vdl_finalize_end(c, p, 0) : VDL_OK;
+}
+
+/* The merge of the gathered partial words on the HOST: the same per-word rule the device kernel applies (merge_word,
+ * vdl_kernels.h), exported so that hosts and CPU tests can check a transport without a GPU. */
+int vdl_comm_merge_host(int world, int64_t n_words, const int32_t *ops, const int64_t *gathered, int64_t *out) {
+    if (world < 1 || n_words < 0 || (n_words && (!ops || !gathered || !out))) return VDL_ERR_ARG;
+    for (int64_t i = 0; i < n_words; i++) out[i] = merge_word(gathered, world, n_words, ops[i], i);
+    return VDL_OK;
+}
+
+}  // extern "C"

@@ -341,6 +341,7 @@ void vdl_close(vdl_ctx *c) {
     if (c->device >= 0) {
         (void)hipSetDevice(c->device);
         (void)hipDeviceSynchronize();
+        c->comm.reset();
         c->cols.clear();
         c->pool->trim();
         c->pool->closed = true;

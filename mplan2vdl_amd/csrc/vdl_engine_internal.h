@@ -104,6 +104,8 @@ using SelP = std::shared_ptr<Sel>;
 
 struct ExprNode;
 struct LazyGather;
+struct CommState;        // vdl_comm.cpp: the context's communicator (RCCL or host transport)
+struct ShardState;       // vdl_comm.cpp: per-plan buffers of the sharded fold route
 
 struct DVec {
     enum Kind { NONE, DENSE, COLUMN, RANGE, ONEHOT, OHCONST, SPARSE, EXPR, LAZYG } kind = NONE;
@@ -170,6 +172,7 @@ struct vdl_ctx {
     std::map<std::string, Column> cols;
     uint64_t catalog_version = 1;      // bumped on every catalog change: plans re-bind only when it moved
     std::shared_ptr<Pool> pool = std::make_shared<Pool>();
+    std::shared_ptr<CommState> comm;       // vdl_comm_init / vdl_comm_init_host
     std::string err;
 };
 
@@ -212,6 +215,8 @@ struct vdl_plan {
         std::vector<int> nodes;
         int64_t pmin = 0, pcount = 0;
     } ex;
+    std::shared_ptr<ShardState> shard;     // vdl_run_sharded: send / receive / merged word buffers
+    BufP shard_keep;                       // vdl_run_sharded: received rows while the tail of an exchange plan reads them
     std::string sharded_table;             // placement named in the last vdl_exchange_spec ("" = not stated)
     std::vector<int> cut_folds;            // general plan sharded through its global folds: the folds of the last vdl_run_local
     std::vector<int64_t> cut_n;            // and the lengths of their operands on this rank

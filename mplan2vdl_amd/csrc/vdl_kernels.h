@@ -121,6 +121,35 @@ struct PredProg {
 // out bit i = predicate(i) & valid bit i (valid null = every slot)
 hipError_t launch_pred(const PredProg &prog, const uint64_t *valid, uint64_t *out, int64_t n, hipStream_t s);
 // global fold record {value, first slot, count} <-> three words that merge across shards (reduce: 0 sum, 1 min, 2 max)
+// Merge of the partial words gathered from all ranks (vdl_comm.cpp).  Layout: rank r's block is 2 * n_words int64 at
+// g + r * 2 * n_words -- the words, then the words again with FoldChoose (VDL_REDUCE_FIRST) entries resolved to the value
+// at that rank's own smallest row id.  SUM / MIN / MAX fold the first halves; FIRST takes the value of the rank holding
+// the smallest global row id (0 when no rank has a row in the group).  Host and device use this one definition.
+#if defined(__HIPCC__)
+#define VDL_HD __host__ __device__
+#else
+#define VDL_HD
+#endif
+VDL_HD inline int64_t merge_word(const int64_t *g, int world, int64_t n_words, int op, int64_t i) {
+    const int64_t stride = 2 * n_words;
+    if (op == 4 /* VDL_REDUCE_FIRST */) {
+        int64_t best = INT64_MAX, val = 0;
+        for (int r = 0; r < world; r++) {
+            const int64_t id = g[(int64_t)r * stride + i];
+            if (id < best) { best = id; val = g[(int64_t)r * stride + n_words + i]; }
+        }
+        return val;
+    }
+    int64_t acc = g[i];
+    for (int r = 1; r < world; r++) {
+        const int64_t x = g[(int64_t)r * stride + i];
+        if (op == 2 /* MIN */) acc = x < acc ? x : acc;
+        else if (op == 3 /* MAX */) acc = x > acc ? x : acc;
+        else acc = (int64_t)((uint64_t)acc + (uint64_t)x);
+    }
+    return acc;
+}
+hipError_t launch_merge_words(const int64_t *gathered, int world, int64_t n_words, const int32_t *ops, int64_t *out, hipStream_t s);
 hipError_t launch_fold_words(const int64_t *rec, int reduce, int64_t row0, int64_t *out, hipStream_t s);
 hipError_t launch_fold_record(const int64_t *words, int64_t *rec, hipStream_t s);
 // Gather out of a sparse vector without densifying it: counts[w] = popcount of bitmap word w (the caller turns them into

@@ -494,6 +494,16 @@ hipError_t launch_fold_record(const int64_t *words, int64_t *rec, hipStream_t s)
     k_fold_record<<<1, 1, 0, s>>>(words, rec);
     return launch_status();
 }
+__global__ void k_merge_words(const int64_t *g, int world, int64_t n_words, const int32_t *ops, int64_t *out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_words) out[i] = merge_word(g, world, n_words, ops[i], i);
+}
+hipError_t launch_merge_words(const int64_t *gathered, int world, int64_t n_words, const int32_t *ops, int64_t *out, hipStream_t s) {
+    (void)hipGetLastError();
+    if (n_words <= 0) return hipSuccess;
+    k_merge_words<<<(int)((n_words + 255) / 256), 256, 0, s>>>(gathered, world, n_words, ops, out);
+    return launch_status();
+}
 __global__ void k_onehot_dense(const int64_t *oh, int64_t *out, uint64_t *valid, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t slot = oh[2] > 0 ? oh[1] : -1;

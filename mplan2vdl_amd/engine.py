@@ -169,6 +169,20 @@ class Plan:
         self._e._check(self._e._L.vdl_exchange_finish(self._e._c, self._h, ctypes.c_void_p(dev_ptr or 0), int(n_recv)))
         return self._collect(as_numpy)
 
+    # ---- multi-GPU behind the C ABI (Engine.comm_init_*): the collectives happen inside libvdl ----
+    def run_sharded(self, as_numpy=False):
+        """Local phase over this rank's rows, collectives, finalisation (vdl_run_sharded).  Fold plans: every rank gets the
+        full result; plans with a Partition: this rank's slice (the ranks' slices concatenate in rank order)."""
+        self._e._check(self._e._L.vdl_run_sharded(self._e._c, self._h))
+        return self._collect(as_numpy)
+
+    def run_sharded_begin(self, slot):
+        self._e._check(self._e._L.vdl_run_sharded_begin(self._e._c, self._h, int(slot)))
+
+    def run_sharded_end(self, slot):
+        self._e._check(self._e._L.vdl_run_sharded_end(self._e._c, self._h, int(slot)))
+        return self._collect()
+
     def finalize_begin(self, dev_ptr, slot):
         self._e._check(self._e._L.vdl_finalize_begin(self._e._c, self._h, ctypes.c_void_p(dev_ptr), int(slot)))
 
@@ -231,6 +245,63 @@ class Engine:
 
     def use_own_stream(self):
         self._check(self._L.vdl_use_own_stream(self._c))
+
+    # ---- communicator (one process per GPU; see include/vdl.h "multi-GPU behind this boundary") ----
+    def comm_unique_id(self):
+        """128 bytes made by ONE rank (ncclGetUniqueId); hand them to the other ranks over any channel."""
+        buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+        self._check(self._L.vdl_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init_rccl(self, rank, world, unique_id):
+        if len(unique_id) != _lib.COMM_ID_BYTES:
+            raise VdlError(_lib.VDL_ERR_ARG, "the communicator id is %d bytes" % _lib.COMM_ID_BYTES)
+        self._check(self._L.vdl_comm_init(self._c, int(rank), int(world), ctypes.c_char_p(unique_id)))
+
+    def comm_init_host(self, rank, world, all_gather, all_to_all):
+        """Collectives supplied by the caller over host memory:
+        all_gather(send: bytes) -> list of `world` bytes objects (rank order);
+        all_to_all(pieces: list of `world` bytes objects, one per destination) -> list of `world` bytes objects, one per source."""
+        def c_all_gather(_user, send, recv, nbytes):
+            try:
+                parts = all_gather(ctypes.string_at(send, nbytes))
+                for r, part in enumerate(parts):
+                    if len(part) != nbytes:
+                        return 1
+                    ctypes.memmove(recv + r * nbytes, part, nbytes)
+                return 0
+            except Exception:              # noqa: BLE001 -- must not propagate through the C frame
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def c_all_to_all(_user, send, send_bytes, recv, recv_bytes):
+            try:
+                pieces, at = [], 0
+                for r in range(world):
+                    pieces.append(ctypes.string_at(send + at, send_bytes[r]) if send_bytes[r] else b"")
+                    at += send_bytes[r]
+                got = all_to_all(pieces)
+                at = 0
+                for r in range(world):
+                    if len(got[r]) != recv_bytes[r]:
+                        return 1
+                    if recv_bytes[r]:
+                        ctypes.memmove(recv + at, got[r], recv_bytes[r])
+                    at += recv_bytes[r]
+                return 0
+            except Exception:              # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._comm_host = _lib.CommHost(None, _lib.ALL_GATHER_FN(c_all_gather), _lib.ALL_TO_ALL_FN(c_all_to_all))     # kept alive with the engine
+        self._check(self._L.vdl_comm_init_host(self._c, int(rank), int(world), ctypes.byref(self._comm_host)))
+
+    def comm_info(self):
+        rank, world, name = ctypes.c_int(), ctypes.c_int(), ctypes.c_char_p()
+        self._check(self._L.vdl_comm_info(self._c, ctypes.byref(rank), ctypes.byref(world), ctypes.byref(name)))
+        return rank.value, world.value, name.value.decode()
 
     # ---- catalog ----
     def register_tensor(self, name, tensor):

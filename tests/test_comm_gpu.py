@@ -1,0 +1,188 @@
+"""The multi-GPU path behind the C ABI (vdl_comm.cpp: vdl_comm_init*, vdl_run_sharded*) on ONE GPU.
+
+RCCL refuses two ranks on one device, so N > 1 is driven here with the HOST transport: W ranks = W threads of this
+process, one context each on device 0, each holding its row range; the all-gather / all-to-all callbacks rendezvous
+through a barrier.  Everything else is the production path: vdl_run_sharded picks the route, packs, merges with the
+device kernel, exchanges rows, runs the tail.  RCCL itself is exercised at world = 1 (real ncclCommInitRank,
+all-gather-free merge, grouped send/receive to self is skipped by construction)."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import mplan2vdl_amd as m
+from mplan2vdl_amd import catalog, datagen, frontend, shard_rows
+from conftest import ROOT, golden
+from helpers import engine_with, lineitem, oracle_run
+
+pytestmark = pytest.mark.gpu
+META = os.path.join(ROOT, "tests", "golden", "tpch10noorder")
+
+
+class Rendezvous:
+    """In-process stand-in for a host collective library (TEST ONLY)."""
+
+    def __init__(self, world):
+        self.world, self.barrier = world, threading.Barrier(world)
+        self.slots = [None] * world
+
+    def transport(self, rank):
+        def all_gather(send):
+            self.slots[rank] = send
+            self.barrier.wait()
+            out = list(self.slots)
+            self.barrier.wait()
+            return out
+
+        def all_to_all(pieces):
+            self.slots[rank] = pieces
+            self.barrier.wait()
+            out = [self.slots[src][rank] for src in range(self.world)]
+            self.barrier.wait()
+            return out
+
+        return all_gather, all_to_all
+
+
+def run_ranks(world, work):
+    """work(rank, rendezvous) in `world` threads; returns the per-rank results, re-raising the first failure."""
+    rv = Rendezvous(world)
+    out, errs = [None] * world, []
+
+    def body(rank):
+        try:
+            out[rank] = work(rank, rv)
+        except BaseException as exc:          # noqa: BLE001
+            errs.append(exc)
+            rv.barrier.abort()
+
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    if errs:
+        raise errs[0]
+    return out
+
+
+def lineitem_shards(cols, world):
+    n = len(next(v for k, v in cols.items() if k.startswith("lineitem.") and not k.endswith(".heap")))
+    shards = []
+    for r in range(world):
+        r0, r1 = shard_rows(n, r, world)
+        shards.append((r0, {k: (v[r0:r1] if k.startswith("lineitem.") and not k.endswith(".heap") else v) for k, v in cols.items()}))
+    return shards
+
+
+def sharded_run(text, shards, world, table=None, pipelined=0):
+    def work(rank, rv):
+        r0, cols = shards[rank]
+        e = engine_with(cols)
+        e.comm_init_host(rank, world, *rv.transport(rank))
+        assert e.comm_info() == (rank, world, "host")
+        p = e.parse(text)
+        if table:
+            p.set_sharded_table(table)
+        p.set_row_offset(r0)
+        if pipelined:
+            res = []
+            for k in range(pipelined):
+                p.run_sharded_begin(k & 1)
+                if k:
+                    res.append(p.run_sharded_end(1 - (k & 1))["results"])
+            res.append(p.run_sharded_end((pipelined - 1) & 1)["results"])
+            e.close()
+            return res
+        res = p.run_sharded()["results"]
+        e.close()
+        return res
+
+    return run_ranks(world, work)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("query", ["q6", "q1"])
+def test_fused_plans_merge_through_one_all_gather(query, world):
+    """Q6 (two SUM words) and Q1 (289 words: SUM, MIN / MAX and FoldChoose pairs): every rank ends with the whole answer."""
+    text = golden(query + ".vdl")
+    names = datagen.Q6_COLUMNS if query == "q6" else datagen.Q1_COLUMNS
+    n = 300007
+    whole = lineitem(names, n)
+    want = oracle_run(text, whole)
+    shards = [(lo, {k: v[lo:hi] for k, v in whole.items()}) for lo, hi in (shard_rows(n, r, world) for r in range(world))]
+    for got in sharded_run(text, shards, world):
+        assert got == want
+
+
+def test_pipelined_begin_end_gives_every_query_its_answer():
+    text = golden("q6.vdl")
+    n = 200003
+    whole = lineitem(datagen.Q6_COLUMNS, n)
+    want = oracle_run(text, whole)
+    shards = [(lo, {k: v[lo:hi] for k, v in whole.items()}) for lo, hi in (shard_rows(n, r, 2) for r in range(2))]
+    for got in sharded_run(text, shards, 2, pipelined=5):
+        assert got == [want] * 5
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("plan_no", [14, 19])
+def test_join_then_ungrouped_aggregate_merges_its_fold_records(plan_no, world):
+    cfg = frontend.load_metadata(META)
+    text = frontend.compile_plan(open(os.path.join(META, "%02d.sql.mplan" % plan_no)).read(), cfg)
+    cols = catalog.synth_columns(META, cfg, text, scale=1e-3, seed=7)
+    want = oracle_run(text, cols)
+    assert any(len(list(v.values())[0]) for v in want.values())
+    for got in sharded_run(text, lineitem_shards(cols, world), world, table="lineitem"):
+        assert got == want
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("plan_no", [3, 5, 9, 10, 12, 20])
+def test_plans_with_a_partition_exchange_rows_and_concatenate(plan_no, world):
+    """ONE all-gather of {status, counts} + ONE all-to-all of every column: the ranks' outputs, in rank order, are the
+    unsharded result."""
+    cfg = frontend.load_metadata(META)
+    text = frontend.compile_plan(open(os.path.join(META, "%02d.sql.mplan" % plan_no)).read(), cfg)
+    cols = catalog.synth_columns(META, cfg, text, scale=6e-4, seed=3)
+    want = oracle_run(text, cols)
+    parts = sharded_run(text, lineitem_shards(cols, world), world, table="lineitem")
+    got = {k: {name: sum((part[k][name] for part in parts), []) for name in v} for k, v in want.items()}
+    assert got == want
+    assert any(len(list(v.values())[0]) for v in want.values())
+
+
+def test_a_failure_on_one_rank_is_reported_on_every_rank():
+    """A key outside the Partition pivots on one rank: nobody is left waiting in a collective, everybody gets an error."""
+    text = golden("q3.vdl")
+    t = datagen.q3_tables(3000)
+    shards = lineitem_shards(t, 2)
+    bad = dict(shards[1][1])
+    bad["lineitem.l_orderkey"] = bad["lineitem.l_orderkey"].copy()
+    bad["lineitem.l_orderkey"][:] = 2 ** 40                # far outside the compiled key domain
+    shards[1] = (shards[1][0], bad)
+    with pytest.raises(m.VdlError):
+        sharded_run(text, shards, 2, table="lineitem")
+
+
+def test_rccl_communicator_of_one_rank_runs_both_routes(q6_text):
+    """Real RCCL on this box's one GPU: ncclGetUniqueId, ncclCommInitRank, the fold route and the exchange route."""
+    n = 100003
+    cols = lineitem(datagen.Q6_COLUMNS, n)
+    e = engine_with(cols)
+    e.comm_init_rccl(0, 1, e.comm_unique_id())
+    assert e.comm_info() == (0, 1, "rccl")
+    p = e.parse(q6_text)
+    assert p.run_sharded()["results"] == oracle_run(q6_text, cols)
+    for k in range(4):                                       # pipelined slots on the communication stream
+        p.run_sharded_begin(k & 1)
+        assert p.run_sharded_end(k & 1)["results"] == oracle_run(q6_text, cols)
+    e.close()
+    t = datagen.q3_tables(2000)
+    e = engine_with(t)
+    e.comm_init_rccl(0, 1, e.comm_unique_id())
+    p = e.parse(golden("q3.vdl"))
+    p.set_sharded_table("lineitem")
+    assert p.run_sharded()["results"] == oracle_run(golden("q3.vdl"), t)
+    e.close()

@@ -302,3 +302,86 @@ def test_two_rank_gloo_partition_exchange(fail_rank):
     assert outs[0]["keys"] + outs[1]["keys"] == [int(k) for k in keys]
     assert outs[0]["sums"] + outs[1]["sums"] == [int(whole.v[whole.key == k].sum()) for k in keys]
     assert max(outs[0]["keys"]) < min(outs[1]["keys"])
+
+
+# ---- the collective formulation behind the C ABI (vdl_comm.cpp): ONE all-gather of the partial words + a per-word merge ----
+def _grouped_partials(lo, hi, groups=6):
+    """Stand-in (TEST ONLY) for the partial words of a grouped scan over rows [lo, hi): per group {count SUM, sum SUM,
+    max MAX, min MIN, FoldChoose FIRST}; returns (words, words-with-FIRST-resolved) as the local phase leaves them."""
+    rng = np.random.default_rng(12345)
+    n_all = 5000
+    key = rng.integers(0, groups, n_all)
+    val = rng.integers(-1000, 1000, n_all)
+    key[:37] = 0                                          # group 5 may be missing from a shard; group 0 starts early
+    words, resolved = [], []
+    for g in range(groups):
+        rows = np.nonzero(key[lo:hi] == g)[0] + lo
+        v = val[rows]
+        first = int(rows[0]) if len(rows) else np.iinfo(np.int64).max
+        w = [len(rows), int(v.sum()) if len(rows) else 0, int(v.max()) if len(rows) else np.iinfo(np.int64).min,
+             int(v.min()) if len(rows) else np.iinfo(np.int64).max, first]
+        words += w
+        resolved += w[:4] + [int(val[first]) if len(rows) else 0]
+    return np.array(words, np.int64), np.array(resolved, np.int64)
+
+
+GROUP_OPS = [_lib.REDUCE_SUM, _lib.REDUCE_SUM, _lib.REDUCE_MAX, _lib.REDUCE_MIN, _lib.REDUCE_FIRST]
+
+
+def _merge_host(world, ops, gathered):
+    import ctypes
+
+    L = _lib.load()
+    nw = len(ops)
+    out = np.zeros(nw, np.int64)
+    c_ops = (ctypes.c_int32 * nw)(*ops)
+    g = np.ascontiguousarray(gathered, np.int64)
+    i64p = ctypes.POINTER(ctypes.c_int64)
+    assert L.vdl_comm_merge_host(world, nw, c_ops, g.ctypes.data_as(i64p), out.ctypes.data_as(i64p)) == 0
+    return out
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = m.shard_rows(5000, rank, world)
+    words, resolved = _grouped_partials(lo, hi)
+    send = torch.from_numpy(np.concatenate([words, resolved]))
+    recv = [torch.zeros_like(send) for _ in range(world)]
+    dist.all_gather(recv, send)                           # the one collective of the fold route
+    merged = _merge_host(world, GROUP_OPS * 6, torch.cat(recv).numpy())
+    q.put((rank, merged.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("world", [2, 3])
+def test_gathered_partial_words_merge_to_the_single_rank_table(world):
+    """World-2 / world-3 gloo ranks all-gather {words, resolved words} once and apply the C merge rule
+    (vdl_comm_merge_host = what k_merge_words runs on the GPU): SUM / MIN / MAX per word, FoldChoose = the value of the rank
+    holding the smallest global row id -- equal to the table of the whole row range on every rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31000 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=150) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    _, whole = _grouped_partials(0, 5000)                  # one rank: FIRST words resolved = the values
+    for r in range(world):
+        assert outs[r] == whole.tolist()
+
+
+def test_merge_rule_edge_cases():
+    big, small = np.iinfo(np.int64).max, np.iinfo(np.int64).min
+    ops = [_lib.REDUCE_SUM, _lib.REDUCE_MIN, _lib.REDUCE_MAX, _lib.REDUCE_FIRST]
+    # no rank has a row in the group: FIRST stays "no value" (0), MIN / MAX keep their identities, SUM wraps like the engine's
+    g = np.array([big, big, small, big, big, big, small, 0] * 3, np.int64)
+    assert _merge_host(3, ops, g).tolist() == [np.int64(3 * np.uint64(big)).item() if False else int((3 * big + 2 ** 63) % 2 ** 64 - 2 ** 63), big, small, 0]
+    # one rank: the resolved half is the answer
+    assert _merge_host(1, ops, np.array([1, 2, 3, 40, 1, 2, 3, 77], np.int64)).tolist() == [1, 2, 3, 77]
