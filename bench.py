@@ -186,33 +186,37 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-    # Rehearsal switches (one-GPU boxes): VDL_BENCH_SHARE_DEVICE=1 puts every rank on device 0 and
-    # VDL_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device).  Not for reported numbers.
-    backend = os.environ.get("VDL_BENCH_BACKEND", "nccl")
+    # torch.distributed is the launcher's control channel only (communicator id hand-over, barriers, MAX of the timings):
+    # gloo over CPU tensors.  The data-path collectives run inside libvdl on its own RCCL communicator (vdl_comm_init).
+    # Rehearsal on one-GPU boxes: VDL_BENCH_SHARE_DEVICE=1 puts every rank on device 0; RCCL refuses two ranks on one
+    # device, so VDL_BENCH_COMM=host then routes the collectives through libvdl's host transport over gloo.  VDL_BENCH_COMM=torch
+    # is the previous formulation (torch.distributed nccl all-reduce from Python), kept as the fallback when RCCL cannot be
+    # bound from libvdl.  Neither rehearsal mode is for reported numbers; the JSON line says which one ran.
+    comm_mode = os.environ.get("VDL_BENCH_COMM", "native")
+    if os.environ.get("VDL_BENCH_BACKEND") == "gloo" and comm_mode == "native":
+        comm_mode = "host"                                        # (round-1 spelling of the rehearsal switch)
     if os.environ.get("VDL_BENCH_SHARE_DEVICE") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         if dist.get_world_size() != args.gpus:
-            print("bench.py: the communicator has %d rank(s), --gpus asked for %d" % (dist.get_world_size(), args.gpus), file=sys.stderr)
+            print("bench.py: the launcher's group has %d rank(s), --gpus asked for %d" % (dist.get_world_size(), args.gpus), file=sys.stderr)
             sys.exit(2)
-    n_ranks = dist.get_world_size() if world > 1 else 1      # what the JSON line reports: the communicator's size, not the flag
+
+    def everybody(ok):
+        """True when `ok` holds on every rank (one gloo all-reduce)."""
+        if world == 1:
+            return bool(ok)
+        t = torch.tensor([0 if ok else 1], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return int(t.item()) == 0
 
     total_rows = args.rows or datagen.LINEITEM_ROWS[args.sf]
     lo, hi = m.shard_rows(total_rows, rank, world)
     my_rows = hi - lo
 
     eng = m.Engine(device=local_rank)
-    # one dedicated stream for everything: engine kernels, torch tensor ops and the RCCL all-reduce
-    # (torch orders its collective against the current stream) -- no implicit default-stream syncs
-    side = torch.cuda.Stream()
-    torch.cuda.set_stream(side)
-    eng.use_torch_stream()
     q_cols = datagen.Q6_COLUMNS if args.query == "q6" else datagen.Q1_COLUMNS
     q_bytes = datagen.Q6_BYTES_PER_ROW if args.query == "q6" else datagen.Q1_BYTES_PER_ROW
     for name in q_cols:
@@ -224,18 +228,86 @@ def main():
     plan.set_profiling(True)
     plan.set_row_offset(lo)
     nw, ops = plan.partial_spec()
-    bufs = [torch.zeros(max(nw, 1), dtype=torch.int64, device="cuda") for _ in range(2)]
-    query = m.ShardedQuery(plan, bufs[0], dist if world > 1 else None)
+
+    n_ranks, transport, torch_group = 1, "none (single GPU)", None
+    if world > 1 and comm_mode == "native":
+        # every rank binds RCCL first (so that nobody blocks in ncclCommInitRank while a peer could not even load the
+        # library), rank 0's id travels over the control channel, then the communicator is built
+        uid, why = None, ""
+        try:
+            uid = eng.comm_unique_id()
+        except m.VdlError as exc:
+            why = str(exc)
+        if everybody(uid is not None):
+            box = [uid if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            try:
+                eng.comm_init_rccl(rank, world, box[0])
+                why = ""
+            except m.VdlError as exc:
+                why = str(exc)
+            if not everybody(why == ""):
+                comm_mode = "torch"
+        else:
+            comm_mode = "torch"
+        if comm_mode == "torch" and why:
+            print("bench.py[%d]: libvdl could not set up RCCL (%s); falling back to torch.distributed collectives" % (rank, why), file=sys.stderr)
+    if world > 1 and comm_mode == "host":
+        def gloo_all_gather(send):
+            t = torch.frombuffer(bytearray(send), dtype=torch.uint8)
+            parts = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(parts, t)
+            return [bytes(x.numpy()) for x in parts]
+
+        def gloo_all_to_all(pieces):                              # (the fold route never exchanges rows; complete for the interface)
+            box = [None] * world
+            dist.all_gather_object(box, pieces)
+            return [box[src][rank] for src in range(world)]
+
+        eng.comm_init_host(rank, world, gloo_all_gather, gloo_all_to_all)
+    if world > 1 and comm_mode in ("native", "host"):
+        _, n_ranks, name = eng.comm_info()
+        transport = {"rccl": "RCCL inside libvdl: one all-gather of %d int64 words + merge kernel per query, on a communication stream",
+                     "host": "libvdl host transport over gloo (REHEARSAL): one all-gather of %d int64 words + merge kernel per query"}[name] % (2 * nw)
+        if n_ranks != args.gpus:
+            print("bench.py: the communicator has %d rank(s), --gpus asked for %d" % (n_ranks, args.gpus), file=sys.stderr)
+            sys.exit(2)
+    query, bufs = None, None
+    if world == 1 or comm_mode == "torch":
+        # one dedicated stream for everything: engine kernels, torch tensor ops and the collective
+        side = torch.cuda.Stream()
+        torch.cuda.set_stream(side)
+        eng.use_torch_stream()
+        if world > 1:
+            torch_group = dist.new_group(backend="nccl")
+            n_ranks = dist.get_world_size(torch_group)
+            transport = "torch.distributed nccl all-reduce of %d int64 words from Python (fallback)" % nw
+        bufs = [torch.zeros(max(nw, 1), dtype=torch.int64, device="cuda") for _ in range(2)]
+        query = m.ShardedQuery(plan, bufs[0], dist if world > 1 else None, torch_group)
 
     scan_us = []
 
     def run_steps(k, record):
-        """k full queries.  Q6: pipelined (host side of query i overlaps the kernels of query i+1; every
-        query runs completely and every result is produced).  Q1: plain vdl_run per query."""
+        """k full queries, pipelined: the host side of query i (and, N > 1, its collective) overlaps the scan of query
+        i+1; every query runs completely and every result is produced."""
         def on_result(out):
             if record:
                 scan_us.append(plan.scan_stats()[2])
-        return query.run_pipelined(k, bufs, on_result, overlap_merge=os.environ.get("VDL_BENCH_SYNC_MERGE") != "1")
+        if query is not None:
+            return query.run_pipelined(k, bufs, on_result, overlap_merge=os.environ.get("VDL_BENCH_SYNC_MERGE") != "1")
+        out = None
+        for i in range(k):
+            plan.run_sharded_begin(i & 1)
+            if i >= 1:
+                out = plan.run_sharded_end(1 - (i & 1))
+                on_result(out)
+        if k:
+            out = plan.run_sharded_end((k - 1) & 1)
+            on_result(out)
+        return out
+
+    def one_query():
+        return query.step() if query is not None else plan.run_sharded()
 
     def sync_all():
         torch.cuda.synchronize()
@@ -244,8 +316,7 @@ def main():
         torch.cuda.synchronize()
 
     if world > 1:
-        # communicator set-up (seconds on the first collective) must not land in the timed region even with --warmup 0
-        dist.all_reduce(torch.zeros(1, dtype=torch.int64, device="cuda"))
+        one_query()                  # communicator warm-up (the first collective takes seconds) stays out of the timed region even with --warmup 0
         torch.cuda.synchronize()
     result = run_steps(args.warmup, False) if args.warmup > 0 else None
     sync_all()
@@ -254,7 +325,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -266,10 +337,10 @@ def main():
         for _ in range(args.latency_steps):
             sync_all()
             t1 = time.perf_counter()
-            query.step()
+            one_query()
             torch.cuda.synchronize()
             lat.append(time.perf_counter() - t1)
-        lt = torch.tensor([sum(lat[1:]) / max(len(lat) - 1, 1) if len(lat) > 1 else lat[0]], dtype=torch.float64, device="cuda")
+        lt = torch.tensor([sum(lat[1:]) / max(len(lat) - 1, 1) if len(lat) > 1 else lat[0]], dtype=torch.float64)
         if world > 1:
             dist.all_reduce(lt, op=dist.ReduceOp.MAX)
         latency_ms = float(lt.item()) * 1e3
@@ -342,9 +413,7 @@ def main():
             "config": {"workload": "tpch_%s_%s" % (args.query, args.sf if not args.rows else "rows%d" % args.rows),
                        "rows_total": total_rows, "rows_per_gpu": my_rows, "bytes_per_row": q_bytes,
                        "sharding": "row-range, one process per GPU" if world > 1 else "single GPU",
-                       "finalise": ("%s all-reduce of %d int64 words%s" % ("RCCL" if backend == "nccl" else backend, nw,
-                                    "" if os.environ.get("VDL_BENCH_SYNC_MERGE") == "1" or args.query != "q6" else ", overlapped with the next query's scan"))
-                       if world > 1 else "local"},
+                       "finalise": transport if world > 1 else "local"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel_label, "kernel_us": kern_us,

@@ -76,13 +76,14 @@ def lineitem_shards(cols, world):
     return shards
 
 
-def sharded_run(text, shards, world, table=None, pipelined=0):
+def sharded_run(text, shards, world, table=None, pipelined=0, fuse=True):
     def work(rank, rv):
         r0, cols = shards[rank]
         e = engine_with(cols)
         e.comm_init_host(rank, world, *rv.transport(rank))
         assert e.comm_info() == (rank, world, "host")
         p = e.parse(text)
+        p.set_fusion(fuse)
         if table:
             p.set_sharded_table(table)
         p.set_row_offset(r0)
@@ -154,16 +155,41 @@ def test_plans_with_a_partition_exchange_rows_and_concatenate(plan_no, world):
 
 
 def test_a_failure_on_one_rank_is_reported_on_every_rank():
-    """A key outside the Partition pivots on one rank: nobody is left waiting in a collective, everybody gets an error."""
-    text = golden("q3.vdl")
-    t = datagen.q3_tables(3000)
-    shards = lineitem_shards(t, 2)
-    bad = dict(shards[1][1])
-    bad["lineitem.l_orderkey"] = bad["lineitem.l_orderkey"].copy()
-    bad["lineitem.l_orderkey"][:] = 2 ** 40                # far outside the compiled key domain
-    shards[1] = (shards[1][0], bad)
-    with pytest.raises(m.VdlError):
-        sharded_run(text, shards, 2, table="lineitem")
+    """A key outside the Partition pivots on ONE rank (the local phase of that rank fails): the status travels with the
+    counts, nobody is left waiting in a collective, every rank returns an error."""
+    from helpers import prog
+
+    text = prog("1,Load,t.k", "2,Project,val,Id 1,k", "3,Load,t.x", "4,Project,val,Id 3,x",
+                "5,RangeC,val,0,64,1", "6,Partition,val,Id 2,val,Id 5,val",
+                "7,RangeV,val,0,Id 2,1", "8,Scatter,Id 2,Id 7,val,Id 6,val", "9,Scatter,Id 4,Id 7,val,Id 6,val",
+                "10,FoldSum,val,Id 8,val,Id 9,val", "11,MaterializeCompact,Id 10")
+    rng = np.random.default_rng(5)
+    cols = {"t.k": rng.integers(0, 64, 4000).astype(np.int64), "t.x": rng.integers(0, 100, 4000).astype(np.int64)}
+    shards = [(lo, {k: v[lo:hi] for k, v in cols.items()}) for lo, hi in (shard_rows(4000, r, 2) for r in range(2))]
+    want = oracle_run(text, cols)["tmp11"][".val"]
+    assert [g["tmp11"][".val"] for g in sharded_run(text, shards, 2, table="t")] == [want, want]       # fused: the fold route, whole answer everywhere
+    good = sharded_run(text, shards, 2, table="t", fuse=False)                                         # statement by statement: rows are exchanged
+    assert sum((g["tmp11"][".val"] for g in good), []) == want
+    shards[1][1]["t.k"] = shards[1][1]["t.k"].copy()
+    shards[1][1]["t.k"][7] = 1000                          # outside RangeC 0 64 1
+    errors = []
+
+    def work(rank, rv):
+        r0, c = shards[rank]
+        e = engine_with(c)
+        e.comm_init_host(rank, 2, *rv.transport(rank))
+        p = e.parse(text)
+        p.set_fusion(False)
+        p.set_sharded_table("t")
+        try:
+            p.run_sharded()
+        except m.VdlError as exc:
+            errors.append((rank, str(exc)))
+        e.close()
+
+    run_ranks(2, work)
+    assert sorted(r for r, _ in errors) == [0, 1]
+    assert any("outside the pivots" in msg for _, msg in errors) and any("failed on rank 1" in msg for _, msg in errors)
 
 
 def test_rccl_communicator_of_one_rank_runs_both_routes(q6_text):

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from mplan2vdl_amd import catalog, datagen, frontend, resolve
-from conftest import ROOT
+from conftest import ROOT, golden
 from helpers import lineitem, oracle_run
 
 pytestmark = pytest.mark.gpu
@@ -93,3 +93,31 @@ def test_plain_c_host_runs_q6_on_the_device(tmp_path, q6_text, fuse):
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     got = json.loads(r.stdout)["results"]
     assert got == oracle_run(q6_text, lineitem(datagen.Q6_COLUMNS, rows))
+
+
+@pytest.mark.parametrize("query", ["q6", "q1"])
+def test_vdlrun_gpus_forks_its_ranks_and_runs_through_rccl(query):
+    """`vdlrun --gpus N`: ranks forked before HIP is touched, RCCL communicator id through a file, vdl_run_sharded.  This box
+    has one GPU, so N = 1 here -- the same code path with a one-rank RCCL communicator (the driver's node runs N = 8)."""
+    text = golden(query + ".vdl")
+    reply = pipe(text, ["--gpus", "1", "--rows", "60175"])
+    names = datagen.Q6_COLUMNS if query == "q6" else datagen.Q1_COLUMNS
+    assert reply["results"] == oracle_run(text, lineitem(names, 60175))
+
+
+@pytest.mark.parametrize("plan", [3, 14])
+def test_vdlrun_gpus_with_a_data_directory(tmp_path, plan):
+    """--gpus with --data / --shard: the exchange route (Q3) and the fold-record route (Q14) from exported column files."""
+    cfg = frontend.load_metadata(META)
+    text = frontend.compile_plan(open(os.path.join(META, "%02d.sql.mplan" % plan)).read(), cfg)
+    text = "\n".join(ln.split(";;")[0].rstrip() for ln in text.splitlines()) + "\n"
+    cols = catalog.synth_columns(META, cfg, text, scale=1e-3, seed=5)
+    coldir = str(tmp_path / "cols")
+    catalog.export_columns(cols, coldir)
+    reply = pipe(text, ["--gpus", "1", "--shard", "lineitem", "--data", coldir])
+    assert reply["results"] == oracle_run(text, cols)
+
+
+def test_vdlrun_gpus_reports_a_missing_device():
+    r = subprocess.run([VDLRUN, "--gpus", "64", "--rows", "1000"], input=golden("q6.vdl").encode(), capture_output=True, timeout=300)
+    assert r.returncode != 0 and b"rank(s) failed" in r.stderr
