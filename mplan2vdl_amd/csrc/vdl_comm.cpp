@@ -222,6 +222,7 @@ static void sharded_begin(vdl_ctx *c, vdl_plan *p, int slot) {
     hipStream_t cs = overlap ? m.stream : c->stream;
     if (overlap && m.ev_merged[slot]) HIP_CHECK(hipStreamWaitEvent(c->stream, m.ev_merged[slot], 0));    // the previous query of this slot has left the send buffer
     if (vdl_run_local(c, p, send) != VDL_OK) throw Error(VDL_ERR_DEVICE, c->err);
+    p->ev_buf[p->last_ev] = st.merged[slot]->p;            // the scan's timing is claimed by the finalisation of the MERGED words
     if (overlap) {
         if (!m.ev_local[slot]) {
             HIP_CHECK(hipEventCreateWithFlags(&m.ev_local[slot], hipEventDisableTiming));

@@ -12,6 +12,7 @@
 // table (--shard, default lineitem) and the other tables in full, joins an RCCL communicator (rank 0's id travels through a
 // file in a private temporary directory) and calls vdl_run_sharded.  The parent prints ONE reply: the common answer of a
 // fold plan, or the ranks' slices concatenated in rank order for a plan with a Partition.
+#include <signal.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -253,6 +254,7 @@ int main(int argc, char **argv) {
         const pid_t pid = fork();
         if (pid < 0) { std::perror("vdlrun: fork"); return 1; }
         if (pid == 0) {
+            dup2(2, 1);                                      // stdout carries the parent's reply only (RCCL prints a banner at start-up)
             Reply mine;
             int rc = run_rank(o, text, r, o.gpus, dir, mine);
             if (rc == 0 && !write_reply(std::string(dir) + "/out." + std::to_string(r), mine)) rc = 1;
@@ -261,10 +263,17 @@ int main(int argc, char **argv) {
         }
         kids.push_back(pid);
     }
+    // a rank that fails leaves its peers waiting in the communicator: the first failure ends the others
     int failed = 0;
-    for (pid_t pid : kids) {
+    for (size_t left = kids.size(); left > 0; left--) {
         int st = 0;
-        if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) failed++;
+        const pid_t pid = waitpid(-1, &st, 0);
+        if (pid < 0) { failed++; break; }
+        if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) {
+            if (!failed)
+                for (pid_t other : kids) if (other != pid) kill(other, SIGTERM);
+            failed++;
+        }
     }
     Reply all;
     for (int r = 0; r < o.gpus && !failed; r++) {
