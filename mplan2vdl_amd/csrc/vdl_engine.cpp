@@ -41,7 +41,10 @@ int64_t plan_words(const vdl_plan *p, std::vector<int32_t> *ops, bool *shardable
 }
 
 // single-aggregate scans over <= 4 columns take the tuned k_scan; everything else k_mscan
-static bool use_kscan(const ScanPlan &sp) { return sp.aggs.size() == 1 && sp.cols.size() <= 4; }
+static bool use_kscan(const ScanPlan &sp) {
+    for (const ScanColumn &c : sp.cols) if (c.kind != VC_DIRECT) return false;       // derived columns (fused join scans): k_mscan
+    return sp.aggs.size() == 1 && sp.cols.size() <= 4;
+}
 
 template <typename PlanT>
 int64_t bind_mscan(vdl_ctx *c, const PlanT &sp, MScanCols &cols, MScanDesc &d, int64_t *bytes_per_row, int64_t row0) {
@@ -52,15 +55,27 @@ int64_t bind_mscan(vdl_ctx *c, const PlanT &sp, MScanCols &cols, MScanDesc &d, i
     int64_t n = -1;
     *bytes_per_row = 0;
     for (int k = 0; k < cols.ncol; k++) {
-        const Column &col = find_col(c, sp.cols[(size_t)k].name);
-        if (n >= 0 && col.n != n)
-            throw Error(VDL_ERR_SHAPE, "columns of table '" + sp.table + "' have different lengths in the catalog");
-        n = col.n;
-        cols.ptr[k] = col.dev; cols.width[k] = col.width;
-        cols.lo[k] = sp.cols[(size_t)k].lo; cols.hi[k] = sp.cols[(size_t)k].hi;
+        const ScanColumn &sc = sp.cols[(size_t)k];
+        cols.kind[k] = sc.kind;
+        cols.lo[k] = sc.lo; cols.hi[k] = sc.hi;
         cols.filtered[k] = (cols.lo[k] != INT64_MIN || cols.hi[k] != INT64_MAX) ? 1 : 0;
         d.flo[k] = cols.lo[k]; d.fhi[k] = cols.hi[k];
-        *bytes_per_row += col.width;
+        d.dkind[k] = sc.kind; d.dsrc[k] = sc.idx; d.dsrc2[k] = sc.idx2;
+        if (sc.kind == VC_DIRECT) {
+            const Column &col = find_col(c, sc.name);
+            if (n >= 0 && col.n != n)
+                throw Error(VDL_ERR_SHAPE, "columns of table '" + sp.table + "' have different lengths in the catalog");
+            n = col.n;
+            cols.ptr[k] = col.dev; cols.width[k] = col.width;
+            *bytes_per_row += col.width;
+        } else if (sc.kind == VC_GATHER || sc.kind == VC_INRANGE) {      // a column of another table, looked up / its length
+            const Column &col = find_col(c, sc.name);
+            cols.ptr[k] = col.dev; cols.width[k] = col.width;
+            d.dn[k] = col.n;
+        } else {                                                          // VC_BITS / VC_LUT: filled in by run_prelude before every launch
+            cols.ptr[k] = nullptr; cols.width[k] = 8;
+            d.dn[k] = 0;
+        }
     }
     cols.n = n;
     cols.row0 = row0;
@@ -166,12 +181,62 @@ void bind_fused(vdl_ctx *c, vdl_plan *p) {
     p->bound = true;
 }
 
+// Dimension-side work of scans with derived columns (FusedPlan::prelude): the per-operator executor runs the statements
+// that hold the dimension selections (filters on the dimension table, joins of dimensions with further dimensions) and
+// their validity bitmaps become the lookup tables of the fact scan; LIKE patterns are evaluated once per heap offset.
+// Part of the query: runs on every execution.
+void run_prelude(vdl_ctx *c, vdl_plan *p) {
+    const FusedPlan &F = p->fused;
+    if (F.prelude.empty()) return;
+    p->prelude_buf.assign(F.prelude.size(), nullptr);
+    p->prelude_n.assign(F.prelude.size(), 0);
+    std::vector<int> witnesses;
+    for (const PreludeItem &it : F.prelude) if (it.kind == PreludeItem::DIM_BITMAP) witnesses.push_back(it.witness);
+    if (!witnesses.empty()) {
+        GenExec g(c, p);
+        g.run_nodes(witnesses, nullptr);
+        for (size_t k = 0; k < F.prelude.size(); k++) {
+            if (F.prelude[k].kind != PreludeItem::DIM_BITMAP) continue;
+            const DVec &v = g.vec[(size_t)F.prelude[k].witness];
+            p->prelude_n[k] = v.n;
+            if (v.kind == DVec::SPARSE) p->prelude_buf[k] = g.bitmap_of(v.sel);
+            else p->prelude_buf[k] = g.densify(v).valid;                  // null: every dimension row holds a value
+        }
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    for (size_t k = 0; k < F.prelude.size(); k++) {
+        const PreludeItem &it = F.prelude[k];
+        if (it.kind != PreludeItem::LIKE_LUT) continue;
+        const Column &heap = find_col(c, it.heap);
+        Src offs; offs.kind = SRC_RANGE; offs.from = 0; offs.step = 1;
+        Src hs; hs.p = heap.dev; hs.kind = heap.width == 8 ? SRC_I64 : heap.width == 4 ? SRC_I32 : heap.width == 2 ? SRC_I16 : SRC_I8;
+        LikePattern pat{};
+        pat.len = (int)it.pattern.size();
+        memcpy(pat.p, it.pattern.data(), it.pattern.size());
+        p->prelude_buf[k] = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(heap.n, 1));
+        p->prelude_n[k] = heap.n;
+        HIP_CHECK(launch_like(offs, nullptr, heap.n, hs, nullptr, heap.n, pat, (int64_t *)p->prelude_buf[k]->p, c->stream));
+    }
+    // hand the tables to the scans that look them up
+    const size_t ns = F.scans.size();
+    for (size_t s = 0; s < ns + F.gscans.size(); s++) {
+        const std::vector<ScanColumn> &sc = s < ns ? F.scans[s].cols : F.gscans[s - ns].cols;
+        for (size_t k = 0; k < sc.size(); k++) {
+            if (sc[k].kind != VC_BITS && sc[k].kind != VC_LUT) continue;
+            const BufP &b = p->prelude_buf[(size_t)sc[k].prelude];
+            p->mcols[s].ptr[k] = b ? b->p : nullptr;
+            p->mdesc[s].dn[k] = p->prelude_n[(size_t)sc[k].prelude];
+        }
+    }
+}
+
 void run_fused_local(vdl_ctx *c, vdl_plan *p, int64_t *dev_words, bool single_rank) {
     const char *tune_a = getenv("VDL_SCAN_TUNE"), *tune_b = getenv("VDL_GROUP_TUNE");
     if (!p->bound || p->bound_version != c->catalog_version || tune_a || tune_b) {   // tuning sweeps re-bind every run
         bind_fused(c, p);
         p->bound_version = c->catalog_version;
     }
+    run_prelude(c, p);
     const int ei = (int)(p->run_seq++ % (unsigned)vdl_plan::kEvRing);
     if (p->profiling && !p->ev0[ei]) { HIP_CHECK(hipEventCreate(&p->ev0[ei])); HIP_CHECK(hipEventCreate(&p->ev1[ei])); }
     p->ev_pending[ei] = false;

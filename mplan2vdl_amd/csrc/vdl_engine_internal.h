@@ -200,6 +200,8 @@ struct vdl_plan {
     std::vector<MScanDesc> mdesc;
     std::vector<ScanLaunch> mcfg;
     std::vector<BufP> mparts, mdev;
+    std::vector<BufP> prelude_buf;           // fused join scans: dimension bitmaps / LIKE tables of the current run (FusedPlan::prelude)
+    std::vector<int64_t> prelude_n;
     std::vector<int64_t> gword_offset;
     int dominant = -1;
     std::string dominant_kernel;

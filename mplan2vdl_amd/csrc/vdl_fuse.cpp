@@ -20,8 +20,13 @@ namespace {
 struct Row;
 using RowP = std::shared_ptr<const Row>;
 struct Row {
-    enum K { COL, CONST, IOTA, BIN } k = CONST;
-    std::string col;
+    //  VIA  : l = an index expression over THIS table (a join-index column, possibly itself looked up), r = an
+    //         expression over the rows of table `dim`: the value of r at dim row l (Gather through a foreign key);
+    //         `dsel` = selection under which the dim-side vector holds values, `col` = a column of `dim` (its length)
+    //  LIKE : l = argument (heap offsets), col = the heap column, pat = the pattern
+    enum K { COL, CONST, IOTA, BIN, VIA, LIKE } k = CONST;
+    std::string col, dim, pat;
+    int dsel = 0;
     int64_t c0 = 0, c1 = 0;  // CONST: value; IOTA: from, step
     int bin = -1;
     RowP l, r;
@@ -30,11 +35,52 @@ struct Row {
 RowP mk_col(const std::string &c) { auto p = std::make_shared<Row>(); p->k = Row::COL; p->col = c; return p; }
 RowP mk_const(int64_t v) { auto p = std::make_shared<Row>(); p->k = Row::CONST; p->c0 = v; return p; }
 RowP mk_iota(int64_t f, int64_t s) { auto p = std::make_shared<Row>(); p->k = Row::IOTA; p->c0 = f; p->c1 = s; return p; }
+static bool is_const(const RowP &e, int64_t v) { return e->k == Row::CONST && e->c0 == v; }
 RowP mk_bin(int op, RowP l, RowP r) {
     if (l->k == Row::CONST && r->k == Row::CONST) return mk_const(apply_bin(op, l->c0, r->c0));
+    // value identities (validity lives in the selection, not in the expression): the emitter multiplies by the
+    // constants of CASE WHEN (Vlite.hs:240-245: cond * a + (1 - cond) * b with b = 0) and adds zeros
+    if (op == B_MUL) {
+        if (is_const(l, 0) || is_const(r, 0)) return mk_const(0);
+        if (is_const(l, 1)) return r;
+        if (is_const(r, 1)) return l;
+    }
+    if (op == B_ADD && is_const(l, 0)) return r;
+    if ((op == B_ADD || op == B_SUB) && is_const(r, 0)) return l;
     auto p = std::make_shared<Row>(); p->k = Row::BIN; p->bin = op; p->l = std::move(l); p->r = std::move(r); return p;
 }
+RowP mk_via(RowP idx, RowP inner, const std::string &dim, int dsel, const std::string &len_col) {
+    auto p = std::make_shared<Row>(); p->k = Row::VIA; p->l = std::move(idx); p->r = std::move(inner); p->dim = dim; p->dsel = dsel; p->col = len_col; return p;
+}
+RowP mk_like(RowP arg, const std::string &heap, const std::string &pat) {
+    auto p = std::make_shared<Row>(); p->k = Row::LIKE; p->l = std::move(arg); p->col = heap; p->pat = pat; return p;
+}
 
+// canonical text of an expression: structural identity (selections, virtual columns)
+void row_key(const RowP &e, std::string &o) {
+    switch (e->k) {
+    case Row::COL: o += e->col; break;
+    case Row::CONST: o += "#" + std::to_string(e->c0); break;
+    case Row::IOTA: o += "iota(" + std::to_string(e->c0) + "," + std::to_string(e->c1) + ")"; break;
+    case Row::BIN: o += kBinNames[e->bin]; o += "("; row_key(e->l, o); o += ","; row_key(e->r, o); o += ")"; break;
+    case Row::VIA: o += "via(" + e->dim + ":" + std::to_string(e->dsel) + ";"; row_key(e->l, o); o += ";"; row_key(e->r, o); o += ")"; break;
+    case Row::LIKE: o += "like(" + e->col + ";" + e->pat + ";"; row_key(e->l, o); o += ")"; break;
+    }
+}
+std::string row_key(const RowP &e) { std::string o; row_key(e, o); return o; }
+
+// Atoms = what a scan can hold in a register per row: a table column, a value looked up through an index atom (VIA of
+// a plain dim column), a LIKE over an atom of heap offsets, or the difference of two atoms (column against column).
+bool is_atom(const RowP &e) {
+    switch (e->k) {
+    case Row::COL: return true;
+    case Row::VIA: return is_atom(e->l) && (e->r->k == Row::COL || is_const(e->r, 1));
+    case Row::LIKE: return is_atom(e->l);
+    case Row::BIN: return e->bin == B_SUB && is_atom(e->l) && is_atom(e->r);
+    default: return false;
+    }
+}
+bool is_boolean_atom(const RowP &e) { return e->k == Row::LIKE || (e->k == Row::VIA && is_const(e->r, 1)); }
 
 // SUM of a constant k over the selected rows = k * (number of selected rows), and every scan already carries
 // that count as word 0 of its partials (count(*) lowers to FoldSum of ones, Vlite.hs:1044-1046): no aggregate
@@ -69,11 +115,12 @@ bool row_equal(const RowP &a, const RowP &b) {
     case Row::COL: return a->col == b->col;
     case Row::CONST: return a->c0 == b->c0;
     case Row::IOTA: return a->c0 == b->c0 && a->c1 == b->c1;
-    default: return a->bin == b->bin && row_equal(a->l, b->l) && row_equal(a->r, b->r);
+    case Row::BIN: return a->bin == b->bin && row_equal(a->l, b->l) && row_equal(a->r, b->r);
+    default: return row_key(a) == row_key(b);
     }
 }
 
-struct Selection { std::string table; RowP pred; };   // pred == nullptr: all rows
+struct Selection { std::string table; RowP pred; std::string key; };   // pred == nullptr: all rows; key: canonical conjunct set
 
 // ---- closed-interval sets over int64 ---------------------------------------------
 using Iv = std::pair<int64_t, int64_t>;
@@ -101,21 +148,33 @@ IvSet iv_and(const IvSet &a, const IvSet &b) {
 IvSet iv_or(IvSet a, const IvSet &b) { a.insert(a.end(), b.begin(), b.end()); return iv_norm(a); }
 
 // conjunction over columns of (column in IvSet); `never` = constant false
-struct Clause { std::map<std::string, IvSet> cols; bool never = false; };
+// (`cols` is keyed by the canonical text of an atom; `atoms` keeps the atoms themselves for the lowering)
+struct Clause { std::map<std::string, IvSet> cols; std::map<std::string, RowP> atoms; bool never = false; };
 
-bool leaf_cmp(const Row &p, std::string &col, IvSet &set) {
+static void clause_and(Clause &out, const RowP &atom, const IvSet &set) {
+    const std::string key = row_key(atom);
+    out.atoms[key] = atom;
+    auto it = out.cols.find(key);
+    if (it == out.cols.end()) out.cols[key] = iv_norm(set); else it->second = iv_and(it->second, set);
+}
+
+bool leaf_cmp(const Row &p, RowP &atom, IvSet &set) {
     if (p.k != Row::BIN) return false;
-    const Row &l = *p.l, &r = *p.r;
+    const RowP &l = p.l, &r = p.r;
     if (p.bin == B_GT) {
-        if (l.k == Row::COL && r.k == Row::CONST) {       // col > k
-            col = l.col; set = r.c0 == INT64_MAX ? IvSet{} : IvSet{{r.c0 + 1, INT64_MAX}}; return true;
+        if (is_atom(l) && r->k == Row::CONST) {           // col > k
+            atom = l; set = r->c0 == INT64_MAX ? IvSet{} : IvSet{{r->c0 + 1, INT64_MAX}}; return true;
         }
-        if (l.k == Row::CONST && r.k == Row::COL) {       // k > col
-            col = r.col; set = l.c0 == INT64_MIN ? IvSet{} : IvSet{{INT64_MIN, l.c0 - 1}}; return true;
+        if (l->k == Row::CONST && is_atom(r)) {           // k > col
+            atom = r; set = l->c0 == INT64_MIN ? IvSet{} : IvSet{{INT64_MIN, l->c0 - 1}}; return true;
+        }
+        if (is_atom(l) && is_atom(r)) {                   // column against column: a > b  <=>  a - b >= 1 (no wrap-around for the
+            atom = mk_bin(B_SUB, l, r); set = IvSet{{1, INT64_MAX}}; return true;      // date / key / quantity magnitudes compared this way)
         }
     } else if (p.bin == B_EQ) {
-        if (l.k == Row::COL && r.k == Row::CONST) { col = l.col; set = {{r.c0, r.c0}}; return true; }
-        if (l.k == Row::CONST && r.k == Row::COL) { col = r.col; set = {{l.c0, l.c0}}; return true; }
+        if (is_atom(l) && r->k == Row::CONST) { atom = l; set = {{r->c0, r->c0}}; return true; }
+        if (l->k == Row::CONST && is_atom(r)) { atom = r; set = {{l->c0, l->c0}}; return true; }
+        if (is_atom(l) && is_atom(r)) { atom = mk_bin(B_SUB, l, r); set = {{0, 0}}; return true; }
     }
     return false;
 }
@@ -124,19 +183,14 @@ bool leaf_cmp(const Row &p, std::string &col, IvSet &set) {
 bool to_clause(const RowP &p, Clause &out) {
     if (!p) return true;
     if (p->k == Row::CONST) { if (p->c0 == 0) out.never = true; return true; }
-    if (p->k == Row::COL) {
-        IvSet nz{{INT64_MIN, -1}, {1, INT64_MAX}};
-        auto it = out.cols.find(p->col);
-        if (it == out.cols.end()) out.cols[p->col] = nz; else it->second = iv_and(it->second, nz);
+    if (is_atom(p)) {                                      // a value read as a truth value (also: a lookup's validity, a LIKE)
+        if (is_boolean_atom(p)) clause_and(out, p, IvSet{{1, 1}});
+        else clause_and(out, p, IvSet{{INT64_MIN, -1}, {1, INT64_MAX}});
         return true;
     }
     if (p->k != Row::BIN) return false;
-    std::string col; IvSet set;
-    if (leaf_cmp(*p, col, set)) {
-        auto it = out.cols.find(col);
-        if (it == out.cols.end()) out.cols[col] = iv_norm(set); else it->second = iv_and(it->second, set);
-        return true;
-    }
+    RowP atom; IvSet set;
+    if (leaf_cmp(*p, atom, set)) { clause_and(out, atom, set); return true; }
     if (p->bin == B_LAND) return to_clause(p->l, out) && to_clause(p->r, out);
     if (p->bin == B_LOR) {
         // only a disjunction of conditions on ONE column stays a per-column filter
@@ -144,36 +198,39 @@ bool to_clause(const RowP &p, Clause &out) {
         Clause a, b;
         if (!to_clause(p->l, a) || !to_clause(p->r, b)) return false;
         if (a.never && b.never) { out.never = true; return true; }
-        if (a.never) { for (auto &kv : b.cols) { auto it = out.cols.find(kv.first); if (it == out.cols.end()) out.cols[kv.first] = kv.second; else it->second = iv_and(it->second, kv.second); } return true; }
-        if (b.never) { for (auto &kv : a.cols) { auto it = out.cols.find(kv.first); if (it == out.cols.end()) out.cols[kv.first] = kv.second; else it->second = iv_and(it->second, kv.second); } return true; }
+        if (a.never) { for (auto &kv : b.cols) clause_and(out, b.atoms.at(kv.first), kv.second); return true; }
+        if (b.never) { for (auto &kv : a.cols) clause_and(out, a.atoms.at(kv.first), kv.second); return true; }
         if (a.cols.empty() || b.cols.empty()) return true;   // one side is constant true
         if (a.cols.size() != 1 || b.cols.size() != 1 || a.cols.begin()->first != b.cols.begin()->first) return false;
-        IvSet u = iv_or(a.cols.begin()->second, b.cols.begin()->second);
-        const std::string &c = a.cols.begin()->first;
-        auto it = out.cols.find(c);
-        if (it == out.cols.end()) out.cols[c] = u; else it->second = iv_and(it->second, u);
+        clause_and(out, a.atoms.begin()->second, iv_or(a.cols.begin()->second, b.cols.begin()->second));
         return true;
     }
     return false;
 }
 
 // ---- aggregate data: product of affine single-column factors ----------------------
-struct Affine { bool has_col = false; std::string col; int64_t a = 0, s = 0; };   // a + s*col
+struct Affine { bool has_col = false; std::string col; int64_t a = 0, s = 0; RowP atom; };   // a + s*atom (col = the atom's canonical text)
 
 bool to_affine(const RowP &e, Affine &out) {
-    switch (e->k) {
-    case Row::CONST: out = Affine{false, "", e->c0, 0}; return true;
-    case Row::COL: out = Affine{true, e->col, 0, 1}; return true;
-    case Row::IOTA: return false;
-    case Row::BIN: break;
+    if (e->k == Row::CONST) { out = Affine{false, "", e->c0, 0, nullptr}; return true; }
+    if (e->k != Row::BIN || e->bin != B_SUB) {             // (a difference of atoms is affine algebra, not a SUB atom, when it can be)
+        if (is_atom(e)) { out = Affine{true, row_key(e), 0, 1, e}; return true; }
     }
+    if (e->k != Row::BIN) return false;
     Affine x, y;
+    // NOT of a 0 / 1 atom, as the emitter writes it: Equals(x, 0) (negcond = cond ==. zeros, Vlite.hs:240)
+    if (e->bin == B_EQ && ((is_const(e->r, 0) && is_boolean_atom(e->l)) || (is_const(e->l, 0) && is_boolean_atom(e->r)))) {
+        const RowP &b = is_const(e->r, 0) ? e->l : e->r;
+        out = Affine{true, row_key(b), 1, -1, b};
+        return true;
+    }
     if (e->bin == B_ADD || e->bin == B_SUB) {
         if (!to_affine(e->l, x) || !to_affine(e->r, y)) return false;
         if (x.has_col && y.has_col && x.col != y.col) return false;
         int64_t sign = e->bin == B_ADD ? 1 : -1;
         out.has_col = x.has_col || y.has_col;
         out.col = x.has_col ? x.col : y.col;
+        out.atom = x.has_col ? x.atom : y.atom;
         out.a = apply_bin(B_ADD, x.a, apply_bin(B_MUL, sign, y.a));
         out.s = apply_bin(B_ADD, x.s, apply_bin(B_MUL, sign, y.s));
         return true;
@@ -182,7 +239,7 @@ bool to_affine(const RowP &e, Affine &out) {
         if (!to_affine(e->l, x) || !to_affine(e->r, y)) return false;
         if (x.has_col && y.has_col) return false;          // quadratic: handled as two factors
         const Affine &k = x.has_col ? y : x, &v = x.has_col ? x : y;
-        out.has_col = v.has_col; out.col = v.col;
+        out.has_col = v.has_col; out.col = v.col; out.atom = v.atom;
         out.a = apply_bin(B_MUL, v.a, k.a);
         out.s = apply_bin(B_MUL, v.s, k.a);
         return true;
@@ -211,7 +268,38 @@ struct Builder {
 
     explicit Builder(const Program &p) : P(p), sym(p.nodes.size()) {}
 
-    int new_sel(const std::string &table, RowP pred) { sels.push_back({table, std::move(pred)}); return (int)sels.size(); }
+    std::map<std::string, int> sel_intern;                     // canonical conjunct set -> selection index
+    std::map<int, int> witness;                                // selection -> first statement whose vector is EPS exactly outside it
+    std::map<std::string, std::string> table_col;              // table -> one of its columns (for the table's length)
+
+    // A selection is a SET of conjuncts: two routes to the same filter (the emitter gathers every column of a join
+    // separately, each gather adding the same validity conditions) must be one selection, or their folds would land
+    // in different scans.  Conjunctions are flattened, constants dropped, duplicates merged, the rest ordered by text.
+    static void flatten(const RowP &p, std::map<std::string, RowP> &out, bool &never) {
+        if (!p) return;
+        if (p->k == Row::CONST) { if (p->c0 == 0) never = true; return; }
+        if (p->k == Row::BIN && p->bin == B_LAND) { flatten(p->l, out, never); flatten(p->r, out, never); return; }
+        out[row_key(p)] = p;
+    }
+    int new_sel(const std::string &table, RowP pred) {
+        std::map<std::string, RowP> conj;
+        bool never = false;
+        flatten(pred, conj, never);
+        if (never) { conj.clear(); conj["#0"] = mk_const(0); }
+        if (conj.empty()) return 0;                             // constant true: every row
+        std::string key = table + "|";
+        RowP all;
+        for (auto &kv : conj) {
+            key += kv.first + "&";
+            if (!all) all = kv.second;
+            else { auto n = std::make_shared<Row>(); n->k = Row::BIN; n->bin = B_LAND; n->l = all; n->r = kv.second; all = n; }
+        }
+        auto it = sel_intern.find(key);
+        if (it != sel_intern.end()) return it->second;
+        sels.push_back({table, all, key});
+        sel_intern[key] = (int)sels.size();
+        return (int)sels.size();
+    }
     RowP pred_of(int s) const { return s ? sels[(size_t)s - 1].pred : nullptr; }
 
     int combine_sel(const std::string &table, int a, int b) {
@@ -220,7 +308,8 @@ struct Builder {
         auto key = std::make_pair(std::min(a, b), std::max(a, b));
         auto it = conj_memo.find(key);
         if (it != conj_memo.end()) return it->second;
-        int s = new_sel(table, mk_bin(B_LAND, pred_of(a), pred_of(b)));
+        auto both = std::make_shared<Row>(); both->k = Row::BIN; both->bin = B_LAND; both->l = pred_of(a); both->r = pred_of(b);
+        int s = new_sel(table, both);
         conj_memo[key] = s;
         return s;
     }
@@ -240,6 +329,9 @@ struct Builder {
             size_t dot = n.column.find('.');
             out.table = dot == std::string::npos ? n.column : n.column.substr(0, dot);
             out.e = mk_col(n.column);
+            const bool heap = n.column.size() > 5 && n.column.compare(n.column.size() - 5, 5, ".heap") == 0;
+            if (heap) out.table = n.column;                     // a string heap is a vector of its own length, not a column of the table
+            else if (!table_col.count(out.table)) table_col[out.table] = n.column;
             return out;
         }
         case Op::Project: case Op::Shuffle: case Op::Materialize:
@@ -258,6 +350,14 @@ struct Builder {
         case Op::Scatter: {
             // sorted keys / sorted aggregate inputs, Vlite.hs:1058-1059
             const Sym &src = S(n.a), &fold = S(n.b), &pos = S(n.c);
+            if (src.kind == Sym::ROW && pos.kind == Sym::ROW && fold.kind == Sym::ROW && src.table == pos.table && fold.table == pos.table &&
+                pos.e->k == Row::IOTA && pos.e->c0 == 0 && pos.e->c1 == 1) {
+                // positions = the slots' own ids (the dimension side of a join scatters ones / row ids back by
+                // Gather(rowids, FoldSelect(..)), Vlite.hs:1268-1275): the source, restricted to those slots
+                out.kind = Sym::ROW; out.table = src.table; out.e = src.e;
+                out.sel = combine_sel(src.table, src.sel, pos.sel);
+                return out;
+            }
             if (src.kind != Sym::ROW || pos.kind != Sym::PART || fold.kind != Sym::ROW) return out;
             if (src.table != pos.table || fold.table != pos.table) return out;
             out.kind = Sym::SORTED; out.table = src.table; out.e = src.e; out.part = pos.part;
@@ -316,7 +416,20 @@ struct Builder {
         }
         case Op::Gather: {
             const Sym &src = S(n.a), &pos = S(n.b);
-            if (src.kind != Sym::ROW || pos.kind != Sym::ROW || src.table != pos.table) return out;
+            if (src.kind != Sym::ROW || pos.kind != Sym::ROW) return out;
+            if (src.table != pos.table) {
+                // a lookup into another table's vector through an index expression: the FK-join lowering seen from the fact
+                // side (Vlite.hs:1199-1282).  The result lives on pos' table; it is EPS where the index is EPS or out of
+                // range or the looked-up slot is EPS: that condition joins the selection.
+                auto len = table_col.find(src.table);
+                if (len == table_col.end() || !is_atom(pos.e)) return out;
+                out.kind = Sym::ROW; out.table = pos.table;
+                out.sel = combine_sel(pos.table, pos.sel, new_sel(pos.table, mk_via(pos.e, mk_const(1), src.table, src.sel, len->second)));
+                if (src.e->k == Row::IOTA && src.e->c0 == 0 && src.e->c1 == 1) out.e = pos.e;       // row ids looked up by row id
+                else if (src.e->k == Row::CONST) out.e = src.e;
+                else out.e = mk_via(pos.e, src.e, src.table, src.sel, len->second);
+                return out;
+            }
             if (pos.e->k != Row::IOTA || pos.e->c0 != 0 || pos.e->c1 != 1) return out;   // identity positions with holes
             out.kind = Sym::ROW; out.table = src.table; out.e = src.e;
             out.sel = combine_sel(src.table, src.sel, pos.sel);
@@ -366,6 +479,14 @@ struct Builder {
             auto s = std::make_shared<Scalar>(); s->k = Scalar::AGG; s->agg = idx; out.sc = s;
             return out;
         }
+        case Op::Like: {
+            // Like over a vector of heap offsets and the (unfiltered) heap itself, Vdl.hs:444-447
+            const Sym &d = S(n.a), &heap = S(n.b);
+            if (d.kind != Sym::ROW || heap.kind != Sym::ROW || heap.e->k != Row::COL || heap.sel != 0) return out;
+            out.kind = Sym::ROW; out.table = d.table; out.sel = d.sel;
+            out.e = mk_like(d.e, heap.e->col, n.pattern);
+            return out;
+        }
         default:
             return out;
         }
@@ -378,6 +499,7 @@ void show_row(const RowP &e, std::ostringstream &o) {
     case Row::CONST: o << e->c0; break;
     case Row::IOTA: o << "iota(" << e->c0 << "," << e->c1 << ")"; break;
     case Row::BIN: o << kBinNames[e->bin] << "("; show_row(e->l, o); o << ","; show_row(e->r, o); o << ")"; break;
+    default: o << row_key(e); break;
     }
 }
 
@@ -385,7 +507,7 @@ void show_row(const RowP &e, std::ostringstream &o) {
 // key expression -> two-accumulator program (vdl_fuse.h KeyStep); false if the tree is not
 // left/right-deep with single-column leaves
 bool single_column_chain(const RowP &e) {
-    if (e->k == Row::COL) return true;
+    if (is_atom(e) && e->k != Row::BIN) return true;
     if (e->k != Row::BIN) return false;
     if (e->r->k == Row::CONST) return single_column_chain(e->l);
     if (e->l->k == Row::CONST) return single_column_chain(e->r);
@@ -395,7 +517,7 @@ bool single_column_chain(const RowP &e) {
 template <typename ColIndex>
 bool emit_key(const RowP &e, int target, std::vector<KeyStep> &prog, ColIndex &col_index) {
     KeyStep st;
-    if (e->k == Row::COL) { st.kind = KeyStep::LOAD; st.target = target; st.col = col_index(e->col); prog.push_back(st); return true; }
+    if (is_atom(e) && e->k != Row::BIN) { st.kind = KeyStep::LOAD; st.target = target; st.col = col_index(e); if (st.col < 0) return false; prog.push_back(st); return true; }
     if (e->k != Row::BIN) return false;
     if (e->r->k == Row::CONST || e->l->k == Row::CONST) {
         const bool left = e->r->k != Row::CONST;
@@ -419,9 +541,70 @@ bool emit_key(const RowP &e, int target, std::vector<KeyStep> &prog, ColIndex &c
     return false;
 }
 
+// Atoms -> the scan's virtual columns (vdl_fuse.h VColKind); dependencies are appended before their dependents, so a
+// column only ever refers to earlier ones.  -1 with `why` set when an atom has no column form.
+struct VCols {
+    std::vector<ScanColumn> &cols;
+    FusedPlan &F;
+    const Builder &B;
+    std::string &why;
+    std::map<std::string, int> index;                   // canonical text -> column
+
+    int prelude_bitmap(int dsel) {
+        auto w = B.witness.find(dsel);
+        if (w == B.witness.end()) { why = "no statement holds the dimension-side selection " + std::to_string(dsel); return -1; }
+        for (size_t k = 0; k < F.prelude.size(); k++)
+            if (F.prelude[k].kind == PreludeItem::DIM_BITMAP && F.prelude[k].witness == w->second) return (int)k;
+        PreludeItem it; it.kind = PreludeItem::DIM_BITMAP; it.witness = w->second;
+        F.prelude.push_back(it);
+        return (int)F.prelude.size() - 1;
+    }
+    int prelude_lut(const std::string &heap, const std::string &pattern) {
+        for (size_t k = 0; k < F.prelude.size(); k++)
+            if (F.prelude[k].kind == PreludeItem::LIKE_LUT && F.prelude[k].heap == heap && F.prelude[k].pattern == pattern) return (int)k;
+        PreludeItem it; it.kind = PreludeItem::LIKE_LUT; it.heap = heap; it.pattern = pattern;
+        F.prelude.push_back(it);
+        return (int)F.prelude.size() - 1;
+    }
+    int operator()(const RowP &atom) {
+        const std::string key = row_key(atom);
+        auto it = index.find(key);
+        if (it != index.end()) return it->second;
+        ScanColumn c;
+        switch (atom->k) {
+        case Row::COL: c.kind = VC_DIRECT; c.name = atom->col; break;
+        case Row::VIA: {
+            c.idx = (*this)(atom->l);
+            if (c.idx < 0) return -1;
+            if (atom->r->k == Row::COL && atom->dsel == 0) { c.kind = VC_GATHER; c.name = atom->r->col; }
+            else if (is_const(atom->r, 1) && atom->dsel == 0) { c.kind = VC_INRANGE; c.name = atom->col; }
+            else if (is_const(atom->r, 1)) { c.kind = VC_BITS; c.prelude = prelude_bitmap(atom->dsel); if (c.prelude < 0) return -1; }
+            else if (atom->r->k == Row::COL) {          // a column of a FILTERED dimension vector: the filter is a condition of its own
+                c.kind = VC_GATHER; c.name = atom->r->col;    // (the selection carries via(..;#1) with the same dsel: see Gather in visit)
+            } else { why = "value looked up through a foreign key is not a plain column: " + key; return -1; }
+            break;
+        }
+        case Row::LIKE:
+            c.idx = (*this)(atom->l);
+            if (c.idx < 0) return -1;
+            c.kind = VC_LUT; c.prelude = prelude_lut(atom->col, atom->pat);
+            break;
+        case Row::BIN:                                  // SUB of two atoms
+            c.idx = (*this)(atom->l); c.idx2 = (*this)(atom->r);
+            if (c.idx < 0 || c.idx2 < 0) return -1;
+            c.kind = VC_SUB;
+            break;
+        default: why = "not a column form: " + key; return -1;
+        }
+        cols.push_back(c);
+        index[key] = (int)cols.size() - 1;
+        return (int)cols.size() - 1;
+    }
+};
+
 // predicate + aggregate inputs -> ScanColumn filters and ScanAgg products; shared by scans and group scans
 template <typename Plan>
-bool lower_common(const RowP &pred, const std::vector<RowP> &data, const std::vector<int> &kind, Plan &sp, std::string &why) {
+bool lower_common(const RowP &pred, const std::vector<RowP> &data, const std::vector<int> &kind, Plan &sp, VCols &col_index, std::string &why) {
     Clause cl;
     if (!to_clause(pred, cl)) {
         std::ostringstream o; o << "predicate is not a conjunction of per-column ranges: ";
@@ -430,23 +613,21 @@ bool lower_common(const RowP &pred, const std::vector<RowP> &data, const std::ve
         return false;
     }
     sp.never = cl.never;
-    auto col_index = [&](const std::string &name) -> int {
-        for (size_t i = 0; i < sp.cols.size(); i++) if (sp.cols[i].name == name) return (int)i;
-        sp.cols.push_back(ScanColumn{name, INT64_MIN, INT64_MAX});
-        return (int)sp.cols.size() - 1;
-    };
     for (auto &kv : cl.cols) {
-        if (kv.second.empty()) { sp.never = true; col_index(kv.first); continue; }
+        const int c = col_index(cl.atoms.at(kv.first));
+        if (c < 0) return false;
+        if (kv.second.empty()) { sp.never = true; continue; }
         if (kv.second.size() != 1) { why = "filter on " + kv.first + " is not a single range"; return false; }
-        int c = col_index(kv.first);
-        sp.cols[(size_t)c].lo = kv.second[0].first;
-        sp.cols[(size_t)c].hi = kv.second[0].second;
+        sp.cols[(size_t)c].lo = std::max(sp.cols[(size_t)c].lo, kv.second[0].first);
+        sp.cols[(size_t)c].hi = std::min(sp.cols[(size_t)c].hi, kv.second[0].second);
     }
     for (size_t j = 0; j < data.size(); j++) {
         ScanAgg ag;
         ag.kind = kind[j];
         if (ag.kind == AGG_FIRST) {
-            ag.fac.push_back(ScanFactor{col_index(data[j]->col), 0, 1});
+            const int c = col_index(data[j]);
+            if (c < 0 || sp.cols[(size_t)c].kind != VC_DIRECT) { if (why.empty()) why = "FoldChoose source is not a table column"; return false; }
+            ag.fac.push_back(ScanFactor{c, 0, 1});
             sp.aggs.push_back(ag);
             continue;
         }
@@ -461,7 +642,8 @@ bool lower_common(const RowP &pred, const std::vector<RowP> &data, const std::ve
         bool repeated = false;
         for (auto &f : fac) {
             if (!f.has_col || f.s == 0) { mult = apply_bin(B_MUL, mult, f.a); continue; }
-            const int ci = col_index(f.col);
+            const int ci = col_index(f.atom);
+            if (ci < 0) return false;
             for (auto &g : ag.fac) repeated |= g.col == ci;
             ag.fac.push_back(ScanFactor{ci, f.a, f.s});
         }
@@ -487,7 +669,11 @@ int64_t eval_scalar(const Scalar &s, const int64_t *agg) {
 FusedPlan fuse_program(const Program &P) {
     FusedPlan F;
     Builder B(P);
-    for (int id : P.order) B.sym[(size_t)id] = B.visit(P.at(id));
+    for (int id : P.order) {
+        B.sym[(size_t)id] = B.visit(P.at(id));
+        const Sym &s = B.sym[(size_t)id];
+        if (s.kind == Sym::ROW && s.sel && !B.witness.count(s.sel)) B.witness[s.sel] = id;
+    }
     F.filters = B.filters;
     if (P.outputs.empty()) { F.why_not = "program has no MaterializeCompact output"; return F; }
     for (int id : P.outputs) {
@@ -501,8 +687,11 @@ FusedPlan fuse_program(const Program &P) {
     for (auto &ps : B.scans) {
         ScanPlan sp;
         sp.table = ps.table;
-        if (!lower_common(B.pred_of(ps.sel), ps.data, ps.kind, sp, F.why_not)) return F;
-        if (sp.cols.empty()) { F.why_not = "scan touches no column (row count unknown)"; return F; }
+        VCols vc{sp.cols, F, B, F.why_not, {}};
+        if (!lower_common(B.pred_of(ps.sel), ps.data, ps.kind, sp, vc, F.why_not)) return F;
+        bool direct = false;
+        for (const ScanColumn &c : sp.cols) direct |= c.kind == VC_DIRECT && c.name.compare(0, sp.table.size() + 1, sp.table + ".") == 0;
+        if (!direct) { F.why_not = "scan touches no column of its table (row count unknown)"; return F; }
         if ((int)sp.cols.size() > kMaxScanCols) { F.why_not = "scan touches more than 8 columns"; return F; }
         if ((int)sp.aggs.size() > kMaxScanAggs) { F.why_not = "scan has more than 8 aggregates"; return F; }
         F.scans.push_back(sp);
@@ -510,17 +699,20 @@ FusedPlan fuse_program(const Program &P) {
     for (auto &pg : B.groups) {
         GroupScanPlan gp;
         gp.table = pg.table; gp.pmin = pg.pmin; gp.pcount = pg.pcount;
-        if (!lower_common(B.pred_of(pg.sel), pg.data, pg.kind, gp, F.why_not)) return F;
-        auto col_index = [&](const std::string &name) -> int {
-            for (size_t i = 0; i < gp.cols.size(); i++) if (gp.cols[i].name == name) return (int)i;
-            gp.cols.push_back(ScanColumn{name, INT64_MIN, INT64_MAX});
-            return (int)gp.cols.size() - 1;
-        };
+        VCols col_index{gp.cols, F, B, F.why_not, {}};
+        if (!lower_common(B.pred_of(pg.sel), pg.data, pg.kind, gp, col_index, F.why_not)) return F;
         if (!emit_key(pg.key, 0, gp.key, col_index)) {
-            std::ostringstream o; o << "group key is not a chain of single-column terms: ";
-            show_row(pg.key, o);
-            F.why_not = o.str();
+            if (F.why_not.empty()) {
+                std::ostringstream o; o << "group key is not a chain of single-column terms: ";
+                show_row(pg.key, o);
+                F.why_not = o.str();
+            }
             return F;
+        }
+        {
+            bool direct = false;
+            for (const ScanColumn &c : gp.cols) direct |= c.kind == VC_DIRECT && c.name.compare(0, gp.table.size() + 1, gp.table + ".") == 0;
+            if (!direct) { F.why_not = "grouped scan touches no column of its table (row count unknown)"; return F; }
         }
         if ((int)gp.key.size() > kMaxKeySteps) { F.why_not = "group key program too long"; return F; }
         if ((int)gp.cols.size() > kMaxScanCols) { F.why_not = "grouped scan touches more than 8 columns"; return F; }
@@ -535,6 +727,7 @@ FusedPlan fuse_program(const Program &P) {
         if (s.kind == Sym::FOLD) fo.scan = s.scan; else fo.gscan = s.scan;
         F.outputs.push_back(fo);
     }
+    F.why_not.clear();
     F.ok = true;
     return F;
 }
@@ -597,23 +790,37 @@ int composite_key(const KeyStep *steps, int n, KeyComp *comps, int *masked_out, 
     return f[0].n;
 }
 
+static void show_col(const ScanColumn &c, size_t k, std::ostringstream &o) {
+    o << "  col " << k << " ";
+    switch (c.kind) {
+    case VC_DIRECT: o << c.name; break;
+    case VC_GATHER: o << c.name << "[col" << c.idx << "]"; break;
+    case VC_BITS: o << "prelude" << c.prelude << ".bit[col" << c.idx << "]"; break;
+    case VC_LUT: o << "prelude" << c.prelude << ".lut[col" << c.idx << "]"; break;
+    case VC_INRANGE: o << "inrange(col" << c.idx << ", rows of " << c.name << ")"; break;
+    default: o << "col" << c.idx << " - col" << c.idx2; break;
+    }
+    if (c.lo != INT64_MIN || c.hi != INT64_MAX) {
+        o << " in [";
+        if (c.lo == INT64_MIN) o << "-inf"; else o << c.lo;
+        o << ",";
+        if (c.hi == INT64_MAX) o << "+inf"; else o << c.hi;
+        o << "]";
+    }
+    o << "\n";
+}
+
 std::string describe_fused(const FusedPlan &F) {
     std::ostringstream o;
     if (!F.ok) { o << "not fused: " << F.why_not << "\n"; return o.str(); }
+    for (size_t k = 0; k < F.prelude.size(); k++) {
+        if (F.prelude[k].kind == PreludeItem::DIM_BITMAP) o << "prelude " << k << ": bitmap of the dimension-side selection held by statement " << F.prelude[k].witness << " (per-operator executor)\n";
+        else o << "prelude " << k << ": LIKE '" << F.prelude[k].pattern << "' over every offset of " << F.prelude[k].heap << "\n";
+    }
     for (size_t i = 0; i < F.scans.size(); i++) {
         const ScanPlan &sp = F.scans[i];
         o << "scan " << i << " table=" << sp.table << (sp.never ? " [never]" : "") << "\n";
-        for (size_t c = 0; c < sp.cols.size(); c++) {
-            o << "  col " << c << " " << sp.cols[c].name;
-            if (sp.cols[c].lo != INT64_MIN || sp.cols[c].hi != INT64_MAX) {
-                o << " in [";
-                if (sp.cols[c].lo == INT64_MIN) o << "-inf"; else o << sp.cols[c].lo;
-                o << ",";
-                if (sp.cols[c].hi == INT64_MAX) o << "+inf"; else o << sp.cols[c].hi;
-                o << "]";
-            }
-            o << "\n";
-        }
+        for (size_t c = 0; c < sp.cols.size(); c++) show_col(sp.cols[c], c, o);
         for (size_t a = 0; a < sp.aggs.size(); a++) {
             const ScanAgg &ag = sp.aggs[a];
             o << "  agg" << a << " " << (ag.kind == AGG_SUM ? "sum" : ag.kind == AGG_MIN ? "min" : "max") << " ";
@@ -629,17 +836,7 @@ std::string describe_fused(const FusedPlan &F) {
         const GroupScanPlan &gp = F.gscans[i];
         o << "group-scan " << i << " table=" << gp.table << " buckets=[" << gp.pmin << "," << gp.pmin + gp.pcount - 1 << "]"
           << (gp.never ? " [never]" : "") << "\n";
-        for (size_t c = 0; c < gp.cols.size(); c++) {
-            o << "  col " << c << " " << gp.cols[c].name;
-            if (gp.cols[c].lo != INT64_MIN || gp.cols[c].hi != INT64_MAX) {
-                o << " in [";
-                if (gp.cols[c].lo == INT64_MIN) o << "-inf"; else o << gp.cols[c].lo;
-                o << ",";
-                if (gp.cols[c].hi == INT64_MAX) o << "+inf"; else o << gp.cols[c].hi;
-                o << "]";
-            }
-            o << "\n";
-        }
+        for (size_t c = 0; c < gp.cols.size(); c++) show_col(gp.cols[c], c, o);
         o << "  key:";
         for (const KeyStep &k : gp.key) {
             const char *t = k.target ? "tmp" : "acc";

@@ -20,10 +20,33 @@ constexpr int kMaxFactors = 4;
 
 enum AggKind : int { AGG_SUM = 0, AGG_MIN = 1, AGG_MAX = 2, AGG_FIRST = 3 };   // FIRST: value of a column at the group's first row
 
+// A scan reads table columns row by row (VC_DIRECT) and may derive further per-row values from them -- the FK-join
+// lowering of the compiler (/root/reference/src/Vlite.hs:1199-1282) seen from the fact table: the dimension side of a
+// join is a lookup through the join-index column, so a fact-table scan whose extra "columns" are dim_col[fk[row]] or
+// dim_bitmap[fk[row]] evaluates the join, its filters and its aggregates in one pass.
+enum VColKind : int {
+    VC_DIRECT = 0,   // name = catalog column of the scanned table
+    VC_GATHER = 1,   // value = column `name` (of another table) at row v[idx]; v[idx] outside that column -> the row is EPS
+    VC_BITS = 2,     // value = bit v[idx] of a dimension-side selection bitmap (FusedPlan::prelude[prelude]): 0 / 1; outside -> EPS
+    VC_LUT = 3,      // value = prelude[prelude] (a lookup table) at v[idx]; outside the table -> 0 (Like over heap offsets)
+    VC_INRANGE = 4,  // value = 1; the row is EPS unless 0 <= v[idx] < rows of column `name` (a Gather out of an unfiltered table)
+    VC_SUB = 5       // value = v[idx] - v[idx2] (column against column comparisons become a range filter on the difference)
+};
 struct ScanColumn {
-    std::string name;          // catalog key path
+    std::string name;          // catalog key path (VC_DIRECT / VC_GATHER / VC_INRANGE)
     int64_t lo = INT64_MIN;    // row passes iff lo <= value <= hi for every column
     int64_t hi = INT64_MAX;
+    int kind = VC_DIRECT;
+    int idx = -1, idx2 = -1;   // source virtual column(s): always earlier in the list
+    int prelude = -1;
+};
+// Work on the dimension side that has to happen before a scan with derived columns: the bitmap of a dimension-side
+// selection (the validity of a `witness` statement, run by the per-operator executor: dimension filters, joins of
+// dimensions with further dimensions), or the 0 / 1 table of a LIKE pattern over every offset of a string heap.
+struct PreludeItem {
+    enum Kind : int { DIM_BITMAP = 0, LIKE_LUT = 1 } kind = DIM_BITMAP;
+    int witness = 0;           // DIM_BITMAP: statement whose vector is EPS exactly where the dimension selection rejects the row
+    std::string heap, pattern; // LIKE_LUT
 };
 
 struct ScanFactor {            // (a + s * column[col])
@@ -103,6 +126,7 @@ struct FilterColumn { std::string name; int n = 0; int64_t lo[kMaxFilterIvs] = {
 struct FilterSpec { std::string table; std::vector<FilterColumn> cols; bool never = false; };
 
 struct FusedPlan {
+    std::vector<PreludeItem> prelude;    // dimension-side work the scans' derived columns need (empty for single-table plans)
     std::map<int, FilterSpec> filters;   // FoldSelect statement id -> its column filter (filled whether or not the plan fuses)
     bool ok = false;
     std::string why_not;         // reason the program did not fuse (reported by describe)

@@ -53,10 +53,11 @@ constexpr int kMaxGroupAggs = 16;
 struct MScanCols {                           // by-value kernel argument: keeps column loads in the global address space
     int ncol = 0;
     int64_t n = 0, row0 = 0;
-    const void *ptr[kMaxScanCols] = {};
+    const void *ptr[kMaxScanCols] = {};      // VC_DIRECT: the column; derived columns: the table looked up (column / bitmap words / LUT)
     int width[kMaxScanCols] = {};
     int filtered[kMaxScanCols] = {};
     int64_t lo[kMaxScanCols] = {}, hi[kMaxScanCols] = {};
+    int kind[kMaxScanCols] = {};             // VColKind (vdl_fuse.h); 0 = read from the scanned table
 };
 struct MAggDesc {
     int kind = 0;                            // AGG_SUM / AGG_MIN / AGG_MAX / AGG_FIRST
@@ -70,6 +71,8 @@ struct MScanDesc {                           // lives in device memory, read wit
     int64_t pmin = 0, pcount = 0;            // grouped: bucket = key - pmin in [0, pcount)
     int64_t *block_partials = nullptr;       // global: [grid][1 + nagg]; grouped: [grid][pcount * (1 + nagg) + 1]
     int64_t flo[kMaxScanCols] = {}, fhi[kMaxScanCols] = {};      // range filter per column (read only for filtered columns)
+    int dkind[kMaxScanCols] = {}, dsrc[kMaxScanCols] = {}, dsrc2[kMaxScanCols] = {};   // derived columns: VColKind, source column(s)
+    int64_t dn[kMaxScanCols] = {};           // derived columns: entries of the table looked up
     int ncomp = 0, key_masked = 0;           // ncomp > 0: the key program is this canonical form
     int64_t key_mask = 0;
     KeyComp comp[kMaxKeyComps];

@@ -132,6 +132,7 @@ struct MsArgs {
     int ncol = 0;
     uint32_t widths = 0;                     // 4 bits per column: bytes
     uint32_t filtered = 0;                   // bit c: column c has a range filter (MScanDesc::flo / fhi)
+    uint32_t derived = 0;                    // bit c: column c is derived from earlier columns (MScanDesc::dkind ...), ptr[c] = its table
     int64_t n = 0, row0 = 0;
     const void *ptr[kMaxScanCols] = {};
     __host__ __device__ int width(int c) const { return (int)((widths >> (4 * c)) & 15u); }
@@ -143,6 +144,7 @@ static MsArgs ms_args(const MScanCols &cols) {
         a.ptr[c] = cols.ptr[c];
         a.widths |= (uint32_t)cols.width[c] << (4 * c);
         if (cols.filtered[c]) a.filtered |= 1u << c;
+        if (cols.kind[c] != VC_DIRECT) a.derived |= 1u << c;
     }
     return a;
 }
@@ -152,7 +154,7 @@ __device__ __forceinline__ void load_tile(const MsArgs &C, int64_t base, int64_t
     constexpr int BS = kMsBlock;
 #pragma unroll
     for (int c = 0; c < NC; c++) {
-        if (c < C.ncol) {                                  // wave-uniform
+        if (c < C.ncol && !((C.derived >> c) & 1u)) {      // wave-uniform
             const char *p = (const char *)C.ptr[c];
             const int w = C.width(c);
             if (!VEC) {
@@ -188,6 +190,72 @@ __device__ __forceinline__ void eval_pass(const MsArgs &C, const MScanDesc &D, c
             const int64_t lo = D.flo[c], hi = D.fhi[c];
 #pragma unroll
             for (int r = 0; r < RW; r++) pass[r] = pass[r] & (v[c][r] >= lo) & (v[c][r] <= hi);
+        }
+    }
+}
+
+// Derived columns (vdl_fuse.h VColKind): values looked up through an earlier column -- the dimension side of an FK join
+// seen from the fact table (Vlite.hs:1199-1282).  `alive` starts as "the direct range filters pass", so rows a cheap
+// filter already rejects do no lookups (Q14 keeps 1 row in 84); a lookup out of range makes the row EPS (alive = false).
+template <int NC, int RW>
+__device__ __forceinline__ void derive(const MsArgs &C, const MScanDesc &D, int64_t (&v)[NC][RW], bool (&alive)[RW]) {
+#pragma unroll
+    for (int r = 0; r < RW; r++) alive[r] = true;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        if (((C.filtered >> c) & 1u) && !((C.derived >> c) & 1u)) {
+            const int64_t lo = D.flo[c], hi = D.fhi[c];
+#pragma unroll
+            for (int r = 0; r < RW; r++) alive[r] = alive[r] & (v[c][r] >= lo) & (v[c][r] <= hi);
+        }
+    }
+#pragma unroll
+    for (int c = 1; c < NC; c++) {
+        if ((C.derived >> c) & 1u) {                       // wave-uniform
+            const int kind = D.dkind[c], a = D.dsrc[c], b = D.dsrc2[c];
+            int64_t x[RW], y[RW];
+#pragma unroll
+            for (int r = 0; r < RW; r++) { x[r] = 0; y[r] = 0; }
+#pragma unroll
+            for (int k = 0; k < NC; k++) {                 // register files are not indexable: select the source column by comparison
+                if (k < c && k == a) {
+#pragma unroll
+                    for (int r = 0; r < RW; r++) x[r] = v[k][r];
+                }
+                if (k < c && k == b) {
+#pragma unroll
+                    for (int r = 0; r < RW; r++) y[r] = v[k][r];
+                }
+            }
+            if (kind == VC_SUB) {
+#pragma unroll
+                for (int r = 0; r < RW; r++) v[c][r] = (int64_t)((uint64_t)x[r] - (uint64_t)y[r]);
+                continue;
+            }
+            const int64_t n = D.dn[c];
+            const char *t = (const char *)C.ptr[c];
+            const int w = C.width(c);
+            bool in[RW];
+#pragma unroll
+            for (int r = 0; r < RW; r++) in[r] = alive[r] & (x[r] >= 0) & (x[r] < n);
+            if (kind == VC_GATHER) {
+#pragma unroll
+                for (int r = 0; r < RW; r++) { v[c][r] = 0; if (in[r]) v[c][r] = load_scalar(t, w, x[r]); alive[r] = in[r]; }
+            } else if (kind == VC_BITS) {
+#pragma unroll
+                for (int r = 0; r < RW; r++) {
+                    uint64_t word = ~0ull;                  // no bitmap: every dimension row is selected
+                    if (in[r] && t) word = ((const uint64_t *)t)[x[r] >> 6];
+                    v[c][r] = in[r] ? (int64_t)((word >> (x[r] & 63)) & 1ull) : 0;
+                    alive[r] = in[r];
+                }
+            } else if (kind == VC_LUT) {                    // outside the table: 0, not EPS (Like over an offset outside the heap)
+#pragma unroll
+                for (int r = 0; r < RW; r++) { v[c][r] = 0; if (in[r]) v[c][r] = ((const int64_t *)t)[x[r]]; }
+            } else {                                        // VC_INRANGE
+#pragma unroll
+                for (int r = 0; r < RW; r++) { v[c][r] = 1; alive[r] = in[r]; }
+            }
         }
     }
 }
@@ -241,7 +309,7 @@ __device__ __forceinline__ void eval_term(const MAggDesc &d, const int64_t (&v)[
 }
 
 // LDS use: global form (1 + nagg) * 256 lane slots; grouped form replicas * (pcount * (1 + nagg) | 1) + 256 + nagg + 1 trash words
-template <int NC, int U, bool VEC, bool NT, bool GROUPED>
+template <int NC, int U, bool VEC, bool NT, bool GROUPED, bool DER>
 __global__ __launch_bounds__(kMsBlock) void k_mscan(const MsArgs C, const MScanDesc *__restrict__ Dp) {
     extern __shared__ int64_t lds[];
     const MScanDesc &D = *Dp;
@@ -274,10 +342,18 @@ __global__ __launch_bounds__(kMsBlock) void k_mscan(const MsArgs C, const MScanD
     }
     __syncthreads();
 
-    auto process = [&](auto rows_tag, const int64_t (&v)[NC][decltype(rows_tag)::value], const int64_t (&rowid)[decltype(rows_tag)::value]) {
+    auto process = [&](auto rows_tag, int64_t (&v)[NC][decltype(rows_tag)::value], const int64_t (&rowid)[decltype(rows_tag)::value]) {
         constexpr int RW = decltype(rows_tag)::value;
         bool pass[RW];
-        eval_pass<NC, RW>(C, D, v, pass);
+        if (DER) {
+            bool alive[RW];
+            derive<NC, RW>(C, D, v, alive);
+            eval_pass<NC, RW>(C, D, v, pass);
+#pragma unroll
+            for (int r = 0; r < RW; r++) pass[r] = pass[r] & alive[r];
+        } else {
+            eval_pass<NC, RW>(C, D, v, pass);
+        }
         int off[RW];
         if (GROUPED) {
             // group key: two-accumulator program (vdl_fuse.h KeyStep)
@@ -409,7 +485,7 @@ __global__ __launch_bounds__(kMsBlock) void k_mscan(const MsArgs C, const MScanD
             rid[0] = C.row0 + i;
 #pragma unroll
             for (int c = 0; c < NC; c++)
-                if (c < C.ncol) v1[c][0] = load_scalar(C.ptr[c], C.width(c), i);
+                if (c < C.ncol && !((C.derived >> c) & 1u)) v1[c][0] = load_scalar(C.ptr[c], C.width(c), i);
             process(std::integral_constant<int, 1>{}, v1, rid);
         }
     }
@@ -487,16 +563,21 @@ __global__ void k_mscan_first(const MsArgs C, const MScanDesc *__restrict__ Dp, 
 }
 
 typedef void (*mscan_fn)(const MsArgs, const MScanDesc *);
-struct MsVariant { int nc, u; bool vec, grouped; mscan_fn fn; const char *name; };
-#define VDL_MS(NC, U, VEC, NT, GR) {NC, U, VEC, GR, k_mscan<NC, U, VEC, NT, GR>, "k_mscan<" #NC "," #U "," #VEC "," #NT "," #GR ">"}
+struct MsVariant { int nc, u; bool vec, grouped, der; mscan_fn fn; const char *name; };
+#define VDL_MS(NC, U, VEC, NT, GR) {NC, U, VEC, GR, false, k_mscan<NC, U, VEC, NT, GR, false>, "k_mscan<" #NC "," #U "," #VEC "," #NT "," #GR ">"}
+#define VDL_MSJ(NC, U, VEC, NT, GR) {NC, U, VEC, GR, true, k_mscan<NC, U, VEC, NT, GR, true>, "k_mscan_join<" #NC "," #U "," #VEC "," #NT "," #GR ">"}
 const MsVariant kMsVariants[] = {
     VDL_MS(4, 6, true, true, false),  VDL_MS(8, 4, true, true, false),
     VDL_MS(4, 4, false, false, false), VDL_MS(8, 4, false, false, false),
     VDL_MS(4, 6, true, true, true),   VDL_MS(8, 2, true, true, true),   VDL_MS(8, 4, true, true, true),
     VDL_MS(4, 4, false, false, true),  VDL_MS(8, 4, false, false, true),
     VDL_MS(8, 1, true, true, true),   VDL_MS(8, 3, true, true, true),      // VDL_GROUP_U sweeps (tools/q1_ab.sh)
+    // scans with derived columns (FK lookups: fused join scans)
+    VDL_MSJ(8, 4, true, true, false), VDL_MSJ(8, 4, false, false, false),
+    VDL_MSJ(8, 2, true, true, true),  VDL_MSJ(8, 4, false, false, true),
 };
 #undef VDL_MS
+#undef VDL_MSJ
 constexpr int kNumMsVariants = sizeof(kMsVariants) / sizeof(kMsVariants[0]);
 
 size_t ms_lds_bytes(const MScanDesc &d, bool grouped) {
@@ -507,16 +588,18 @@ size_t ms_lds_bytes(const MScanDesc &d, bool grouped) {
 }  // namespace
 
 ScanLaunch mscan_launch_config(const MScanCols &cols, MScanDesc &d, bool grouped, int num_cus) {
-    bool vec = true;
-    for (int c = 0; c < cols.ncol; c++)
+    bool vec = true, der = false;
+    for (int c = 0; c < cols.ncol; c++) {
+        if (cols.kind[c] != VC_DIRECT) { der = true; continue; }
         if (((uintptr_t)cols.ptr[c]) % (uintptr_t)(2 * cols.width[c]) != 0) vec = false;
+    }
     ScanLaunch cfg;
     cfg.variant = -1;
     const char *want_u = getenv("VDL_GROUP_U");
     for (int pass = 0; pass < 2 && cfg.variant < 0; pass++)
         for (int i = 0; i < kNumMsVariants; i++) {
             const MsVariant &v = kMsVariants[i];
-            if (v.vec != vec || v.grouped != grouped || cols.ncol > v.nc) continue;
+            if (v.vec != vec || v.grouped != grouped || v.der != der || cols.ncol > v.nc) continue;
             if (pass == 0 && want_u && grouped && v.u != atoi(want_u)) continue;
             cfg.variant = i;
             break;
