@@ -400,6 +400,7 @@ struct Builder {
                     fs.table = d.table; fs.never = cl.never;
                     bool fits = true;
                     for (auto &kv : cl.cols) {
+                        if (cl.atoms.at(kv.first)->k != Row::COL) { fits = false; break; }     // k_filter_columns reads table columns only
                         FilterColumn fc;
                         fc.name = kv.first;
                         if ((int)kv.second.size() > kMaxFilterIvs) { fits = false; break; }

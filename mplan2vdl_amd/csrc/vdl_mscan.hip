@@ -200,8 +200,6 @@ __device__ __forceinline__ void eval_pass(const MsArgs &C, const MScanDesc &D, c
 template <int NC, int RW>
 __device__ __forceinline__ void derive(const MsArgs &C, const MScanDesc &D, int64_t (&v)[NC][RW], bool (&alive)[RW]) {
 #pragma unroll
-    for (int r = 0; r < RW; r++) alive[r] = true;
-#pragma unroll
     for (int c = 0; c < NC; c++) {
         if (((C.filtered >> c) & 1u) && !((C.derived >> c) & 1u)) {
             const int64_t lo = D.flo[c], hi = D.fhi[c];
@@ -238,20 +236,26 @@ __device__ __forceinline__ void derive(const MsArgs &C, const MScanDesc &D, int6
             bool in[RW];
 #pragma unroll
             for (int r = 0; r < RW; r++) in[r] = alive[r] & (x[r] >= 0) & (x[r] < n);
+            // lookups are issued for every lane (rows that are out already read entry 0: one cached line), so the loads of
+            // a tile go out together instead of one exec-masked region per row
             if (kind == VC_GATHER) {
+                if (n > 0) {
 #pragma unroll
-                for (int r = 0; r < RW; r++) { v[c][r] = 0; if (in[r]) v[c][r] = load_scalar(t, w, x[r]); alive[r] = in[r]; }
+                    for (int r = 0; r < RW; r++) { const int64_t q = load_scalar(t, w, in[r] ? x[r] : 0); v[c][r] = in[r] ? q : 0; }
+                }
+#pragma unroll
+                for (int r = 0; r < RW; r++) { if (n <= 0) v[c][r] = 0; alive[r] = in[r]; }
             } else if (kind == VC_BITS) {
 #pragma unroll
                 for (int r = 0; r < RW; r++) {
                     uint64_t word = ~0ull;                  // no bitmap: every dimension row is selected
-                    if (in[r] && t) word = ((const uint64_t *)t)[x[r] >> 6];
+                    if (t && n > 0) word = ((const uint64_t *)t)[(in[r] ? x[r] : 0) >> 6];
                     v[c][r] = in[r] ? (int64_t)((word >> (x[r] & 63)) & 1ull) : 0;
                     alive[r] = in[r];
                 }
             } else if (kind == VC_LUT) {                    // outside the table: 0, not EPS (Like over an offset outside the heap)
 #pragma unroll
-                for (int r = 0; r < RW; r++) { v[c][r] = 0; if (in[r]) v[c][r] = ((const int64_t *)t)[x[r]]; }
+                for (int r = 0; r < RW; r++) { v[c][r] = 0; if (n > 0) { const int64_t q = ((const int64_t *)t)[in[r] ? x[r] : 0]; v[c][r] = in[r] ? q : 0; } }
             } else {                                        // VC_INRANGE
 #pragma unroll
                 for (int r = 0; r < RW; r++) { v[c][r] = 1; alive[r] = in[r]; }
@@ -342,11 +346,15 @@ __global__ __launch_bounds__(kMsBlock) void k_mscan(const MsArgs C, const MScanD
     }
     __syncthreads();
 
-    auto process = [&](auto rows_tag, int64_t (&v)[NC][decltype(rows_tag)::value], const int64_t (&rowid)[decltype(rows_tag)::value]) {
+    auto process = [&](auto rows_tag, int64_t (&v)[NC][decltype(rows_tag)::value], const int64_t (&rowid)[decltype(rows_tag)::value], int64_t rows_left) {
         constexpr int RW = decltype(rows_tag)::value;
         bool pass[RW];
         if (DER) {
+            // (scans with derived columns run their last, partial tile through this same code: rows past the end are
+            // switched off here -- `rows_left` counts from the lane's first row)
             bool alive[RW];
+#pragma unroll
+            for (int r = 0; r < RW; r++) alive[r] = (int64_t)((r >> 1) * (BS * 2) + (r & 1)) < rows_left;
             derive<NC, RW>(C, D, v, alive);
             eval_pass<NC, RW>(C, D, v, pass);
 #pragma unroll
@@ -474,19 +482,38 @@ __global__ __launch_bounds__(kMsBlock) void k_mscan(const MsArgs C, const MScanD
 #pragma unroll
         for (int u = 0; u < U; u++) { rowid[2 * u] = C.row0 + base + (int64_t)u * (BS * 2); rowid[2 * u + 1] = rowid[2 * u] + 1; }
         load_tile<NC, U, VEC, NT>(C, base, v);
-        process(std::integral_constant<int, ROWS>{}, v, rowid);
+        process(std::integral_constant<int, ROWS>{}, v, rowid, (int64_t)1 << 40);
 #ifdef VDL_MS_REPEAT          // timing experiment only (results are wrong): how much of the kernel is the per-tile work?
-        for (int rep = 1; rep < VDL_MS_REPEAT; rep++) process(std::integral_constant<int, ROWS>{}, v, rowid);
+        for (int rep = 1; rep < VDL_MS_REPEAT; rep++) process(std::integral_constant<int, ROWS>{}, v, rowid, (int64_t)1 << 40);
 #endif
     }
-    if (blockIdx.x == gridDim.x - 1) {                     // tail rows, one per lane
-        for (int64_t i = ntiles * TILE + tid; i < C.n; i += BS) {
-            int64_t v1[NC][1], rid[1];
-            rid[0] = C.row0 + i;
+    if (blockIdx.x == gridDim.x - 1 && ntiles * TILE < C.n) {
+        if (DER) {
+            // the partial tile, in the tile's own row layout with clamped scalar loads
+            int64_t v[NC][ROWS], rowid[ROWS];
+            const int64_t base = ntiles * TILE + (int64_t)tid * 2;
 #pragma unroll
-            for (int c = 0; c < NC; c++)
-                if (c < C.ncol && !((C.derived >> c) & 1u)) v1[c][0] = load_scalar(C.ptr[c], C.width(c), i);
-            process(std::integral_constant<int, 1>{}, v1, rid);
+            for (int r = 0; r < ROWS; r++) rowid[r] = C.row0 + base + (int64_t)(r >> 1) * (BS * 2) + (r & 1);
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                if (c < C.ncol && !((C.derived >> c) & 1u)) {
+#pragma unroll
+                    for (int r = 0; r < ROWS; r++) {
+                        const int64_t i = base + (int64_t)(r >> 1) * (BS * 2) + (r & 1);
+                        v[c][r] = load_scalar(C.ptr[c], C.width(c), i < C.n ? i : C.n - 1);
+                    }
+                }
+            }
+            process(std::integral_constant<int, ROWS>{}, v, rowid, C.n - base);
+        } else {
+            for (int64_t i = ntiles * TILE + tid; i < C.n; i += BS) {      // tail rows, one per lane
+                int64_t v1[NC][1], rid[1];
+                rid[0] = C.row0 + i;
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+                    if (c < C.ncol) v1[c][0] = load_scalar(C.ptr[c], C.width(c), i);
+                process(std::integral_constant<int, 1>{}, v1, rid, 1);
+            }
         }
     }
     __syncthreads();
