@@ -184,19 +184,19 @@ void bind_fused(vdl_ctx *c, vdl_plan *p) {
 // Dimension-side work of scans with derived columns (FusedPlan::prelude): the per-operator executor runs the statements
 // that hold the dimension selections (filters on the dimension table, joins of dimensions with further dimensions) and
 // their validity bitmaps become the lookup tables of the fact scan; LIKE patterns are evaluated once per heap offset.
-// Part of the query: runs on every execution.
-void run_prelude(vdl_ctx *c, vdl_plan *p) {
+// Part of the query: runs on every execution.  `wanted[k]`: item k is referred to by a scan that is about to run.
+void run_prelude_items(vdl_ctx *c, vdl_plan *p, const std::vector<char> &wanted) {
     const FusedPlan &F = p->fused;
-    if (F.prelude.empty()) return;
     p->prelude_buf.assign(F.prelude.size(), nullptr);
     p->prelude_n.assign(F.prelude.size(), 0);
     std::vector<int> witnesses;
-    for (const PreludeItem &it : F.prelude) if (it.kind == PreludeItem::DIM_BITMAP) witnesses.push_back(it.witness);
+    for (size_t k = 0; k < F.prelude.size(); k++)
+        if (wanted[k] && F.prelude[k].kind == PreludeItem::DIM_BITMAP) witnesses.push_back(F.prelude[k].witness);
     if (!witnesses.empty()) {
         GenExec g(c, p);
         g.run_nodes(witnesses, nullptr);
         for (size_t k = 0; k < F.prelude.size(); k++) {
-            if (F.prelude[k].kind != PreludeItem::DIM_BITMAP) continue;
+            if (!wanted[k] || F.prelude[k].kind != PreludeItem::DIM_BITMAP) continue;
             const DVec &v = g.vec[(size_t)F.prelude[k].witness];
             p->prelude_n[k] = v.n;
             if (v.kind == DVec::SPARSE) p->prelude_buf[k] = g.bitmap_of(v.sel);
@@ -206,7 +206,7 @@ void run_prelude(vdl_ctx *c, vdl_plan *p) {
     }
     for (size_t k = 0; k < F.prelude.size(); k++) {
         const PreludeItem &it = F.prelude[k];
-        if (it.kind != PreludeItem::LIKE_LUT) continue;
+        if (!wanted[k] || it.kind != PreludeItem::LIKE_LUT) continue;
         const Column &heap = find_col(c, it.heap);
         Src offs; offs.kind = SRC_RANGE; offs.from = 0; offs.step = 1;
         Src hs; hs.p = heap.dev; hs.kind = heap.width == 8 ? SRC_I64 : heap.width == 4 ? SRC_I32 : heap.width == 2 ? SRC_I16 : SRC_I8;
@@ -217,17 +217,26 @@ void run_prelude(vdl_ctx *c, vdl_plan *p) {
         p->prelude_n[k] = heap.n;
         HIP_CHECK(launch_like(offs, nullptr, heap.n, hs, nullptr, heap.n, pat, (int64_t *)p->prelude_buf[k]->p, c->stream));
     }
-    // hand the tables to the scans that look them up
-    const size_t ns = F.scans.size();
-    for (size_t s = 0; s < ns + F.gscans.size(); s++) {
-        const std::vector<ScanColumn> &sc = s < ns ? F.scans[s].cols : F.gscans[s - ns].cols;
-        for (size_t k = 0; k < sc.size(); k++) {
-            if (sc[k].kind != VC_BITS && sc[k].kind != VC_LUT) continue;
-            const BufP &b = p->prelude_buf[(size_t)sc[k].prelude];
-            p->mcols[s].ptr[k] = b ? b->p : nullptr;
-            p->mdesc[s].dn[k] = p->prelude_n[(size_t)sc[k].prelude];
-        }
+}
+// hand the tables to a scan that looks them up
+void patch_prelude(const vdl_plan *p, const std::vector<ScanColumn> &sc, MScanCols &cols, MScanDesc &d) {
+    for (size_t k = 0; k < sc.size(); k++) {
+        if (sc[k].kind != VC_BITS && sc[k].kind != VC_LUT) continue;
+        const BufP &b = p->prelude_buf[(size_t)sc[k].prelude];
+        cols.ptr[k] = b ? b->p : nullptr;
+        d.dn[k] = p->prelude_n[(size_t)sc[k].prelude];
     }
+}
+void run_prelude(vdl_ctx *c, vdl_plan *p) {
+    const FusedPlan &F = p->fused;
+    if (F.prelude.empty()) return;
+    std::vector<char> wanted(F.prelude.size(), 0);
+    const size_t ns = F.scans.size();
+    for (size_t s = 0; s < ns + F.gscans.size(); s++)
+        for (const ScanColumn &sc : (s < ns ? F.scans[s].cols : F.gscans[s - ns].cols))
+            if (sc.prelude >= 0) wanted[(size_t)sc.prelude] = 1;
+    run_prelude_items(c, p, wanted);
+    for (size_t s = 0; s < ns + F.gscans.size(); s++) patch_prelude(p, s < ns ? F.scans[s].cols : F.gscans[s - ns].cols, p->mcols[s], p->mdesc[s]);
 }
 
 void run_fused_local(vdl_ctx *c, vdl_plan *p, int64_t *dev_words, bool single_rank) {
@@ -347,6 +356,90 @@ void finalize_end(vdl_ctx *c, vdl_plan *p, int slot) {
 
 namespace vdl {
 namespace eng {
+
+// The fused front of a plan that does not fuse as a whole (ProjPlan, vdl_fuse.h): one scan over the fact table -- two
+// passes: count per tile, then write -- produces the statements of `proj.nodes` as SPARSE vectors on one shared selection;
+// the per-operator executor starts from them (`over`).  false: the plan has no such front (or it is switched off).
+bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
+    const ProjPlan &J = p->fused.proj;
+    if (!J.ok || (p->use_fusion && p->fused.ok) || !p->use_fusion || getenv("VDL_NO_PROJECTION")) return false;
+    MScanCols cols;
+    auto desc = std::make_unique<MScanDesc>();
+    MScanDesc &d = *desc;
+    cols.ncol = (int)J.cols.size();
+    int64_t n = -1;
+    std::vector<char> wanted(p->fused.prelude.size(), 0);
+    for (int k = 0; k < cols.ncol; k++) {
+        const ScanColumn &sc = J.cols[(size_t)k];
+        cols.kind[k] = sc.kind;
+        cols.lo[k] = sc.lo; cols.hi[k] = sc.hi;
+        cols.filtered[k] = (sc.lo != INT64_MIN || sc.hi != INT64_MAX) ? 1 : 0;
+        d.flo[k] = sc.lo; d.fhi[k] = sc.hi;
+        d.dkind[k] = sc.kind; d.dsrc[k] = sc.idx; d.dsrc2[k] = sc.idx2;
+        if (sc.kind == VC_DIRECT) {
+            const Column &col = find_col(c, sc.name);
+            if (n >= 0 && col.n != n) throw Error(VDL_ERR_SHAPE, "columns of table '" + J.table + "' have different lengths in the catalog");
+            n = col.n;
+            cols.ptr[k] = col.dev; cols.width[k] = col.width;
+        } else if (sc.kind == VC_GATHER || sc.kind == VC_INRANGE) {
+            const Column &col = find_col(c, sc.name);
+            cols.ptr[k] = col.dev; cols.width[k] = col.width;
+            d.dn[k] = col.n;
+        } else {
+            cols.ptr[k] = nullptr; cols.width[k] = 8;
+            if (sc.prelude >= 0) wanted[(size_t)sc.prelude] = 1;
+        }
+    }
+    cols.n = n;
+    run_prelude_items(c, p, wanted);
+    patch_prelude(p, J.cols, cols, d);
+    // produced columns: one packed vector each (statements that are the same column share it)
+    std::vector<int> distinct;
+    for (int oc : J.node_col) if (oc >= 0 && std::find(distinct.begin(), distinct.end(), oc) == distinct.end()) distinct.push_back(oc);
+    SelP sel = std::make_shared<Sel>();
+    sel->n = n;
+    const int64_t ntiles = project_tiles(n);
+    int64_t m = 0;
+    std::vector<BufP> outs(distinct.size());
+    if (n > 0 && !J.never) {
+        BufP counts = dev_alloc(c, sizeof(int64_t) * (size_t)(ntiles + 1));
+        BufP ddev = dev_alloc(c, sizeof(MScanDesc));
+        d.tile_counts = (int64_t *)counts->p;
+        HIP_CHECK(hipMemcpyAsync(ddev->p, &d, sizeof d, hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(launch_project(cols, (const MScanDesc *)ddev->p, false, c->num_cus, c->stream));
+        HIP_CHECK(launch_compact_scan((int64_t *)counts->p, ntiles, c->stream));
+        HIP_CHECK(hipMemcpyAsync(&m, (int64_t *)counts->p + ntiles, sizeof m, hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));             // (also: `d` has been read by the first copy)
+        sel->idx = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(m, 1));
+        d.out_idx = (int64_t *)sel->idx->p;
+        d.nout = (int)distinct.size();
+        for (size_t o = 0; o < distinct.size(); o++) {
+            outs[o] = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(m, 1));
+            d.out_col[o] = distinct[o];
+            d.out_ptr[o] = (int64_t *)outs[o]->p;
+        }
+        if (m > 0) {
+            HIP_CHECK(hipMemcpyAsync(ddev->p, &d, sizeof d, hipMemcpyHostToDevice, c->stream));
+            HIP_CHECK(launch_project(cols, (const MScanDesc *)ddev->p, true, c->num_cus, c->stream));
+            HIP_CHECK(hipStreamSynchronize(c->stream));         // `d` lives on this frame
+        }
+    } else {
+        sel->idx = dev_alloc(c, sizeof(int64_t));
+        for (size_t o = 0; o < distinct.size(); o++) outs[o] = dev_alloc(c, sizeof(int64_t));
+    }
+    sel->m = m;
+    sel->first_slot = -1;
+    for (size_t k = 0; k < J.nodes.size(); k++) {
+        DVec v;
+        v.kind = DVec::SPARSE; v.n = n; v.sel = sel;
+        if (J.node_col[k] < 0) { v.data = sel->idx; v.ids = true; }
+        else v.data = outs[(size_t)(std::find(distinct.begin(), distinct.end(), J.node_col[k]) - distinct.begin())];
+        over[J.nodes[k]] = v;
+    }
+    p->front_note = "fusedFront: one scan of " + J.table + " produced " + std::to_string(J.nodes.size()) + " statement vectors; rows kept";
+    p->front_rows = m;
+    return true;
+}
 
 std::string describe_plan(const vdl_plan *p) {
     std::ostringstream o;
@@ -603,8 +696,11 @@ int vdl_run(vdl_ctx *c, vdl_plan *p) {
                 p->fallback_note = e.what();          // exact for any data: rerun statement by statement
             }
         }
+        std::map<int, DVec> over;
+        const bool front = run_projection(c, p, over);
         GenExec g(c, p);
-        g.run();
+        g.run_nodes(p->prog.outputs, front ? &over : nullptr);
+        if (front) p->timings.push_back({p->front_note, (double)p->front_rows});
         if (!p->fallback_note.empty()) { p->timings.push_back({"fusedPlanAbandoned: " + p->fallback_note, 0.0}); p->fallback_note.clear(); }
     });
 }

@@ -224,7 +224,8 @@ struct vdl_plan {
     std::vector<int64_t> cut_n;            // and the lengths of their operands on this rank
     BufP words;
     int64_t words_cap = 0;
-    std::string fallback_note;
+    std::string fallback_note, front_note;
+    int64_t front_rows = 0;
     bool bound = false;
     uint64_t bound_version = 0;
     // pipelined finalisation: two pinned host slots, one event each
@@ -308,6 +309,7 @@ inline const Column &find_col(vdl_ctx *c, const std::string &name) {
 }
 
 std::string describe_plan(const vdl_plan *p);
+bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over);     // vdl_engine.cpp: the fused front of a plan that does not fuse as a whole
 // general (not fused) plans sharded by rows through their global folds, vdl_exchange.cpp
 bool general_partial_spec(const vdl_plan *p, std::vector<int32_t> &ops, std::string &why);
 void general_run_local(vdl_ctx *c, vdl_plan *p, int64_t *dev_words);

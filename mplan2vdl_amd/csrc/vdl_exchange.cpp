@@ -310,8 +310,10 @@ int vdl_exchange_begin(vdl_ctx *c, vdl_plan *p, int world, int64_t *counts_host)
         need_device(c);
         ExchangeSpec x = analyse_exchange(p->prog, p->sharded_table);
         if (!x.ok) throw Error(VDL_ERR_UNSUPPORTED, "no sharded-Partition structure: " + x.why);
+        std::map<int, DVec> front;                          // the fused front of the local phase (ProjPlan), when the plan has one
+        const bool has_front = run_projection(c, p, front);
         GenExec g(c, p);
-        g.run_nodes(x.sources, nullptr);
+        g.run_nodes(x.sources, has_front ? &front : nullptr);
         vdl_plan::ExState &ex = p->ex;
         ex = vdl_plan::ExState{};
         ex.world = world; ex.nodes = x.sources; ex.pmin = x.pmin; ex.pcount = x.pcount;

@@ -667,6 +667,75 @@ int64_t eval_scalar(const Scalar &s, const int64_t *agg) {
     }
 }
 
+// ProjPlan (vdl_fuse.h): the selection of the program's Partition key, and the atom statements living on it that the
+// rest of the program reads.
+static void build_projection(const Program &P, Builder &B, FusedPlan &F) {
+    ProjPlan &J = F.proj;
+    int part = -1;
+    for (int id : P.order) if (P.at(id).op == Op::Partition) { if (part < 0) part = id; }
+    if (part < 0) { J.why = "no Partition"; return; }
+    const Sym &pt = B.sym[(size_t)part];
+    if (pt.kind != Sym::PART || pt.sel == 0) { J.why = "the Partition key is not a filtered row expression"; return; }
+    J.table = pt.table;
+    // candidates: statements whose vector is an atom (or the row ids) on exactly that selection
+    std::vector<char> cand(P.nodes.size(), 0);
+    for (int id : P.order) {
+        const Sym &s = B.sym[(size_t)id];
+        if (s.kind != Sym::ROW || s.table != pt.table || s.sel != pt.sel) continue;
+        const Op op = P.at(id).op;
+        if (op == Op::Project || op == Op::Shuffle || op == Op::Materialize) continue;      // aliases: their operand is the candidate
+        const bool ids = s.e->k == Row::IOTA && s.e->c0 == 0 && s.e->c1 == 1;
+        if (ids || (is_atom(s.e) && s.e->k != Row::BIN)) cand[(size_t)id] = 1;
+    }
+    // which of them does the rest of the program read?  (walk back from the outputs, stopping at candidates)
+    std::vector<char> needed(P.nodes.size(), 0), used(P.nodes.size(), 0);
+    for (int id : P.outputs) needed[(size_t)id] = 1;
+    for (auto it = P.order.rbegin(); it != P.order.rend(); ++it) {
+        const Node &n = P.at(*it);
+        if (!needed[(size_t)n.id]) continue;
+        if (cand[(size_t)n.id]) { used[(size_t)n.id] = 1; continue; }
+        for (int opnd : {n.a, n.b, n.c}) if (opnd > 0) needed[(size_t)opnd] = 1;
+    }
+    Clause cl;
+    if (!to_clause(B.pred_of(pt.sel), cl)) { J.why = "the selection is not a conjunction of per-column ranges"; return; }
+    J.never = cl.never;
+    VCols vc{J.cols, F, B, J.why, {}};
+    for (auto &kv : cl.cols) {
+        const int c = vc(cl.atoms.at(kv.first));
+        if (c < 0) return;
+        if (kv.second.empty()) { J.never = true; continue; }
+        if (kv.second.size() != 1) { J.why = "filter on " + kv.first + " is not a single range"; return; }
+        J.cols[(size_t)c].lo = std::max(J.cols[(size_t)c].lo, kv.second[0].first);
+        J.cols[(size_t)c].hi = std::min(J.cols[(size_t)c].hi, kv.second[0].second);
+    }
+    for (int id : P.order) {
+        if (!used[(size_t)id]) continue;
+        const Sym &s = B.sym[(size_t)id];
+        int c = -1;
+        if (s.e->k != Row::IOTA) { c = vc(s.e); if (c < 0) return; }
+        J.nodes.push_back(id); J.node_col.push_back(c);
+    }
+    if (J.nodes.empty()) { J.why = "nothing downstream reads a column on the Partition's selection"; return; }
+    if ((int)J.nodes.size() > kMaxProjOuts) { J.why = "more than " + std::to_string(kMaxProjOuts) + " vectors to produce"; return; }
+    // a range check that a lookup through the same index column performs anyway needs no column of its own
+    for (size_t k = 0; k < J.cols.size();) {
+        bool redundant = false;
+        if (J.cols[k].kind == VC_INRANGE)
+            for (const ScanColumn &o : J.cols) redundant |= (o.kind == VC_GATHER || o.kind == VC_BITS) && o.idx == J.cols[k].idx;
+        for (int nc : J.node_col) if (nc == (int)k) redundant = false;
+        if (!redundant) { k++; continue; }
+        J.cols.erase(J.cols.begin() + (long)k);
+        for (ScanColumn &o : J.cols) { if (o.idx > (int)k) o.idx--; if (o.idx2 > (int)k) o.idx2--; }
+        for (int &nc : J.node_col) if (nc > (int)k) nc--;
+    }
+    if ((int)J.cols.size() > kMaxProjCols) { J.why = "more than " + std::to_string(kMaxProjCols) + " columns"; return; }
+    bool direct = false;
+    for (const ScanColumn &c : J.cols) direct |= c.kind == VC_DIRECT && c.name.compare(0, J.table.size() + 1, J.table + ".") == 0;
+    if (!direct) { J.why = "no column of the table itself (row count unknown)"; return; }
+    J.why.clear();
+    J.ok = true;
+}
+
 FusedPlan fuse_program(const Program &P) {
     FusedPlan F;
     Builder B(P);
@@ -677,6 +746,7 @@ FusedPlan fuse_program(const Program &P) {
     }
     F.filters = B.filters;
     if (P.outputs.empty()) { F.why_not = "program has no MaterializeCompact output"; return F; }
+    build_projection(P, B, F);
     for (int id : P.outputs) {
         const Sym &s = B.sym[(size_t)id];
         if (s.kind != Sym::FOLD && s.kind != Sym::GFOLD) {
@@ -813,7 +883,18 @@ static void show_col(const ScanColumn &c, size_t k, std::ostringstream &o) {
 
 std::string describe_fused(const FusedPlan &F) {
     std::ostringstream o;
-    if (!F.ok) { o << "not fused: " << F.why_not << "\n"; return o.str(); }
+    if (!F.ok) {
+        o << "not fused: " << F.why_not << "\n";
+        if (F.proj.ok) {
+            o << "fused front: one scan of " << F.proj.table << (F.proj.never ? " [never]" : "") << " hands these statements to the per-operator executor as sparse vectors:";
+            for (size_t k = 0; k < F.proj.nodes.size(); k++) o << " Id " << F.proj.nodes[k] << (F.proj.node_col[k] < 0 ? "=rowid" : "=col" + std::to_string(F.proj.node_col[k]));
+            o << "\n";
+            for (size_t c = 0; c < F.proj.cols.size(); c++) show_col(F.proj.cols[c], c, o);
+        } else if (!F.proj.why.empty()) {
+            o << "no fused front: " << F.proj.why << "\n";
+        }
+        return o.str();
+    }
     for (size_t k = 0; k < F.prelude.size(); k++) {
         if (F.prelude[k].kind == PreludeItem::DIM_BITMAP) o << "prelude " << k << ": bitmap of the dimension-side selection held by statement " << F.prelude[k].witness << " (per-operator executor)\n";
         else o << "prelude " << k << ": LIKE '" << F.prelude[k].pattern << "' over every offset of " << F.prelude[k].heap << "\n";

@@ -125,7 +125,24 @@ constexpr int kMaxFilterCols = 6, kMaxFilterIvs = 4;
 struct FilterColumn { std::string name; int n = 0; int64_t lo[kMaxFilterIvs] = {}, hi[kMaxFilterIvs] = {}; };
 struct FilterSpec { std::string table; std::vector<FilterColumn> cols; bool never = false; };
 
+// A plan that does not fuse as a whole (its Partition has a sparse domain: joins feeding a GROUP BY, TPC-H Q3) can still
+// have the front of its fact side fused: ONE scan evaluates the Select steps and the FK-join filters of the fact table and
+// writes, for the surviving rows only, the columns the rest of the program reads -- fact columns, dimension columns looked
+// up through the join index, row ids -- as sparse vectors on one shared selection.  The per-operator executor then starts
+// at those statements (they are handed to it ready-made) instead of running the ~15 filter / gather statements that
+// produce them one kernel at a time over the whole fact table.
+constexpr int kMaxProjCols = 12, kMaxProjOuts = 10;
+struct ProjPlan {
+    bool ok = false;
+    std::string table, why;
+    std::vector<ScanColumn> cols;    // as in ScanPlan (filters, derived columns)
+    bool never = false;
+    std::vector<int> nodes;          // statements the scan produces ...
+    std::vector<int> node_col;       // ... and the column each one is (-1: the row ids themselves)
+};
+
 struct FusedPlan {
+    ProjPlan proj;
     std::vector<PreludeItem> prelude;    // dimension-side work the scans' derived columns need (empty for single-table plans)
     std::map<int, FilterSpec> filters;   // FoldSelect statement id -> its column filter (filled whether or not the plan fuses)
     bool ok = false;

@@ -50,14 +50,16 @@ const char *scan_kernel_name(const ScanLaunch &cfg);
 
 // ---- multi-aggregate fused scans (vdl_mscan.hip): global and grouped (dense-domain GROUP BY) ----
 constexpr int kMaxGroupAggs = 16;
-struct MScanCols {                           // by-value kernel argument: keeps column loads in the global address space
+constexpr int kMaxVCols = kMaxProjCols;      // columns of a scan descriptor: 8 for the aggregate scans, up to 12 for the projection scan
+static_assert(kMaxVCols >= kMaxScanCols, "the aggregate scans' columns fit the descriptor");
+struct MScanCols {                           // host-side description of a scan's columns
     int ncol = 0;
     int64_t n = 0, row0 = 0;
-    const void *ptr[kMaxScanCols] = {};      // VC_DIRECT: the column; derived columns: the table looked up (column / bitmap words / LUT)
-    int width[kMaxScanCols] = {};
-    int filtered[kMaxScanCols] = {};
-    int64_t lo[kMaxScanCols] = {}, hi[kMaxScanCols] = {};
-    int kind[kMaxScanCols] = {};             // VColKind (vdl_fuse.h); 0 = read from the scanned table
+    const void *ptr[kMaxVCols] = {};         // VC_DIRECT: the column; derived columns: the table looked up (column / bitmap words / LUT)
+    int width[kMaxVCols] = {};
+    int filtered[kMaxVCols] = {};
+    int64_t lo[kMaxVCols] = {}, hi[kMaxVCols] = {};
+    int kind[kMaxVCols] = {};                // VColKind (vdl_fuse.h); 0 = read from the scanned table
 };
 struct MAggDesc {
     int kind = 0;                            // AGG_SUM / AGG_MIN / AGG_MAX / AGG_FIRST
@@ -70,9 +72,14 @@ struct MScanDesc {                           // lives in device memory, read wit
     int nagg = 0, nkey = 0, replicas = 1, pad = 0;
     int64_t pmin = 0, pcount = 0;            // grouped: bucket = key - pmin in [0, pcount)
     int64_t *block_partials = nullptr;       // global: [grid][1 + nagg]; grouped: [grid][pcount * (1 + nagg) + 1]
-    int64_t flo[kMaxScanCols] = {}, fhi[kMaxScanCols] = {};      // range filter per column (read only for filtered columns)
-    int dkind[kMaxScanCols] = {}, dsrc[kMaxScanCols] = {}, dsrc2[kMaxScanCols] = {};   // derived columns: VColKind, source column(s)
-    int64_t dn[kMaxScanCols] = {};           // derived columns: entries of the table looked up
+    int64_t flo[kMaxVCols] = {}, fhi[kMaxVCols] = {};            // range filter per column (read only for filtered columns)
+    int dkind[kMaxVCols] = {}, dsrc[kMaxVCols] = {}, dsrc2[kMaxVCols] = {};   // derived columns: VColKind, source column(s)
+    int64_t dn[kMaxVCols] = {};              // derived columns: entries of the table looked up
+    // projection scan (k_project): what to write for the surviving rows
+    int nout = 0, out_col[kMaxProjOuts] = {};
+    int64_t *out_ptr[kMaxProjOuts] = {};     // one packed int64 vector per produced column
+    int64_t *out_idx = nullptr;              // the surviving rows' slot ids, ascending
+    int64_t *tile_counts = nullptr;          // [tiles + 1]: survivors per tile (count pass), then their exclusive prefix (write pass)
     int ncomp = 0, key_masked = 0;           // ncomp > 0: the key program is this canonical form
     int64_t key_mask = 0;
     KeyComp comp[kMaxKeyComps];
@@ -86,6 +93,10 @@ const char *mscan_kernel_name(const ScanLaunch &cfg);
 // resolve_first: turn AGG_FIRST row ids into column values (single rank only).
 hipError_t launch_mscan(const MScanCols &cols, const MScanDesc &d, const MScanDesc *dev_desc, const ScanLaunch &cfg, bool grouped,
                         bool never, int64_t *out, bool resolve_first, hipStream_t s);
+// Projection scan (ProjPlan, vdl_fuse.h): pass 1 counts the surviving rows of every tile into d.tile_counts, pass 2 (after an
+// exclusive prefix sum over the counts) writes their slot ids and the produced columns, packed, in row order.
+int64_t project_tiles(int64_t n);
+hipError_t launch_project(const MScanCols &cols, const MScanDesc *dev_desc, bool write, int num_cus, hipStream_t s);
 // sharded FoldChoose: after the MIN all-reduce of the row-id words, the owning rank substitutes the value, others 0
 hipError_t launch_mscan_resolve_first(const MScanCols &cols, const MScanDesc &d, const MScanDesc *dev_desc, int64_t *table, hipStream_t s);
 

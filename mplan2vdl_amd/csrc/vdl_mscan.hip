@@ -130,11 +130,11 @@ __device__ __forceinline__ void key_combine(int op, int swap, int64_t (&acc)[RW]
 // bounds now sit in the device descriptor and are read where a column is actually filtered.)
 struct MsArgs {
     int ncol = 0;
-    uint32_t widths = 0;                     // 4 bits per column: bytes
+    uint64_t widths = 0;                     // 4 bits per column: bytes
     uint32_t filtered = 0;                   // bit c: column c has a range filter (MScanDesc::flo / fhi)
     uint32_t derived = 0;                    // bit c: column c is derived from earlier columns (MScanDesc::dkind ...), ptr[c] = its table
     int64_t n = 0, row0 = 0;
-    const void *ptr[kMaxScanCols] = {};
+    const void *ptr[kMaxVCols] = {};
     __host__ __device__ int width(int c) const { return (int)((widths >> (4 * c)) & 15u); }
 };
 static MsArgs ms_args(const MScanCols &cols) {
@@ -142,7 +142,7 @@ static MsArgs ms_args(const MScanCols &cols) {
     a.ncol = cols.ncol; a.n = cols.n; a.row0 = cols.row0;
     for (int c = 0; c < cols.ncol; c++) {
         a.ptr[c] = cols.ptr[c];
-        a.widths |= (uint32_t)cols.width[c] << (4 * c);
+        a.widths |= (uint64_t)cols.width[c] << (4 * c);
         if (cols.filtered[c]) a.filtered |= 1u << c;
         if (cols.kind[c] != VC_DIRECT) a.derived |= 1u << c;
     }
@@ -589,6 +589,86 @@ __global__ void k_mscan_first(const MsArgs C, const MScanDesc *__restrict__ Dp, 
     }
 }
 
+// ---- projection scan (ProjPlan, vdl_fuse.h): filters + FK lookups of the fact table in one pass, survivors written packed ----
+// Row order inside a tile is (sub-iteration u, wave, lane, row of the lane's pair): a survivor's rank is the survivors of the
+// (u, wave) groups before its own plus the ballots of its group below its lane.
+template <int NC, int U, bool VEC, bool NT, bool WRITE>
+__global__ __launch_bounds__(kMsBlock) void k_project(const MsArgs C, const MScanDesc *__restrict__ Dp) {
+    const MScanDesc &D = *Dp;
+    constexpr int BS = kMsBlock, ROWS = 2 * U, TILE = BS * ROWS, NW = BS / kWave;
+    __shared__ int wcnt[U][NW];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const int64_t full = C.n / TILE, ntiles = (C.n + TILE - 1) / TILE;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int64_t v[NC][ROWS];
+        const int64_t base = tile * TILE + (int64_t)tid * 2;
+        if (tile < full) {
+            load_tile<NC, U, VEC, NT>(C, base, v);
+        } else {                                           // the partial last tile: clamped scalar loads
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                if (c < C.ncol && !((C.derived >> c) & 1u)) {
+#pragma unroll
+                    for (int r = 0; r < ROWS; r++) {
+                        const int64_t i = base + (int64_t)(r >> 1) * (BS * 2) + (r & 1);
+                        v[c][r] = load_scalar(C.ptr[c], C.width(c), i < C.n ? i : C.n - 1);
+                    }
+                }
+            }
+        }
+        bool alive[ROWS], pass[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) alive[r] = base + (int64_t)(r >> 1) * (BS * 2) + (r & 1) < C.n;
+        derive<NC, ROWS>(C, D, v, alive);
+        eval_pass<NC, ROWS>(C, D, v, pass);
+        uint64_t m[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) { pass[r] = pass[r] & alive[r]; m[r] = __ballot(pass[r]); }
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < U; u++) wcnt[u][wave] = __popcll(m[2 * u]) + __popcll(m[2 * u + 1]);
+        }
+        __syncthreads();
+        int total = 0, mybase[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+#pragma unroll
+            for (int w = 0; w < NW; w++) { if (w == wave) mybase[u] = total; total += wcnt[u][w]; }
+        }
+        if (!WRITE) {
+            if (tid == 0) D.tile_counts[tile] = total;
+        } else {
+            const int64_t off = D.tile_counts[tile];
+            const uint64_t below = (1ull << lane) - 1;
+            int64_t dst[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                const int u = r >> 1;
+                dst[r] = off + mybase[u] + __popcll(m[2 * u] & below) + __popcll(m[2 * u + 1] & below) + ((r & 1) && pass[2 * u] ? 1 : 0);
+                if (pass[r]) D.out_idx[dst[r]] = base + (int64_t)u * (BS * 2) + (r & 1);
+            }
+            for (int o = 0; o < D.nout; o++) {             // wave-uniform loop over the produced columns
+                const int oc = D.out_col[o];
+                int64_t *out = D.out_ptr[o];
+                int64_t x[ROWS];
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) x[r] = 0;
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    if (c == oc) {
+#pragma unroll
+                        for (int r = 0; r < ROWS; r++) x[r] = v[c][r];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) if (pass[r]) out[dst[r]] = x[r];
+            }
+        }
+        __syncthreads();                                   // wcnt is rewritten by the next tile
+    }
+}
+constexpr int kProjU = 2;
+
 typedef void (*mscan_fn)(const MsArgs, const MScanDesc *);
 struct MsVariant { int nc, u; bool vec, grouped, der; mscan_fn fn; const char *name; };
 #define VDL_MS(NC, U, VEC, NT, GR) {NC, U, VEC, GR, false, k_mscan<NC, U, VEC, NT, GR, false>, "k_mscan<" #NC "," #U "," #VEC "," #NT "," #GR ">"}
@@ -674,6 +754,28 @@ hipError_t launch_mscan(const MScanCols &cols, const MScanDesc &d, const MScanDe
     const int64_t words = grouped ? d.pcount * (d.nagg + 1) + 1 : d.nagg + 1;
     k_mscan_finish<<<(int)((words + 3) / 4), 256, 0, s>>>(dev_desc, nblocks, grouped ? 1 : 0, out);
     if (grouped && resolve_first) k_mscan_first<<<(int)((d.pcount + 255) / 256), 256, 0, s>>>(ms_args(cols), dev_desc, 0, out);
+    return hipGetLastError();
+}
+
+int64_t project_tiles(int64_t n) { const int64_t tile = (int64_t)kMsBlock * 2 * kProjU; return (n + tile - 1) / tile; }
+
+hipError_t launch_project(const MScanCols &cols, const MScanDesc *dev_desc, bool write, int num_cus, hipStream_t s) {
+    (void)hipGetLastError();
+    if (cols.n <= 0) return hipSuccess;
+    bool vec = true;
+    for (int c = 0; c < cols.ncol; c++)
+        if (cols.kind[c] == VC_DIRECT && ((uintptr_t)cols.ptr[c]) % (uintptr_t)(2 * cols.width[c]) != 0) vec = false;
+    int64_t grid = project_tiles(cols.n);
+    if (grid > (int64_t)num_cus * 8) grid = (int64_t)num_cus * 8;
+    const MsArgs a = ms_args(cols);
+    constexpr int NC = kMaxVCols;
+    if (vec) {
+        if (write) k_project<NC, kProjU, true, true, true><<<(int)grid, kMsBlock, 0, s>>>(a, dev_desc);
+        else k_project<NC, kProjU, true, true, false><<<(int)grid, kMsBlock, 0, s>>>(a, dev_desc);
+    } else {
+        if (write) k_project<NC, kProjU, false, false, true><<<(int)grid, kMsBlock, 0, s>>>(a, dev_desc);
+        else k_project<NC, kProjU, false, false, false><<<(int)grid, kMsBlock, 0, s>>>(a, dev_desc);
+    }
     return hipGetLastError();
 }
 

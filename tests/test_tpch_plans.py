@@ -159,7 +159,7 @@ def test_engine_matches_oracle_on_the_vlite_dialect(cfg, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["VDL_SPARSE_ALWAYS", "VDL_NO_SPARSE", "VDL_NO_EXPR_FUSION", "VDL_NO_FILTER_FUSION"])
+@pytest.mark.parametrize("mode", ["VDL_SPARSE_ALWAYS", "VDL_NO_SPARSE", "VDL_NO_EXPR_FUSION", "VDL_NO_FILTER_FUSION", "VDL_NO_PROJECTION"])
 def test_sparse_vector_routes_agree(cfg, monkeypatch, mode):
     """The general executor keeps vectors that only hold values on a selection in compact form after selective
     filters, and runs chains of single-reader element-wise operators as one fused kernel.  Sparse forced on for
@@ -180,6 +180,22 @@ def test_sparse_vector_routes_agree(cfg, monkeypatch, mode):
         got = e.run_vdl(text)["results"]
         e.close()
         assert got == want, (mode, "hierarchical", n)
+
+
+def test_which_plans_have_a_fused_front(cfg):
+    """Host-only: plans that do not fuse as a whole but whose fact-side filters / FK lookups run as one projection scan
+    (ProjPlan, vdl_fuse.h) handing sparse vectors to the per-operator executor."""
+    import mplan2vdl_amd as m
+
+    e = m.Engine(device=None)
+    front = []
+    for n in PLANS:
+        d = e.parse(frontend.compile_plan(open(os.path.join(META, "%02d.sql.mplan" % n)).read(), cfg)).describe()
+        if "\nfused front:" in d:
+            front.append(n)
+    assert front == [3, 9, 10, 11, 15, 20]
+    q3 = e.parse(open(os.path.join(ROOT, "tests", "golden", "q3.vdl")).read()).describe()
+    assert "\nfused front: one scan of lineitem" in q3 and "orders.o_orderdate[col1]" in q3 and "prelude0.bit[col1] in [1,1]" in q3
 
 
 def test_which_plans_have_a_sharded_route(cfg):
