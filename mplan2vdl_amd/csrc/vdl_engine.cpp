@@ -391,6 +391,12 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
         }
     }
     cols.n = n;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (p->profiling) {
+        if (!p->stmt_ev[1]) { HIP_CHECK(hipEventCreate(&p->stmt_ev[0])); HIP_CHECK(hipEventCreate(&p->stmt_ev[1])); }
+        e0 = p->stmt_ev[0]; e1 = p->stmt_ev[1];
+        HIP_CHECK(hipEventRecord(e0, c->stream));
+    }
     run_prelude_items(c, p, wanted);
     patch_prelude(p, J.cols, cols, d);
     // produced columns: one packed vector each (statements that are the same column share it)
@@ -436,8 +442,16 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
         else v.data = outs[(size_t)(std::find(distinct.begin(), distinct.end(), J.node_col[k]) - distinct.begin())];
         over[J.nodes[k]] = v;
     }
-    p->front_note = "fusedFront: one scan of " + J.table + " produced " + std::to_string(J.nodes.size()) + " statement vectors; rows kept";
-    p->front_rows = m;
+    p->front_usec = 0;
+    if (e0) {
+        HIP_CHECK(hipEventRecord(e1, c->stream));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        p->front_usec = (double)ms * 1e3;
+    }
+    p->front_note = "timeInMicrosecondsForFusedFront_" + J.table + "_" + std::to_string(J.nodes.size()) + "_statement_vectors_" + std::to_string(m) + "_of_" +
+                    std::to_string(n) + "_rows_kept_(dimension_side_included)";
     return true;
 }
 
@@ -700,7 +714,7 @@ int vdl_run(vdl_ctx *c, vdl_plan *p) {
         const bool front = run_projection(c, p, over);
         GenExec g(c, p);
         g.run_nodes(p->prog.outputs, front ? &over : nullptr);
-        if (front) p->timings.push_back({p->front_note, (double)p->front_rows});
+        if (front) p->timings.push_back({p->front_note, p->front_usec});
         if (!p->fallback_note.empty()) { p->timings.push_back({"fusedPlanAbandoned: " + p->fallback_note, 0.0}); p->fallback_note.clear(); }
     });
 }

@@ -225,7 +225,7 @@ struct vdl_plan {
     BufP words;
     int64_t words_cap = 0;
     std::string fallback_note, front_note;
-    int64_t front_rows = 0;
+    double front_usec = 0;
     bool bound = false;
     uint64_t bound_version = 0;
     // pipelined finalisation: two pinned host slots, one event each

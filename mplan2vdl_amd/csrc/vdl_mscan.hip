@@ -236,26 +236,23 @@ __device__ __forceinline__ void derive(const MsArgs &C, const MScanDesc &D, int6
             bool in[RW];
 #pragma unroll
             for (int r = 0; r < RW; r++) in[r] = alive[r] & (x[r] >= 0) & (x[r] < n);
-            // lookups are issued for every lane (rows that are out already read entry 0: one cached line), so the loads of
-            // a tile go out together instead of one exec-masked region per row
+            // lookups only for the lanes whose row is still alive (a selective fact filter ahead of the join -- Q14 keeps 1 row
+            // in 84 -- leaves most lanes without a memory request); all the loads of a column's rows are issued before any is used
             if (kind == VC_GATHER) {
-                if (n > 0) {
+                int64_t q[RW];
 #pragma unroll
-                    for (int r = 0; r < RW; r++) { const int64_t q = load_scalar(t, w, in[r] ? x[r] : 0); v[c][r] = in[r] ? q : 0; }
-                }
+                for (int r = 0; r < RW; r++) { q[r] = 0; if (in[r]) q[r] = load_scalar(t, w, x[r]); }
 #pragma unroll
-                for (int r = 0; r < RW; r++) { if (n <= 0) v[c][r] = 0; alive[r] = in[r]; }
+                for (int r = 0; r < RW; r++) { v[c][r] = q[r]; alive[r] = in[r]; }
             } else if (kind == VC_BITS) {
+                uint64_t word[RW];
 #pragma unroll
-                for (int r = 0; r < RW; r++) {
-                    uint64_t word = ~0ull;                  // no bitmap: every dimension row is selected
-                    if (t && n > 0) word = ((const uint64_t *)t)[(in[r] ? x[r] : 0) >> 6];
-                    v[c][r] = in[r] ? (int64_t)((word >> (x[r] & 63)) & 1ull) : 0;
-                    alive[r] = in[r];
-                }
+                for (int r = 0; r < RW; r++) { word[r] = ~0ull; if (in[r] && t) word[r] = ((const uint64_t *)t)[x[r] >> 6]; }      // no bitmap: every dimension row is selected
+#pragma unroll
+                for (int r = 0; r < RW; r++) { v[c][r] = in[r] ? (int64_t)((word[r] >> (x[r] & 63)) & 1ull) : 0; alive[r] = in[r]; }
             } else if (kind == VC_LUT) {                    // outside the table: 0, not EPS (Like over an offset outside the heap)
 #pragma unroll
-                for (int r = 0; r < RW; r++) { v[c][r] = 0; if (n > 0) { const int64_t q = ((const int64_t *)t)[in[r] ? x[r] : 0]; v[c][r] = in[r] ? q : 0; } }
+                for (int r = 0; r < RW; r++) { v[c][r] = 0; if (in[r]) v[c][r] = ((const int64_t *)t)[x[r]]; }
             } else {                                        // VC_INRANGE
 #pragma unroll
                 for (int r = 0; r < RW; r++) { v[c][r] = 1; alive[r] = in[r]; }
