@@ -391,6 +391,29 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
         }
     }
     cols.n = n;
+    // columns that decide a row's survival: the filtered ones and what they are derived from; a lookup whose range check is
+    // done by another deciding column through the same index (the dimension bitmap, an INRANGE) decides nothing itself.
+    // Everything else is read for the surviving rows only, in the write pass.
+    {
+        std::vector<char> decides((size_t)cols.ncol, 0);
+        for (int k = 0; k < cols.ncol; k++) decides[(size_t)k] = cols.filtered[k] || J.cols[(size_t)k].kind == VC_INRANGE;
+        for (int k = 0; k < cols.ncol; k++) {
+            const ScanColumn &sc = J.cols[(size_t)k];
+            if (sc.kind != VC_GATHER || decides[(size_t)k]) continue;
+            bool checked = false;
+            for (int j = 0; j < cols.ncol; j++) {
+                const ScanColumn &o = J.cols[(size_t)j];
+                checked |= j != k && o.idx == sc.idx && (o.kind == VC_INRANGE || o.kind == VC_BITS || (o.kind == VC_GATHER && decides[(size_t)j] && j < k));
+            }
+            if (!checked) decides[(size_t)k] = 1;                     // its own range check can drop the row
+        }
+        for (int k = cols.ncol - 1; k >= 0; k--) {
+            if (!decides[(size_t)k]) continue;
+            if (J.cols[(size_t)k].idx >= 0) decides[(size_t)J.cols[(size_t)k].idx] = 1;
+            if (J.cols[(size_t)k].idx2 >= 0) decides[(size_t)J.cols[(size_t)k].idx2] = 1;
+        }
+        for (int k = 0; k < cols.ncol; k++) cols.lazy[k] = decides[(size_t)k] ? 0 : 1;
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (p->profiling) {
         if (!p->stmt_ev[1]) { HIP_CHECK(hipEventCreate(&p->stmt_ev[0])); HIP_CHECK(hipEventCreate(&p->stmt_ev[1])); }

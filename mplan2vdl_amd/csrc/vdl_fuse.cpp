@@ -717,11 +717,12 @@ static void build_projection(const Program &P, Builder &B, FusedPlan &F) {
     }
     if (J.nodes.empty()) { J.why = "nothing downstream reads a column on the Partition's selection"; return; }
     if ((int)J.nodes.size() > kMaxProjOuts) { J.why = "more than " + std::to_string(kMaxProjOuts) + " vectors to produce"; return; }
-    // a range check that a lookup through the same index column performs anyway needs no column of its own
+    // a range check that a lookup through the same index column performs anyway needs no column of its own (the first such
+    // lookup then decides about the row and is not deferred to the survivors: run_projection)
     for (size_t k = 0; k < J.cols.size();) {
         bool redundant = false;
         if (J.cols[k].kind == VC_INRANGE)
-            for (const ScanColumn &o : J.cols) redundant |= (o.kind == VC_GATHER || o.kind == VC_BITS) && o.idx == J.cols[k].idx;
+            for (const ScanColumn &o : J.cols) redundant |= (o.kind == VC_BITS || o.kind == VC_GATHER) && o.idx == J.cols[k].idx;
         for (int nc : J.node_col) if (nc == (int)k) redundant = false;
         if (!redundant) { k++; continue; }
         J.cols.erase(J.cols.begin() + (long)k);

@@ -60,6 +60,7 @@ struct MScanCols {                           // host-side description of a scan'
     int filtered[kMaxVCols] = {};
     int64_t lo[kMaxVCols] = {}, hi[kMaxVCols] = {};
     int kind[kMaxVCols] = {};                // VColKind (vdl_fuse.h); 0 = read from the scanned table
+    int lazy[kMaxVCols] = {};                // projection scan: the column decides nothing about a row's survival -- read it for survivors only
 };
 struct MAggDesc {
     int kind = 0;                            // AGG_SUM / AGG_MIN / AGG_MAX / AGG_FIRST

@@ -133,6 +133,7 @@ struct MsArgs {
     uint64_t widths = 0;                     // 4 bits per column: bytes
     uint32_t filtered = 0;                   // bit c: column c has a range filter (MScanDesc::flo / fhi)
     uint32_t derived = 0;                    // bit c: column c is derived from earlier columns (MScanDesc::dkind ...), ptr[c] = its table
+    uint32_t lazy = 0;                       // bit c (projection scan): needed for surviving rows only
     int64_t n = 0, row0 = 0;
     const void *ptr[kMaxVCols] = {};
     __host__ __device__ int width(int c) const { return (int)((widths >> (4 * c)) & 15u); }
@@ -145,16 +146,17 @@ static MsArgs ms_args(const MScanCols &cols) {
         a.widths |= (uint64_t)cols.width[c] << (4 * c);
         if (cols.filtered[c]) a.filtered |= 1u << c;
         if (cols.kind[c] != VC_DIRECT) a.derived |= 1u << c;
+        if (cols.lazy[c]) a.lazy |= 1u << c;
     }
     return a;
 }
 
 template <int NC, int U, bool VEC, bool NT>
-__device__ __forceinline__ void load_tile(const MsArgs &C, int64_t base, int64_t (&v)[NC][2 * U]) {
+__device__ __forceinline__ void load_tile(const MsArgs &C, int64_t base, int64_t (&v)[NC][2 * U], uint32_t skip = 0) {
     constexpr int BS = kMsBlock;
 #pragma unroll
     for (int c = 0; c < NC; c++) {
-        if (c < C.ncol && !((C.derived >> c) & 1u)) {      // wave-uniform
+        if (c < C.ncol && !(((C.derived | skip) >> c) & 1u)) {      // wave-uniform
             const char *p = (const char *)C.ptr[c];
             const int w = C.width(c);
             if (!VEC) {
@@ -198,18 +200,20 @@ __device__ __forceinline__ void eval_pass(const MsArgs &C, const MScanDesc &D, c
 // seen from the fact table (Vlite.hs:1199-1282).  `alive` starts as "the direct range filters pass", so rows a cheap
 // filter already rejects do no lookups (Q14 keeps 1 row in 84); a lookup out of range makes the row EPS (alive = false).
 template <int NC, int RW>
-__device__ __forceinline__ void derive(const MsArgs &C, const MScanDesc &D, int64_t (&v)[NC][RW], bool (&alive)[RW]) {
+__device__ __forceinline__ void derive(const MsArgs &C, const MScanDesc &D, int64_t (&v)[NC][RW], bool (&alive)[RW], uint32_t only, bool direct_filters = true) {
+    if (direct_filters) {
 #pragma unroll
-    for (int c = 0; c < NC; c++) {
-        if (((C.filtered >> c) & 1u) && !((C.derived >> c) & 1u)) {
-            const int64_t lo = D.flo[c], hi = D.fhi[c];
+        for (int c = 0; c < NC; c++) {
+            if (((C.filtered >> c) & 1u) && !((C.derived >> c) & 1u)) {
+                const int64_t lo = D.flo[c], hi = D.fhi[c];
 #pragma unroll
-            for (int r = 0; r < RW; r++) alive[r] = alive[r] & (v[c][r] >= lo) & (v[c][r] <= hi);
+                for (int r = 0; r < RW; r++) alive[r] = alive[r] & (v[c][r] >= lo) & (v[c][r] <= hi);
+            }
         }
     }
 #pragma unroll
     for (int c = 1; c < NC; c++) {
-        if ((C.derived >> c) & 1u) {                       // wave-uniform
+        if ((only >> c) & 1u) {                            // wave-uniform
             const int kind = D.dkind[c], a = D.dsrc[c], b = D.dsrc2[c];
             int64_t x[RW], y[RW];
 #pragma unroll
@@ -256,6 +260,13 @@ __device__ __forceinline__ void derive(const MsArgs &C, const MScanDesc &D, int6
             } else {                                        // VC_INRANGE
 #pragma unroll
                 for (int r = 0; r < RW; r++) { v[c][r] = 1; alive[r] = in[r]; }
+            }
+            // a filter on the looked-up value (the dimension selection's bit, a dimension column's range) takes effect at
+            // once: the lookups of the columns after it are then issued for the rows that are still in
+            if ((C.filtered >> c) & 1u) {
+                const int64_t lo = D.flo[c], hi = D.fhi[c];
+#pragma unroll
+                for (int r = 0; r < RW; r++) alive[r] = alive[r] & (v[c][r] >= lo) & (v[c][r] <= hi);
             }
         }
     }
@@ -352,7 +363,7 @@ __global__ __launch_bounds__(kMsBlock) void k_mscan(const MsArgs C, const MScanD
             bool alive[RW];
 #pragma unroll
             for (int r = 0; r < RW; r++) alive[r] = (int64_t)((r >> 1) * (BS * 2) + (r & 1)) < rows_left;
-            derive<NC, RW>(C, D, v, alive);
+            derive<NC, RW>(C, D, v, alive, C.derived);
             eval_pass<NC, RW>(C, D, v, pass);
 #pragma unroll
             for (int r = 0; r < RW; r++) pass[r] = pass[r] & alive[r];
@@ -600,11 +611,11 @@ __global__ __launch_bounds__(kMsBlock) void k_project(const MsArgs C, const MSca
         int64_t v[NC][ROWS];
         const int64_t base = tile * TILE + (int64_t)tid * 2;
         if (tile < full) {
-            load_tile<NC, U, VEC, NT>(C, base, v);
+            load_tile<NC, U, VEC, NT>(C, base, v, C.lazy);
         } else {                                           // the partial last tile: clamped scalar loads
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                if (c < C.ncol && !((C.derived >> c) & 1u)) {
+                if (c < C.ncol && !(((C.derived | C.lazy) >> c) & 1u)) {
 #pragma unroll
                     for (int r = 0; r < ROWS; r++) {
                         const int64_t i = base + (int64_t)(r >> 1) * (BS * 2) + (r & 1);
@@ -616,11 +627,11 @@ __global__ __launch_bounds__(kMsBlock) void k_project(const MsArgs C, const MSca
         bool alive[ROWS], pass[ROWS];
 #pragma unroll
         for (int r = 0; r < ROWS; r++) alive[r] = base + (int64_t)(r >> 1) * (BS * 2) + (r & 1) < C.n;
-        derive<NC, ROWS>(C, D, v, alive);
-        eval_pass<NC, ROWS>(C, D, v, pass);
+        // the columns that decide survival (every filtered column and what it is derived from); filters fold into `alive`
+        derive<NC, ROWS>(C, D, v, alive, C.derived & ~C.lazy);
         uint64_t m[ROWS];
 #pragma unroll
-        for (int r = 0; r < ROWS; r++) { pass[r] = pass[r] & alive[r]; m[r] = __ballot(pass[r]); }
+        for (int r = 0; r < ROWS; r++) { pass[r] = alive[r]; m[r] = __ballot(pass[r]); }
         if (lane == 0) {
 #pragma unroll
             for (int u = 0; u < U; u++) wcnt[u][wave] = __popcll(m[2 * u]) + __popcll(m[2 * u + 1]);
@@ -644,6 +655,17 @@ __global__ __launch_bounds__(kMsBlock) void k_project(const MsArgs C, const MSca
                 dst[r] = off + mybase[u] + __popcll(m[2 * u] & below) + __popcll(m[2 * u + 1] & below) + ((r & 1) && pass[2 * u] ? 1 : 0);
                 if (pass[r]) D.out_idx[dst[r]] = base + (int64_t)u * (BS * 2) + (r & 1);
             }
+            // the other columns, for the survivors only: table columns at the lane's own rows, then lookups
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                if (c < C.ncol && ((C.lazy >> c) & 1u) && !((C.derived >> c) & 1u)) {
+                    const char *t = (const char *)C.ptr[c];
+                    const int w = C.width(c);
+#pragma unroll
+                    for (int r = 0; r < ROWS; r++) { v[c][r] = 0; if (pass[r]) v[c][r] = load_scalar(t, w, base + (int64_t)(r >> 1) * (BS * 2) + (r & 1)); }
+                }
+            }
+            derive<NC, ROWS>(C, D, v, alive, C.derived & C.lazy, false);
             for (int o = 0; o < D.nout; o++) {             // wave-uniform loop over the produced columns
                 const int oc = D.out_col[o];
                 int64_t *out = D.out_ptr[o];
