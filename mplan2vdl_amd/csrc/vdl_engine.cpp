@@ -431,25 +431,36 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
     int64_t m = 0;
     std::vector<BufP> outs(distinct.size());
     if (n > 0 && !J.never) {
-        BufP counts = dev_alloc(c, sizeof(int64_t) * (size_t)(ntiles + 1));
+        BufP counts = dev_alloc(c, sizeof(int64_t) * (size_t)(ntiles + 1)), offsets = dev_alloc(c, sizeof(int64_t) * (size_t)(ntiles + 1));
+        BufP scratch = dev_alloc(c, (size_t)project_scratch_bytes(n));
         BufP ddev = dev_alloc(c, sizeof(MScanDesc));
         d.tile_counts = (int64_t *)counts->p;
+        d.out_idx = (int64_t *)scratch->p;
         HIP_CHECK(hipMemcpyAsync(ddev->p, &d, sizeof d, hipMemcpyHostToDevice, c->stream));
-        HIP_CHECK(launch_project(cols, (const MScanDesc *)ddev->p, false, c->num_cus, c->stream));
-        HIP_CHECK(launch_compact_scan((int64_t *)counts->p, ntiles, c->stream));
-        HIP_CHECK(hipMemcpyAsync(&m, (int64_t *)counts->p + ntiles, sizeof m, hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(launch_project_select(cols, (const MScanDesc *)ddev->p, c->num_cus, c->stream));
+        HIP_CHECK(hipMemcpyAsync(offsets->p, counts->p, sizeof(int64_t) * (size_t)ntiles, hipMemcpyDeviceToDevice, c->stream));
+        HIP_CHECK(launch_compact_scan((int64_t *)offsets->p, ntiles, c->stream));
+        HIP_CHECK(hipMemcpyAsync(&m, (int64_t *)offsets->p + ntiles, sizeof m, hipMemcpyDeviceToHost, c->stream));
         HIP_CHECK(hipStreamSynchronize(c->stream));             // (also: `d` has been read by the first copy)
         sel->idx = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(m, 1));
         d.out_idx = (int64_t *)sel->idx->p;
         d.nout = (int)distinct.size();
+        d.take = 0;
         for (size_t o = 0; o < distinct.size(); o++) {
             outs[o] = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(m, 1));
             d.out_col[o] = distinct[o];
             d.out_ptr[o] = (int64_t *)outs[o]->p;
+            d.take |= 1u << distinct[o];
+        }
+        for (int k = cols.ncol - 1; k >= 0; k--) {               // ... and what they are derived from
+            if (!((d.take >> k) & 1u)) continue;
+            if (J.cols[(size_t)k].idx >= 0) d.take |= 1u << J.cols[(size_t)k].idx;
+            if (J.cols[(size_t)k].idx2 >= 0) d.take |= 1u << J.cols[(size_t)k].idx2;
         }
         if (m > 0) {
             HIP_CHECK(hipMemcpyAsync(ddev->p, &d, sizeof d, hipMemcpyHostToDevice, c->stream));
-            HIP_CHECK(launch_project(cols, (const MScanDesc *)ddev->p, true, c->num_cus, c->stream));
+            HIP_CHECK(launch_project_take(cols, (const MScanDesc *)ddev->p, scratch->p, (const int64_t *)counts->p, (const int64_t *)offsets->p,
+                                          c->num_cus, c->stream));
             HIP_CHECK(hipStreamSynchronize(c->stream));         // `d` lives on this frame
         }
     } else {

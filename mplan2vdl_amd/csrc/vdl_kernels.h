@@ -80,7 +80,8 @@ struct MScanDesc {                           // lives in device memory, read wit
     int nout = 0, out_col[kMaxProjOuts] = {};
     int64_t *out_ptr[kMaxProjOuts] = {};     // one packed int64 vector per produced column
     int64_t *out_idx = nullptr;              // the surviving rows' slot ids, ascending
-    int64_t *tile_counts = nullptr;          // [tiles + 1]: survivors per tile (count pass), then their exclusive prefix (write pass)
+    int64_t *tile_counts = nullptr;          // [tiles + 1]: survivors per tile
+    uint32_t take = 0;                       // k_project_take: the columns the outputs need (with the columns they are derived from)
     int ncomp = 0, key_masked = 0;           // ncomp > 0: the key program is this canonical form
     int64_t key_mask = 0;
     KeyComp comp[kMaxKeyComps];
@@ -97,7 +98,12 @@ hipError_t launch_mscan(const MScanCols &cols, const MScanDesc &d, const MScanDe
 // Projection scan (ProjPlan, vdl_fuse.h): pass 1 counts the surviving rows of every tile into d.tile_counts, pass 2 (after an
 // exclusive prefix sum over the counts) writes their slot ids and the produced columns, packed, in row order.
 int64_t project_tiles(int64_t n);
-hipError_t launch_project(const MScanCols &cols, const MScanDesc *dev_desc, bool write, int num_cus, hipStream_t s);
+int64_t project_scratch_bytes(int64_t n);
+// d.out_idx = the scratch area (project_scratch_bytes), d.tile_counts = [tiles + 1]
+hipError_t launch_project_select(const MScanCols &cols, const MScanDesc *dev_desc, int num_cus, hipStream_t s);
+// d.take = the columns the outputs need, d.out_* = the packed result vectors; counts = survivors per tile, offsets = their prefix
+hipError_t launch_project_take(const MScanCols &cols, const MScanDesc *dev_desc, const void *scratch, const int64_t *counts, const int64_t *offsets,
+                               int num_cus, hipStream_t s);
 // sharded FoldChoose: after the MIN all-reduce of the row-id words, the owning rank substitutes the value, others 0
 hipError_t launch_mscan_resolve_first(const MScanCols &cols, const MScanDesc &d, const MScanDesc *dev_desc, int64_t *table, hipStream_t s);
 

@@ -251,7 +251,11 @@ __device__ __forceinline__ void derive(const MsArgs &C, const MScanDesc &D, int6
             } else if (kind == VC_BITS) {
                 uint64_t word[RW];
 #pragma unroll
-                for (int r = 0; r < RW; r++) { word[r] = ~0ull; if (in[r] && t) word[r] = ((const uint64_t *)t)[x[r] >> 6]; }      // no bitmap: every dimension row is selected
+                for (int r = 0; r < RW; r++) word[r] = ~0ull;                      // no bitmap: every dimension row is selected
+                if (t && n > 0) {                               // (unconditional: rows that are out read word 0; the bitmap is small and cached, and the loads go out together)
+#pragma unroll
+                    for (int r = 0; r < RW; r++) word[r] = ((const uint64_t *)t)[(in[r] ? x[r] : 0) >> 6];
+                }
 #pragma unroll
                 for (int r = 0; r < RW; r++) { v[c][r] = in[r] ? (int64_t)((word[r] >> (x[r] & 63)) & 1ull) : 0; alive[r] = in[r]; }
             } else if (kind == VC_LUT) {                    // outside the table: 0, not EPS (Like over an offset outside the heap)
@@ -597,16 +601,26 @@ __global__ void k_mscan_first(const MsArgs C, const MScanDesc *__restrict__ Dp, 
     }
 }
 
-// ---- projection scan (ProjPlan, vdl_fuse.h): filters + FK lookups of the fact table in one pass, survivors written packed ----
-// Row order inside a tile is (sub-iteration u, wave, lane, row of the lane's pair): a survivor's rank is the survivors of the
-// (u, wave) groups before its own plus the ballots of its group below its lane.
-template <int NC, int U, bool VEC, bool NT, bool WRITE>
-__global__ __launch_bounds__(kMsBlock) void k_project(const MsArgs C, const MScanDesc *__restrict__ Dp) {
+// ---- projection scan (ProjPlan, vdl_fuse.h) -----------------------------------------------------------------------------
+// k_project_select: ONE pass over the columns that decide a row's survival (filtered columns and what they are derived from:
+// for Q3 the ship date and the join index, 12 B/row, plus the dimension bitmap looked up through the index).  Per tile it
+// leaves the number of survivors and their positions inside the tile (16 bits each, in row order) in a scratch area.
+// k_project_take: after a prefix sum over the tile counts, one WAVE per tile reads the survivors' positions and, with every
+// lane busy, loads what the rest of the program wants of them -- fact columns at the row, dimension columns through the
+// index -- and writes the packed vectors.  (A second full pass with exec-masked loads for 5 % of the lanes took 4x as long.)
+// Row order inside a tile is (sub-iteration u, wave, lane, row of the lane's pair).
+constexpr int kProjU = 4;
+constexpr int kProjTile = kMsBlock * 2 * kProjU;
+static_assert(kProjTile <= 65536, "positions inside a tile fit 16 bits");
+
+template <int NC, int U, bool VEC, bool NT>
+__global__ __launch_bounds__(kMsBlock) void k_project_select(const MsArgs C, const MScanDesc *__restrict__ Dp) {
     const MScanDesc &D = *Dp;
     constexpr int BS = kMsBlock, ROWS = 2 * U, TILE = BS * ROWS, NW = BS / kWave;
     __shared__ int wcnt[U][NW];
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     const int64_t full = C.n / TILE, ntiles = (C.n + TILE - 1) / TILE;
+    uint16_t *__restrict__ scratch = (uint16_t *)D.out_idx;            // [tiles][TILE] positions
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int64_t v[NC][ROWS];
         const int64_t base = tile * TILE + (int64_t)tid * 2;
@@ -624,14 +638,13 @@ __global__ __launch_bounds__(kMsBlock) void k_project(const MsArgs C, const MSca
                 }
             }
         }
-        bool alive[ROWS], pass[ROWS];
+        bool alive[ROWS];
 #pragma unroll
         for (int r = 0; r < ROWS; r++) alive[r] = base + (int64_t)(r >> 1) * (BS * 2) + (r & 1) < C.n;
-        // the columns that decide survival (every filtered column and what it is derived from); filters fold into `alive`
-        derive<NC, ROWS>(C, D, v, alive, C.derived & ~C.lazy);
+        derive<NC, ROWS>(C, D, v, alive, C.derived & ~C.lazy);      // filters fold into `alive` as they are derived
         uint64_t m[ROWS];
 #pragma unroll
-        for (int r = 0; r < ROWS; r++) { pass[r] = alive[r]; m[r] = __ballot(pass[r]); }
+        for (int r = 0; r < ROWS; r++) m[r] = __ballot(alive[r]);
         if (lane == 0) {
 #pragma unroll
             for (int u = 0; u < U; u++) wcnt[u][wave] = __popcll(m[2 * u]) + __popcll(m[2 * u + 1]);
@@ -643,50 +656,54 @@ __global__ __launch_bounds__(kMsBlock) void k_project(const MsArgs C, const MSca
 #pragma unroll
             for (int w = 0; w < NW; w++) { if (w == wave) mybase[u] = total; total += wcnt[u][w]; }
         }
-        if (!WRITE) {
-            if (tid == 0) D.tile_counts[tile] = total;
-        } else {
-            const int64_t off = D.tile_counts[tile];
-            const uint64_t below = (1ull << lane) - 1;
-            int64_t dst[ROWS];
+        if (tid == 0) D.tile_counts[tile] = total;
+        const uint64_t below = (1ull << lane) - 1;
 #pragma unroll
-            for (int r = 0; r < ROWS; r++) {
-                const int u = r >> 1;
-                dst[r] = off + mybase[u] + __popcll(m[2 * u] & below) + __popcll(m[2 * u + 1] & below) + ((r & 1) && pass[2 * u] ? 1 : 0);
-                if (pass[r]) D.out_idx[dst[r]] = base + (int64_t)u * (BS * 2) + (r & 1);
-            }
-            // the other columns, for the survivors only: table columns at the lane's own rows, then lookups
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-                if (c < C.ncol && ((C.lazy >> c) & 1u) && !((C.derived >> c) & 1u)) {
-                    const char *t = (const char *)C.ptr[c];
-                    const int w = C.width(c);
-#pragma unroll
-                    for (int r = 0; r < ROWS; r++) { v[c][r] = 0; if (pass[r]) v[c][r] = load_scalar(t, w, base + (int64_t)(r >> 1) * (BS * 2) + (r & 1)); }
-                }
-            }
-            derive<NC, ROWS>(C, D, v, alive, C.derived & C.lazy, false);
-            for (int o = 0; o < D.nout; o++) {             // wave-uniform loop over the produced columns
-                const int oc = D.out_col[o];
-                int64_t *out = D.out_ptr[o];
-                int64_t x[ROWS];
-#pragma unroll
-                for (int r = 0; r < ROWS; r++) x[r] = 0;
-#pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    if (c == oc) {
-#pragma unroll
-                        for (int r = 0; r < ROWS; r++) x[r] = v[c][r];
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < ROWS; r++) if (pass[r]) out[dst[r]] = x[r];
-            }
+        for (int r = 0; r < ROWS; r++) {
+            const int u = r >> 1;
+            const int rank = mybase[u] + __popcll(m[2 * u] & below) + __popcll(m[2 * u + 1] & below) + ((r & 1) && alive[2 * u] ? 1 : 0);
+            if (alive[r]) scratch[tile * TILE + rank] = (uint16_t)(tid * 2 + u * (BS * 2) + (r & 1));
         }
         __syncthreads();                                   // wcnt is rewritten by the next tile
     }
 }
-constexpr int kProjU = 2;
+
+// one wave per tile; lane k takes the tile's survivors k, k + 64, ...
+template <int NC>
+__global__ __launch_bounds__(kMsBlock) void k_project_take(const MsArgs C, const MScanDesc *__restrict__ Dp, const uint16_t *__restrict__ scratch,
+                                                           const int64_t *__restrict__ counts /* raw */, const int64_t *__restrict__ offsets /* exclusive prefix */) {
+    const MScanDesc &D = *Dp;
+    constexpr int TILE = kProjTile;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t ntiles = (C.n + TILE - 1) / TILE;
+    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave);
+    for (int64_t tile = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; tile < ntiles; tile += wstride) {
+        const int cnt = (int)counts[tile];
+        const int64_t off = offsets[tile];
+        for (int k0 = 0; k0 < cnt; k0 += kWave) {          // wave-uniform
+            const int k = k0 + lane;
+            const bool on = k < cnt;
+            const int64_t row = tile * TILE + (on ? (int64_t)scratch[tile * TILE + k] : 0);      // idle lanes re-read a row of the tile
+            int64_t v[NC][1];
+            // every table column the outputs need (directly or as a lookup's index), at the row; then the lookups
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                v[c][0] = 0;
+                if (c < C.ncol && ((D.take >> c) & 1u) && !((C.derived >> c) & 1u)) v[c][0] = load_scalar(C.ptr[c], C.width(c), row < C.n ? row : C.n - 1);
+            }
+            bool alive[1] = {on};
+            derive<NC, 1>(C, D, v, alive, C.derived & D.take, false);
+            if (on) D.out_idx[off + k] = row;
+            for (int o = 0; o < D.nout; o++) {
+                const int oc = D.out_col[o];
+                int64_t x = 0;
+#pragma unroll
+                for (int c = 0; c < NC; c++) if (c == oc) x = v[c][0];
+                if (on) D.out_ptr[o][off + k] = x;
+            }
+        }
+    }
+}
 
 typedef void (*mscan_fn)(const MsArgs, const MScanDesc *);
 struct MsVariant { int nc, u; bool vec, grouped, der; mscan_fn fn; const char *name; };
@@ -776,25 +793,29 @@ hipError_t launch_mscan(const MScanCols &cols, const MScanDesc &d, const MScanDe
     return hipGetLastError();
 }
 
-int64_t project_tiles(int64_t n) { const int64_t tile = (int64_t)kMsBlock * 2 * kProjU; return (n + tile - 1) / tile; }
+int64_t project_tiles(int64_t n) { return (n + kProjTile - 1) / kProjTile; }
+int64_t project_scratch_bytes(int64_t n) { return project_tiles(n) * kProjTile * (int64_t)sizeof(uint16_t); }
 
-hipError_t launch_project(const MScanCols &cols, const MScanDesc *dev_desc, bool write, int num_cus, hipStream_t s) {
+hipError_t launch_project_select(const MScanCols &cols, const MScanDesc *dev_desc, int num_cus, hipStream_t s) {
     (void)hipGetLastError();
     if (cols.n <= 0) return hipSuccess;
     bool vec = true;
     for (int c = 0; c < cols.ncol; c++)
-        if (cols.kind[c] == VC_DIRECT && ((uintptr_t)cols.ptr[c]) % (uintptr_t)(2 * cols.width[c]) != 0) vec = false;
+        if (cols.kind[c] == VC_DIRECT && !cols.lazy[c] && ((uintptr_t)cols.ptr[c]) % (uintptr_t)(2 * cols.width[c]) != 0) vec = false;
     int64_t grid = project_tiles(cols.n);
     if (grid > (int64_t)num_cus * 8) grid = (int64_t)num_cus * 8;
     const MsArgs a = ms_args(cols);
-    constexpr int NC = kMaxVCols;
-    if (vec) {
-        if (write) k_project<NC, kProjU, true, true, true><<<(int)grid, kMsBlock, 0, s>>>(a, dev_desc);
-        else k_project<NC, kProjU, true, true, false><<<(int)grid, kMsBlock, 0, s>>>(a, dev_desc);
-    } else {
-        if (write) k_project<NC, kProjU, false, false, true><<<(int)grid, kMsBlock, 0, s>>>(a, dev_desc);
-        else k_project<NC, kProjU, false, false, false><<<(int)grid, kMsBlock, 0, s>>>(a, dev_desc);
-    }
+    if (vec) k_project_select<kMaxVCols, kProjU, true, true><<<(int)grid, kMsBlock, 0, s>>>(a, dev_desc);
+    else k_project_select<kMaxVCols, kProjU, false, false><<<(int)grid, kMsBlock, 0, s>>>(a, dev_desc);
+    return hipGetLastError();
+}
+hipError_t launch_project_take(const MScanCols &cols, const MScanDesc *dev_desc, const void *scratch, const int64_t *counts, const int64_t *offsets,
+                               int num_cus, hipStream_t s) {
+    (void)hipGetLastError();
+    if (cols.n <= 0) return hipSuccess;
+    int64_t grid = (project_tiles(cols.n) + 3) / 4;
+    if (grid > (int64_t)num_cus * 16) grid = (int64_t)num_cus * 16;
+    k_project_take<kMaxVCols><<<(int)grid, kMsBlock, 0, s>>>(ms_args(cols), dev_desc, (const uint16_t *)scratch, counts, offsets);
     return hipGetLastError();
 }
 
