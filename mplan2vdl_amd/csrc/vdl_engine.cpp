@@ -433,11 +433,28 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
     if (n > 0 && !J.never) {
         BufP counts = dev_alloc(c, sizeof(int64_t) * (size_t)(ntiles + 1)), offsets = dev_alloc(c, sizeof(int64_t) * (size_t)(ntiles + 1));
         BufP scratch = dev_alloc(c, (size_t)project_scratch_bytes(n));
-        BufP ddev = dev_alloc(c, sizeof(MScanDesc));
-        d.tile_counts = (int64_t *)counts->p;
-        d.out_idx = (int64_t *)scratch->p;
-        HIP_CHECK(hipMemcpyAsync(ddev->p, &d, sizeof d, hipMemcpyHostToDevice, c->stream));
-        HIP_CHECK(launch_project_select(cols, (const MScanDesc *)ddev->p, c->num_cus, c->stream));
+        BufP ddev = dev_alloc(c, sizeof(MScanDesc)), sdev = dev_alloc(c, sizeof(MScanDesc));
+        // the select pass sees only the columns that decide survival, renumbered (its register use grows with the column count)
+        MScanCols scols;
+        auto sdesc = std::make_unique<MScanDesc>();
+        std::vector<int> renum((size_t)cols.ncol, -1);
+        for (int k = 0; k < cols.ncol; k++) {
+            if (cols.lazy[k]) continue;
+            const int j = scols.ncol++;
+            renum[(size_t)k] = j;
+            scols.ptr[j] = cols.ptr[k]; scols.width[j] = cols.width[k]; scols.filtered[j] = cols.filtered[k];
+            scols.lo[j] = cols.lo[k]; scols.hi[j] = cols.hi[k]; scols.kind[j] = cols.kind[k];
+            sdesc->flo[j] = d.flo[k]; sdesc->fhi[j] = d.fhi[k]; sdesc->dkind[j] = d.dkind[k]; sdesc->dn[j] = d.dn[k];
+            sdesc->dsrc[j] = d.dsrc[k] >= 0 ? renum[(size_t)d.dsrc[k]] : -1;
+            sdesc->dsrc2[j] = d.dsrc2[k] >= 0 ? renum[(size_t)d.dsrc2[k]] : -1;
+        }
+        scols.n = n;
+        sel->bitmap = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>((n + 63) >> 6, 1));
+        sdesc->tile_counts = (int64_t *)counts->p;
+        sdesc->out_idx = (int64_t *)scratch->p;
+        sdesc->out_ptr[0] = (int64_t *)sel->bitmap->p;
+        HIP_CHECK(hipMemcpyAsync(sdev->p, sdesc.get(), sizeof(MScanDesc), hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(launch_project_select(scols, (const MScanDesc *)sdev->p, c->num_cus, c->stream));
         HIP_CHECK(hipMemcpyAsync(offsets->p, counts->p, sizeof(int64_t) * (size_t)ntiles, hipMemcpyDeviceToDevice, c->stream));
         HIP_CHECK(launch_compact_scan((int64_t *)offsets->p, ntiles, c->stream));
         HIP_CHECK(hipMemcpyAsync(&m, (int64_t *)offsets->p + ntiles, sizeof m, hipMemcpyDeviceToHost, c->stream));

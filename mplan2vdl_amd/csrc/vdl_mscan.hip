@@ -657,6 +657,21 @@ __global__ __launch_bounds__(kMsBlock) void k_project_select(const MsArgs C, con
             for (int w = 0; w < NW; w++) { if (w == wave) mybase[u] = total; total += wcnt[u][w]; }
         }
         if (tid == 0) D.tile_counts[tile] = total;
+        // the selection's bitmap over the table's rows, for whoever asks the sparse vectors for their validity: lanes 2l, 2l+1
+        // of the two ballots of a sub-iteration are rows 2l, 2l+1 of the wave's 128 -- interleave them into two words
+        if (D.out_ptr[0] && lane < 2 * U) {
+            const int u = lane >> 1, half = lane & 1;
+            uint64_t a = 0, b = 0;
+#pragma unroll
+            for (int uu = 0; uu < U; uu++) if (uu == u) { a = m[2 * uu]; b = m[2 * uu + 1]; }
+            uint64_t x = half ? (a >> 32) : (a & 0xffffffffull), y = half ? (b >> 32) : (b & 0xffffffffull);
+            x = (x | (x << 16)) & 0x0000ffff0000ffffull; x = (x | (x << 8)) & 0x00ff00ff00ff00ffull; x = (x | (x << 4)) & 0x0f0f0f0f0f0f0f0full;
+            x = (x | (x << 2)) & 0x3333333333333333ull; x = (x | (x << 1)) & 0x5555555555555555ull;
+            y = (y | (y << 16)) & 0x0000ffff0000ffffull; y = (y | (y << 8)) & 0x00ff00ff00ff00ffull; y = (y | (y << 4)) & 0x0f0f0f0f0f0f0f0full;
+            y = (y | (y << 2)) & 0x3333333333333333ull; y = (y | (y << 1)) & 0x5555555555555555ull;
+            const int64_t word = (tile * TILE + (int64_t)u * (BS * 2) + (int64_t)wave * 128) / 64 + half;
+            if (word < ((C.n + 63) >> 6)) ((uint64_t *)D.out_ptr[0])[word] = x | (y << 1);
+        }
         const uint64_t below = (1ull << lane) - 1;
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
@@ -805,8 +820,10 @@ hipError_t launch_project_select(const MScanCols &cols, const MScanDesc *dev_des
     int64_t grid = project_tiles(cols.n);
     if (grid > (int64_t)num_cus * 8) grid = (int64_t)num_cus * 8;
     const MsArgs a = ms_args(cols);
-    if (vec) k_project_select<kMaxVCols, kProjU, true, true><<<(int)grid, kMsBlock, 0, s>>>(a, dev_desc);
-    else k_project_select<kMaxVCols, kProjU, false, false><<<(int)grid, kMsBlock, 0, s>>>(a, dev_desc);
+#define VDL_PJ(NC) do { if (vec) k_project_select<NC, kProjU, true, true><<<(int)grid, kMsBlock, 0, s>>>(a, dev_desc); \
+                        else k_project_select<NC, kProjU, false, false><<<(int)grid, kMsBlock, 0, s>>>(a, dev_desc); } while (0)
+    if (cols.ncol <= 4) VDL_PJ(4); else if (cols.ncol <= 8) VDL_PJ(8); else VDL_PJ(kMaxVCols);      // (registers: NC x 8 rows x 64 bits)
+#undef VDL_PJ
     return hipGetLastError();
 }
 hipError_t launch_project_take(const MScanCols &cols, const MScanDesc *dev_desc, const void *scratch, const int64_t *counts, const int64_t *offsets,
