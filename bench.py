@@ -50,6 +50,28 @@ def q1_matches_sql(results, total_rows, threads, report=None):
     return ok
 
 
+def q3_matches_sql(eng, res):
+    """Q3's SQL (tests/golden/tpch10noorder/03.sql.mplan:1-19) evaluated with numpy over the columns in HBM (downloaded):
+    a checker, outside every timed region.  Result rows are compared as a sorted list (the query carries no ORDER BY)."""
+    import numpy as np
+
+    c = {n: eng.download(n) for n in ("customer.c_mktsegment", "orders.o_orderdate", "orders.o_shippriority", "orders.orders_customer",
+                                      "lineitem.lineitem_orders", "lineitem.l_orderkey", "lineitem.l_shipdate", "lineitem.l_extendedprice",
+                                      "lineitem.l_discount")}
+    order_ok = (c["orders.o_orderdate"] < 728732) & (c["customer.c_mktsegment"][c["orders.orders_customer"]] == 16)     # date '1995-03-15', 'BUILDING'
+    l_ord = c["lineitem.lineitem_orders"]
+    rows = np.nonzero((c["lineitem.l_shipdate"] > 728732) & order_ok[l_ord])[0]
+    okey = c["lineitem.l_orderkey"][rows].astype(np.int64)
+    uniq, first, inv = np.unique(okey, return_index=True, return_inverse=True)      # one order = one (orderkey, date, priority) group
+    rev = np.zeros(len(uniq), np.int64)
+    np.add.at(rev, inv.reshape(-1), c["lineitem.l_extendedprice"][rows] * (100 - c["lineitem.l_discount"][rows]))
+    fr = l_ord[rows[first]]
+    want = np.stack([uniq, rev, c["orders.o_orderdate"][fr].astype(np.int64), c["orders.o_shippriority"][fr].astype(np.int64)], axis=1)
+    got = np.stack([np.asarray(res["tmp93"][".l_orderkey__lineitem__l_orderkey"]), np.asarray(res["tmp110"][".revenue"]),
+                    np.asarray(res["tmp115"][".o_orderdate__orders__o_orderdate"]), np.asarray(res["tmp120"][".o_shippriority__orders__o_shippriority"])], axis=1)
+    return bool(np.array_equal(got[np.argsort(got[:, 0])], want[np.argsort(want[:, 0])]))
+
+
 def secondary_measurements(eng, rows):
     """Not the headline metric: the other two single-GPU configurations of BASELINE.json on the same box, measured
     after the timed region (Q1 grouped fused scan over the same lineitem rows; Q3 at SF10 through the statement-by-
@@ -84,17 +106,56 @@ def secondary_measurements(eng, rows):
         n_orders = 15000000                       # SF10: 60 M lineitems, 15 M orders, 1.5 M customers
         keep = datagen.register_q3_columns(eng, n_orders)
         q3 = eng.parse(open(os.path.join(ROOT, "tests", "golden", "q3.vdl")).read())
-        wall = []
-        for k in range(7):
-            torch.cuda.synchronize(); t0 = time.perf_counter(); q3.execute(); wall.append(time.perf_counter() - t0)
+        times = {}
+        for dev_out in (True, False):
+            q3.set_device_outputs(dev_out)
+            wall = []
+            for k in range(7):
+                torch.cuda.synchronize(); t0 = time.perf_counter(); q3.execute(); torch.cuda.synchronize(); wall.append(time.perf_counter() - t0)
+            times[dev_out] = sum(wall[2:]) / len(wall[2:])
         res = q3.collect(as_numpy=True)["results"]
-        dt = sum(wall[2:]) / len(wall[2:])
-        also["tpch_q3_sf10"] = {"lineitem_rows": 4 * n_orders, "ms_per_query": 1e3 * dt, "lineitem_rows_per_s": 4 * n_orders / dt,
-                                "result_rows": int(len(res["tmp110"][".revenue"])), "path": "statement by statement (not fused)"}
+        also["tpch_q3_sf10"] = {"lineitem_rows": 4 * n_orders, "ms_per_query": 1e3 * times[False], "lineitem_rows_per_s": 4 * n_orders / times[False],
+                                "ms_per_query_results_left_in_hbm": 1e3 * times[True], "result_rows": int(len(res["tmp110"][".revenue"])),
+                                "path": "fused front (one projection scan of lineitem: ship-date filter + join filter through the orders bitmap, "
+                                        "survivors' columns packed) then Partition / Scatter / Fold statement by statement",
+                                "verified_vs_numpy_sql": q3_matches_sql(eng, res)}
         q3.close()
+        for name in list(keep) + ["customer.c_mktsegment", "orders.o_orderdate", "orders.o_shippriority", "orders.orders_customer",
+                                  "lineitem.l_shipdate", "lineitem.l_extendedprice", "lineitem.l_discount"]:
+            try:
+                eng.drop(name)
+            except Exception:                     # noqa: BLE001
+                pass
         del keep
     except Exception as exc:                      # noqa: BLE001
         also["tpch_q3_sf10"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    try:
+        n_li = datagen.LINEITEM_ROWS["sf10"]
+        keep = datagen.register_q14_columns(eng, n_li)
+        q14 = eng.parse(open(os.path.join(ROOT, "tests", "golden", "q14.vdl")).read())
+        q14.set_profiling(True)
+        us, wall = [], []
+        for k in range(8):
+            torch.cuda.synchronize(); t0 = time.perf_counter(); r = q14.run(); wall.append(time.perf_counter() - t0)
+            us.append(next(v for lbl, v in r["timings"].items() if "FusedScan" in lbl))
+        k_us = sum(us[2:]) / len(us[2:])
+        t = datagen.q14_tables(n_li)
+        import numpy as np
+        sel = (t["lineitem.l_shipdate"] >= 728902) & (t["lineitem.l_shipdate"] <= 728931)              # 1995-09-01 <= d < 1995-10-01
+        rev = t["lineitem.l_extendedprice"][sel] * (100 - t["lineitem.l_discount"][sel])
+        heap = bytes(t["part.p_type.heap"].tobytes())
+        promo_off = {o for o in set(t["part.p_type"].tolist()) if heap[o:o + 5] == b"PROMO"}
+        promo = np.isin(t["part.p_type"][t["lineitem.lineitem_part"][sel]], sorted(promo_off))
+        want = int(rev[promo].sum()) * 10000 // int(rev.sum())
+        also["tpch_q14_sf10"] = {"lineitem_rows": n_li, "ms_per_query": 1e3 * sum(wall[2:]) / len(wall[2:]), "kernel_us": k_us,
+                                 "bytes_per_row": datagen.Q14_BYTES_PER_ROW,
+                                 "roofline_frac": n_li * datagen.Q14_BYTES_PER_ROW / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                 "path": "fused JOIN scan: lineitem columns + part.p_type looked up through the join index + a LIKE table, one pass",
+                                 "verified_vs_numpy_sql": r["results"]["tmp65"][".promo_revenue"] == [want]}
+        q14.close()
+        del keep
+    except Exception as exc:                      # noqa: BLE001
+        also["tpch_q14_sf10"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     return also
 
 

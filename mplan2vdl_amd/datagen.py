@@ -146,3 +146,56 @@ def register_q3_columns(engine, n_orders, li_rows=None, device="cuda", seed=SEED
     reg("lineitem.l_orderkey", (1 + (lo // 8) * 32 + (lo % 8)).to(torch.int32))
     torch.cuda.synchronize()
     return keep
+
+
+# ---- TPC-H Q14 shape: lineitem with a join index into part, part.p_type as offsets into a string heap ---------------
+# (p_type: 150 strings "<size> <finish> <metal>" in TPC-H, a fifth of them starting with PROMO; here 25 strings, 5 of them
+# PROMO ..., at 8-byte aligned offsets of a MonetDB-style heap.)  lineitem_part is drawn with the counter-based generator,
+# so any row range of lineitem can be produced independently.
+Q14_COLUMNS = ["lineitem.l_shipdate", "lineitem.l_extendedprice", "lineitem.l_discount", "lineitem.lineitem_part",
+               "lineitem.lineitem_l_orderkey_l_linenumber_pkey", "part.part_p_partkey_pkey", "part.p_type", "part.p_type.heap"]
+Q14_BYTES_PER_ROW = 4 + 8 + 8 + 8            # what the fused join scan reads of every lineitem row (the part side is looked up)
+_P_TYPES = ["%s %s %s" % (a, b, c) for a in ("PROMO", "STANDARD", "SMALL", "MEDIUM", "ECONOMY") for b in ("ANODIZED", "BRUSHED", "PLATED", "POLISHED", "BURNISHED")
+            for c in ("TIN",)]
+
+
+def q14_part(n_part, seed=SEED):
+    heap = bytearray(8)
+    offs = []
+    for s_ in _P_TYPES:
+        while len(heap) % 8:
+            heap.append(0)
+        offs.append(len(heap))
+        heap += s_.encode() + b"\0"
+    pick = generate(ColumnSpec("part.p_type", np.int64, 0, len(offs) - 1, 1, 0), 0, n_part, seed)
+    return {"part.part_p_partkey_pkey": np.zeros(n_part, np.int64), "part.p_type": np.asarray(offs, np.int64)[pick],
+            "part.p_type.heap": np.frombuffer(bytes(heap), dtype=np.int8).copy()}
+
+
+def q14_tables(n_li, seed=SEED):
+    """Host (numpy) Q14 catalog: n_li lineitems, n_li // 30 parts."""
+    n_part = max(n_li // 30, 1)
+    t = q14_part(n_part, seed)
+    for name in ("lineitem.l_shipdate", "lineitem.l_extendedprice", "lineitem.l_discount"):
+        t[name] = generate(LINEITEM[name], 0, n_li, seed)
+    t["lineitem.lineitem_part"] = generate(ColumnSpec("lineitem.lineitem_part", np.int64, 0, n_part - 1, 1, 0), 0, n_li, seed)
+    t["lineitem.lineitem_l_orderkey_l_linenumber_pkey"] = np.zeros(n_li, np.int64)
+    return t
+
+
+def register_q14_columns(engine, n_li, li_rows=None, device="cuda", seed=SEED):
+    """The Q14 catalog of `q14_tables` built on the GPU: part in full (uploaded: 1/30 of lineitem), lineitem rows
+    [li_rows[0], li_rows[1]) generated in place.  Returns the tensors backing registered columns."""
+    import torch
+
+    n_part = max(n_li // 30, 1)
+    r0, r1 = li_rows if li_rows is not None else (0, n_li)
+    for name, v in q14_part(n_part, seed).items():
+        engine.upload(name, v)
+    for name in ("lineitem.l_shipdate", "lineitem.l_extendedprice", "lineitem.l_discount"):
+        engine.generate(LINEITEM[name], r0, r1 - r0, seed)
+    engine.generate(ColumnSpec("lineitem.lineitem_part", np.int64, 0, n_part - 1, 1, 0), r0, r1 - r0, seed)
+    keep = {"lineitem.lineitem_l_orderkey_l_linenumber_pkey": torch.zeros(r1 - r0, dtype=torch.int64, device=device)}
+    engine.register_tensor("lineitem.lineitem_l_orderkey_l_linenumber_pkey", keep["lineitem.lineitem_l_orderkey_l_linenumber_pkey"])
+    torch.cuda.synchronize()
+    return keep
