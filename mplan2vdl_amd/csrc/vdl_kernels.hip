@@ -272,13 +272,14 @@ const ScanVariant kScanVariants[] = {
     VDL_SV(4, 1, 4, false, false, 256),
     // small inputs: smaller tiles so that every CU gets work
     VDL_SV(4, 1, 4, true, true, 256),
-    // tuning family for sweeps (VDL_SCAN_TUNE)
+#ifdef VDL_SCAN_TUNING_FAMILY      // tools/build_variant.sh: the family VDL_SCAN_TUNE sweeps over (profiles/r01/tune_scan.md); not shipped
     VDL_SV(4, 1, 2, true, false, 256), VDL_SV(4, 1, 4, true, false, 256), VDL_SV(4, 1, 8, true, false, 256),
     VDL_SV(4, 1, 2, true, true, 256),  VDL_SV(4, 1, 8, true, true, 256),
     VDL_SV(4, 1, 2, true, false, 512), VDL_SV(4, 1, 4, true, false, 512), VDL_SV(4, 1, 8, true, false, 512),
     VDL_SV(4, 1, 2, true, true, 512),  VDL_SV(4, 1, 4, true, true, 512),  VDL_SV(4, 1, 8, true, true, 512),
     VDL_SV(4, 1, 10, true, true, 256), VDL_SV(4, 1, 14, true, true, 256), VDL_SV(4, 1, 12, true, false, 256), VDL_SV(4, 1, 6, true, true, 512),
     VDL_SV(4, 1, 2, true, false, 1024), VDL_SV(4, 1, 2, true, true, 1024),
+#endif
 };
 #undef VDL_SV
 constexpr int kNumScanVariants = sizeof(kScanVariants) / sizeof(kScanVariants[0]);

@@ -409,11 +409,7 @@ __global__ __launch_bounds__(kMsBlock) void k_mscan(const MsArgs C, const MScanD
                     for (int r = 0; r < RW; r++) acc[r] &= mk;
                 }
             } else
-#ifdef VDL_MS_NOKEY           // timing experiment only (results are wrong): what does the interpreted key program cost?
-            for (int s = 0; s < 0; s++) {
-#else
             for (int s = 0; s < D.nkey; s++) {
-#endif
                 const KeyStep st = D.key[s];               // wave-uniform
                 if (st.kind == KeyStep::LOAD) {
 #pragma unroll
@@ -449,11 +445,7 @@ __global__ __launch_bounds__(kMsBlock) void k_mscan(const MsArgs C, const MScanD
 #pragma unroll
             for (int r = 0; r < RW; r++) cnt += pass[r] ? 1 : 0;
         }
-#ifdef VDL_MS_NOAGG          // timing experiment only (results are wrong): what do the aggregates cost?
-        for (int j = 0; j < 0; j++) {
-#else
         for (int j = 0; j < nagg; j++) {                   // runtime loop: descriptors by scalar loads
-#endif
             const MAggDesc d = D.agg[j];                   // whole descriptor into SGPRs: one scalar-load wait per aggregate
             const int rk = rk_of(d.kind);
             int64_t t[RW];
@@ -495,9 +487,6 @@ __global__ __launch_bounds__(kMsBlock) void k_mscan(const MsArgs C, const MScanD
         for (int u = 0; u < U; u++) { rowid[2 * u] = C.row0 + base + (int64_t)u * (BS * 2); rowid[2 * u + 1] = rowid[2 * u] + 1; }
         load_tile<NC, U, VEC, NT>(C, base, v);
         process(std::integral_constant<int, ROWS>{}, v, rowid, (int64_t)1 << 40);
-#ifdef VDL_MS_REPEAT          // timing experiment only (results are wrong): how much of the kernel is the per-tile work?
-        for (int rep = 1; rep < VDL_MS_REPEAT; rep++) process(std::integral_constant<int, ROWS>{}, v, rowid, (int64_t)1 << 40);
-#endif
     }
     if (blockIdx.x == gridDim.x - 1 && ntiles * TILE < C.n) {
         if (DER) {

@@ -9,6 +9,6 @@ mkdir -p "$OUT"
 cd "$ROOT/mplan2vdl_amd/csrc"
 /opt/rocm/bin/hipcc -x hip --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$ROOT/include" -Wall -Wno-unused-result "$@" -c vdl_mscan.hip -o "$OUT/vdl_mscan_$TAG.o"
 L=$ROOT/mplan2vdl_amd/lib
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o "$OUT/libvdl_$TAG.so" "$L/vdl_parse.o" "$L/vdl_fuse.o" "$L/vdl_kernels.o" "$L/vdl_ops.o" "$L/vdl_partition.o" "$OUT/vdl_mscan_$TAG.o" "$L/vdl_engine.o" "$L/vdl_exchange.o"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o "$OUT/libvdl_$TAG.so" "$L/vdl_parse.o" "$L/vdl_fuse.o" "$L/vdl_kernels.o" "$L/vdl_ops.o" "$L/vdl_partition.o" "$OUT/vdl_mscan_$TAG.o" "$L/vdl_engine.o" "$L/vdl_exchange.o" "$L/vdl_comm.o" -ldl
 rm -f "$OUT/vdl_mscan_$TAG.o"
 echo "$OUT/libvdl_$TAG.so"
