@@ -181,29 +181,50 @@ void bind_fused(vdl_ctx *c, vdl_plan *p) {
     p->bound = true;
 }
 
+void patch_prelude(const vdl_plan *p, const std::vector<ScanColumn> &sc, MScanCols &cols, MScanDesc &d);
+// The columns of a scan with derived columns (fused front, dimension scans) as kernel arguments; the table's row count.
+// Tables of the prelude are patched in later (patch_prelude); `wanted` collects which ones.
+static int64_t bind_vcols(vdl_ctx *c, const std::string &table, const std::vector<ScanColumn> &sc, MScanCols &cols, MScanDesc &d, std::vector<char> &wanted) {
+    cols.ncol = (int)sc.size();
+    int64_t n = -1;
+    for (int k = 0; k < cols.ncol; k++) {
+        const ScanColumn &s = sc[(size_t)k];
+        cols.kind[k] = s.kind;
+        cols.lo[k] = s.lo; cols.hi[k] = s.hi;
+        cols.filtered[k] = (s.lo != INT64_MIN || s.hi != INT64_MAX) ? 1 : 0;
+        d.flo[k] = s.lo; d.fhi[k] = s.hi;
+        d.dkind[k] = s.kind; d.dsrc[k] = s.idx; d.dsrc2[k] = s.idx2;
+        if (s.kind == VC_DIRECT) {
+            const Column &col = find_col(c, s.name);
+            if (n >= 0 && col.n != n) throw Error(VDL_ERR_SHAPE, "columns of table '" + table + "' have different lengths in the catalog");
+            n = col.n;
+            cols.ptr[k] = col.dev; cols.width[k] = col.width;
+        } else if (s.kind == VC_GATHER || s.kind == VC_INRANGE) {
+            const Column &col = find_col(c, s.name);
+            cols.ptr[k] = col.dev; cols.width[k] = col.width;
+            d.dn[k] = col.n;
+        } else {
+            cols.ptr[k] = nullptr; cols.width[k] = 8;
+            if (s.prelude >= 0) wanted[(size_t)s.prelude] = 1;
+        }
+    }
+    cols.n = n;
+    return n;
+}
+
 // Dimension-side work of scans with derived columns (FusedPlan::prelude): the per-operator executor runs the statements
 // that hold the dimension selections (filters on the dimension table, joins of dimensions with further dimensions) and
 // their validity bitmaps become the lookup tables of the fact scan; LIKE patterns are evaluated once per heap offset.
 // Part of the query: runs on every execution.  `wanted[k]`: item k is referred to by a scan that is about to run.
-void run_prelude_items(vdl_ctx *c, vdl_plan *p, const std::vector<char> &wanted) {
+void run_prelude_items(vdl_ctx *c, vdl_plan *p, const std::vector<char> &asked) {
     const FusedPlan &F = p->fused;
     p->prelude_buf.assign(F.prelude.size(), nullptr);
     p->prelude_n.assign(F.prelude.size(), 0);
-    std::vector<int> witnesses;
-    for (size_t k = 0; k < F.prelude.size(); k++)
-        if (wanted[k] && F.prelude[k].kind == PreludeItem::DIM_BITMAP) witnesses.push_back(F.prelude[k].witness);
-    if (!witnesses.empty()) {
-        GenExec g(c, p);
-        g.run_nodes(witnesses, nullptr);
-        for (size_t k = 0; k < F.prelude.size(); k++) {
-            if (!wanted[k] || F.prelude[k].kind != PreludeItem::DIM_BITMAP) continue;
-            const DVec &v = g.vec[(size_t)F.prelude[k].witness];
-            p->prelude_n[k] = v.n;
-            if (v.kind == DVec::SPARSE) p->prelude_buf[k] = g.bitmap_of(v.sel);
-            else p->prelude_buf[k] = g.densify(v).valid;                  // null: every dimension row holds a value
-        }
-        HIP_CHECK(hipStreamSynchronize(c->stream));
-    }
+    std::vector<char> wanted(asked);
+    for (size_t k = F.prelude.size(); k-- > 0;)                 // what a wanted dimension scan looks up itself (earlier items)
+        if (wanted[k] && F.prelude[k].scan)
+            for (const ScanColumn &sc : F.prelude[k].cols) if (sc.prelude >= 0) wanted[(size_t)sc.prelude] = 1;
+    const bool scans = !getenv("VDL_NO_DIM_SCAN");
     for (size_t k = 0; k < F.prelude.size(); k++) {
         const PreludeItem &it = F.prelude[k];
         if (!wanted[k] || it.kind != PreludeItem::LIKE_LUT) continue;
@@ -217,6 +238,43 @@ void run_prelude_items(vdl_ctx *c, vdl_plan *p, const std::vector<char> &wanted)
         p->prelude_n[k] = heap.n;
         HIP_CHECK(launch_like(offs, nullptr, heap.n, hs, nullptr, heap.n, pat, (int64_t *)p->prelude_buf[k]->p, c->stream));
     }
+    std::vector<int> witnesses;
+    for (size_t k = 0; k < F.prelude.size(); k++)
+        if (wanted[k] && F.prelude[k].kind == PreludeItem::DIM_BITMAP && !(scans && F.prelude[k].scan)) witnesses.push_back(F.prelude[k].witness);
+    if (!witnesses.empty()) {
+        GenExec g(c, p);
+        g.run_nodes(witnesses, nullptr);
+        for (size_t k = 0; k < F.prelude.size(); k++) {
+            if (!wanted[k] || F.prelude[k].kind != PreludeItem::DIM_BITMAP || (scans && F.prelude[k].scan)) continue;
+            const DVec &v = g.vec[(size_t)F.prelude[k].witness];
+            p->prelude_n[k] = v.n;
+            if (v.kind == DVec::SPARSE) p->prelude_buf[k] = g.bitmap_of(v.sel);
+            else p->prelude_buf[k] = g.densify(v).valid;                  // null: every dimension row holds a value
+        }
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    // dimension scans, in order: an item only looks up earlier ones
+    std::vector<BufP> descs;
+    std::vector<std::unique_ptr<MScanDesc>> host_descs;
+    for (size_t k = 0; scans && k < F.prelude.size(); k++) {
+        const PreludeItem &it = F.prelude[k];
+        if (!wanted[k] || it.kind != PreludeItem::DIM_BITMAP || !it.scan) continue;
+        MScanCols cols;
+        host_descs.push_back(std::make_unique<MScanDesc>());
+        MScanDesc *d = host_descs.back().get();
+        std::vector<char> unused(F.prelude.size(), 0);
+        const int64_t n = bind_vcols(c, it.table, it.cols, cols, *d, unused);
+        patch_prelude(p, it.cols, cols, *d);
+        const size_t words = (size_t)std::max<int64_t>((n + 63) >> 6, 1);
+        p->prelude_buf[k] = dev_alloc(c, sizeof(uint64_t) * words);
+        p->prelude_n[k] = n;
+        if (it.never || n <= 0) { HIP_CHECK(hipMemsetAsync(p->prelude_buf[k]->p, 0, sizeof(uint64_t) * words, c->stream)); continue; }
+        d->out_ptr[0] = (int64_t *)p->prelude_buf[k]->p;           // bitmap only: no positions, no counts
+        descs.push_back(dev_alloc(c, sizeof(MScanDesc)));
+        HIP_CHECK(hipMemcpyAsync(descs.back()->p, d, sizeof(MScanDesc), hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(launch_project_select(cols, (const MScanDesc *)descs.back()->p, c->num_cus, c->stream));
+    }
+    if (!host_descs.empty()) HIP_CHECK(hipStreamSynchronize(c->stream));      // the descriptors live on this frame
 }
 // hand the tables to a scan that looks them up
 void patch_prelude(const vdl_plan *p, const std::vector<ScanColumn> &sc, MScanCols &cols, MScanDesc &d) {
@@ -366,31 +424,8 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
     MScanCols cols;
     auto desc = std::make_unique<MScanDesc>();
     MScanDesc &d = *desc;
-    cols.ncol = (int)J.cols.size();
-    int64_t n = -1;
     std::vector<char> wanted(p->fused.prelude.size(), 0);
-    for (int k = 0; k < cols.ncol; k++) {
-        const ScanColumn &sc = J.cols[(size_t)k];
-        cols.kind[k] = sc.kind;
-        cols.lo[k] = sc.lo; cols.hi[k] = sc.hi;
-        cols.filtered[k] = (sc.lo != INT64_MIN || sc.hi != INT64_MAX) ? 1 : 0;
-        d.flo[k] = sc.lo; d.fhi[k] = sc.hi;
-        d.dkind[k] = sc.kind; d.dsrc[k] = sc.idx; d.dsrc2[k] = sc.idx2;
-        if (sc.kind == VC_DIRECT) {
-            const Column &col = find_col(c, sc.name);
-            if (n >= 0 && col.n != n) throw Error(VDL_ERR_SHAPE, "columns of table '" + J.table + "' have different lengths in the catalog");
-            n = col.n;
-            cols.ptr[k] = col.dev; cols.width[k] = col.width;
-        } else if (sc.kind == VC_GATHER || sc.kind == VC_INRANGE) {
-            const Column &col = find_col(c, sc.name);
-            cols.ptr[k] = col.dev; cols.width[k] = col.width;
-            d.dn[k] = col.n;
-        } else {
-            cols.ptr[k] = nullptr; cols.width[k] = 8;
-            if (sc.prelude >= 0) wanted[(size_t)sc.prelude] = 1;
-        }
-    }
-    cols.n = n;
+    const int64_t n = bind_vcols(c, J.table, J.cols, cols, d, wanted);
     // columns that decide a row's survival: the filtered ones and what they are derived from; a lookup whose range check is
     // done by another deciding column through the same index (the dimension bitmap, an INRANGE) decides nothing itself.
     // Everything else is read for the surviving rows only, in the write pass.

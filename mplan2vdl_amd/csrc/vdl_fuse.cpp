@@ -557,8 +557,46 @@ struct VCols {
         for (size_t k = 0; k < F.prelude.size(); k++)
             if (F.prelude[k].kind == PreludeItem::DIM_BITMAP && F.prelude[k].witness == w->second) return (int)k;
         PreludeItem it; it.kind = PreludeItem::DIM_BITMAP; it.witness = w->second;
+        lower_dimension(dsel, it);                              // (may append the items ITS lookups need: they come first)
         F.prelude.push_back(it);
         return (int)F.prelude.size() - 1;
+    }
+    // the dimension-side selection as a scan of its own (PreludeItem::scan), when it has the form
+    void lower_dimension(int dsel, PreludeItem &it) {
+        const Selection &S = B.sels[(size_t)dsel - 1];
+        Clause cl;
+        if (!to_clause(S.pred, cl)) return;
+        std::string inner_why;
+        std::vector<ScanColumn> dc;
+        VCols inner{dc, F, B, inner_why, {}};
+        bool never = cl.never;
+        for (auto &kv : cl.cols) {
+            const int c = inner(cl.atoms.at(kv.first));
+            if (c < 0) return;
+            if (kv.second.empty()) { never = true; continue; }
+            if (kv.second.size() != 1) return;
+            dc[(size_t)c].lo = std::max(dc[(size_t)c].lo, kv.second[0].first);
+            dc[(size_t)c].hi = std::min(dc[(size_t)c].hi, kv.second[0].second);
+        }
+        prune_range_checks(dc, nullptr);
+        if ((int)dc.size() > kMaxProjCols) return;
+        bool direct = false;
+        for (const ScanColumn &c : dc) direct |= c.kind == VC_DIRECT && c.name.compare(0, S.table.size() + 1, S.table + ".") == 0;
+        if (!direct) return;
+        it.scan = true; it.table = S.table; it.cols = dc; it.never = never;
+    }
+    // a range check that a lookup through the same index column performs anyway needs no column of its own
+    static void prune_range_checks(std::vector<ScanColumn> &cols, std::vector<int> *node_col) {
+        for (size_t k = 0; k < cols.size();) {
+            bool redundant = false;
+            if (cols[k].kind == VC_INRANGE)
+                for (const ScanColumn &o : cols) redundant |= (o.kind == VC_BITS || o.kind == VC_GATHER) && o.idx == cols[k].idx;
+            if (node_col) for (int nc : *node_col) if (nc == (int)k) redundant = false;
+            if (!redundant) { k++; continue; }
+            cols.erase(cols.begin() + (long)k);
+            for (ScanColumn &o : cols) { if (o.idx > (int)k) o.idx--; if (o.idx2 > (int)k) o.idx2--; }
+            if (node_col) for (int &nc : *node_col) if (nc > (int)k) nc--;
+        }
     }
     int prelude_lut(const std::string &heap, const std::string &pattern) {
         for (size_t k = 0; k < F.prelude.size(); k++)
@@ -719,16 +757,7 @@ static void build_projection(const Program &P, Builder &B, FusedPlan &F) {
     if ((int)J.nodes.size() > kMaxProjOuts) { J.why = "more than " + std::to_string(kMaxProjOuts) + " vectors to produce"; return; }
     // a range check that a lookup through the same index column performs anyway needs no column of its own (the first such
     // lookup then decides about the row and is not deferred to the survivors: run_projection)
-    for (size_t k = 0; k < J.cols.size();) {
-        bool redundant = false;
-        if (J.cols[k].kind == VC_INRANGE)
-            for (const ScanColumn &o : J.cols) redundant |= (o.kind == VC_BITS || o.kind == VC_GATHER) && o.idx == J.cols[k].idx;
-        for (int nc : J.node_col) if (nc == (int)k) redundant = false;
-        if (!redundant) { k++; continue; }
-        J.cols.erase(J.cols.begin() + (long)k);
-        for (ScanColumn &o : J.cols) { if (o.idx > (int)k) o.idx--; if (o.idx2 > (int)k) o.idx2--; }
-        for (int &nc : J.node_col) if (nc > (int)k) nc--;
-    }
+    VCols::prune_range_checks(J.cols, &J.node_col);
     if ((int)J.cols.size() > kMaxProjCols) { J.why = "more than " + std::to_string(kMaxProjCols) + " columns"; return; }
     bool direct = false;
     for (const ScanColumn &c : J.cols) direct |= c.kind == VC_DIRECT && c.name.compare(0, J.table.size() + 1, J.table + ".") == 0;
@@ -882,11 +911,23 @@ static void show_col(const ScanColumn &c, size_t k, std::ostringstream &o) {
     o << "\n";
 }
 
+static void show_prelude(const FusedPlan &F, std::ostringstream &o) {
+    for (size_t k = 0; k < F.prelude.size(); k++) {
+        const PreludeItem &it = F.prelude[k];
+        if (it.kind == PreludeItem::LIKE_LUT) { o << "prelude " << k << ": LIKE '" << it.pattern << "' over every offset of " << it.heap << "\n"; continue; }
+        o << "prelude " << k << ": bitmap of the dimension-side selection held by statement " << it.witness;
+        if (!it.scan) { o << " (per-operator executor)\n"; continue; }
+        o << ": one scan of " << it.table << (it.never ? " [never]" : "") << "\n";
+        for (size_t c = 0; c < it.cols.size(); c++) show_col(it.cols[c], c, o);
+    }
+}
+
 std::string describe_fused(const FusedPlan &F) {
     std::ostringstream o;
     if (!F.ok) {
         o << "not fused: " << F.why_not << "\n";
         if (F.proj.ok) {
+            show_prelude(F, o);
             o << "fused front: one scan of " << F.proj.table << (F.proj.never ? " [never]" : "") << " hands these statements to the per-operator executor as sparse vectors:";
             for (size_t k = 0; k < F.proj.nodes.size(); k++) o << " Id " << F.proj.nodes[k] << (F.proj.node_col[k] < 0 ? "=rowid" : "=col" + std::to_string(F.proj.node_col[k]));
             o << "\n";
@@ -896,10 +937,7 @@ std::string describe_fused(const FusedPlan &F) {
         }
         return o.str();
     }
-    for (size_t k = 0; k < F.prelude.size(); k++) {
-        if (F.prelude[k].kind == PreludeItem::DIM_BITMAP) o << "prelude " << k << ": bitmap of the dimension-side selection held by statement " << F.prelude[k].witness << " (per-operator executor)\n";
-        else o << "prelude " << k << ": LIKE '" << F.prelude[k].pattern << "' over every offset of " << F.prelude[k].heap << "\n";
-    }
+    show_prelude(F, o);
     for (size_t i = 0; i < F.scans.size(); i++) {
         const ScanPlan &sp = F.scans[i];
         o << "scan " << i << " table=" << sp.table << (sp.never ? " [never]" : "") << "\n";

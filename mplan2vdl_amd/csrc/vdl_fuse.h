@@ -47,6 +47,14 @@ struct PreludeItem {
     enum Kind : int { DIM_BITMAP = 0, LIKE_LUT = 1 } kind = DIM_BITMAP;
     int witness = 0;           // DIM_BITMAP: statement whose vector is EPS exactly where the dimension selection rejects the row
     std::string heap, pattern; // LIKE_LUT
+    // DIM_BITMAP whose selection is itself a conjunction of range filters over columns of the dimension table and lookups
+    // through ITS foreign keys (orders filtered by date and by the customer's segment): one scan over the dimension table
+    // writes the bitmap -- the select pass of the fused front with nothing to take -- instead of the per-operator executor
+    // running the witness statement and everything under it.
+    bool scan = false;
+    std::string table;
+    std::vector<ScanColumn> cols;
+    bool never = false;
 };
 
 struct ScanFactor {            // (a + s * column[col])

@@ -634,18 +634,6 @@ __global__ __launch_bounds__(kMsBlock) void k_project_select(const MsArgs C, con
         uint64_t m[ROWS];
 #pragma unroll
         for (int r = 0; r < ROWS; r++) m[r] = __ballot(alive[r]);
-        if (lane == 0) {
-#pragma unroll
-            for (int u = 0; u < U; u++) wcnt[u][wave] = __popcll(m[2 * u]) + __popcll(m[2 * u + 1]);
-        }
-        __syncthreads();
-        int total = 0, mybase[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-#pragma unroll
-            for (int w = 0; w < NW; w++) { if (w == wave) mybase[u] = total; total += wcnt[u][w]; }
-        }
-        if (tid == 0) D.tile_counts[tile] = total;
         // the selection's bitmap over the table's rows, for whoever asks the sparse vectors for their validity: lanes 2l, 2l+1
         // of the two ballots of a sub-iteration are rows 2l, 2l+1 of the wave's 128 -- interleave them into two words
         if (D.out_ptr[0] && lane < 2 * U) {
@@ -661,6 +649,19 @@ __global__ __launch_bounds__(kMsBlock) void k_project_select(const MsArgs C, con
             const int64_t word = (tile * TILE + (int64_t)u * (BS * 2) + (int64_t)wave * 128) / 64 + half;
             if (word < ((C.n + 63) >> 6)) ((uint64_t *)D.out_ptr[0])[word] = x | (y << 1);
         }
+        if (!scratch) continue;                            // a dimension scan wants the bitmap only (block-uniform)
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < U; u++) wcnt[u][wave] = __popcll(m[2 * u]) + __popcll(m[2 * u + 1]);
+        }
+        __syncthreads();
+        int total = 0, mybase[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+#pragma unroll
+            for (int w = 0; w < NW; w++) { if (w == wave) mybase[u] = total; total += wcnt[u][w]; }
+        }
+        if (tid == 0) D.tile_counts[tile] = total;
         const uint64_t below = (1ull << lane) - 1;
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {

@@ -159,7 +159,7 @@ def test_engine_matches_oracle_on_the_vlite_dialect(cfg, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["VDL_SPARSE_ALWAYS", "VDL_NO_SPARSE", "VDL_NO_EXPR_FUSION", "VDL_NO_FILTER_FUSION", "VDL_NO_PROJECTION"])
+@pytest.mark.parametrize("mode", ["VDL_SPARSE_ALWAYS", "VDL_NO_SPARSE", "VDL_NO_EXPR_FUSION", "VDL_NO_FILTER_FUSION", "VDL_NO_PROJECTION", "VDL_NO_DIM_SCAN"])
 def test_sparse_vector_routes_agree(cfg, monkeypatch, mode):
     """The general executor keeps vectors that only hold values on a selection in compact form after selective
     filters, and runs chains of single-reader element-wise operators as one fused kernel.  Sparse forced on for
@@ -194,6 +194,14 @@ def test_which_plans_have_a_fused_front(cfg):
         if "\nfused front:" in d:
             front.append(n)
     assert front == [3, 9, 10, 11, 15, 20]
+    # ... and whose dimension-side selections are scans of the dimension table themselves (PreludeItem::scan)
+    dims = {}
+    for n in PLANS:
+        d = e.parse(frontend.compile_plan(open(os.path.join(META, "%02d.sql.mplan" % n)).read(), cfg)).describe()
+        tables = [l.split("one scan of ")[1].strip() for l in d.split("\n") if l.startswith("prelude") and "one scan of" in l]
+        if tables:
+            dims[n] = tables
+    assert dims == {3: ["customer", "orders"], 9: ["part"], 10: ["orders"], 11: ["nation", "supplier"], 20: ["part", "partsupp"]}
     q3 = e.parse(open(os.path.join(ROOT, "tests", "golden", "q3.vdl")).read()).describe()
     assert "\nfused front: one scan of lineitem" in q3 and "orders.o_orderdate[col1]" in q3 and "prelude0.bit[col1] in [1,1]" in q3
 
