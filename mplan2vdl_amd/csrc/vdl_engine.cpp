@@ -46,6 +46,17 @@ static bool use_kscan(const ScanPlan &sp) {
     return sp.aggs.size() == 1 && sp.cols.size() <= 4;
 }
 
+// formula columns (VC_FORM): their steps, one column after the other, into the descriptor's pool
+static void bind_forms(const std::vector<ScanColumn> &sc, MScanDesc &d) {
+    int used = 0;
+    for (size_t k = 0; k < sc.size(); k++) {
+        if (sc[k].kind != VC_FORM) continue;
+        if (used + (int)sc[k].form.size() > kMaxFormSteps) throw Error(VDL_ERR_UNSUPPORTED, "the scan's conditions have more than " + std::to_string(kMaxFormSteps) + " steps in all");
+        d.dsrc[k] = used; d.dsrc2[k] = (int)sc[k].form.size();
+        for (const FormStep &f : sc[k].form) d.form[used++] = f;
+    }
+}
+
 template <typename PlanT>
 int64_t bind_mscan(vdl_ctx *c, const PlanT &sp, MScanCols &cols, MScanDesc &d, int64_t *bytes_per_row, int64_t row0) {
     cols = MScanCols{};
@@ -77,6 +88,7 @@ int64_t bind_mscan(vdl_ctx *c, const PlanT &sp, MScanCols &cols, MScanDesc &d, i
             d.dn[k] = 0;
         }
     }
+    bind_forms(sp.cols, d);
     cols.n = n;
     cols.row0 = row0;
     for (int j = 0; j < d.nagg; j++) {
@@ -208,6 +220,7 @@ static int64_t bind_vcols(vdl_ctx *c, const std::string &table, const std::vecto
             if (s.prelude >= 0) wanted[(size_t)s.prelude] = 1;
         }
     }
+    bind_forms(sc, d);
     cols.n = n;
     return n;
 }
@@ -444,8 +457,7 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
         }
         for (int k = cols.ncol - 1; k >= 0; k--) {
             if (!decides[(size_t)k]) continue;
-            if (J.cols[(size_t)k].idx >= 0) decides[(size_t)J.cols[(size_t)k].idx] = 1;
-            if (J.cols[(size_t)k].idx2 >= 0) decides[(size_t)J.cols[(size_t)k].idx2] = 1;
+            for (int src : J.cols[(size_t)k].sources()) decides[(size_t)src] = 1;
         }
         for (int k = 0; k < cols.ncol; k++) cols.lazy[k] = decides[(size_t)k] ? 0 : 1;
     }
@@ -480,6 +492,14 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
             scols.ptr[j] = cols.ptr[k]; scols.width[j] = cols.width[k]; scols.filtered[j] = cols.filtered[k];
             scols.lo[j] = cols.lo[k]; scols.hi[j] = cols.hi[k]; scols.kind[j] = cols.kind[k];
             sdesc->flo[j] = d.flo[k]; sdesc->fhi[j] = d.fhi[k]; sdesc->dkind[j] = d.dkind[k]; sdesc->dn[j] = d.dn[k];
+            if (d.dkind[k] == VC_FORM) {                          // its steps stay where they are in the pool; their columns are renumbered
+                sdesc->dsrc[j] = d.dsrc[k]; sdesc->dsrc2[j] = d.dsrc2[k];
+                for (int f = d.dsrc[k]; f < d.dsrc[k] + d.dsrc2[k]; f++) {
+                    sdesc->form[f] = d.form[f];
+                    if (d.form[f].op == FormStep::LEAF) sdesc->form[f].col = renum[(size_t)d.form[f].col];
+                }
+                continue;
+            }
             sdesc->dsrc[j] = d.dsrc[k] >= 0 ? renum[(size_t)d.dsrc[k]] : -1;
             sdesc->dsrc2[j] = d.dsrc2[k] >= 0 ? renum[(size_t)d.dsrc2[k]] : -1;
         }
@@ -506,8 +526,7 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
         }
         for (int k = cols.ncol - 1; k >= 0; k--) {               // ... and what they are derived from
             if (!((d.take >> k) & 1u)) continue;
-            if (J.cols[(size_t)k].idx >= 0) d.take |= 1u << J.cols[(size_t)k].idx;
-            if (J.cols[(size_t)k].idx2 >= 0) d.take |= 1u << J.cols[(size_t)k].idx2;
+            for (int src : J.cols[(size_t)k].sources()) d.take |= 1u << src;
         }
         if (m > 0) {
             HIP_CHECK(hipMemcpyAsync(ddev->p, &d, sizeof d, hipMemcpyHostToDevice, c->stream));

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <functional>
 #include <sstream>
 
 namespace vdl {
@@ -179,8 +180,37 @@ bool leaf_cmp(const Row &p, RowP &atom, IvSet &set) {
     return false;
 }
 
-// predicate "p != 0" -> Clause; false when p has a shape the scan kernel cannot express
+// A 0 / 1 valued expression built from range tests of atoms with AND / OR / NOT (NOT as the emitter writes it: Equals(x, 0),
+// Subtract(1, x): Vlite.hs:240-245).  What does not reduce to per-column ranges is evaluated per row as a formula column
+// (VC_FORM): disjunctions across columns, CASE WHEN conditions that are aggregate inputs.
+bool is_formula(const RowP &e) {
+    if (e->k == Row::CONST) return e->c0 == 0 || e->c0 == 1;
+    if (is_boolean_atom(e)) return true;
+    if (e->k != Row::BIN) return false;
+    RowP a; IvSet s;
+    if (leaf_cmp(*e, a, s)) return true;
+    if (e->bin == B_LAND || e->bin == B_LOR) return is_formula(e->l) && is_formula(e->r);
+    if (e->bin == B_EQ) return (is_const(e->r, 0) && is_formula(e->l)) || (is_const(e->l, 0) && is_formula(e->r));
+    if (e->bin == B_SUB) return is_const(e->l, 1) && is_formula(e->r);
+    return false;
+}
+
+bool to_clause_strict(const RowP &p, Clause &out);
+// predicate "p != 0" -> Clause: per-atom interval sets, conjuncts of any other boolean shape as formula "atoms" that must be 1;
+// false when p has a shape the scan kernels cannot express
 bool to_clause(const RowP &p, Clause &out) {
+    if (!p) return true;
+    if (p->k == Row::BIN && p->bin == B_LAND) return to_clause(p->l, out) && to_clause(p->r, out);
+    Clause tmp;
+    if (to_clause_strict(p, tmp)) {
+        out.never |= tmp.never;
+        for (auto &kv : tmp.cols) clause_and(out, tmp.atoms.at(kv.first), kv.second);
+        return true;
+    }
+    if (is_formula(p)) { clause_and(out, p, IvSet{{1, 1}}); return true; }
+    return false;
+}
+bool to_clause_strict(const RowP &p, Clause &out) {
     if (!p) return true;
     if (p->k == Row::CONST) { if (p->c0 == 0) out.never = true; return true; }
     if (is_atom(p)) {                                      // a value read as a truth value (also: a lookup's validity, a LIKE)
@@ -191,12 +221,12 @@ bool to_clause(const RowP &p, Clause &out) {
     if (p->k != Row::BIN) return false;
     RowP atom; IvSet set;
     if (leaf_cmp(*p, atom, set)) { clause_and(out, atom, set); return true; }
-    if (p->bin == B_LAND) return to_clause(p->l, out) && to_clause(p->r, out);
+    if (p->bin == B_LAND) return to_clause_strict(p->l, out) && to_clause_strict(p->r, out);
     if (p->bin == B_LOR) {
         // only a disjunction of conditions on ONE column stays a per-column filter
         // (e.g. `<=` printed as LogicalOr(Greater, Equals), /root/reference/src/Vdl.hs:143-144)
         Clause a, b;
-        if (!to_clause(p->l, a) || !to_clause(p->r, b)) return false;
+        if (!to_clause_strict(p->l, a) || !to_clause_strict(p->r, b)) return false;
         if (a.never && b.never) { out.never = true; return true; }
         if (a.never) { for (auto &kv : b.cols) clause_and(out, b.atoms.at(kv.first), kv.second); return true; }
         if (b.never) { for (auto &kv : a.cols) clause_and(out, a.atoms.at(kv.first), kv.second); return true; }
@@ -219,9 +249,15 @@ bool to_affine(const RowP &e, Affine &out) {
     if (e->k != Row::BIN) return false;
     Affine x, y;
     // NOT of a 0 / 1 atom, as the emitter writes it: Equals(x, 0) (negcond = cond ==. zeros, Vlite.hs:240)
-    if (e->bin == B_EQ && ((is_const(e->r, 0) && is_boolean_atom(e->l)) || (is_const(e->l, 0) && is_boolean_atom(e->r)))) {
+    auto boolean = [](const RowP &x) { return is_boolean_atom(x) || (x->k == Row::BIN && is_formula(x)); };
+    if (e->bin == B_EQ && ((is_const(e->r, 0) && boolean(e->l)) || (is_const(e->l, 0) && boolean(e->r)))) {
         const RowP &b = is_const(e->r, 0) ? e->l : e->r;
         out = Affine{true, row_key(b), 1, -1, b};
+        return true;
+    }
+    // a condition as a number (CASE WHEN c THEN x ELSE 0 is c * x): a formula column
+    if ((e->bin == B_LAND || e->bin == B_LOR || e->bin == B_GT || e->bin == B_EQ) && is_formula(e)) {
+        out = Affine{true, row_key(e), 0, 1, e};
         return true;
     }
     if (e->bin == B_ADD || e->bin == B_SUB) {
@@ -561,6 +597,111 @@ struct VCols {
         F.prelude.push_back(it);
         return (int)F.prelude.size() - 1;
     }
+    // formula -> postfix steps; the columns of its leaves are appended first
+    void push_leaf(std::vector<FormStep> &out, int col, const IvSet &set, int &depth, int &deepest) {
+        if (set.empty()) out.push_back(FormStep{FormStep::FALSE_, -1, 0, 0});
+        for (size_t i = 0; i < set.size(); i++) {
+            out.push_back(FormStep{FormStep::LEAF, col, set[i].first, set[i].second});
+            if (i) out.push_back(FormStep{FormStep::OR, -1, 0, 0});
+        }
+        depth += 1; deepest = std::max(deepest, depth + (set.size() > 1 ? 1 : 0));
+    }
+    bool compile_formula(const RowP &e, std::vector<FormStep> &out, int &depth, int &deepest) {
+        if (deepest >= kMaxFormDepth) { why = "condition nested too deeply"; return false; }
+        if (e->k == Row::CONST) { out.push_back(FormStep{e->c0 ? FormStep::TRUE_ : FormStep::FALSE_, -1, 0, 0}); depth++; deepest = std::max(deepest, depth); return true; }
+        {   // a sub-formula over ONE atom: a single leaf with that atom's interval set
+            Clause one;
+            if (to_clause_strict(e, one) && !one.never && one.cols.size() == 1) {
+                const int col = (*this)(one.atoms.begin()->second);
+                if (col < 0) return false;
+                push_leaf(out, col, one.cols.begin()->second, depth, deepest);
+                return true;
+            }
+        }
+        if (is_boolean_atom(e)) {
+            const int col = (*this)(e);
+            if (col < 0) return false;
+            push_leaf(out, col, IvSet{{1, 1}}, depth, deepest);
+            return true;
+        }
+        if (e->k != Row::BIN) { why = "not a condition: " + row_key(e); return false; }
+        RowP a; IvSet set;
+        if (leaf_cmp(*e, a, set)) {
+            const int col = (*this)(a);
+            if (col < 0) return false;
+            push_leaf(out, col, iv_norm(set), depth, deepest);
+            return true;
+        }
+        if (e->bin == B_LAND) {
+            // the conjuncts that are range tests merge per atom (q >= 100 and q <= 1100 is one leaf); the others are formulas
+            std::vector<RowP> conj, rest;
+            std::function<void(const RowP &)> flat = [&](const RowP &x) {
+                if (x->k == Row::BIN && x->bin == B_LAND) { flat(x->l); flat(x->r); } else conj.push_back(x);
+            };
+            flat(e);
+            Clause acc;
+            for (const RowP &x : conj) {
+                Clause t;
+                if (to_clause_strict(x, t)) { acc.never |= t.never; for (auto &kv : t.cols) clause_and(acc, t.atoms.at(kv.first), kv.second); }
+                else rest.push_back(x);
+            }
+            for (auto &kv : acc.cols) acc.never |= kv.second.empty();
+            if (acc.never) { out.push_back(FormStep{FormStep::FALSE_, -1, 0, 0}); depth++; deepest = std::max(deepest, depth); return true; }
+            int terms = 0;
+            for (auto &kv : acc.cols) {
+                const int col = (*this)(acc.atoms.at(kv.first));
+                if (col < 0) return false;
+                push_leaf(out, col, kv.second, depth, deepest);
+                terms++;
+            }
+            for (const RowP &x : rest) { if (!compile_formula(x, out, depth, deepest)) return false; terms++; }
+            if (terms == 0) { out.push_back(FormStep{FormStep::TRUE_, -1, 0, 0}); depth++; deepest = std::max(deepest, depth); return true; }
+            for (int k = 1; k < terms; k++) { out.push_back(FormStep{FormStep::AND, -1, 0, 0}); depth--; }
+            return true;
+        }
+        if (e->bin == B_LOR) {
+            if (!compile_formula(e->l, out, depth, deepest) || !compile_formula(e->r, out, depth, deepest)) return false;
+            out.push_back(FormStep{FormStep::OR, -1, 0, 0});
+            depth--;
+            return true;
+        }
+        const RowP *inner = nullptr;
+        if (e->bin == B_EQ) inner = is_const(e->r, 0) ? &e->l : is_const(e->l, 0) ? &e->r : nullptr;
+        else if (e->bin == B_SUB && is_const(e->l, 1)) inner = &e->r;
+        if (!inner) { why = "not a condition: " + row_key(e); return false; }
+        if (!compile_formula(*inner, out, depth, deepest)) return false;
+        out.push_back(FormStep{FormStep::NOT, -1, 0, 0});
+        return true;
+    }
+    // filters of a clause -> range filters of the columns; an interval SET on one atom (IN lists) -> a formula column that must be 1
+    bool lower_filters(const Clause &cl, bool &never) {
+        for (auto &kv : cl.cols) {
+            const RowP &atom = cl.atoms.at(kv.first);
+            const int c = (*this)(atom);
+            if (c < 0) return false;
+            if (kv.second.empty()) { never = true; continue; }
+            if (kv.second.size() == 1) {
+                cols[(size_t)c].lo = std::max(cols[(size_t)c].lo, kv.second[0].first);
+                cols[(size_t)c].hi = std::min(cols[(size_t)c].hi, kv.second[0].second);
+                continue;
+            }
+            std::string key = "in(" + kv.first;
+            for (auto &iv : kv.second) key += ";" + std::to_string(iv.first) + ".." + std::to_string(iv.second);
+            key += ")";
+            if (!index.count(key)) {
+                ScanColumn f;
+                f.kind = VC_FORM;
+                int depth = 0, deepest = 0;
+                push_leaf(f.form, c, kv.second, depth, deepest);
+                if ((int)f.form.size() > kMaxFormSteps) { why = "filter on " + kv.first + " has too many ranges"; return false; }
+                cols.push_back(f);
+                index[key] = (int)cols.size() - 1;
+            }
+            ScanColumn &f = cols[(size_t)index[key]];
+            f.lo = 1; f.hi = 1;
+        }
+        return true;
+    }
     // the dimension-side selection as a scan of its own (PreludeItem::scan), when it has the form
     void lower_dimension(int dsel, PreludeItem &it) {
         const Selection &S = B.sels[(size_t)dsel - 1];
@@ -570,33 +711,72 @@ struct VCols {
         std::vector<ScanColumn> dc;
         VCols inner{dc, F, B, inner_why, {}};
         bool never = cl.never;
-        for (auto &kv : cl.cols) {
-            const int c = inner(cl.atoms.at(kv.first));
-            if (c < 0) return;
-            if (kv.second.empty()) { never = true; continue; }
-            if (kv.second.size() != 1) return;
-            dc[(size_t)c].lo = std::max(dc[(size_t)c].lo, kv.second[0].first);
-            dc[(size_t)c].hi = std::min(dc[(size_t)c].hi, kv.second[0].second);
-        }
-        prune_range_checks(dc, nullptr);
+        if (!inner.lower_filters(cl, never)) return;
+        tidy_columns(dc, {});
         if ((int)dc.size() > kMaxProjCols) return;
         bool direct = false;
         for (const ScanColumn &c : dc) direct |= c.kind == VC_DIRECT && c.name.compare(0, S.table.size() + 1, S.table + ".") == 0;
         if (!direct) return;
         it.scan = true; it.table = S.table; it.cols = dc; it.never = never;
     }
-    // a range check that a lookup through the same index column performs anyway needs no column of its own
-    static void prune_range_checks(std::vector<ScanColumn> &cols, std::vector<int> *node_col) {
-        for (size_t k = 0; k < cols.size();) {
+    // Last step of a lowering: drops range checks that a lookup through the same index column performs anyway, and orders the
+    // columns so that the scan kernels (which derive columns in index order and fold a filter the moment its column exists,
+    // so that later lookups only go out for rows still alive) meet the cheap deciding columns first: table columns, then
+    // differences / conditions over them, bitmap lookups, and last the lookups of dimension columns.  Returns old -> new
+    // index (-1: dropped) for whoever refers to columns by index.
+    static std::vector<int> tidy_columns(std::vector<ScanColumn> &cols, const std::vector<int> &keep) {
+        const size_t n = cols.size();
+        std::vector<char> drop(n, 0);
+        for (size_t k = 0; k < n; k++) {
+            if (cols[k].kind != VC_INRANGE) continue;
             bool redundant = false;
-            if (cols[k].kind == VC_INRANGE)
-                for (const ScanColumn &o : cols) redundant |= (o.kind == VC_BITS || o.kind == VC_GATHER) && o.idx == cols[k].idx;
-            if (node_col) for (int nc : *node_col) if (nc == (int)k) redundant = false;
-            if (!redundant) { k++; continue; }
-            cols.erase(cols.begin() + (long)k);
-            for (ScanColumn &o : cols) { if (o.idx > (int)k) o.idx--; if (o.idx2 > (int)k) o.idx2--; }
-            if (node_col) for (int &nc : *node_col) if (nc > (int)k) nc--;
+            for (const ScanColumn &o : cols) redundant |= (o.kind == VC_BITS || o.kind == VC_GATHER) && o.idx == cols[k].idx;
+            for (int kc : keep) if (kc == (int)k) redundant = false;
+            for (const ScanColumn &o : cols) for (int src : o.sources()) if (src == (int)k) redundant = false;
+            drop[k] = redundant;
         }
+        // does the column, or something computed from it, carry a filter?
+        std::vector<char> drives(n, 0);
+        for (size_t k = n; k-- > 0;) {
+            if (drop[k]) continue;
+            if (cols[k].lo != INT64_MIN || cols[k].hi != INT64_MAX || cols[k].kind == VC_INRANGE) drives[k] = 1;
+            if (drives[k]) for (int src : cols[k].sources()) drives[(size_t)src] = 1;
+        }
+        auto cost = [&](size_t k) {
+            switch (cols[k].kind) {
+            case VC_DIRECT: return 0;
+            case VC_SUB: case VC_FORM: return 1;
+            case VC_BITS: case VC_INRANGE: return 2;
+            default: return 3;
+            }
+        };
+        std::vector<int> map(n, -1), order;
+        std::vector<char> placed(n, 0);
+        for (size_t round = 0; round < n; round++) {
+            int best = -1;
+            for (size_t k = 0; k < n; k++) {
+                if (placed[k] || drop[k]) continue;
+                bool ready = true;
+                for (int src : cols[k].sources()) ready &= (bool)placed[(size_t)src];
+                if (!ready) continue;
+                auto key = [&](size_t c) { return std::make_tuple(cols[c].kind == VC_DIRECT ? 0 : 1, drives[c] ? 0 : 1, cost(c), (int)c); };
+                if (best < 0 || key(k) < key((size_t)best)) best = (int)k;
+            }
+            if (best < 0) break;
+            placed[(size_t)best] = 1;
+            map[(size_t)best] = (int)order.size();
+            order.push_back(best);
+        }
+        std::vector<ScanColumn> out;
+        for (int k : order) {
+            ScanColumn c = cols[(size_t)k];
+            if (c.idx >= 0) c.idx = map[(size_t)c.idx];
+            if (c.idx2 >= 0) c.idx2 = map[(size_t)c.idx2];
+            for (FormStep &f : c.form) if (f.op == FormStep::LEAF) f.col = map[(size_t)f.col];
+            out.push_back(c);
+        }
+        cols = out;
+        return map;
     }
     int prelude_lut(const std::string &heap, const std::string &pattern) {
         for (size_t k = 0; k < F.prelude.size(); k++)
@@ -628,10 +808,17 @@ struct VCols {
             if (c.idx < 0) return -1;
             c.kind = VC_LUT; c.prelude = prelude_lut(atom->col, atom->pat);
             break;
-        case Row::BIN:                                  // SUB of two atoms
-            c.idx = (*this)(atom->l); c.idx2 = (*this)(atom->r);
-            if (c.idx < 0 || c.idx2 < 0) return -1;
-            c.kind = VC_SUB;
+        case Row::BIN:
+            if (atom->bin == B_SUB && is_atom(atom->l) && is_atom(atom->r)) {      // SUB of two atoms
+                c.idx = (*this)(atom->l); c.idx2 = (*this)(atom->r);
+                if (c.idx < 0 || c.idx2 < 0) return -1;
+                c.kind = VC_SUB;
+                break;
+            }
+            if (!is_formula(atom)) { why = "not a column form: " + key; return -1; }
+            c.kind = VC_FORM;
+            { int depth = 0, deepest = 0; if (!compile_formula(atom, c.form, depth, deepest)) return -1; }
+            if ((int)c.form.size() > kMaxFormSteps) { why = "condition with more than " + std::to_string(kMaxFormSteps) + " steps"; return -1; }
             break;
         default: why = "not a column form: " + key; return -1;
         }
@@ -652,14 +839,7 @@ bool lower_common(const RowP &pred, const std::vector<RowP> &data, const std::ve
         return false;
     }
     sp.never = cl.never;
-    for (auto &kv : cl.cols) {
-        const int c = col_index(cl.atoms.at(kv.first));
-        if (c < 0) return false;
-        if (kv.second.empty()) { sp.never = true; continue; }
-        if (kv.second.size() != 1) { why = "filter on " + kv.first + " is not a single range"; return false; }
-        sp.cols[(size_t)c].lo = std::max(sp.cols[(size_t)c].lo, kv.second[0].first);
-        sp.cols[(size_t)c].hi = std::min(sp.cols[(size_t)c].hi, kv.second[0].second);
-    }
+    if (!col_index.lower_filters(cl, sp.never)) return false;
     for (size_t j = 0; j < data.size(); j++) {
         ScanAgg ag;
         ag.kind = kind[j];
@@ -693,6 +873,17 @@ bool lower_common(const RowP &pred, const std::vector<RowP> &data, const std::ve
         sp.aggs.push_back(ag);
     }
     return true;
+}
+
+// tidy_columns for an aggregate scan: its aggregates (and group key) refer to columns by index
+template <typename Plan>
+void tidy_scan(Plan &sp, std::vector<KeyStep> *key) {
+    std::vector<int> keep;
+    for (const ScanAgg &ag : sp.aggs) for (const ScanFactor &f : ag.fac) keep.push_back(f.col);
+    if (key) for (const KeyStep &k : *key) if (k.kind == KeyStep::LOAD) keep.push_back(k.col);
+    const std::vector<int> map = VCols::tidy_columns(sp.cols, keep);
+    for (ScanAgg &ag : sp.aggs) for (ScanFactor &f : ag.fac) f.col = map[(size_t)f.col];
+    if (key) for (KeyStep &k : *key) if (k.kind == KeyStep::LOAD) k.col = map[(size_t)k.col];
 }
 
 }  // namespace
@@ -738,14 +929,7 @@ static void build_projection(const Program &P, Builder &B, FusedPlan &F) {
     if (!to_clause(B.pred_of(pt.sel), cl)) { J.why = "the selection is not a conjunction of per-column ranges"; return; }
     J.never = cl.never;
     VCols vc{J.cols, F, B, J.why, {}};
-    for (auto &kv : cl.cols) {
-        const int c = vc(cl.atoms.at(kv.first));
-        if (c < 0) return;
-        if (kv.second.empty()) { J.never = true; continue; }
-        if (kv.second.size() != 1) { J.why = "filter on " + kv.first + " is not a single range"; return; }
-        J.cols[(size_t)c].lo = std::max(J.cols[(size_t)c].lo, kv.second[0].first);
-        J.cols[(size_t)c].hi = std::min(J.cols[(size_t)c].hi, kv.second[0].second);
-    }
+    if (!vc.lower_filters(cl, J.never)) return;
     for (int id : P.order) {
         if (!used[(size_t)id]) continue;
         const Sym &s = B.sym[(size_t)id];
@@ -757,7 +941,10 @@ static void build_projection(const Program &P, Builder &B, FusedPlan &F) {
     if ((int)J.nodes.size() > kMaxProjOuts) { J.why = "more than " + std::to_string(kMaxProjOuts) + " vectors to produce"; return; }
     // a range check that a lookup through the same index column performs anyway needs no column of its own (the first such
     // lookup then decides about the row and is not deferred to the survivors: run_projection)
-    VCols::prune_range_checks(J.cols, &J.node_col);
+    {
+        const std::vector<int> map = VCols::tidy_columns(J.cols, J.node_col);
+        for (int &nc : J.node_col) if (nc >= 0) nc = map[(size_t)nc];
+    }
     if ((int)J.cols.size() > kMaxProjCols) { J.why = "more than " + std::to_string(kMaxProjCols) + " columns"; return; }
     bool direct = false;
     for (const ScanColumn &c : J.cols) direct |= c.kind == VC_DIRECT && c.name.compare(0, J.table.size() + 1, J.table + ".") == 0;
@@ -790,10 +977,11 @@ FusedPlan fuse_program(const Program &P) {
         sp.table = ps.table;
         VCols vc{sp.cols, F, B, F.why_not, {}};
         if (!lower_common(B.pred_of(ps.sel), ps.data, ps.kind, sp, vc, F.why_not)) return F;
+        tidy_scan(sp, (std::vector<KeyStep> *)nullptr);
         bool direct = false;
         for (const ScanColumn &c : sp.cols) direct |= c.kind == VC_DIRECT && c.name.compare(0, sp.table.size() + 1, sp.table + ".") == 0;
         if (!direct) { F.why_not = "scan touches no column of its table (row count unknown)"; return F; }
-        if ((int)sp.cols.size() > kMaxScanCols) { F.why_not = "scan touches more than 8 columns"; return F; }
+        if ((int)sp.cols.size() > kMaxJoinScanCols) { F.why_not = "scan needs more than 12 columns (table columns, lookups, conditions)"; return F; }
         if ((int)sp.aggs.size() > kMaxScanAggs) { F.why_not = "scan has more than 8 aggregates"; return F; }
         F.scans.push_back(sp);
     }
@@ -815,8 +1003,9 @@ FusedPlan fuse_program(const Program &P) {
             for (const ScanColumn &c : gp.cols) direct |= c.kind == VC_DIRECT && c.name.compare(0, gp.table.size() + 1, gp.table + ".") == 0;
             if (!direct) { F.why_not = "grouped scan touches no column of its table (row count unknown)"; return F; }
         }
+        tidy_scan(gp, &gp.key);
         if ((int)gp.key.size() > kMaxKeySteps) { F.why_not = "group key program too long"; return F; }
-        if ((int)gp.cols.size() > kMaxScanCols) { F.why_not = "grouped scan touches more than 8 columns"; return F; }
+        if ((int)gp.cols.size() > kMaxJoinScanCols) { F.why_not = "grouped scan needs more than 12 columns (table columns, lookups, conditions)"; return F; }
         if ((int)gp.aggs.size() > 2 * kMaxScanAggs) { F.why_not = "grouped scan has more than 16 aggregates"; return F; }
         if (gp.pcount * (int64_t)(gp.aggs.size() + 1) > 8192) { F.why_not = "group domain too large for the LDS-resident grouped scan"; return F; }
         F.gscans.push_back(gp);
@@ -899,6 +1088,21 @@ static void show_col(const ScanColumn &c, size_t k, std::ostringstream &o) {
     case VC_BITS: o << "prelude" << c.prelude << ".bit[col" << c.idx << "]"; break;
     case VC_LUT: o << "prelude" << c.prelude << ".lut[col" << c.idx << "]"; break;
     case VC_INRANGE: o << "inrange(col" << c.idx << ", rows of " << c.name << ")"; break;
+    case VC_FORM:
+        o << "cond(";
+        for (size_t i = 0; i < c.form.size(); i++) {
+            const FormStep &f = c.form[i];
+            if (i) o << " ";
+            if (f.op == FormStep::LEAF) {
+                o << "col" << f.col << ":[";
+                if (f.lo == INT64_MIN) o << "-inf"; else o << f.lo;
+                o << ",";
+                if (f.hi == INT64_MAX) o << "+inf"; else o << f.hi;
+                o << "]";
+            } else o << (f.op == FormStep::AND ? "and" : f.op == FormStep::OR ? "or" : f.op == FormStep::NOT ? "not" : f.op == FormStep::TRUE_ ? "true" : "false");
+        }
+        o << ")";
+        break;
     default: o << "col" << c.idx << " - col" << c.idx2; break;
     }
     if (c.lo != INT64_MIN || c.hi != INT64_MAX) {

@@ -14,7 +14,8 @@
 
 namespace vdl {
 
-constexpr int kMaxScanCols = 8;
+constexpr int kMaxScanCols = 8;          // plain scans (table columns only)
+constexpr int kMaxJoinScanCols = 12;     // scans with derived columns (lookups, differences, formulas): each one is a column too
 constexpr int kMaxScanAggs = 8;
 constexpr int kMaxFactors = 4;
 
@@ -30,8 +31,17 @@ enum VColKind : int {
     VC_BITS = 2,     // value = bit v[idx] of a dimension-side selection bitmap (FusedPlan::prelude[prelude]): 0 / 1; outside -> EPS
     VC_LUT = 3,      // value = prelude[prelude] (a lookup table) at v[idx]; outside the table -> 0 (Like over heap offsets)
     VC_INRANGE = 4,  // value = 1; the row is EPS unless 0 <= v[idx] < rows of column `name` (a Gather out of an unfiltered table)
-    VC_SUB = 5       // value = v[idx] - v[idx2] (column against column comparisons become a range filter on the difference)
+    VC_SUB = 5,      // value = v[idx] - v[idx2] (column against column comparisons become a range filter on the difference)
+    VC_FORM = 6      // value = 0 / 1: a boolean formula over range tests of earlier columns (ScanColumn::form) -- IN lists, disjunctions
+                     // across columns (Q19), CASE WHEN conditions used as aggregate inputs (Q12, Q14)
 };
+// One step of a formula in postfix order, evaluated per row on a stack of bits: LEAF pushes lo <= v[col] <= hi.
+struct FormStep {
+    enum Op : int { LEAF = 0, AND = 1, OR = 2, NOT = 3, TRUE_ = 4, FALSE_ = 5 };
+    int op = LEAF, col = -1;
+    int64_t lo = 0, hi = 0;
+};
+constexpr int kMaxFormSteps = 64, kMaxFormDepth = 30;
 struct ScanColumn {
     std::string name;          // catalog key path (VC_DIRECT / VC_GATHER / VC_INRANGE)
     int64_t lo = INT64_MIN;    // row passes iff lo <= value <= hi for every column
@@ -39,6 +49,15 @@ struct ScanColumn {
     int kind = VC_DIRECT;
     int idx = -1, idx2 = -1;   // source virtual column(s): always earlier in the list
     int prelude = -1;
+    std::vector<FormStep> form; // VC_FORM
+    // the earlier columns this one is computed from
+    std::vector<int> sources() const {
+        std::vector<int> o;
+        if (kind == VC_FORM) { for (const FormStep &f : form) if (f.op == FormStep::LEAF) o.push_back(f.col); return o; }
+        if (idx >= 0) o.push_back(idx);
+        if (idx2 >= 0) o.push_back(idx2);
+        return o;
+    }
 };
 // Work on the dimension side that has to happen before a scan with derived columns: the bitmap of a dimension-side
 // selection (the validity of a `witness` statement, run by the per-operator executor: dimension filters, joins of

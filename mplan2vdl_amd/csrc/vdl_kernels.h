@@ -50,8 +50,8 @@ const char *scan_kernel_name(const ScanLaunch &cfg);
 
 // ---- multi-aggregate fused scans (vdl_mscan.hip): global and grouped (dense-domain GROUP BY) ----
 constexpr int kMaxGroupAggs = 16;
-constexpr int kMaxVCols = kMaxProjCols;      // columns of a scan descriptor: 8 for the aggregate scans, up to 12 for the projection scan
-static_assert(kMaxVCols >= kMaxScanCols, "the aggregate scans' columns fit the descriptor");
+constexpr int kMaxVCols = kMaxProjCols;      // columns of a scan descriptor: 8 for plain aggregate scans, up to 12 with derived columns / for the projection scan
+static_assert(kMaxVCols >= kMaxScanCols && kMaxVCols >= kMaxJoinScanCols, "the aggregate scans' columns fit the descriptor");
 struct MScanCols {                           // host-side description of a scan's columns
     int ncol = 0;
     int64_t n = 0, row0 = 0;
@@ -67,14 +67,15 @@ struct MAggDesc {
     uint32_t used = 0, plain = 0;            // bit c: column c contributes a factor / the factor is the bare column
     int pad = 0;
     int64_t constant = 0;                    // datum when there is no column factor
-    int64_t fa[kMaxScanCols] = {}, fs[kMaxScanCols] = {};
+    int64_t fa[kMaxProjCols] = {}, fs[kMaxProjCols] = {};
 };
 struct MScanDesc {                           // lives in device memory, read with scalar loads
     int nagg = 0, nkey = 0, replicas = 1, pad = 0;
     int64_t pmin = 0, pcount = 0;            // grouped: bucket = key - pmin in [0, pcount)
     int64_t *block_partials = nullptr;       // global: [grid][1 + nagg]; grouped: [grid][pcount * (1 + nagg) + 1]
     int64_t flo[kMaxVCols] = {}, fhi[kMaxVCols] = {};            // range filter per column (read only for filtered columns)
-    int dkind[kMaxVCols] = {}, dsrc[kMaxVCols] = {}, dsrc2[kMaxVCols] = {};   // derived columns: VColKind, source column(s)
+    int dkind[kMaxVCols] = {}, dsrc[kMaxVCols] = {}, dsrc2[kMaxVCols] = {};   // derived columns: VColKind, source column(s); VC_FORM: first step, steps
+    FormStep form[kMaxFormSteps];            // the formula columns' steps, one after the other
     int64_t dn[kMaxVCols] = {};              // derived columns: entries of the table looked up
     // projection scan (k_project): what to write for the surviving rows
     int nout = 0, out_col[kMaxProjOuts] = {};

@@ -215,6 +215,52 @@ __device__ __forceinline__ void derive(const MsArgs &C, const MScanDesc &D, int6
     for (int c = 1; c < NC; c++) {
         if ((only >> c) & 1u) {                            // wave-uniform
             const int kind = D.dkind[c], a = D.dsrc[c], b = D.dsrc2[c];
+            if (kind == VC_FORM) {
+                // postfix formula over range tests of earlier columns, on a stack of bits per row (bit 0 = top); the steps
+                // are wave-uniform scalar loads
+                uint32_t stk[RW];
+#pragma unroll
+                for (int r = 0; r < RW; r++) stk[r] = 0;
+                for (int s = a; s < a + b; s++) {
+                    const int op = D.form[s].op;
+                    if (op == FormStep::LEAF) {
+                        const int col = D.form[s].col;
+                        const int64_t lo = D.form[s].lo, hi = D.form[s].hi;
+                        int64_t z[RW];
+#pragma unroll
+                        for (int r = 0; r < RW; r++) z[r] = 0;
+#pragma unroll
+                        for (int k = 0; k < NC; k++) {
+                            if (k < c && k == col) {
+#pragma unroll
+                                for (int r = 0; r < RW; r++) z[r] = v[k][r];
+                            }
+                        }
+#pragma unroll
+                        for (int r = 0; r < RW; r++) stk[r] = (stk[r] << 1) | (uint32_t)((z[r] >= lo) & (z[r] <= hi));
+                    } else if (op == FormStep::AND) {
+#pragma unroll
+                        for (int r = 0; r < RW; r++) stk[r] = ((stk[r] >> 1) & ~1u) | (stk[r] & (stk[r] >> 1) & 1u);
+                    } else if (op == FormStep::OR) {
+#pragma unroll
+                        for (int r = 0; r < RW; r++) stk[r] = (stk[r] >> 1) | (stk[r] & 1u);
+                    } else if (op == FormStep::NOT) {
+#pragma unroll
+                        for (int r = 0; r < RW; r++) stk[r] ^= 1u;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < RW; r++) stk[r] = (stk[r] << 1) | (op == FormStep::TRUE_ ? 1u : 0u);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < RW; r++) v[c][r] = (int64_t)(stk[r] & 1u);
+                if ((C.filtered >> c) & 1u) {
+                    const int64_t lo = D.flo[c], hi = D.fhi[c];
+#pragma unroll
+                    for (int r = 0; r < RW; r++) alive[r] = alive[r] & (v[c][r] >= lo) & (v[c][r] <= hi);
+                }
+                continue;
+            }
             int64_t x[RW], y[RW];
 #pragma unroll
             for (int r = 0; r < RW; r++) { x[r] = 0; y[r] = 0; }
@@ -232,6 +278,11 @@ __device__ __forceinline__ void derive(const MsArgs &C, const MScanDesc &D, int6
             if (kind == VC_SUB) {
 #pragma unroll
                 for (int r = 0; r < RW; r++) v[c][r] = (int64_t)((uint64_t)x[r] - (uint64_t)y[r]);
+                if ((C.filtered >> c) & 1u) {               // (the projection scan has no second look at the filters: fold it here)
+                    const int64_t lo = D.flo[c], hi = D.fhi[c];
+#pragma unroll
+                    for (int r = 0; r < RW; r++) alive[r] = alive[r] & (v[c][r] >= lo) & (v[c][r] <= hi);
+                }
                 continue;
             }
             const int64_t n = D.dn[c];
@@ -582,7 +633,7 @@ __global__ void k_mscan_first(const MsArgs C, const MScanDesc *__restrict__ Dp, 
     for (int j = 0; j < D.nagg; j++) {
         if (D.agg[j].kind != AGG_FIRST) continue;
         int c = 0;
-        for (int k = 0; k < kMaxScanCols; k++) if ((D.agg[j].used >> k) & 1u) c = k;
+        for (int k = 0; k < kMaxVCols; k++) if ((D.agg[j].used >> k) & 1u) c = k;
         const int64_t r = table[b * W + 1 + j] - C.row0;
         const bool mine = live && r >= 0 && r < C.n;
         if (mine) table[b * W + 1 + j] = load_scalar(C.ptr[c], C.width(c), r);
@@ -723,6 +774,8 @@ const MsVariant kMsVariants[] = {
     // scans with derived columns (FK lookups: fused join scans)
     VDL_MSJ(8, 4, true, true, false), VDL_MSJ(8, 4, false, false, false),
     VDL_MSJ(8, 2, true, true, true),  VDL_MSJ(8, 4, false, false, true),
+    VDL_MSJ(12, 2, true, true, false), VDL_MSJ(12, 2, false, false, false),
+    VDL_MSJ(12, 2, true, true, true),  VDL_MSJ(12, 2, false, false, true),
 };
 #undef VDL_MS
 #undef VDL_MSJ
@@ -741,6 +794,7 @@ ScanLaunch mscan_launch_config(const MScanCols &cols, MScanDesc &d, bool grouped
         if (cols.kind[c] != VC_DIRECT) { der = true; continue; }
         if (((uintptr_t)cols.ptr[c]) % (uintptr_t)(2 * cols.width[c]) != 0) vec = false;
     }
+    if (cols.ncol > kMaxScanCols) der = true;              // the 12-column instantiations exist in the derived-column form only
     ScanLaunch cfg;
     cfg.variant = -1;
     const char *want_u = getenv("VDL_GROUP_U");

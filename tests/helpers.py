@@ -158,10 +158,11 @@ def explain_mismatch(tag, seed, text, cols, got, want, reruns=3):
         for k, v in cols.items():
             orc.add_column(k, v)
         orc.run(text)
-        for attempt in range(reruns):
+        for attempt in range(reruns + 1):
             e = engine_with(cols)
             p = e.parse(text)
-            p.set_fusion(False)
+            as_planned = attempt == 0                      # first with the fused front (if the plan has one), then without any fusion
+            p.set_fusion(as_planned)
             p.set_trace(True)
             forms = ""
             try:
@@ -180,8 +181,8 @@ def explain_mismatch(tag, seed, text, cols, got, want, reruns=3):
                     cap.seek(0)
                     forms = cap.read().decode(errors="replace")
                 first = compare_traced(p, orc, text)
-                f.write("---- traced rerun %d (statement by statement): results %s the oracle; first diverging statement: %s\n"
-                        % (attempt, "EQUAL" if again == want else "DIFFER FROM", json.dumps(first)))
+                f.write("---- traced rerun %d (%s): results %s the oracle; first diverging statement: %s\n"
+                        % (attempt, "as planned" if as_planned else "statement by statement", "EQUAL" if again == want else "DIFFER FROM", json.dumps(first)))
                 if again != want or first is not None or attempt == 0:
                     f.write(forms)
             finally:

@@ -127,10 +127,19 @@ def test_fusion_of_range_predicates_and_affine_products():
     assert "(200 + -2*col" in d                                                       # (100 - c) * 2 folded into one factor
 
 
-def test_disjunction_across_columns_is_not_fused():
+def test_disjunction_across_columns_is_a_condition_column():
     p = plan_of(["7,RangeV,val,10,Id 2,0", "8,Greater,val,Id 2,val,Id 7,val",
                  "9,Greater,val,Id 4,val,Id 7,val", "10,LogicalOr,val,Id 8,val,Id 9,val",  # a > 10 or b > 10
                  "11,RangeV,val,0,Id 10,1", "12,FoldSelect,val,Id 11,val,Id 10,val",
+                 "13,Gather,Id 6,Id 12,val", "14,RangeV,val,0,Id 13,0", "15,FoldSum,val,Id 14,val,Id 13,val",
+                 "16,MaterializeCompact,Id 15"])
+    d = p.describe()                                       # (round 1 refused this shape; TPC-H Q19's predicate has it)
+    assert p.is_fused and "cond(col0:[11,+inf] col1:[11,+inf] or) in [1,1]" in d, d
+
+
+def test_value_that_is_not_a_condition_does_not_fuse_as_one():
+    p = plan_of(["7,Multiply,val,Id 2,val,Id 4,val", "8,LogicalOr,val,Id 7,val,Id 6,val",          # (a * b) or c
+                 "11,RangeV,val,0,Id 8,1", "12,FoldSelect,val,Id 11,val,Id 8,val",
                  "13,Gather,Id 6,Id 12,val", "14,RangeV,val,0,Id 13,0", "15,FoldSum,val,Id 14,val,Id 13,val",
                  "16,MaterializeCompact,Id 15"])
     assert not p.is_fused and "not a conjunction of per-column ranges" in p.describe()

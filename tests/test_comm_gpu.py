@@ -128,27 +128,29 @@ def test_pipelined_begin_end_gives_every_query_its_answer():
 
 
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("plan_no", [14, 19])
-def test_join_then_ungrouped_aggregate_merges_its_fold_records(plan_no, world):
+@pytest.mark.parametrize("plan_no,fuse", [(12, True), (14, True), (19, True), (14, False), (19, False)])
+def test_join_then_aggregate_merges_its_words(plan_no, fuse, world):
+    """Fused join scans (Q12 grouped, Q14, Q19) merge their partial words like any fused plan; statement by statement the
+    ungrouped ones merge their fold records.  Every rank ends with the whole answer."""
     cfg = frontend.load_metadata(META)
     text = frontend.compile_plan(open(os.path.join(META, "%02d.sql.mplan" % plan_no)).read(), cfg)
     cols = catalog.synth_columns(META, cfg, text, scale=1e-3, seed=7)
     want = oracle_run(text, cols)
     assert any(len(list(v.values())[0]) for v in want.values())
-    for got in sharded_run(text, lineitem_shards(cols, world), world, table="lineitem"):
+    for got in sharded_run(text, lineitem_shards(cols, world), world, table="lineitem", fuse=fuse):
         assert got == want
 
 
 @pytest.mark.parametrize("world", [1, 2, 3])
-@pytest.mark.parametrize("plan_no", [3, 5, 9, 10, 12, 20])
-def test_plans_with_a_partition_exchange_rows_and_concatenate(plan_no, world):
+@pytest.mark.parametrize("plan_no,fuse", [(3, True), (5, True), (9, True), (10, True), (20, True), (12, False)])
+def test_plans_with_a_partition_exchange_rows_and_concatenate(plan_no, fuse, world):
     """ONE all-gather of {status, counts} + ONE all-to-all of every column: the ranks' outputs, in rank order, are the
     unsharded result."""
     cfg = frontend.load_metadata(META)
     text = frontend.compile_plan(open(os.path.join(META, "%02d.sql.mplan" % plan_no)).read(), cfg)
     cols = catalog.synth_columns(META, cfg, text, scale=6e-4, seed=3)
     want = oracle_run(text, cols)
-    parts = sharded_run(text, lineitem_shards(cols, world), world, table="lineitem")
+    parts = sharded_run(text, lineitem_shards(cols, world), world, table="lineitem", fuse=fuse)
     got = {k: {name: sum((part[k][name] for part in parts), []) for name in v} for k, v in want.items()}
     assert got == want
     assert any(len(list(v.values())[0]) for v in want.values())

@@ -618,7 +618,7 @@ def test_tpch_plans_with_a_sharded_route_match_the_oracle(plan_no, world):
     assert sum(sum(c) for c in counts) > 0
 
 
-def _emulated_fold_merge(text, shards, row0s, table):
+def _emulated_fold_merge(text, shards, row0s, table, fuse=True):
     """Ranks emulated with one context each on one GPU: local phase per rank, the all-reduce of the partial words done
     in numpy by their VDL_REDUCE_* tags, finalisation on every rank (all must print the same answer)."""
     import torch
@@ -627,6 +627,7 @@ def _emulated_fold_merge(text, shards, row0s, table):
     engines = [engine_with(cols) for cols in shards]
     plans = [e.parse(text) for e in engines]
     for p, r0 in zip(plans, row0s):
+        p.set_fusion(fuse)
         p.set_sharded_table(table)
         p.set_row_offset(r0)
     nw, ops = plans[0].partial_spec()
@@ -651,8 +652,9 @@ def _emulated_fold_merge(text, shards, row0s, table):
 @pytest.mark.parametrize("plan_no", [14, 19])
 @pytest.mark.parametrize("world", [1, 2, 3])
 def test_join_plus_global_aggregate_plans_shard_through_their_folds(plan_no, world):
-    """TPC-H Q14 and Q19 do not fuse (a join) and have no Partition: with lineitem split by rows, each rank folds its rows
-    and the fold records merge like the partial words of a fused scan (vdl_plan_set_sharded_table)."""
+    """TPC-H Q14 and Q19 have no Partition: with lineitem split by rows, each rank folds its rows.  As fused join scans their
+    partial words merge like any fused plan's; statement by statement their fold records merge the same way
+    (vdl_plan_set_sharded_table)."""
     import os
     from conftest import ROOT
     from mplan2vdl_amd import catalog, frontend, shard_rows
@@ -670,6 +672,7 @@ def test_join_plus_global_aggregate_plans_shard_through_their_folds(plan_no, wor
         row0s.append(r0)
         shards.append({k: (v[r0:r1] if k.startswith("lineitem.") and not k.endswith(".heap") else v) for k, v in cols.items()})
     assert _emulated_fold_merge(text, shards, row0s, "lineitem") == want
+    assert _emulated_fold_merge(text, shards, row0s, "lineitem", fuse=False) == want
     if world == 1:              # the driver class the fused plans use (no process group: merge is a no-op), pipelined too
         import torch
         import mplan2vdl_amd as m
@@ -713,14 +716,17 @@ def test_global_folds_of_every_kind_merge_across_shards():
             r0, r1 = shard_rows(n, r, world)
             row0s.append(r0)
             shards.append({k: (v[r0:r1] if k.startswith("t.") else v) for k, v in cols.items()})
+        # (since round 2 the filter `f != 0` -- two ranges -- is a condition column and the program fuses: both routes)
         assert _emulated_fold_merge(text, shards, row0s, "t") == want, world
+        assert _emulated_fold_merge(text, shards, row0s, "t", fuse=False) == want, world
     # more ranks than rows: some shards are empty
     tiny = {"t.a": np.array([5, -2, 9], dtype=np.int64), "t.f": np.array([1, 0, 1], dtype=np.int64)}
     ttext = prog("1,Load,t.a", "2,Project,val,Id 1,a", "3,Load,t.f", "4,Project,val,Id 3,f", "5,RangeV,val,0,Id 4,1", "6,FoldSelect,val,Id 5,val,Id 4,val",
                  "7,Gather,Id 2,Id 6,val", "8,RangeV,val,0,Id 7,0", "9,FoldSum,val,Id 8,val,Id 7,val", "10,FoldMax,val,Id 8,val,Id 7,val",
                  "11,MaterializeCompact,Id 9", "12,MaterializeCompact,Id 10")
     bounds = [shard_rows(3, r, 5) for r in range(5)]
-    assert _emulated_fold_merge(ttext, [{k: v[r0:r1] for k, v in tiny.items()} for r0, r1 in bounds], [r0 for r0, _ in bounds], "t") == oracle_run(ttext, tiny)
+    for fuse in (True, False):
+        assert _emulated_fold_merge(ttext, [{k: v[r0:r1] for k, v in tiny.items()} for r0, r1 in bounds], [r0 for r0, _ in bounds], "t", fuse=fuse) == oracle_run(ttext, tiny)
     e = m.Engine(device=None)
     bad = e.parse(prog(*(head + ["16,FoldSum,val,Id 15,val,Id 14,val", "17,Multiply,val,Id 16,val,Id 11,val", "18,MaterializeCompact,Id 17"])))
     bad.set_sharded_table("t")
@@ -731,6 +737,7 @@ def test_global_folds_of_every_kind_merge_across_shards():
     with pytest.raises(m.VdlError, match="rank-local row numbers"):
         rows.partial_spec()
     none = e.parse(text)
+    none.set_fusion(False)
     with pytest.raises(m.VdlError, match="no row-sharded table named"):
         none.partial_spec()
 

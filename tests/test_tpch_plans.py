@@ -201,7 +201,7 @@ def test_which_plans_have_a_fused_front(cfg):
         tables = [l.split("one scan of ")[1].strip() for l in d.split("\n") if l.startswith("prelude") and "one scan of" in l]
         if tables:
             dims[n] = tables
-    assert dims == {3: ["customer", "orders"], 9: ["part"], 10: ["orders"], 11: ["nation", "supplier"], 20: ["part", "partsupp"]}
+    assert dims == {3: ["customer", "orders"], 9: ["part"], 10: ["orders"], 11: ["nation", "supplier"], 19: ["part"], 20: ["part", "partsupp"]}
     q3 = e.parse(open(os.path.join(ROOT, "tests", "golden", "q3.vdl")).read()).describe()
     assert "\nfused front: one scan of lineitem" in q3 and "orders.o_orderdate[col1]" in q3 and "prelude0.bit[col1] in [1,1]" in q3
 
@@ -222,9 +222,19 @@ def test_which_plans_have_a_sharded_route(cfg):
             verdict[n] = "exchange"
         except m.VdlError as ex:
             verdict[n] = str(ex)
-    assert sorted(n for n, v in verdict.items() if v == "fused") == [1, 6, 14]      # Q14: a fused JOIN scan (lineitem with part looked up through the join index)
-    assert sorted(n for n, v in verdict.items() if v == "exchange") == [3, 5, 9, 10, 12, 20]
-    assert "more than one Partition" in verdict[18] and "no Partition" in verdict[19] and "below the Partition" in verdict[4]
+    # fused JOIN scans: Q14 (lineitem with part looked up through the join index), Q12 (orders' priority looked up, IN lists and
+    # CASE conditions as condition columns), Q19 (a disjunction across lineitem and part columns as one condition column)
+    assert sorted(n for n, v in verdict.items() if v == "fused") == [1, 6, 12, 14, 19]
+    assert sorted(n for n, v in verdict.items() if v == "exchange") == [3, 5, 9, 10, 20]
+    assert "more than one Partition" in verdict[18] and "below the Partition" in verdict[4]
+    for n in (12, 19):                                         # ... and the routes they take with fusion off
+        p = e.parse(frontend.compile_plan(open(os.path.join(META, "%02d.sql.mplan" % n)).read(), cfg))
+        p.set_fusion(False)
+        if n == 12:
+            p.exchange_columns("lineitem")
+        else:
+            with pytest.raises(m.VdlError, match="no Partition"):
+                p.exchange_columns("lineitem")
     # a join + ungrouped aggregate that does not fuse shards through its global folds instead (Q14 does too with fusion off)
     for n, folds in ((14, 2), (19, 1)):
         p = e.parse(frontend.compile_plan(open(os.path.join(META, "%02d.sql.mplan" % n)).read(), cfg))
