@@ -46,14 +46,28 @@ static bool use_kscan(const ScanPlan &sp) {
     return sp.aggs.size() == 1 && sp.cols.size() <= 4;
 }
 
-// formula columns (VC_FORM): their steps, one column after the other, into the descriptor's pool
+// formula columns (VC_FORM) into the descriptor's pool, in the kernels' layout (MScanDesc::form): the range tests sorted by
+// column, then the postfix program with every test replaced by a reference to its result bit
 static void bind_forms(const std::vector<ScanColumn> &sc, MScanDesc &d) {
     int used = 0;
     for (size_t k = 0; k < sc.size(); k++) {
         if (sc[k].kind != VC_FORM) continue;
-        if (used + (int)sc[k].form.size() > kMaxFormSteps) throw Error(VDL_ERR_UNSUPPORTED, "the scan's conditions have more than " + std::to_string(kMaxFormSteps) + " steps in all");
-        d.dsrc[k] = used; d.dsrc2[k] = (int)sc[k].form.size();
-        for (const FormStep &f : sc[k].form) d.form[used++] = f;
+        const std::vector<FormStep> &prog = sc[k].form;
+        std::vector<int> tests;
+        for (size_t i = 0; i < prog.size(); i++) if (prog[i].op == FormStep::LEAF) tests.push_back((int)i);
+        std::stable_sort(tests.begin(), tests.end(), [&](int x, int y) { return prog[(size_t)x].col < prog[(size_t)y].col; });
+        if (tests.size() > 64 || used + (int)(tests.size() + prog.size()) > kMaxFormPool)
+            throw Error(VDL_ERR_UNSUPPORTED, "the scan's conditions do not fit the descriptor (" + std::to_string(kMaxFormPool) + " steps in all, 64 tests per condition)");
+        std::vector<int> bit_of(prog.size(), -1);
+        d.dsrc[k] = used;
+        d.dn[k] = (int64_t)tests.size();
+        for (size_t t = 0; t < tests.size(); t++) { bit_of[(size_t)tests[t]] = (int)t; d.form[used++] = prog[(size_t)tests[t]]; }
+        for (size_t i = 0; i < prog.size(); i++) {
+            FormStep f = prog[i];
+            if (f.op == FormStep::LEAF) { f.op = FormStep::REF; f.col = bit_of[i]; f.lo = f.hi = 0; }
+            d.form[used++] = f;
+        }
+        d.dsrc2[k] = used - d.dsrc[k];
     }
 }
 
@@ -492,8 +506,8 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
             scols.ptr[j] = cols.ptr[k]; scols.width[j] = cols.width[k]; scols.filtered[j] = cols.filtered[k];
             scols.lo[j] = cols.lo[k]; scols.hi[j] = cols.hi[k]; scols.kind[j] = cols.kind[k];
             sdesc->flo[j] = d.flo[k]; sdesc->fhi[j] = d.fhi[k]; sdesc->dkind[j] = d.dkind[k]; sdesc->dn[j] = d.dn[k];
-            if (d.dkind[k] == VC_FORM) {                          // its steps stay where they are in the pool; their columns are renumbered
-                sdesc->dsrc[j] = d.dsrc[k]; sdesc->dsrc2[j] = d.dsrc2[k];
+            if (d.dkind[k] == VC_FORM) {                          // its steps stay where they are in the pool; the tests' columns are
+                sdesc->dsrc[j] = d.dsrc[k]; sdesc->dsrc2[j] = d.dsrc2[k];      // renumbered (monotonic: they stay sorted by column)
                 for (int f = d.dsrc[k]; f < d.dsrc[k] + d.dsrc2[k]; f++) {
                     sdesc->form[f] = d.form[f];
                     if (d.form[f].op == FormStep::LEAF) sdesc->form[f].col = renum[(size_t)d.form[f].col];

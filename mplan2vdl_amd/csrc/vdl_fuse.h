@@ -37,11 +37,13 @@ enum VColKind : int {
 };
 // One step of a formula in postfix order, evaluated per row on a stack of bits: LEAF pushes lo <= v[col] <= hi.
 struct FormStep {
-    enum Op : int { LEAF = 0, AND = 1, OR = 2, NOT = 3, TRUE_ = 4, FALSE_ = 5 };
+    enum Op : int { LEAF = 0, AND = 1, OR = 2, NOT = 3, TRUE_ = 4, FALSE_ = 5,
+                    REF = 6 };   // kernel layout only (MScanDesc::form): push the result of test number `col`
     int op = LEAF, col = -1;
     int64_t lo = 0, hi = 0;
 };
-constexpr int kMaxFormSteps = 64, kMaxFormDepth = 30;
+constexpr int kMaxFormSteps = 64, kMaxFormDepth = 30;   // (at most 64 tests per formula: their results are the bits of one word)
+constexpr int kMaxFormPool = 160;                       // all formula columns of one scan, tests + programs
 struct ScanColumn {
     std::string name;          // catalog key path (VC_DIRECT / VC_GATHER / VC_INRANGE)
     int64_t lo = INT64_MIN;    // row passes iff lo <= value <= hi for every column

@@ -75,7 +75,9 @@ struct MScanDesc {                           // lives in device memory, read wit
     int64_t *block_partials = nullptr;       // global: [grid][1 + nagg]; grouped: [grid][pcount * (1 + nagg) + 1]
     int64_t flo[kMaxVCols] = {}, fhi[kMaxVCols] = {};            // range filter per column (read only for filtered columns)
     int dkind[kMaxVCols] = {}, dsrc[kMaxVCols] = {}, dsrc2[kMaxVCols] = {};   // derived columns: VColKind, source column(s); VC_FORM: first step, steps
-    FormStep form[kMaxFormSteps];            // the formula columns' steps, one after the other
+    // formula columns (VC_FORM), one after the other: column c owns form[dsrc[c] .. dsrc[c] + dsrc2[c]) -- first its dn[c]
+    // range tests sorted by column, then the postfix program over their results (FormStep::REF)
+    FormStep form[kMaxFormPool];
     int64_t dn[kMaxVCols] = {};              // derived columns: entries of the table looked up
     // projection scan (k_project): what to write for the surviving rows
     int nout = 0, out_col[kMaxProjOuts] = {};

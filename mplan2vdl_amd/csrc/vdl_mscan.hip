@@ -216,28 +216,37 @@ __device__ __forceinline__ void derive(const MsArgs &C, const MScanDesc &D, int6
         if ((only >> c) & 1u) {                            // wave-uniform
             const int kind = D.dkind[c], a = D.dsrc[c], b = D.dsrc2[c];
             if (kind == VC_FORM) {
-                // postfix formula over range tests of earlier columns, on a stack of bits per row (bit 0 = top); the steps
-                // are wave-uniform scalar loads
+                // A boolean formula over range tests of earlier columns.  Descriptor layout (bind_forms, vdl_engine.cpp): D.dn[c]
+                // tests sorted by column -- so each column's tests run with the column index a compile-time constant, no
+                // chain of selects -- then the postfix program over their result bits (REF j pushes test j), evaluated on a
+                // stack of bits (bit 0 = top).  The tests of a row slice in which no lane is still alive are skipped
+                // (wave-uniform; its value is never read -- for Q19, where the cheap filters and the part bitmap leave 1 row
+                // in 400, that is 5 slices in 6).  An instruction budget matters here: at 8 TB/s a wave has about 140 vector
+                // instructions per row slice of a 28 B/row scan.
+                const int L = (int)D.dn[c];
+                bool live[RW];
+                uint64_t bits[RW];
                 uint32_t stk[RW];
 #pragma unroll
-                for (int r = 0; r < RW; r++) stk[r] = 0;
-                for (int s = a; s < a + b; s++) {
-                    const int op = D.form[s].op;
-                    if (op == FormStep::LEAF) {
-                        const int col = D.form[s].col;
-                        const int64_t lo = D.form[s].lo, hi = D.form[s].hi;
-                        int64_t z[RW];
+                for (int r = 0; r < RW; r++) { live[r] = __ballot(alive[r]) != 0; bits[r] = 0; stk[r] = 0; }
+                for (int j = 0; j < L; j++) {              // (runtime loops outside, the unrolled ones inside: the column array stays in registers)
+                    const int col = D.form[a + j].col;
+                    const int64_t lo = D.form[a + j].lo, hi = D.form[a + j].hi;
 #pragma unroll
-                        for (int r = 0; r < RW; r++) z[r] = 0;
+                    for (int k = 0; k < NC; k++) {
+                        if (k < c && k == col) {           // scalar branch: one body runs
 #pragma unroll
-                        for (int k = 0; k < NC; k++) {
-                            if (k < c && k == col) {
-#pragma unroll
-                                for (int r = 0; r < RW; r++) z[r] = v[k][r];
-                            }
+                            for (int r = 0; r < RW; r++)
+                                if (live[r]) bits[r] |= (uint64_t)((v[k][r] >= lo) & (v[k][r] <= hi)) << j;
                         }
+                    }
+                }
+                for (int s = a + L; s < a + b; s++) {
+                    const int op = D.form[s].op;
+                    if (op == FormStep::REF) {
+                        const int j = D.form[s].col;
 #pragma unroll
-                        for (int r = 0; r < RW; r++) stk[r] = (stk[r] << 1) | (uint32_t)((z[r] >= lo) & (z[r] <= hi));
+                        for (int r = 0; r < RW; r++) stk[r] = (stk[r] << 1) | (uint32_t)((bits[r] >> j) & 1ull);
                     } else if (op == FormStep::AND) {
 #pragma unroll
                         for (int r = 0; r < RW; r++) stk[r] = ((stk[r] >> 1) & ~1u) | (stk[r] & (stk[r] >> 1) & 1u);
@@ -773,9 +782,9 @@ const MsVariant kMsVariants[] = {
     VDL_MS(8, 1, true, true, true),   VDL_MS(8, 3, true, true, true),      // VDL_GROUP_U sweeps (tools/q1_ab.sh)
     // scans with derived columns (FK lookups: fused join scans)
     VDL_MSJ(8, 4, true, true, false), VDL_MSJ(8, 4, false, false, false),
-    VDL_MSJ(8, 2, true, true, true),  VDL_MSJ(8, 4, false, false, true),
+    VDL_MSJ(8, 2, true, true, true),  VDL_MSJ(8, 2, false, false, true),
     VDL_MSJ(12, 2, true, true, false), VDL_MSJ(12, 2, false, false, false),
-    VDL_MSJ(12, 2, true, true, true),  VDL_MSJ(12, 2, false, false, true),
+    VDL_MSJ(12, 1, true, true, true),  VDL_MSJ(12, 1, false, false, true),      // (U = 2 spills 720 B/lane in the grouped form)
 };
 #undef VDL_MS
 #undef VDL_MSJ
