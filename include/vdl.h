@@ -111,6 +111,20 @@ int  vdl_plan_is_fused(const vdl_plan *plan);
  * every operator kernel against the oracle on programs that would otherwise fuse. */
 int  vdl_plan_set_fusion(vdl_plan *plan, int enabled);
 
+/* Run-time specialisation of a fused plan's multi-aggregate scans: the scan kernels' own device code compiled by hiprtc with
+ * this plan's descriptor (column kinds, filters, group key, aggregate terms, conditions) as compile-time constants, at the
+ * next run after it is switched on -- seconds, once per distinct scan per process (kept under $VDL_JIT_CACHE when that
+ * names a directory).  Off by default (VDL_JIT=1 in the environment switches it on for every plan parsed afterwards).
+ * enabled = 2 (VDL_JIT=2) also tunes: at the first run each specialised scan is built with 2, 3, 4 and 6 row pairs per
+ * lane and the quickest of a few timed launches over the real columns stays (a few seconds more, once).  A scan
+ * whose specialisation does not build runs on the precompiled kernels; vdl_plan_jit_note says which did and which did not.
+ * vdl_plan_jit_check builds the specialised kernels against the columns registered now without loading or running them
+ * (no GPU needed): VDL_OK, or VDL_ERR_UNSUPPORTED with the compiler's message in vdl_last_error.
+ * (The reference hands its text to an engine that generates code per program: /root/reference/README.md:57.) */
+int  vdl_plan_set_jit(vdl_plan *plan, int enabled);
+const char *vdl_plan_jit_note(const vdl_plan *plan);
+int  vdl_plan_jit_check(vdl_ctx *ctx, vdl_plan *plan);
+
 /* Execute: binds Loads to the catalog, runs all kernels, copies the MaterializeCompact
  * outputs to the host and synchronises. */
 int  vdl_run(vdl_ctx *ctx, vdl_plan *plan);

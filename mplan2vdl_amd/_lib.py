@@ -57,6 +57,9 @@ def load():
         "vdl_plan_set_fusion": (i32, [vp, i32]),
         "vdl_plan_set_profiling": (i32, [vp, i32]),
         "vdl_plan_set_trace": (i32, [vp, i32]),
+        "vdl_plan_set_jit": (i32, [vp, i32]),
+        "vdl_plan_jit_note": (ctypes.c_char_p, [vp]),
+        "vdl_plan_jit_check": (i32, [vp, vp]),
         "vdl_n_traced": (i32, [vp]),
         "vdl_traced": (i32, [vp, i32, P(i32), P(cp), P(i64), P(P(i64)), P(P(ctypes.c_uint8))]),
         "vdl_run": (i32, [vp, vp]),
@@ -103,7 +106,7 @@ ABI_SYMBOLS = [
     "vdl_open", "vdl_close", "vdl_last_error", "vdl_version", "vdl_set_stream", "vdl_use_own_stream", "vdl_register_column",
     "vdl_upload_column", "vdl_generate_column", "vdl_drop_column", "vdl_column_info", "vdl_download_column",
     "vdl_parse", "vdl_plan_free", "vdl_plan_describe", "vdl_plan_is_fused", "vdl_plan_set_fusion",
-    "vdl_plan_set_profiling", "vdl_plan_set_trace", "vdl_n_traced", "vdl_traced", "vdl_run", "vdl_n_outputs", "vdl_output", "vdl_plan_set_device_outputs", "vdl_output_device", "vdl_n_timings", "vdl_timing",
+    "vdl_plan_set_profiling", "vdl_plan_set_jit", "vdl_plan_jit_note", "vdl_plan_jit_check", "vdl_plan_set_trace", "vdl_n_traced", "vdl_traced", "vdl_run", "vdl_n_outputs", "vdl_output", "vdl_plan_set_device_outputs", "vdl_output_device", "vdl_n_timings", "vdl_timing",
     "vdl_plan_scan_stats", "vdl_plan_partial_spec", "vdl_run_local", "vdl_finalize", "vdl_finalize_begin", "vdl_finalize_end", "vdl_plan_set_row_offset", "vdl_plan_set_sharded_table", "vdl_resolve_first", "vdl_exchange_spec", "vdl_exchange_begin", "vdl_exchange_pack",
     "vdl_exchange_finish", "vdl_comm_unique_id", "vdl_comm_init", "vdl_comm_init_host", "vdl_comm_info", "vdl_comm_free", "vdl_run_sharded",
     "vdl_run_sharded_begin", "vdl_run_sharded_end", "vdl_comm_merge_host",

@@ -43,6 +43,7 @@ int64_t plan_words(const vdl_plan *p, std::vector<int32_t> *ops, bool *shardable
 // single-aggregate scans over <= 4 columns take the tuned k_scan; everything else k_mscan
 static bool use_kscan(const ScanPlan &sp) {
     for (const ScanColumn &c : sp.cols) if (c.kind != VC_DIRECT) return false;       // derived columns (fused join scans): k_mscan
+    if (getenv("VDL_NO_KSCAN")) return false;                                         // experiments: everything through k_mscan
     return sp.aggs.size() == 1 && sp.cols.size() <= 4;
 }
 
@@ -60,7 +61,7 @@ static void bind_forms(const std::vector<ScanColumn> &sc, MScanDesc &d) {
             throw Error(VDL_ERR_UNSUPPORTED, "the scan's conditions do not fit the descriptor (" + std::to_string(kMaxFormPool) + " steps in all, 64 tests per condition)");
         std::vector<int> bit_of(prog.size(), -1);
         d.dsrc[k] = used;
-        d.dn[k] = (int64_t)tests.size();
+        d.dtests[k] = (int)tests.size();
         for (size_t t = 0; t < tests.size(); t++) { bit_of[(size_t)tests[t]] = (int)t; d.form[used++] = prog[(size_t)tests[t]]; }
         for (size_t i = 0; i < prog.size(); i++) {
             FormStep f = prog[i];
@@ -119,6 +120,105 @@ int64_t bind_mscan(vdl_ctx *c, const PlanT &sp, MScanCols &cols, MScanDesc &d, i
     return n;
 }
 
+// Run-time specialisation of one multi-aggregate scan (vdl_jit.cpp): the shape of the precompiled variant the launch
+// configuration chose, with exactly this scan's column count, and the descriptor as constants.  On success the kernel, its
+// grid (occupancy of the specialised code) and name replace the variant's; on failure the variant stays and the note says why.
+static jit::Shape jit_shape(const MScanCols &cols, const ScanLaunch &cfg) {
+    jit::Shape sh;
+    mscan_variant_shape(cfg, &sh.nc, &sh.u, &sh.vec, &sh.grouped, &sh.der);
+    sh.nc = cols.ncol;
+    for (int k = 0; k < cols.ncol; k++) sh.der |= cols.kind[k] != VC_DIRECT;
+    const char *u = getenv(sh.grouped ? "VDL_JIT_GROUP_U" : "VDL_JIT_U");
+    if (u && atoi(u) >= 1 && atoi(u) <= 8) sh.u = atoi(u);
+    return sh;
+}
+static std::string jit_name(const jit::Shape &sh) {
+    return "k_mscan_specialised<" + std::to_string(sh.nc) + "," + std::to_string(sh.u) + "," + (sh.vec ? "vec" : "novec") + "," + (sh.grouped ? "grouped" : "global") +
+           (sh.der ? ",derived" : "") + ">";
+}
+struct Specialised { std::shared_ptr<jit::Kernel> k; int grid = 0, per_cu = 0; size_t code_bytes = 0; std::string name; };
+static bool build_specialised(vdl_ctx *c, vdl_plan *p, size_t s, bool grouped, int u, Specialised &out, std::string &why) {
+    jit::Shape sh = jit_shape(p->mcols[s], p->mcfg[s]);
+    if (u > 0) sh.u = u;
+    std::vector<char> code;
+    if (!jit::compile(jit::mscan_source(mscan_args(p->mcols[s]), p->mdesc[s], sh), c->arch, code, why)) { why = why.substr(0, 400); return false; }
+    out.k = jit::load(code, why);
+    if (!out.k) return false;
+    int per_cu = 0;
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, out.k->fn, 256, mscan_lds_bytes(p->mdesc[s], grouped)) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 2;
+    }
+    if (per_cu > 8) per_cu = 8;
+    const int64_t tile = (int64_t)256 * 2 * sh.u;
+    int64_t grid = (int64_t)c->num_cus * per_cu;
+    if (grid > p->mcols[s].n / tile) grid = p->mcols[s].n / tile;
+    if (grid < 1) grid = 1;
+    out.grid = (int)grid; out.per_cu = per_cu; out.code_bytes = code.size(); out.name = jit_name(sh);
+    return true;
+}
+static bool specialise_scan(vdl_ctx *c, vdl_plan *p, size_t s, bool grouped, std::string *kname) {
+    Specialised sp;
+    std::string why;
+    if (!build_specialised(c, p, s, grouped, 0, sp, why)) { p->jit_note += "scan " + std::to_string(s) + ": not specialised (" + why + "); "; return false; }
+    p->mcfg[s].grid = sp.grid;
+    p->mjit[s] = sp.k;
+    *kname = sp.name;
+    p->jit_note += "scan " + std::to_string(s) + ": " + sp.name + ", " + std::to_string(sp.code_bytes) + " B of code, " + std::to_string(sp.per_cu) + " blocks/CU; ";
+    return true;
+}
+// blocks a specialised scan may be launched with, whatever rows-per-lane the tuner settles on: the partials area is sized for it
+static int max_scan_grid(const vdl_ctx *c, const vdl_plan *p, int chosen) { return p->use_jit ? std::max(chosen, c->num_cus * 8) : chosen; }
+
+// vdl_plan_set_jit(plan, 2): at the first run, with the real columns and lookup tables in place, every specialised scan is
+// built with 2, 3, 4 and 6 row pairs per lane (a second each) and the quickest of three timed launches stays.  Which one
+// wins depends on the registers the specialised code needs and on how its blocks fill the CUs: Q1 at SF100 measured
+// 4.13 / 4.04 / 4.30 / 3.96 ms for 2 / 3 / 4 / 6.
+static void tune_specialised(vdl_ctx *c, vdl_plan *p, int64_t *dev_words) {
+    const size_t ns = p->fused.scans.size(), ng = p->fused.gscans.size();
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    for (size_t s = 0; s < ns + ng; s++) {
+        if (!p->mjit[s]) continue;
+        const bool grouped = s >= ns;
+        int64_t *out = dev_words + (grouped ? p->gword_offset[s - ns] : p->word_offset[s]);
+        Specialised best;
+        float best_ms = 0;
+        std::string tried;
+        for (int u : {2, 3, 4, 6}) {
+            if ((int64_t)256 * 2 * u > p->mcols[s].n) continue;
+            Specialised cand;
+            std::string why;
+            if (!build_specialised(c, p, s, grouped, u, cand, why)) continue;
+            ScanLaunch cfg = p->mcfg[s];
+            cfg.grid = cand.grid;
+            HIP_CHECK(hipMemcpyAsync(p->mdev[s]->p, &p->mdesc[s], sizeof(MScanDesc), hipMemcpyHostToDevice, c->stream));
+            float ms = 1e30f;
+            for (int rep = 0; rep < 4; rep++) {
+                HIP_CHECK(hipEventRecord(e0, c->stream));
+                HIP_CHECK(launch_mscan(p->mcols[s], p->mdesc[s], (const MScanDesc *)p->mdev[s]->p, cfg, grouped, false, out, false, c->stream, cand.k->fn));
+                HIP_CHECK(hipEventRecord(e1, c->stream));
+                HIP_CHECK(hipEventSynchronize(e1));
+                float t = 0;
+                HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+                if (rep > 0 && t < ms) ms = t;                  // the first launch of a module pays for its load
+            }
+            tried += " u=" + std::to_string(u) + ":" + std::to_string((int)(ms * 1000)) + "us";
+            if (!best.k || ms < best_ms) { best = cand; best_ms = ms; }
+        }
+        if (!best.k) continue;
+        p->mjit[s] = best.k;
+        p->mcfg[s].grid = best.grid;
+        p->jit_note += "scan " + std::to_string(s) + " tuned:" + tried + " -> " + best.name + "; ";
+        if ((int)s == p->dominant)
+            p->dominant_kernel = best.name + "_grid" + std::to_string(best.grid) + (grouped ? "_rep" + std::to_string(p->mdesc[s].replicas) : "");
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    p->description = describe_plan(p);
+}
+
 void bind_fused(vdl_ctx *c, vdl_plan *p) {
     const FusedPlan &F = p->fused;
     const size_t ns = F.scans.size(), ng = F.gscans.size();
@@ -131,6 +231,9 @@ void bind_fused(vdl_ctx *c, vdl_plan *p) {
     p->mcfg.assign(ns + ng, ScanLaunch{});
     p->mparts.assign(ns + ng, nullptr);
     p->mdev.resize(ns + ng);
+    p->mjit.assign(ns + ng, nullptr);
+    p->jit_note.clear();
+    p->jit_tuned = false;
     p->gword_offset.assign(ng, 0);
     p->reduce_ops.clear();
     bool shardable = true;
@@ -173,10 +276,12 @@ void bind_fused(vdl_ctx *c, vdl_plan *p) {
             n = bind_mscan(c, sp, p->mcols[s], p->mdesc[s], &bpr, p->row_offset);
             p->mcfg[s] = mscan_launch_config(p->mcols[s], p->mdesc[s], false, c->num_cus);
             if (p->mcfg[s].variant < 0) throw Error(VDL_ERR_UNSUPPORTED, "no multi-aggregate scan kernel variant for this shape");
-            p->mparts[s] = dev_alloc(c, sizeof(int64_t) * (size_t)p->mcfg[s].grid * (size_t)(p->mdesc[s].nagg + 1));
+            std::string jname;
+            const bool spec = p->use_jit && !sp.never && specialise_scan(c, p, s, false, &jname);
+            p->mparts[s] = dev_alloc(c, sizeof(int64_t) * (size_t)max_scan_grid(c, p, p->mcfg[s].grid) * (size_t)(p->mdesc[s].nagg + 1));
             p->mdesc[s].block_partials = (int64_t *)p->mparts[s]->p;
             if (!p->mdev[s]) p->mdev[s] = dev_alloc(c, sizeof(MScanDesc));
-            kname = std::string(mscan_kernel_name(p->mcfg[s])) + "_grid" + std::to_string(p->mcfg[s].grid);
+            kname = (spec ? jname : std::string(mscan_kernel_name(p->mcfg[s]))) + "_grid" + std::to_string(p->mcfg[s].grid);
         }
         p->word_offset[s] = off;
         off += (int64_t)sp.aggs.size() + 1;
@@ -193,15 +298,17 @@ void bind_fused(vdl_ctx *c, vdl_plan *p) {
         d.pmin = gp.pmin; d.pcount = gp.pcount;
         p->mcfg[m] = mscan_launch_config(p->mcols[m], d, true, c->num_cus);
         if (p->mcfg[m].variant < 0) throw Error(VDL_ERR_UNSUPPORTED, "no grouped-scan kernel variant for this shape");
+        std::string jname;
+        const bool spec = p->use_jit && !gp.never && specialise_scan(c, p, m, true, &jname);
         const int64_t words = d.pcount * (d.nagg + 1) + 1;
-        p->mparts[m] = dev_alloc(c, sizeof(int64_t) * (size_t)p->mcfg[m].grid * (size_t)words);
+        p->mparts[m] = dev_alloc(c, sizeof(int64_t) * (size_t)max_scan_grid(c, p, p->mcfg[m].grid) * (size_t)words);
         d.block_partials = (int64_t *)p->mparts[m]->p;
         if (!p->mdev[m]) p->mdev[m] = dev_alloc(c, sizeof(MScanDesc));
         p->gword_offset[g] = off;
         off += words;
         if (!gp.never && n * bpr > p->scan_bytes) {
             p->scan_bytes = n * bpr; p->scan_rows = n; p->dominant = (int)m;
-            p->dominant_kernel = std::string(mscan_kernel_name(p->mcfg[m])) + "_grid" + std::to_string(p->mcfg[m].grid) + "_rep" + std::to_string(d.replicas);
+            p->dominant_kernel = (spec ? jname : std::string(mscan_kernel_name(p->mcfg[m]))) + "_grid" + std::to_string(p->mcfg[m].grid) + "_rep" + std::to_string(d.replicas);
         }
     }
     p->bound = true;
@@ -331,6 +438,14 @@ void run_fused_local(vdl_ctx *c, vdl_plan *p, int64_t *dev_words, bool single_ra
         p->bound_version = c->catalog_version;
     }
     run_prelude(c, p);
+    if (p->use_jit && p->jit_tune && !p->jit_tuned) {
+        p->jit_tuned = true;
+        for (size_t s = 0; s < p->mcols.size(); s++) {            // (the lookup tables of this run are in place)
+            const size_t ns0 = p->fused.scans.size();
+            if (p->mjit[s]) patch_prelude(p, s < ns0 ? p->fused.scans[s].cols : p->fused.gscans[s - ns0].cols, p->mcols[s], p->mdesc[s]);
+        }
+        tune_specialised(c, p, dev_words);
+    }
     const int ei = (int)(p->run_seq++ % (unsigned)vdl_plan::kEvRing);
     if (p->profiling && !p->ev0[ei]) { HIP_CHECK(hipEventCreate(&p->ev0[ei])); HIP_CHECK(hipEventCreate(&p->ev1[ei])); }
     p->ev_pending[ei] = false;
@@ -361,7 +476,7 @@ void run_fused_local(vdl_ctx *c, vdl_plan *p, int64_t *dev_words, bool single_ra
             // events bracket the scan together with its tiny finish kernel(s)
             if (timed) HIP_CHECK(hipEventRecord(p->ev0[ei], c->stream));
             HIP_CHECK(launch_mscan(p->mcols[s], p->mdesc[s], (const MScanDesc *)p->mdev[s]->p, p->mcfg[s], grouped, never, out,
-                                   grouped && single_rank, c->stream));
+                                   grouped && single_rank, c->stream, p->mjit[s] ? p->mjit[s]->fn : nullptr));
             if (timed) { HIP_CHECK(hipEventRecord(p->ev1[ei], c->stream)); p->ev_pending[ei] = true; }
         }
     }
@@ -505,7 +620,7 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
             renum[(size_t)k] = j;
             scols.ptr[j] = cols.ptr[k]; scols.width[j] = cols.width[k]; scols.filtered[j] = cols.filtered[k];
             scols.lo[j] = cols.lo[k]; scols.hi[j] = cols.hi[k]; scols.kind[j] = cols.kind[k];
-            sdesc->flo[j] = d.flo[k]; sdesc->fhi[j] = d.fhi[k]; sdesc->dkind[j] = d.dkind[k]; sdesc->dn[j] = d.dn[k];
+            sdesc->flo[j] = d.flo[k]; sdesc->fhi[j] = d.fhi[k]; sdesc->dkind[j] = d.dkind[k]; sdesc->dn[j] = d.dn[k]; sdesc->dtests[j] = d.dtests[k];
             if (d.dkind[k] == VC_FORM) {                          // its steps stay where they are in the pool; the tests' columns are
                 sdesc->dsrc[j] = d.dsrc[k]; sdesc->dsrc2[j] = d.dsrc2[k];      // renumbered (monotonic: they stay sorted by column)
                 for (int f = d.dsrc[k]; f < d.dsrc[k] + d.dsrc2[k]; f++) {
@@ -578,6 +693,7 @@ std::string describe_plan(const vdl_plan *p) {
     std::ostringstream o;
     if (p->use_fusion && p->fused.ok) {
         o << "fused: " << p->fused.scans.size() << " scan(s)\n" << describe_fused(p->fused);
+        if (p->use_jit) o << "scan kernels specialised for this plan at first run (hiprtc)" << (p->jit_note.empty() ? "" : ": " + p->jit_note) << "\n";
     } else {
         if (!p->fused.ok) o << describe_fused(p->fused);
         else o << "fusion disabled\n";
@@ -615,6 +731,9 @@ int vdl_open(vdl_ctx **out, int device) {
             hipDeviceProp_t prop;
             HIP_CHECK(hipGetDeviceProperties(&prop, device));
             c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            c->arch = prop.gcnArchName;
+            if (c->arch.find(':') != std::string::npos) c->arch.resize(c->arch.find(':'));      // "gfx950:sramecc+:xnack-" -> "gfx950"
+            if (c->arch.empty()) c->arch = "gfx950";
             HIP_CHECK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
             c->stream = c->own_stream;
         }
@@ -758,6 +877,7 @@ int vdl_parse(vdl_ctx *c, const char *text, size_t len, vdl_plan **out) {
         p->device = c->device;
         p->prog = parse_program(text, len);
         p->fused = fuse_program(p->prog);
+        { const char *j = getenv("VDL_JIT"); p->use_jit = j && *j && *j != '0'; p->jit_tune = p->use_jit && atoi(j) >= 2; }
         p->description = describe_plan(p.get());
         *out = p.release();
     });
@@ -777,6 +897,51 @@ int vdl_plan_set_fusion(vdl_plan *p, int enabled) {
     p->use_fusion = enabled != 0;
     p->description = describe_plan(p);
     return VDL_OK;
+}
+int vdl_plan_set_jit(vdl_plan *p, int enabled) {
+    if (!p) return VDL_ERR_ARG;
+    if (p->use_jit != (enabled != 0)) p->bound = false;       // the scans are bound again, with or without their specialised kernels
+    p->use_jit = enabled != 0;
+    p->jit_tune = enabled >= 2;
+    p->jit_tuned = false;
+    p->description = describe_plan(p);
+    return VDL_OK;
+}
+const char *vdl_plan_jit_note(const vdl_plan *p) { return p ? p->jit_note.c_str() : ""; }
+// Builds (hiprtc; no GPU needed) the specialised kernel of every multi-aggregate scan of the plan against the columns
+// registered now, without loading or running anything: the note lists each kernel with its code size, or why it failed.
+int vdl_plan_jit_check(vdl_ctx *c, vdl_plan *p) {
+    if (!c || !p) return VDL_ERR_ARG;
+    return guard(c, [&] {
+        p->jit_note.clear();
+        if (!p->fused.ok) throw Error(VDL_ERR_UNSUPPORTED, "the plan has no fused scans: " + p->fused.why_not);
+        const FusedPlan &F = p->fused;
+        const size_t ns = F.scans.size();
+        for (size_t s = 0; s < ns + F.gscans.size(); s++) {
+            const bool grouped = s >= ns;
+            if (!grouped && use_kscan(F.scans[s])) { p->jit_note += "scan " + std::to_string(s) + ": k_scan (not specialised); "; continue; }
+            MScanCols cols;
+            auto d = std::make_unique<MScanDesc>();
+            int64_t bpr = 0;
+            if (grouped) {
+                const GroupScanPlan &gp = F.gscans[s - ns];
+                bind_mscan(c, gp, cols, *d, &bpr, 0);
+                d->nkey = (int)gp.key.size();
+                for (int k = 0; k < d->nkey; k++) d->key[k] = gp.key[(size_t)k];
+                d->pmin = gp.pmin; d->pcount = gp.pcount;
+            } else {
+                bind_mscan(c, F.scans[s], cols, *d, &bpr, 0);
+            }
+            const ScanLaunch cfg = mscan_launch_config(cols, *d, grouped, c->num_cus);
+            if (cfg.variant < 0) throw Error(VDL_ERR_UNSUPPORTED, "no scan kernel variant for this shape");
+            const jit::Shape sh = jit_shape(cols, cfg);
+            std::vector<char> code;
+            std::string log;
+            if (!jit::compile(jit::mscan_source(mscan_args(cols), *d, sh), c->arch, code, log))
+                throw Error(VDL_ERR_UNSUPPORTED, "scan " + std::to_string(s) + " does not build: " + log.substr(0, 2000));
+            p->jit_note += "scan " + std::to_string(s) + ": " + jit_name(sh) + ", " + std::to_string(code.size()) + " B of code; ";
+        }
+    });
 }
 int vdl_plan_set_device_outputs(vdl_plan *p, int enabled) {
     if (!p) return VDL_ERR_ARG;

@@ -18,6 +18,7 @@
 #include "vdl.h"
 #include "vdl_fuse.h"
 #include "vdl_ir.h"
+#include "vdl_jit.h"
 #include "vdl_kernels.h"
 
 
@@ -169,6 +170,7 @@ struct vdl_ctx {
     hipStream_t copy_stream = nullptr;     // result copies of the general path run here, behind an event, while later statements compute
     hipEvent_t copy_ev = nullptr;
     int num_cus = 256;
+    std::string arch = "gfx950";           // --offload-arch of run-time specialisation (the device's, when there is one)
     std::map<std::string, Column> cols;
     uint64_t catalog_version = 1;      // bumped on every catalog change: plans re-bind only when it moved
     std::shared_ptr<Pool> pool = std::make_shared<Pool>();
@@ -200,6 +202,10 @@ struct vdl_plan {
     std::vector<MScanDesc> mdesc;
     std::vector<ScanLaunch> mcfg;
     std::vector<BufP> mparts, mdev;
+    bool use_jit = false;                    // vdl_plan_set_jit / VDL_JIT=1: scans specialised for this plan by hiprtc (vdl_jit.cpp)
+    bool jit_tune = false, jit_tuned = false;   // ... =2: rows per lane chosen by timing at the first run
+    std::vector<std::shared_ptr<vdl::jit::Kernel>> mjit;
+    std::string jit_note;                    // what was specialised, or why not
     std::vector<BufP> prelude_buf;           // fused join scans: dimension bitmaps / LIKE tables of the current run (FusedPlan::prelude)
     std::vector<int64_t> prelude_n;
     std::vector<int64_t> gword_offset;

@@ -6,6 +6,7 @@
 // and per-aggregate products of affine column factors.
 #pragma once
 #include "vdl_ir.h"
+#include "vdl_scan_desc.h"
 
 #include <map>
 #include <memory>
@@ -14,36 +15,6 @@
 
 namespace vdl {
 
-constexpr int kMaxScanCols = 8;          // plain scans (table columns only)
-constexpr int kMaxJoinScanCols = 12;     // scans with derived columns (lookups, differences, formulas): each one is a column too
-constexpr int kMaxScanAggs = 8;
-constexpr int kMaxFactors = 4;
-
-enum AggKind : int { AGG_SUM = 0, AGG_MIN = 1, AGG_MAX = 2, AGG_FIRST = 3 };   // FIRST: value of a column at the group's first row
-
-// A scan reads table columns row by row (VC_DIRECT) and may derive further per-row values from them -- the FK-join
-// lowering of the compiler (/root/reference/src/Vlite.hs:1199-1282) seen from the fact table: the dimension side of a
-// join is a lookup through the join-index column, so a fact-table scan whose extra "columns" are dim_col[fk[row]] or
-// dim_bitmap[fk[row]] evaluates the join, its filters and its aggregates in one pass.
-enum VColKind : int {
-    VC_DIRECT = 0,   // name = catalog column of the scanned table
-    VC_GATHER = 1,   // value = column `name` (of another table) at row v[idx]; v[idx] outside that column -> the row is EPS
-    VC_BITS = 2,     // value = bit v[idx] of a dimension-side selection bitmap (FusedPlan::prelude[prelude]): 0 / 1; outside -> EPS
-    VC_LUT = 3,      // value = prelude[prelude] (a lookup table) at v[idx]; outside the table -> 0 (Like over heap offsets)
-    VC_INRANGE = 4,  // value = 1; the row is EPS unless 0 <= v[idx] < rows of column `name` (a Gather out of an unfiltered table)
-    VC_SUB = 5,      // value = v[idx] - v[idx2] (column against column comparisons become a range filter on the difference)
-    VC_FORM = 6      // value = 0 / 1: a boolean formula over range tests of earlier columns (ScanColumn::form) -- IN lists, disjunctions
-                     // across columns (Q19), CASE WHEN conditions used as aggregate inputs (Q12, Q14)
-};
-// One step of a formula in postfix order, evaluated per row on a stack of bits: LEAF pushes lo <= v[col] <= hi.
-struct FormStep {
-    enum Op : int { LEAF = 0, AND = 1, OR = 2, NOT = 3, TRUE_ = 4, FALSE_ = 5,
-                    REF = 6 };   // kernel layout only (MScanDesc::form): push the result of test number `col`
-    int op = LEAF, col = -1;
-    int64_t lo = 0, hi = 0;
-};
-constexpr int kMaxFormSteps = 64, kMaxFormDepth = 30;   // (at most 64 tests per formula: their results are the bits of one word)
-constexpr int kMaxFormPool = 160;                       // all formula columns of one scan, tests + programs
 struct ScanColumn {
     std::string name;          // catalog key path (VC_DIRECT / VC_GATHER / VC_INRANGE)
     int64_t lo = INT64_MIN;    // row passes iff lo <= value <= hi for every column
@@ -107,26 +78,6 @@ struct ScanPlan {
     bool never = false;          // predicate is constant false
 };
 
-// ---- grouped scan (dense-domain GROUP BY) -------------------------------------------------
-// The group key is evaluated per row by a two-accumulator straight-line program:
-//   acc / tmp <- column, then (op constant) steps on either, and `acc = acc op tmp` combines.
-// This is exactly the shape makeCompositeKey emits (/root/reference/src/Vlite.hs:1123-1170):
-// ((c0 >> tz0) - min0) << bits | ((c1 >> tz1) - min1) ... & mask.
-constexpr int kMaxKeySteps = 24;
-struct KeyStep {
-    enum Kind : int { LOAD = 0, OPK = 1, COMBINE = 2 } kind = LOAD;
-    int target = 0;          // 0 = acc, 1 = tmp (LOAD / OPK)
-    int col = -1;            // LOAD: scan column index
-    int bin = -1;            // OPK / COMBINE: BinOp
-    int const_left = 0;      // OPK: result = k op x instead of x op k; COMBINE: acc = tmp op acc
-    int64_t k = 0;
-};
-
-// A group key of the shape makeCompositeKey emits (Vlite.hs:1123-1170): OR over components ((col >> rsh) - sub) << lsh,
-// optionally ANDed with a mask.  The grouped scan evaluates this form in straight-line code; any other key program is
-// interpreted step by step (KeyStep).
-constexpr int kMaxKeyComps = 4;
-struct KeyComp { int col = 0, rsh = 0, lsh = 0, pad = 0; int64_t sub = 0; };
 // KeyStep program -> components, when it has that shape: returns their number (0 = not of the shape; the mask, if
 // any, in *masked / *mask).  VDL_NO_CANON_KEY in the environment makes it answer 0.
 int composite_key(const KeyStep *steps, int n, KeyComp *comps, int *masked, int64_t *mask);
@@ -160,7 +111,6 @@ struct FilterSpec { std::string table; std::vector<FilterColumn> cols; bool neve
 // up through the join index, row ids -- as sparse vectors on one shared selection.  The per-operator executor then starts
 // at those statements (they are handed to it ready-made) instead of running the ~15 filter / gather statements that
 // produce them one kernel at a time over the whole fact table.
-constexpr int kMaxProjCols = 12, kMaxProjOuts = 10;
 struct ProjPlan {
     bool ok = false;
     std::string table, why;

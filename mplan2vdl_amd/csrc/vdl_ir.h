@@ -6,6 +6,8 @@
 #include <string>
 #include <vector>
 
+#include "vdl_scan_desc.h"
+
 namespace vdl {
 
 enum class Op : int {
@@ -13,10 +15,6 @@ enum class Op : int {
     FoldCount, Gather, Scatter, Partition, Shuffle, Materialize, Like, Cross, Semisort
 };
 
-// element-wise binary operators, /root/reference/src/Vdl.hs:110-122
-enum BinOp : int {
-    B_LAND, B_LOR, B_BAND, B_BOR, B_SHIFT, B_EQ, B_ADD, B_SUB, B_GT, B_MUL, B_DIV, B_MOD, B_COUNT
-};
 extern const char *const kBinNames[B_COUNT];
 const char *op_name(Op op, int bin);
 

@@ -1,0 +1,183 @@
+// vdl_jit.cpp -- a fused scan specialised for ONE plan at run time.
+//
+// The precompiled scan kernels (vdl_mscan.hip) interpret a descriptor: which columns are lookups, which carry filters, the
+// group key's steps, every aggregate's factors, the conditions' tests.  That costs vector instructions per row -- selects
+// over all columns to find a source column, dispatch on kinds -- and a 28 B/row scan at 8 TB/s has only about 140 of them
+// per row slice of a wave.  Here the SAME device code (vdl_mscan_body.h, embedded as text at build time) is compiled by
+// hiprtc with the plan's descriptor as a compile-time constant: every descriptor-driven branch and loop folds away and
+// what is left is the straight-line code of this query.  (The text this engine executes "is meant to be executed by a voodoo
+// implementation", /root/reference/README.md:57 -- the system of the cited paper, which generates kernels per program.)
+// One hiprtc compile per distinct (descriptor, shape) per process -- seconds -- cached in memory and, when VDL_JIT_CACHE names a directory, on disk.  Opt-in: vdl_plan_set_jit / VDL_JIT=1; a plan
+// whose specialisation fails to build runs on the precompiled kernels and says so in its description.
+#include "vdl_jit.h"
+
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <mutex>
+#include <sstream>
+
+namespace vdl {
+namespace jit {
+
+namespace {
+
+const char kEmbedded[] =
+#include "vdl_jit_src.inc"
+    ;
+
+// ---- hiprtc, bound at first use ------------------------------------------------------------------------------------------
+struct Rtc {
+    void *lib = nullptr;
+    int (*create)(void **, const char *, const char *, int, const char **, const char **) = nullptr;
+    int (*compile)(void *, int, const char **) = nullptr;
+    int (*log_size)(void *, size_t *) = nullptr;
+    int (*log)(void *, char *) = nullptr;
+    int (*code_size)(void *, size_t *) = nullptr;
+    int (*code)(void *, char *) = nullptr;
+    int (*destroy)(void **) = nullptr;
+    std::string why;
+};
+Rtc &rtc() {
+    static Rtc r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"};
+        for (const char *n : names) if ((r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!r.lib) { r.why = "libhiprtc not found"; return; }
+        auto sym = [&](const char *n) { void *p = dlsym(r.lib, n); if (!p) r.why = std::string("libhiprtc lacks ") + n; return p; };
+        r.create = (decltype(r.create))sym("hiprtcCreateProgram");
+        r.compile = (decltype(r.compile))sym("hiprtcCompileProgram");
+        r.log_size = (decltype(r.log_size))sym("hiprtcGetProgramLogSize");
+        r.log = (decltype(r.log))sym("hiprtcGetProgramLog");
+        r.code_size = (decltype(r.code_size))sym("hiprtcGetCodeSize");
+        r.code = (decltype(r.code))sym("hiprtcGetCode");
+        r.destroy = (decltype(r.destroy))sym("hiprtcDestroyProgram");
+    });
+    return r;
+}
+
+std::string lit(int64_t v) {
+    if (v == INT64_MIN) return "(-9223372036854775807LL - 1)";
+    return std::to_string(v) + "LL";
+}
+
+uint64_t fnv(const std::string &s) {
+    uint64_t h = 0xCBF29CE484222325ull;
+    for (unsigned char ch : s) h = (h ^ ch) * 0x100000001B3ull;
+    return h;
+}
+
+std::mutex g_mu;
+std::map<std::string, std::vector<char>> g_code;        // key (hash + arch) -> code object, per process
+
+}  // namespace
+
+// The descriptor as a constexpr function: only what differs from the defaults is written.
+std::string mscan_source(const MsArgs &C, const MScanDesc &D, const Shape &sh) {
+    std::ostringstream o;
+    o << "#define VDL_SPEC_UNROLL _Pragma(\"unroll\")\n" << kEmbedded << "\nnamespace vdl {\n";
+    o << "constexpr MsArgs jit_args() {\n    MsArgs a{};\n";
+    o << "    a.ncol = " << C.ncol << "; a.widths = " << C.widths << "ull; a.filtered = " << C.filtered << "u; a.derived = " << C.derived
+      << "u; a.lazy = " << C.lazy << "u;\n    return a;\n}\n";
+    o << "constexpr MScanDesc jit_desc() {\n    MScanDesc d{};\n";
+    o << "    d.nagg = " << D.nagg << "; d.nkey = " << D.nkey << "; d.replicas = " << D.replicas << "; d.pmin = " << lit(D.pmin) << "; d.pcount = " << lit(D.pcount) << ";\n";
+    int pool = 0;
+    for (int k = 0; k < C.ncol; k++) {
+        if ((C.filtered >> k) & 1u) o << "    d.flo[" << k << "] = " << lit(D.flo[k]) << "; d.fhi[" << k << "] = " << lit(D.fhi[k]) << ";\n";
+        if ((C.derived >> k) & 1u) {
+            o << "    d.dkind[" << k << "] = " << D.dkind[k] << "; d.dsrc[" << k << "] = " << D.dsrc[k] << "; d.dsrc2[" << k << "] = " << D.dsrc2[k]
+              << "; d.dtests[" << k << "] = " << D.dtests[k] << ";\n";
+            if (D.dkind[k] == VC_FORM) pool = std::max(pool, D.dsrc[k] + D.dsrc2[k]);
+        }
+    }
+    for (int f = 0; f < pool; f++)
+        o << "    d.form[" << f << "].op = " << D.form[f].op << "; d.form[" << f << "].col = " << D.form[f].col << "; d.form[" << f << "].lo = " << lit(D.form[f].lo)
+          << "; d.form[" << f << "].hi = " << lit(D.form[f].hi) << ";\n";
+    o << "    d.ncomp = " << D.ncomp << "; d.key_masked = " << D.key_masked << "; d.key_mask = " << lit(D.key_mask) << ";\n";
+    for (int k = 0; k < D.ncomp; k++)
+        o << "    d.comp[" << k << "].col = " << D.comp[k].col << "; d.comp[" << k << "].rsh = " << D.comp[k].rsh << "; d.comp[" << k << "].lsh = " << D.comp[k].lsh
+          << "; d.comp[" << k << "].sub = " << lit(D.comp[k].sub) << ";\n";
+    for (int s = 0; s < D.nkey; s++)
+        o << "    d.key[" << s << "].kind = (KeyStep::Kind)" << (int)D.key[s].kind << "; d.key[" << s << "].target = " << D.key[s].target << "; d.key[" << s << "].col = "
+          << D.key[s].col << "; d.key[" << s << "].bin = " << D.key[s].bin << "; d.key[" << s << "].const_left = " << D.key[s].const_left << "; d.key[" << s
+          << "].k = " << lit(D.key[s].k) << ";\n";
+    for (int j = 0; j < D.nagg; j++) {
+        const MAggDesc &a = D.agg[j];
+        o << "    d.agg[" << j << "].kind = " << a.kind << "; d.agg[" << j << "].used = " << a.used << "u; d.agg[" << j << "].plain = " << a.plain << "u; d.agg[" << j
+          << "].constant = " << lit(a.constant) << ";\n";
+        for (int k = 0; k < C.ncol; k++)
+            if ((a.used >> k) & 1u) o << "    d.agg[" << j << "].fa[" << k << "] = " << lit(a.fa[k]) << "; d.agg[" << j << "].fs[" << k << "] = " << lit(a.fs[k]) << ";\n";
+    }
+    o << "    return d;\n}\n}  // namespace vdl\n";
+    o << "extern \"C\" __global__ __launch_bounds__(256) void vdl_jit_mscan(const vdl::MsArgs Cr, const vdl::MScanDesc *__restrict__ Dp) {\n"
+         "    constexpr vdl::MsArgs C = vdl::jit_args();\n"
+         "    constexpr vdl::MScanDesc D = vdl::jit_desc();\n"
+         "    vdl::mscan_body<" << sh.nc << ", " << sh.u << ", " << (sh.vec ? "true" : "false") << ", " << (sh.vec ? "true" : "false") << ", "
+      << (sh.grouped ? "true" : "false") << ", " << (sh.der ? "true" : "false") << ">(C, Cr, D, *Dp);\n}\n";
+    return o.str();
+}
+
+bool compile(const std::string &src, const std::string &arch, std::vector<char> &code, std::string &log) {
+    const std::string key = std::to_string(fnv(src)) + "_" + std::to_string(src.size()) + "_" + arch;
+    {
+        std::lock_guard<std::mutex> g(g_mu);
+        auto it = g_code.find(key);
+        if (it != g_code.end()) { code = it->second; return true; }
+    }
+    const char *dir = getenv("VDL_JIT_CACHE");
+    std::string path;
+    if (dir && *dir) {
+        path = std::string(dir) + "/vdl_" + key + ".hsaco";
+        std::ifstream f(path, std::ios::binary);
+        if (f) {
+            code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+            if (!code.empty()) { std::lock_guard<std::mutex> g(g_mu); g_code[key] = code; return true; }
+        }
+    }
+    Rtc &r = rtc();
+    if (!r.lib || !r.why.empty()) { log = r.why.empty() ? "libhiprtc not usable" : r.why; return false; }
+    void *prog = nullptr;
+    if (r.create(&prog, src.c_str(), "vdl_jit_scan.hip", 0, nullptr, nullptr) != 0) { log = "hiprtcCreateProgram failed"; return false; }
+    const std::string a = "--offload-arch=" + arch;
+    const char *opts[] = {a.c_str(), "-O3", "-std=c++17"};
+    const int rc = r.compile(prog, 3, opts);
+    size_t n = 0;
+    if (r.log_size(prog, &n) == 0 && n > 1) { log.resize(n); r.log(prog, &log[0]); }
+    if (rc != 0) { if (log.empty()) log = "hiprtcCompileProgram failed (" + std::to_string(rc) + ")"; r.destroy(&prog); return false; }
+    n = 0;
+    r.code_size(prog, &n);
+    code.resize(n);
+    r.code(prog, code.data());
+    r.destroy(&prog);
+    if (code.empty()) { log = "hiprtc produced no code"; return false; }
+    if (!path.empty()) {
+        mkdir(dir, 0777);
+        const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+        std::ofstream f(tmp, std::ios::binary);
+        if (f && f.write(code.data(), (std::streamsize)code.size()) && (f.close(), true)) rename(tmp.c_str(), path.c_str());
+    }
+    std::lock_guard<std::mutex> g(g_mu);
+    g_code[key] = code;
+    return true;
+}
+
+Kernel::~Kernel() { if (mod) (void)hipModuleUnload(mod); }
+
+std::shared_ptr<Kernel> load(const std::vector<char> &code, std::string &why) {
+    auto k = std::make_shared<Kernel>();
+    hipError_t e = hipModuleLoadData(&k->mod, code.data());
+    if (e != hipSuccess) { why = std::string("hipModuleLoadData: ") + hipGetErrorString(e); k->mod = nullptr; return nullptr; }
+    e = hipModuleGetFunction(&k->fn, k->mod, "vdl_jit_mscan");
+    if (e != hipSuccess) { why = std::string("hipModuleGetFunction: ") + hipGetErrorString(e); return nullptr; }
+    return k;
+}
+
+}  // namespace jit
+}  // namespace vdl

@@ -49,55 +49,18 @@ hipError_t launch_scan_finish(const int64_t *block_partials, int nblocks, int na
 const char *scan_kernel_name(const ScanLaunch &cfg);
 
 // ---- multi-aggregate fused scans (vdl_mscan.hip): global and grouped (dense-domain GROUP BY) ----
-constexpr int kMaxGroupAggs = 16;
-constexpr int kMaxVCols = kMaxProjCols;      // columns of a scan descriptor: 8 for plain aggregate scans, up to 12 with derived columns / for the projection scan
-static_assert(kMaxVCols >= kMaxScanCols && kMaxVCols >= kMaxJoinScanCols, "the aggregate scans' columns fit the descriptor");
-struct MScanCols {                           // host-side description of a scan's columns
-    int ncol = 0;
-    int64_t n = 0, row0 = 0;
-    const void *ptr[kMaxVCols] = {};         // VC_DIRECT: the column; derived columns: the table looked up (column / bitmap words / LUT)
-    int width[kMaxVCols] = {};
-    int filtered[kMaxVCols] = {};
-    int64_t lo[kMaxVCols] = {}, hi[kMaxVCols] = {};
-    int kind[kMaxVCols] = {};                // VColKind (vdl_fuse.h); 0 = read from the scanned table
-    int lazy[kMaxVCols] = {};                // projection scan: the column decides nothing about a row's survival -- read it for survivors only
-};
-struct MAggDesc {
-    int kind = 0;                            // AGG_SUM / AGG_MIN / AGG_MAX / AGG_FIRST
-    uint32_t used = 0, plain = 0;            // bit c: column c contributes a factor / the factor is the bare column
-    int pad = 0;
-    int64_t constant = 0;                    // datum when there is no column factor
-    int64_t fa[kMaxProjCols] = {}, fs[kMaxProjCols] = {};
-};
-struct MScanDesc {                           // lives in device memory, read with scalar loads
-    int nagg = 0, nkey = 0, replicas = 1, pad = 0;
-    int64_t pmin = 0, pcount = 0;            // grouped: bucket = key - pmin in [0, pcount)
-    int64_t *block_partials = nullptr;       // global: [grid][1 + nagg]; grouped: [grid][pcount * (1 + nagg) + 1]
-    int64_t flo[kMaxVCols] = {}, fhi[kMaxVCols] = {};            // range filter per column (read only for filtered columns)
-    int dkind[kMaxVCols] = {}, dsrc[kMaxVCols] = {}, dsrc2[kMaxVCols] = {};   // derived columns: VColKind, source column(s); VC_FORM: first step, steps
-    // formula columns (VC_FORM), one after the other: column c owns form[dsrc[c] .. dsrc[c] + dsrc2[c]) -- first its dn[c]
-    // range tests sorted by column, then the postfix program over their results (FormStep::REF)
-    FormStep form[kMaxFormPool];
-    int64_t dn[kMaxVCols] = {};              // derived columns: entries of the table looked up
-    // projection scan (k_project): what to write for the surviving rows
-    int nout = 0, out_col[kMaxProjOuts] = {};
-    int64_t *out_ptr[kMaxProjOuts] = {};     // one packed int64 vector per produced column
-    int64_t *out_idx = nullptr;              // the surviving rows' slot ids, ascending
-    int64_t *tile_counts = nullptr;          // [tiles + 1]: survivors per tile
-    uint32_t take = 0;                       // k_project_take: the columns the outputs need (with the columns they are derived from)
-    int ncomp = 0, key_masked = 0;           // ncomp > 0: the key program is this canonical form
-    int64_t key_mask = 0;
-    KeyComp comp[kMaxKeyComps];
-    MAggDesc agg[kMaxGroupAggs];
-    KeyStep key[kMaxKeySteps];
-};
 ScanLaunch mscan_launch_config(const MScanCols &cols, MScanDesc &d, bool grouped, int num_cus);
 const char *mscan_kernel_name(const ScanLaunch &cfg);
 // out: global form 1 + nagg words {row count, aggregates}; grouped form pcount * (nagg + 1) + 1 words: per
 // bucket {row count, aggregates...}, last word = rows whose key fell outside [pmin, pmin + pcount).
 // resolve_first: turn AGG_FIRST row ids into column values (single rank only).
+// jit_fn: the scan kernel specialised for this plan (vdl_jit.cpp) instead of the precompiled variant cfg names
 hipError_t launch_mscan(const MScanCols &cols, const MScanDesc &d, const MScanDesc *dev_desc, const ScanLaunch &cfg, bool grouped,
-                        bool never, int64_t *out, bool resolve_first, hipStream_t s);
+                        bool never, int64_t *out, bool resolve_first, hipStream_t s, hipFunction_t jit_fn = nullptr);
+// for the specialiser: the by-value arguments, the chosen variant's shape, the dynamic LDS of a launch
+MsArgs mscan_args(const MScanCols &cols);
+void mscan_variant_shape(const ScanLaunch &cfg, int *nc, int *u, bool *vec, bool *grouped, bool *der);
+size_t mscan_lds_bytes(const MScanDesc &d, bool grouped);
 // Projection scan (ProjPlan, vdl_fuse.h): pass 1 counts the surviving rows of every tile into d.tile_counts, pass 2 (after an
 // exclusive prefix sum over the counts) writes their slot ids and the produced columns, packed, in row order.
 int64_t project_tiles(int64_t n);

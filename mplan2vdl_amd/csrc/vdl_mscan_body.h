@@ -1,0 +1,586 @@
+// vdl_mscan_body.h -- device code of the multi-aggregate fused scans (global and dense-domain grouped form, with or without
+// derived columns): included by vdl_mscan.hip for the precompiled instantiations, and handed as text to hiprtc when a plan's
+// scan is specialised at run time (vdl_jit.cpp).  HIP built-ins only -- no C++ library.
+#pragma once
+#include "vdl_scan_desc.h"
+
+#ifndef VDL_SPEC_UNROLL
+#define VDL_SPEC_UNROLL                     // specialised builds: _Pragma("unroll") on the loops a descriptor drives
+#endif
+
+namespace vdl {
+
+typedef long long ll2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+typedef char i8x2 __attribute__((ext_vector_type(2)));
+
+template <int N> struct IntTag { static constexpr int value = N; };
+
+namespace {
+
+
+constexpr int kWave = 64;
+constexpr int kMsBlock = 256;
+enum { R_SUM = 0, R_MIN = 1, R_MAX = 2 };
+
+__device__ __forceinline__ int rk_of(int kind) { return kind == AGG_SUM ? R_SUM : kind == AGG_MAX ? R_MAX : R_MIN; }
+__device__ __forceinline__ int64_t r_identity(int rk) { return rk == R_SUM ? 0 : rk == R_MIN ? INT64_MAX : INT64_MIN; }
+__device__ __forceinline__ int64_t r_combine(int rk, int64_t a, int64_t b) {
+    if (rk == R_SUM) return (int64_t)((uint64_t)a + (uint64_t)b);
+    if (rk == R_MIN) return a < b ? a : b;
+    return a > b ? a : b;
+}
+__device__ __forceinline__ int64_t wave_reduce(int64_t x, int rk) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) x = r_combine(rk, x, __shfl_down(x, off, kWave));
+    return x;
+}
+__device__ __forceinline__ int64_t load_scalar(const void *p, int width, int64_t i) {
+    switch (width) {
+    case 8: return ((const int64_t *)p)[i];
+    case 4: return ((const int32_t *)p)[i];
+    case 2: return ((const int16_t *)p)[i];
+    default: return ((const int8_t *)p)[i];
+    }
+}
+template <bool NT, typename V>
+__device__ __forceinline__ V stream_load(const char *p) {
+    if (NT) return __builtin_nontemporal_load((const V *)p);
+    return *(const V *)p;
+}
+
+// key-program operators: apply_bin minus Divide / Modulo (the planner keeps those off this path)
+__device__ __forceinline__ int64_t key_bin(int op, int64_t a, int64_t b) {
+    switch (op) {
+    case B_LAND: return (a != 0) && (b != 0);
+    case B_LOR:  return (a != 0) || (b != 0);
+    case B_BAND: return a & b;
+    case B_BOR:  return a | b;
+    case B_SHIFT:
+        if (b >= 0) return a >> (b > 63 ? 63 : b);
+        if (b <= -64) return 0;
+        return (int64_t)((uint64_t)a << (unsigned)(-b));
+    case B_EQ:  return a == b;
+    case B_ADD: return (int64_t)((uint64_t)a + (uint64_t)b);
+    case B_SUB: return (int64_t)((uint64_t)a - (uint64_t)b);
+    case B_GT:  return a > b;
+    default:    return (int64_t)((uint64_t)a * (uint64_t)b);
+    }
+}
+
+// x[r] = x[r] op k (or k op x[r]) for all rows; the operator switch is wave-uniform and sits OUTSIDE
+// the row loop (a per-row switch made the kernel scalar-issue bound)
+#define VDL_ROWS(EXPR) { _Pragma("unroll") for (int r = 0; r < RW; r++) { const int64_t a = x[r]; x[r] = (EXPR); } }
+template <int RW>
+__device__ __forceinline__ void key_rows(int op, int const_left, int64_t (&x)[RW], int64_t k) {
+    switch (op) {
+    case B_BAND: VDL_ROWS(a & k) break;
+    case B_BOR:  VDL_ROWS(a | k) break;
+    case B_ADD:  VDL_ROWS((int64_t)((uint64_t)a + (uint64_t)k)) break;
+    case B_MUL:  VDL_ROWS((int64_t)((uint64_t)a * (uint64_t)k)) break;
+    case B_SUB:  if (const_left) VDL_ROWS((int64_t)((uint64_t)k - (uint64_t)a)) else VDL_ROWS((int64_t)((uint64_t)a - (uint64_t)k)) break;
+    case B_SHIFT:
+        if (const_left) VDL_ROWS(key_bin(B_SHIFT, k, a))
+        else if (k >= 0) { const int sh = k > 63 ? 63 : (int)k; VDL_ROWS(a >> sh) }
+        else if (k <= -64) VDL_ROWS(0 * a)
+        else { const int sh = (int)(-k); VDL_ROWS((int64_t)((uint64_t)a << sh)) }
+        break;
+    default:
+        if (const_left) VDL_ROWS(key_bin(op, k, a)) else VDL_ROWS(key_bin(op, a, k))
+        break;
+    }
+}
+#undef VDL_ROWS
+template <int RW>
+__device__ __forceinline__ void key_combine(int op, int swap, int64_t (&acc)[RW], const int64_t (&tmp)[RW]) {
+    switch (op) {
+    case B_BOR:
+#pragma unroll
+        for (int r = 0; r < RW; r++) acc[r] |= tmp[r];
+        break;
+    case B_BAND:
+#pragma unroll
+        for (int r = 0; r < RW; r++) acc[r] &= tmp[r];
+        break;
+    case B_ADD:
+#pragma unroll
+        for (int r = 0; r < RW; r++) acc[r] = (int64_t)((uint64_t)acc[r] + (uint64_t)tmp[r]);
+        break;
+    default:
+#pragma unroll
+        for (int r = 0; r < RW; r++) acc[r] = swap ? key_bin(op, tmp[r], acc[r]) : key_bin(op, acc[r], tmp[r]);
+        break;
+    }
+}
+
+
+template <int NC, int U, bool VEC, bool NT>
+__device__ __forceinline__ void load_tile(const MsArgs &C, const MsArgs &Cr, int64_t base, int64_t (&v)[NC][2 * U], uint32_t skip = 0) {
+    constexpr int BS = kMsBlock;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        if (c < C.ncol && !(((C.derived | skip) >> c) & 1u)) {      // wave-uniform
+            const char *p = (const char *)Cr.ptr[c];
+            const int w = C.width(c);
+            if (!VEC) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    v[c][2 * u] = load_scalar(p, w, base + (int64_t)u * (BS * 2));
+                    v[c][2 * u + 1] = load_scalar(p, w, base + (int64_t)u * (BS * 2) + 1);
+                }
+            } else if (w == 8) {
+#pragma unroll
+                for (int u = 0; u < U; u++) { ll2 x = stream_load<NT, ll2>(p + (base + (int64_t)u * (BS * 2)) * 8); v[c][2 * u] = x.x; v[c][2 * u + 1] = x.y; }
+            } else if (w == 4) {
+#pragma unroll
+                for (int u = 0; u < U; u++) { i32x2 x = stream_load<NT, i32x2>(p + (base + (int64_t)u * (BS * 2)) * 4); v[c][2 * u] = x.x; v[c][2 * u + 1] = x.y; }
+            } else if (w == 2) {
+#pragma unroll
+                for (int u = 0; u < U; u++) { i16x2 x = stream_load<NT, i16x2>(p + (base + (int64_t)u * (BS * 2)) * 2); v[c][2 * u] = x.x; v[c][2 * u + 1] = x.y; }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; u++) { i8x2 x = stream_load<NT, i8x2>(p + (base + (int64_t)u * (BS * 2))); v[c][2 * u] = x.x; v[c][2 * u + 1] = x.y; }
+            }
+        }
+    }
+}
+
+template <int NC, int RW>
+__device__ __forceinline__ void eval_pass(const MsArgs &C, const MScanDesc &D, const int64_t (&v)[NC][RW], bool (&pass)[RW]) {
+#pragma unroll
+    for (int r = 0; r < RW; r++) pass[r] = true;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        if ((C.filtered >> c) & 1u) {                      // wave-uniform (bits only below ncol)
+            const int64_t lo = D.flo[c], hi = D.fhi[c];
+#pragma unroll
+            for (int r = 0; r < RW; r++) pass[r] = pass[r] & (v[c][r] >= lo) & (v[c][r] <= hi);
+        }
+    }
+}
+
+// Derived columns (vdl_fuse.h VColKind): values looked up through an earlier column -- the dimension side of an FK join
+// seen from the fact table (Vlite.hs:1199-1282).  `alive` starts as "the direct range filters pass", so rows a cheap
+// filter already rejects do no lookups (Q14 keeps 1 row in 84); a lookup out of range makes the row EPS (alive = false).
+template <int NC, int RW>
+__device__ __forceinline__ void derive(const MsArgs &C, const MsArgs &Cr, const MScanDesc &D, const MScanDesc &Dr, int64_t (&v)[NC][RW], bool (&alive)[RW], uint32_t only, bool direct_filters = true) {
+    if (direct_filters) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            if (((C.filtered >> c) & 1u) && !((C.derived >> c) & 1u)) {
+                const int64_t lo = D.flo[c], hi = D.fhi[c];
+#pragma unroll
+                for (int r = 0; r < RW; r++) alive[r] = alive[r] & (v[c][r] >= lo) & (v[c][r] <= hi);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 1; c < NC; c++) {
+        if ((only >> c) & 1u) {                            // wave-uniform
+            const int kind = D.dkind[c], a = D.dsrc[c], b = D.dsrc2[c];
+            if (kind == VC_FORM) {
+                // A boolean formula over range tests of earlier columns.  Descriptor layout (bind_forms, vdl_engine.cpp): D.dtests[c]
+                // tests sorted by column -- so each column's tests run with the column index a compile-time constant, no
+                // chain of selects -- then the postfix program over their result bits (REF j pushes test j), evaluated on a
+                // stack of bits (bit 0 = top).  The tests of a row slice in which no lane is still alive are skipped
+                // (wave-uniform; its value is never read -- for Q19, where the cheap filters and the part bitmap leave 1 row
+                // in 400, that is 5 slices in 6).  An instruction budget matters here: at 8 TB/s a wave has about 140 vector
+                // instructions per row slice of a 28 B/row scan.
+                const int L = D.dtests[c];
+                bool live[RW];
+                uint64_t bits[RW];
+                uint32_t stk[RW];
+#pragma unroll
+                for (int r = 0; r < RW; r++) { live[r] = __ballot(alive[r]) != 0; bits[r] = 0; stk[r] = 0; }
+                VDL_SPEC_UNROLL
+                for (int j = 0; j < L; j++) {              // (runtime loops outside, the unrolled ones inside: the column array stays in registers)
+                    const int col = D.form[a + j].col;
+                    const int64_t lo = D.form[a + j].lo, hi = D.form[a + j].hi;
+#pragma unroll
+                    for (int k = 0; k < NC; k++) {
+                        if (k < c && k == col) {           // scalar branch: one body runs
+#pragma unroll
+                            for (int r = 0; r < RW; r++)
+                                if (live[r]) bits[r] |= (uint64_t)((v[k][r] >= lo) & (v[k][r] <= hi)) << j;
+                        }
+                    }
+                }
+                VDL_SPEC_UNROLL
+                for (int s = a + L; s < a + b; s++) {
+                    const int op = D.form[s].op;
+                    if (op == FormStep::REF) {
+                        const int j = D.form[s].col;
+#pragma unroll
+                        for (int r = 0; r < RW; r++) stk[r] = (stk[r] << 1) | (uint32_t)((bits[r] >> j) & 1ull);
+                    } else if (op == FormStep::AND) {
+#pragma unroll
+                        for (int r = 0; r < RW; r++) stk[r] = ((stk[r] >> 1) & ~1u) | (stk[r] & (stk[r] >> 1) & 1u);
+                    } else if (op == FormStep::OR) {
+#pragma unroll
+                        for (int r = 0; r < RW; r++) stk[r] = (stk[r] >> 1) | (stk[r] & 1u);
+                    } else if (op == FormStep::NOT) {
+#pragma unroll
+                        for (int r = 0; r < RW; r++) stk[r] ^= 1u;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < RW; r++) stk[r] = (stk[r] << 1) | (op == FormStep::TRUE_ ? 1u : 0u);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < RW; r++) v[c][r] = (int64_t)(stk[r] & 1u);
+                if ((C.filtered >> c) & 1u) {
+                    const int64_t lo = D.flo[c], hi = D.fhi[c];
+#pragma unroll
+                    for (int r = 0; r < RW; r++) alive[r] = alive[r] & (v[c][r] >= lo) & (v[c][r] <= hi);
+                }
+                continue;
+            }
+            int64_t x[RW], y[RW];
+#pragma unroll
+            for (int r = 0; r < RW; r++) { x[r] = 0; y[r] = 0; }
+#pragma unroll
+            for (int k = 0; k < NC; k++) {                 // register files are not indexable: select the source column by comparison
+                if (k < c && k == a) {
+#pragma unroll
+                    for (int r = 0; r < RW; r++) x[r] = v[k][r];
+                }
+                if (k < c && k == b) {
+#pragma unroll
+                    for (int r = 0; r < RW; r++) y[r] = v[k][r];
+                }
+            }
+            if (kind == VC_SUB) {
+#pragma unroll
+                for (int r = 0; r < RW; r++) v[c][r] = (int64_t)((uint64_t)x[r] - (uint64_t)y[r]);
+                if ((C.filtered >> c) & 1u) {               // (the projection scan has no second look at the filters: fold it here)
+                    const int64_t lo = D.flo[c], hi = D.fhi[c];
+#pragma unroll
+                    for (int r = 0; r < RW; r++) alive[r] = alive[r] & (v[c][r] >= lo) & (v[c][r] <= hi);
+                }
+                continue;
+            }
+            const int64_t n = Dr.dn[c];
+            const char *t = (const char *)Cr.ptr[c];
+            const int w = C.width(c);
+            bool in[RW];
+#pragma unroll
+            for (int r = 0; r < RW; r++) in[r] = alive[r] & (x[r] >= 0) & (x[r] < n);
+            // lookups only for the lanes whose row is still alive (a selective fact filter ahead of the join -- Q14 keeps 1 row
+            // in 84 -- leaves most lanes without a memory request); all the loads of a column's rows are issued before any is used
+            if (kind == VC_GATHER) {
+                int64_t q[RW];
+#pragma unroll
+                for (int r = 0; r < RW; r++) { q[r] = 0; if (in[r]) q[r] = load_scalar(t, w, x[r]); }
+#pragma unroll
+                for (int r = 0; r < RW; r++) { v[c][r] = q[r]; alive[r] = in[r]; }
+            } else if (kind == VC_BITS) {
+                uint64_t word[RW];
+#pragma unroll
+                for (int r = 0; r < RW; r++) word[r] = ~0ull;                      // no bitmap: every dimension row is selected
+                if (t && n > 0) {                               // (unconditional: rows that are out read word 0; the bitmap is small and cached, and the loads go out together)
+#pragma unroll
+                    for (int r = 0; r < RW; r++) word[r] = ((const uint64_t *)t)[(in[r] ? x[r] : 0) >> 6];
+                }
+#pragma unroll
+                for (int r = 0; r < RW; r++) { v[c][r] = in[r] ? (int64_t)((word[r] >> (x[r] & 63)) & 1ull) : 0; alive[r] = in[r]; }
+            } else if (kind == VC_LUT) {                    // outside the table: 0, not EPS (Like over an offset outside the heap)
+#pragma unroll
+                for (int r = 0; r < RW; r++) { v[c][r] = 0; if (in[r]) v[c][r] = ((const int64_t *)t)[x[r]]; }
+            } else {                                        // VC_INRANGE
+#pragma unroll
+                for (int r = 0; r < RW; r++) { v[c][r] = 1; alive[r] = in[r]; }
+            }
+            // a filter on the looked-up value (the dimension selection's bit, a dimension column's range) takes effect at
+            // once: the lookups of the columns after it are then issued for the rows that are still in
+            if ((C.filtered >> c) & 1u) {
+                const int64_t lo = D.flo[c], hi = D.fhi[c];
+#pragma unroll
+                for (int r = 0; r < RW; r++) alive[r] = alive[r] & (v[c][r] >= lo) & (v[c][r] <= hi);
+            }
+        }
+    }
+}
+
+// term of one aggregate for the lane's rows: product of affine column factors (a + s*col), a constant,
+// or the row id (AGG_FIRST).  Everything read from `d` is wave-uniform (scalar loads).
+template <int NC, int RW>
+__device__ __forceinline__ void eval_term(const MAggDesc &d, const int64_t (&v)[NC][RW], const int64_t (&rowid)[RW], int64_t (&t)[RW]) {
+    if (d.kind == AGG_FIRST) {
+#pragma unroll
+        for (int r = 0; r < RW; r++) t[r] = rowid[r];
+        return;
+    }
+    const uint32_t used = d.used, plain = d.plain;
+    bool first = true;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        if ((used >> c) & 1u) {                            // wave-uniform
+            int64_t x[RW];
+            if ((plain >> c) & 1u) {
+#pragma unroll
+                for (int r = 0; r < RW; r++) x[r] = v[c][r];
+            } else {
+                const int64_t a = d.fa[c], s = d.fs[c];
+                if (s == 1) {
+#pragma unroll
+                    for (int r = 0; r < RW; r++) x[r] = (int64_t)((uint64_t)a + (uint64_t)v[c][r]);
+                } else if (s == -1) {
+#pragma unroll
+                    for (int r = 0; r < RW; r++) x[r] = (int64_t)((uint64_t)a - (uint64_t)v[c][r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < RW; r++) x[r] = (int64_t)((uint64_t)a + (uint64_t)s * (uint64_t)v[c][r]);
+                }
+            }
+            if (first) {
+#pragma unroll
+                for (int r = 0; r < RW; r++) t[r] = x[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < RW; r++) t[r] = (int64_t)((uint64_t)t[r] * (uint64_t)x[r]);
+            }
+            first = false;
+        }
+    }
+    if (first) {
+        const int64_t k = d.constant;
+#pragma unroll
+        for (int r = 0; r < RW; r++) t[r] = k;
+    }
+}
+
+// LDS use: global form (1 + nagg) * 256 lane slots; grouped form replicas * (pcount * (1 + nagg) | 1) + 256 + nagg + 1 trash words
+// C / D: what is known when the plan is bound (column kinds and widths, filters, key, conditions, aggregates); Cr / Dr: what
+// is only known at launch (column bases, row counts, lookup-table sizes, the partials area).  The precompiled kernels pass the
+// same objects for both; a kernel specialised for one plan (vdl_jit.cpp) passes compile-time constants for C and D, and the
+// compiler folds every descriptor-driven branch and loop of this body away.
+template <int NC, int U, bool VEC, bool NT, bool GROUPED, bool DER>
+__device__ __forceinline__ void mscan_body(const MsArgs &C, const MsArgs &Cr, const MScanDesc &D, const MScanDesc &Dr) {
+    extern __shared__ int64_t lds[];
+    constexpr int BS = kMsBlock, TILE = BS * 2 * U, ROWS = 2 * U;
+    const int tid = threadIdx.x;
+    const int nagg = D.nagg;
+    const int W = nagg + 1;
+    const int64_t G = D.pcount;
+    const int64_t words = G * W;
+    const int64_t rstride = words | 1;                     // odd int64 stride: replicas start on different banks
+    const int R = D.replicas;
+
+    int64_t cnt = 0, oob = 0;
+    int64_t *mytab = lds;
+    int trash = 0;
+    if (GROUPED) {
+        for (int r = 0; r < R; r++)
+            for (int64_t i = tid; i < words; i += BS) {
+                const int w = (int)(i % W);
+                lds[(int64_t)r * rstride + i] = r_identity(w == 0 ? R_SUM : rk_of(D.agg[w - 1].kind));
+            }
+        mytab = lds + (int64_t)(tid % R) * rstride;
+        // per-lane trash rows (W words each) live behind the replicas; offset relative to mytab
+        // lane t's trash row is words [t, t + W) of the trash area: rows of neighbouring lanes overlap, but within one
+        // atomic instruction every lane addresses its own word (same 1 + j for all), so there is no conflict
+        trash = (int)((int64_t)R * rstride + (int64_t)tid - (int64_t)(tid % R) * rstride);
+        for (int64_t i = tid; i < BS + W; i += BS) lds[(int64_t)R * rstride + i] = 0;
+    } else {
+        for (int j = 0; j < nagg; j++) lds[(int64_t)j * BS + tid] = r_identity(rk_of(D.agg[j].kind));
+    }
+    __syncthreads();
+
+    auto process = [&](auto rows_tag, int64_t (&v)[NC][decltype(rows_tag)::value], const int64_t (&rowid)[decltype(rows_tag)::value], int64_t rows_left) {
+        constexpr int RW = decltype(rows_tag)::value;
+        bool pass[RW];
+        if (DER) {
+            // (scans with derived columns run their last, partial tile through this same code: rows past the end are
+            // switched off here -- `rows_left` counts from the lane's first row)
+            bool alive[RW];
+#pragma unroll
+            for (int r = 0; r < RW; r++) alive[r] = (int64_t)((r >> 1) * (BS * 2) + (r & 1)) < rows_left;
+            derive<NC, RW>(C, Cr, D, Dr, v, alive, C.derived);
+            eval_pass<NC, RW>(C, D, v, pass);
+#pragma unroll
+            for (int r = 0; r < RW; r++) pass[r] = pass[r] & alive[r];
+        } else {
+            eval_pass<NC, RW>(C, D, v, pass);
+        }
+        int off[RW];
+        if (GROUPED) {
+            // group key: two-accumulator program (vdl_fuse.h KeyStep)
+            int64_t acc[RW], tmp[RW];
+#pragma unroll
+            for (int r = 0; r < RW; r++) { acc[r] = 0; tmp[r] = 0; }
+            const int ncomp = D.ncomp;
+            if (ncomp > 0) {
+                // the composite key in straight-line code: no step records, no operator dispatch (interpreting Q1's nine
+                // steps was a quarter of the kernel)
+#pragma unroll
+                for (int k = 0; k < kMaxKeyComps; k++) {
+                    if (k < ncomp) {                           // wave-uniform
+                        const KeyComp kc = D.comp[k];
+                        int64_t x[RW];
+#pragma unroll
+                        for (int r = 0; r < RW; r++) x[r] = 0;
+#pragma unroll
+                        for (int c = 0; c < NC; c++) {
+                            if (c == kc.col) {
+#pragma unroll
+                                for (int r = 0; r < RW; r++) x[r] = v[c][r];
+                            }
+                        }
+#pragma unroll
+                        for (int r = 0; r < RW; r++)
+                            acc[r] |= (int64_t)(((uint64_t)(x[r] >> kc.rsh) - (uint64_t)kc.sub) << kc.lsh);
+                    }
+                }
+                if (D.key_masked) {
+                    const int64_t mk = D.key_mask;
+#pragma unroll
+                    for (int r = 0; r < RW; r++) acc[r] &= mk;
+                }
+            } else
+            VDL_SPEC_UNROLL
+            for (int s = 0; s < D.nkey; s++) {
+                const KeyStep st = D.key[s];               // wave-uniform
+                if (st.kind == KeyStep::LOAD) {
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        if (c == st.col) {
+                            if (st.target) {
+#pragma unroll
+                                for (int r = 0; r < RW; r++) tmp[r] = v[c][r];
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < RW; r++) acc[r] = v[c][r];
+                            }
+                        }
+                    }
+                } else if (st.kind == KeyStep::OPK) {
+                    if (st.target) key_rows<RW>(st.bin, st.const_left, tmp, st.k);
+                    else key_rows<RW>(st.bin, st.const_left, acc, st.k);
+                } else {
+                    key_combine<RW>(st.bin, st.const_left, acc, tmp);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RW; r++) {
+                const int64_t b = (int64_t)((uint64_t)acc[r] - (uint64_t)D.pmin);
+                const bool in = b >= 0 && b < G;
+                oob += (pass[r] && !in) ? 1 : 0;
+                pass[r] = pass[r] && in;
+                // rows that do not count go to this lane's own trash slot with the identity: no branches
+                off[r] = pass[r] ? (int)b * W : trash;         // the trash row absorbs whatever is added: no selects below
+                atomicAdd((unsigned long long *)&mytab[off[r]], 1ull);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RW; r++) cnt += pass[r] ? 1 : 0;
+        }
+        VDL_SPEC_UNROLL
+        for (int j = 0; j < nagg; j++) {                   // runtime loop: descriptors by scalar loads (specialised: unrolled)
+            const MAggDesc d = D.agg[j];                   // whole descriptor into SGPRs: one scalar-load wait per aggregate
+            const int rk = rk_of(d.kind);
+            int64_t t[RW];
+            eval_term<NC, RW>(d, v, rowid, t);
+            if (GROUPED) {
+                if (rk == R_SUM) {
+#pragma unroll
+                    for (int r = 0; r < RW; r++) atomicAdd((unsigned long long *)&mytab[off[r] + 1 + j], (unsigned long long)t[r]);
+                } else if (rk == R_MAX) {
+#pragma unroll
+                    for (int r = 0; r < RW; r++) atomicMax((long long *)&mytab[off[r] + 1 + j], (long long)t[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < RW; r++) atomicMin((long long *)&mytab[off[r] + 1 + j], (long long)t[r]);
+                }
+            } else {
+                int64_t s = r_identity(rk);
+                if (rk == R_SUM) {
+#pragma unroll
+                    for (int r = 0; r < RW; r++) s = (int64_t)((uint64_t)s + (uint64_t)(pass[r] ? t[r] : 0));
+                } else if (rk == R_MIN) {
+#pragma unroll
+                    for (int r = 0; r < RW; r++) s = (pass[r] && t[r] < s) ? t[r] : s;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < RW; r++) s = (pass[r] && t[r] > s) ? t[r] : s;
+                }
+                int64_t *slot = &lds[(int64_t)j * BS + tid];      // this lane's own slot: no atomics, no conflicts
+                *slot = r_combine(rk, *slot, s);
+            }
+        }
+    };
+
+    const int64_t ntiles = Cr.n / TILE;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int64_t v[NC][ROWS], rowid[ROWS];
+        const int64_t base = tile * TILE + (int64_t)tid * 2;
+#pragma unroll
+        for (int u = 0; u < U; u++) { rowid[2 * u] = Cr.row0 + base + (int64_t)u * (BS * 2); rowid[2 * u + 1] = rowid[2 * u] + 1; }
+        load_tile<NC, U, VEC, NT>(C, Cr, base, v);
+        process(IntTag<ROWS>{}, v, rowid, (int64_t)1 << 40);
+    }
+    if (blockIdx.x == gridDim.x - 1 && ntiles * TILE < Cr.n) {
+        if (DER) {
+            // the partial tile, in the tile's own row layout with clamped scalar loads
+            int64_t v[NC][ROWS], rowid[ROWS];
+            const int64_t base = ntiles * TILE + (int64_t)tid * 2;
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) rowid[r] = Cr.row0 + base + (int64_t)(r >> 1) * (BS * 2) + (r & 1);
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                if (c < C.ncol && !((C.derived >> c) & 1u)) {
+#pragma unroll
+                    for (int r = 0; r < ROWS; r++) {
+                        const int64_t i = base + (int64_t)(r >> 1) * (BS * 2) + (r & 1);
+                        v[c][r] = load_scalar(Cr.ptr[c], C.width(c), i < Cr.n ? i : Cr.n - 1);
+                    }
+                }
+            }
+            process(IntTag<ROWS>{}, v, rowid, Cr.n - base);
+        } else {
+            for (int64_t i = ntiles * TILE + tid; i < Cr.n; i += BS) {      // tail rows, one per lane
+                int64_t v1[NC][1], rid[1];
+                rid[0] = Cr.row0 + i;
+#pragma unroll
+                for (int c = 0; c < NC; c++)
+                    if (c < C.ncol) v1[c][0] = load_scalar(Cr.ptr[c], C.width(c), i);
+                process(IntTag<1>{}, v1, rid, 1);
+            }
+        }
+    }
+    __syncthreads();
+    __shared__ int64_t red[kMsBlock / kWave];
+    const int lane = tid & (kWave - 1), wave = tid / kWave;
+    if (GROUPED) {
+        int64_t *dst = Dr.block_partials + (int64_t)blockIdx.x * (words + 1);
+        for (int64_t i = tid; i < words; i += BS) {
+            const int w = (int)(i % W);
+            const int rk = w == 0 ? R_SUM : rk_of(D.agg[w - 1].kind);
+            int64_t x = lds[i];
+            for (int r = 1; r < R; r++) x = r_combine(rk, x, lds[(int64_t)r * rstride + i]);
+            dst[i] = x;
+        }
+        oob = wave_reduce(oob, R_SUM);
+        if (lane == 0) red[wave] = oob;
+        __syncthreads();
+        if (tid == 0) { int64_t x = 0; for (int w = 0; w < kMsBlock / kWave; w++) x += red[w]; dst[words] = x; }
+    } else {
+        int64_t *dst = Dr.block_partials + (int64_t)blockIdx.x * W;
+        for (int j = -1; j < nagg; j++) {
+            const int rk = j < 0 ? R_SUM : rk_of(D.agg[j].kind);
+            int64_t x = j < 0 ? cnt : lds[(int64_t)j * BS + tid];
+            x = wave_reduce(x, rk);
+            if (lane == 0) red[wave] = x;
+            __syncthreads();
+            if (tid == 0) {
+                int64_t y = red[0];
+                for (int w = 1; w < kMsBlock / kWave; w++) y = r_combine(rk, y, red[w]);
+                dst[j + 1] = y;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace
+}  // namespace vdl

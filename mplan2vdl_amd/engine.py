@@ -64,6 +64,19 @@ class Plan:
     def set_profiling(self, enabled):
         self._e._check(self._e._L.vdl_plan_set_profiling(self._h, int(bool(enabled))))
 
+    def set_jit(self, enabled, tune=False):
+        """Scan kernels specialised for this plan by hiprtc at the next run; tune: rows per lane chosen by timing at that
+        run (vdl.h: vdl_plan_set_jit)."""
+        self._e._check(self._e._L.vdl_plan_set_jit(self._h, (2 if tune else 1) if enabled else 0))
+
+    def jit_note(self):
+        return self._e._L.vdl_plan_jit_note(self._h).decode()
+
+    def jit_check(self):
+        """Build (not load, not run: no GPU needed) the specialised kernels against the registered columns; the note."""
+        self._e._check(self._e._L.vdl_plan_jit_check(self._e._c, self._h))
+        return self.jit_note()
+
     def set_trace(self, enabled):
         """Keep a host copy of every statement's vector (statement-by-statement runs only): see `traced()`."""
         self._e._check(self._e._L.vdl_plan_set_trace(self._h, int(bool(enabled))))
@@ -311,6 +324,10 @@ class Engine:
         self._keep[name] = tensor
         self._check(self._L.vdl_register_column(self._c, name.encode(), ctypes.c_void_p(tensor.data_ptr()),
                                                 tensor.element_size(), tensor.numel()))
+
+    def register_pointer(self, name, dev_ptr, elem_bytes, nrows):
+        """Borrow nrows integers of elem_bytes each at a device address the caller keeps alive (vdl_register_column)."""
+        self._check(self._L.vdl_register_column(self._c, name.encode(), ctypes.c_void_p(dev_ptr), elem_bytes, nrows))
 
     def upload(self, name, array):
         a = np.ascontiguousarray(array)

@@ -1,0 +1,137 @@
+"""Run-time specialisation of the fused scans (vdl_plan_set_jit, csrc/vdl_jit.cpp): the scan kernels' own device code built
+by hiprtc with one plan's descriptor as compile-time constants.  Building needs no GPU (hiprtc cross-compiles), so the CPU
+suite checks that every kind of fused plan yields a kernel that compiles; the GPU suite checks that the specialised kernels
+give the oracle's answers -- TPC-H plans, random filter / join / condition programs, tuned and untuned, sharded."""
+import os
+
+import numpy as np
+import pytest
+
+import mplan2vdl_amd as m
+from mplan2vdl_amd import catalog, frontend
+from conftest import ROOT
+from helpers import check_against_oracle, engine_with, oracle_run
+
+META = os.path.join(ROOT, "tests", "golden", "tpch10noorder")
+FUSED_PLANS = [1, 12, 14, 19]                 # multi-aggregate scans (Q6's single-aggregate scan runs on k_scan, which is not specialised)
+
+
+def compiled(n, scale, seed=3):
+    cfg = frontend.load_metadata(META)
+    text = frontend.compile_plan(open(os.path.join(META, "%02d.sql.mplan" % n)).read(), cfg)
+    return text, catalog.synth_columns(META, cfg, text, scale=scale, seed=seed)
+
+
+def host_engine_with_declared(cols):
+    """No device: the columns are only declared (address, width, length) -- enough to bind a plan's scans and build them."""
+    e = m.Engine(device=None)
+    for k, v in cols.items():
+        e.register_pointer(k, 0x10000, v.dtype.itemsize, len(v))
+    return e
+
+
+@pytest.mark.parametrize("n", FUSED_PLANS)
+def test_specialised_kernels_of_the_tpch_plans_build_without_a_gpu(n, tmp_path, monkeypatch):
+    monkeypatch.setenv("VDL_JIT_CACHE", str(tmp_path))
+    text, cols = compiled(n, 1e-4)
+    e = host_engine_with_declared(cols)
+    p = e.parse(text)
+    note = p.jit_check()
+    assert "k_mscan_specialised<" in note and "B of code" in note, note
+    assert ("derived" in note) == (n != 1)                      # the join scans carry looked-up / condition columns
+    assert [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]          # the code object is kept for the next process
+    assert p.jit_check() == note                                # ... and for this one (no second compile: same text, same key)
+
+
+def test_specialised_kernels_of_random_programs_build_without_a_gpu():
+    from test_random_conditions import Gen as CondGen
+    from test_random_fused import Gen as FusedGen
+    built = 0
+    for gen, seeds in ((FusedGen, range(6)), (CondGen, range(6))):
+        for seed in seeds:
+            text, cols = gen(seed).build()
+            e = host_engine_with_declared(cols)
+            p = e.parse(text)
+            if not p.is_fused:
+                continue
+            note = p.jit_check()
+            assert "not specialised (" not in note, (seed, note)
+            built += "k_mscan_specialised<" in note
+    assert built >= 6
+
+
+def test_a_plan_without_fused_scans_is_refused():
+    text, cols = compiled(3, 1e-4)
+    e = host_engine_with_declared(cols)
+    p = e.parse(text)
+    with pytest.raises(m.VdlError, match="no fused scans"):
+        p.jit_check()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tune", [False, True])
+def test_specialised_tpch_plans_match_the_oracle(tune):
+    for n in FUSED_PLANS + [6]:
+        text, cols = compiled(n, 2e-3)
+        want = oracle_run(text, cols)
+        e = engine_with(cols)
+        p = e.parse(text)
+        plain = p.run()["results"]
+        p.set_jit(True, tune=tune)
+        got = p.run()["results"]
+        again = p.run()["results"]
+        note = p.jit_note()
+        p.set_jit(False)
+        back = p.run()["results"]
+        e.close()
+        assert plain == want and got == want and again == want and back == want, (n, tune, note)
+        if n != 6:
+            assert "k_mscan_specialised<" in note and "not specialised" not in note, note
+            assert ("tuned:" in note) == tune, note
+
+
+@pytest.mark.gpu
+def test_specialised_random_programs_match_the_oracle():
+    from test_random_conditions import Gen as CondGen
+    from test_random_fused import Gen as FusedGen
+    from test_random_joins import Gen as JoinGen
+    ran = 0
+    for tag, gen in (("fused", FusedGen), ("joins", JoinGen), ("conditions", CondGen)):
+        for seed in range(40):
+            text, cols = gen(seed).build()
+            e = engine_with(cols)
+            p = e.parse(text)
+            if not p.is_fused:
+                e.close()
+                continue
+            want = oracle_run(text, cols)
+            p.set_jit(True)
+            got = p.run()["results"]
+            note = p.jit_note()
+            e.close()
+            check_against_oracle("specialised_random_" + tag, seed, text, cols, got, want)
+            ran += "k_mscan_specialised<" in note
+    assert ran >= 60
+
+
+@pytest.mark.gpu
+def test_specialised_scans_shard_like_the_precompiled_ones():
+    from test_comm_gpu import lineitem_shards, run_ranks
+    text, cols = compiled(1, 2e-3)
+    want = oracle_run(text, cols)
+    shards = lineitem_shards(cols, 2)
+
+    def work(rank, rv):
+        r0, part = shards[rank]
+        e = engine_with(part)
+        e.comm_init_host(rank, 2, *rv.transport(rank))
+        p = e.parse(text)
+        p.set_jit(True)
+        p.set_row_offset(r0)
+        res = p.run_sharded()["results"]
+        note = p.jit_note()
+        e.close()
+        return res, note
+
+    for res, note in run_ranks(2, work):
+        assert res == want and "k_mscan_specialised<" in note
