@@ -72,7 +72,7 @@ def q3_matches_sql(eng, res):
     return bool(np.array_equal(got[np.argsort(got[:, 0])], want[np.argsort(want[:, 0])]))
 
 
-def secondary_measurements(eng, rows):
+def secondary_measurements(eng, rows, jit="tune"):
     """Not the headline metric: the other two single-GPU configurations of BASELINE.json on the same box, measured
     after the timed region (Q1 grouped fused scan over the same lineitem rows; Q3 at SF10 through the statement-by-
     statement executor).  Parity for both is the job of tests/; a failure here is reported, not fatal."""
@@ -87,6 +87,8 @@ def secondary_measurements(eng, rows):
                 eng.generate(datagen.LINEITEM[name], 0, rows)
         q1 = eng.parse(open(os.path.join(ROOT, "tests", "golden", "q1.vdl")).read())
         q1.set_profiling(True)
+        if jit != "off":
+            q1.set_jit(True, tune=jit == "tune")
         us, wall = [], []
         for k in range(12):
             torch.cuda.synchronize(); t0 = time.perf_counter(); r = q1.run(); wall.append(time.perf_counter() - t0)
@@ -95,7 +97,7 @@ def secondary_measurements(eng, rows):
         also["tpch_q1_same_rows"] = {"rows": rows, "ms_per_query": 1e3 * sum(wall[2:]) / len(wall[2:]), "rows_per_s": rows / (sum(wall[2:]) / len(wall[2:])),
                                      "kernel_us": k_us, "bytes_per_row": datagen.Q1_BYTES_PER_ROW,
                                      "roofline_frac": rows * datagen.Q1_BYTES_PER_ROW / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
-                                     "groups": len(r["results"]["tmp101"][".count_order"]),
+                                     "groups": len(r["results"]["tmp101"][".count_order"]), "scan_kernels": q1.jit_note(),
                                      "verified_bit_exact_vs_cpu": q1_matches_sql(r["results"], rows, max(1, min(os.cpu_count() or 1, 64)))}
         q1.close()
         for name in datagen.Q1_COLUMNS:
@@ -134,6 +136,8 @@ def secondary_measurements(eng, rows):
         keep = datagen.register_q14_columns(eng, n_li)
         q14 = eng.parse(open(os.path.join(ROOT, "tests", "golden", "q14.vdl")).read())
         q14.set_profiling(True)
+        if jit != "off":
+            q14.set_jit(True, tune=jit == "tune")
         us, wall = [], []
         for k in range(8):
             torch.cuda.synchronize(); t0 = time.perf_counter(); r = q14.run(); wall.append(time.perf_counter() - t0)
@@ -151,6 +155,7 @@ def secondary_measurements(eng, rows):
                                  "bytes_per_row": datagen.Q14_BYTES_PER_ROW,
                                  "roofline_frac": n_li * datagen.Q14_BYTES_PER_ROW / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                                  "path": "fused JOIN scan: lineitem columns + part.p_type looked up through the join index + a LIKE table, one pass",
+                                 "scan_kernels": q14.jit_note(),
                                  "verified_vs_numpy_sql": r["results"]["tmp65"][".promo_revenue"] == [want]}
         q14.close()
         del keep
@@ -223,6 +228,9 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--query", default="q6", choices=["q6", "q1"],
                     help="q6 (default, BASELINE.json's metric) or q1 (grouped fused scan; secondary measurement)")
+    ap.add_argument("--jit", default="tune", choices=["off", "on", "tune"],
+                    help="scan kernels specialised for the plan by hiprtc at the first (untimed) run: off = the precompiled kernels, on = specialised with the "
+                         "precompiled variant's rows per lane, tune (default) = rows per lane chosen by timing at that run, the precompiled kernel staying if it wins")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: check launcher / sharding / merge plumbing only (see dry_run)")
     ap.add_argument("--latency-steps", type=int, default=10, help="queries run one at a time after the timed region to report per-query latency")
     args = ap.parse_args()
@@ -288,6 +296,8 @@ def main():
         raise SystemExit("%s did not fuse:\n%s" % (args.query, plan.describe()))
     plan.set_profiling(True)
     plan.set_row_offset(lo)
+    if args.jit != "off":
+        plan.set_jit(True, tune=args.jit == "tune")
     nw, ops = plan.partial_spec()
 
     n_ranks, transport, torch_group = 1, "none (single GPU)", None
@@ -376,8 +386,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world > 1:
-        one_query()                  # communicator warm-up (the first collective takes seconds) stays out of the timed region even with --warmup 0
+    if world > 1 or args.jit != "off":
+        # communicator warm-up (the first collective takes seconds) and the build / tuning of the specialised scan kernels
+        # (hiprtc: seconds) stay out of the timed region even with --warmup 0
+        one_query()
         torch.cuda.synchronize()
     result = run_steps(args.warmup, False) if args.warmup > 0 else None
     sync_all()
@@ -481,9 +493,10 @@ def main():
                          "algorithmic_bytes_per_launch": my_rows * q_bytes},
             "cpu_baseline": cpu_baseline,
             "revenue": (revenue[0] if revenue else None), "verified_bit_exact_vs_cpu": verified,
+            "scan_kernels": {"mode": args.jit, "note": plan.jit_note()},
         }
         if world == 1 and args.query == "q6" and not args.no_secondary:
-            out["also"] = secondary_measurements(eng, total_rows)
+            out["also"] = secondary_measurements(eng, total_rows, args.jit)
     eng.close()
     if world > 1:
         dist.barrier()

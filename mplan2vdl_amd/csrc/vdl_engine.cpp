@@ -208,6 +208,28 @@ static void tune_specialised(vdl_ctx *c, vdl_plan *p, int64_t *dev_words) {
             if (!best.k || ms < best_ms) { best = cand; best_ms = ms; }
         }
         if (!best.k) continue;
+        if (!grouped && use_kscan(p->fused.scans[s]) && p->block_partials[s]) {
+            // the hand-tuned single-aggregate kernel is a candidate too
+            float ms = 1e30f;
+            for (int rep = 0; rep < 4; rep++) {
+                HIP_CHECK(hipEventRecord(e0, c->stream));
+                HIP_CHECK(launch_scan(p->sargs[s], p->scfg[s], c->stream));
+                HIP_CHECK(launch_scan_finish(p->sargs[s].block_partials, p->scfg[s].grid, p->sargs[s].nagg, nullptr, p->sargs[s], out, c->stream));
+                HIP_CHECK(hipEventRecord(e1, c->stream));
+                HIP_CHECK(hipEventSynchronize(e1));
+                float t = 0;
+                HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
+                if (rep > 0 && t < ms) ms = t;
+            }
+            tried += std::string(" k_scan:") + std::to_string((int)(ms * 1000)) + "us";
+            if (ms <= best_ms) {
+                p->kscan[s] = 1;
+                p->mjit[s] = nullptr;
+                p->jit_note += "scan " + std::to_string(s) + " tuned:" + tried + " -> " + scan_kernel_name(p->scfg[s]) + "; ";
+                if ((int)s == p->dominant) p->dominant_kernel = std::string(scan_kernel_name(p->scfg[s])) + "_grid" + std::to_string(p->scfg[s].grid);
+                continue;
+            }
+        }
         p->mjit[s] = best.k;
         p->mcfg[s].grid = best.grid;
         p->jit_note += "scan " + std::to_string(s) + " tuned:" + tried + " -> " + best.name + "; ";
@@ -232,6 +254,7 @@ void bind_fused(vdl_ctx *c, vdl_plan *p) {
     p->mparts.assign(ns + ng, nullptr);
     p->mdev.resize(ns + ng);
     p->mjit.assign(ns + ng, nullptr);
+    p->kscan.assign(ns + ng, 0);
     p->jit_note.clear();
     p->jit_tuned = false;
     p->gword_offset.assign(ng, 0);
@@ -245,7 +268,9 @@ void bind_fused(vdl_ctx *c, vdl_plan *p) {
         const ScanPlan &sp = F.scans[s];
         int64_t bpr = 0, n = 0;
         std::string kname;
-        if (use_kscan(sp)) {
+        const bool eligible = use_kscan(sp);
+        p->kscan[s] = eligible && !(p->use_jit && !sp.never);    // specialising: the single-aggregate scan runs through the general body too
+        if (eligible) {                                       // (bound either way: the tuner compares the two)
             ScanArgs &a = p->sargs[s];
             a.ncol = (int)sp.cols.size(); a.nagg = 1; a.never = sp.never ? 1 : 0;
             n = -1;
@@ -272,16 +297,19 @@ void bind_fused(vdl_ctx *c, vdl_plan *p) {
             p->block_partials[s] = dev_alloc(c, sizeof(int64_t) * (size_t)p->scfg[s].grid * 2);
             a.block_partials = (int64_t *)p->block_partials[s]->p;
             kname = std::string(scan_kernel_name(p->scfg[s])) + "_grid" + std::to_string(p->scfg[s].grid);
-        } else {
+        }
+        if (!p->kscan[s]) {
+            bpr = 0;
             n = bind_mscan(c, sp, p->mcols[s], p->mdesc[s], &bpr, p->row_offset);
             p->mcfg[s] = mscan_launch_config(p->mcols[s], p->mdesc[s], false, c->num_cus);
             if (p->mcfg[s].variant < 0) throw Error(VDL_ERR_UNSUPPORTED, "no multi-aggregate scan kernel variant for this shape");
             std::string jname;
             const bool spec = p->use_jit && !sp.never && specialise_scan(c, p, s, false, &jname);
+            if (eligible && !spec) { p->kscan[s] = 1; }       // it did not build: the tuned single-aggregate kernel after all
             p->mparts[s] = dev_alloc(c, sizeof(int64_t) * (size_t)max_scan_grid(c, p, p->mcfg[s].grid) * (size_t)(p->mdesc[s].nagg + 1));
             p->mdesc[s].block_partials = (int64_t *)p->mparts[s]->p;
             if (!p->mdev[s]) p->mdev[s] = dev_alloc(c, sizeof(MScanDesc));
-            kname = (spec ? jname : std::string(mscan_kernel_name(p->mcfg[s]))) + "_grid" + std::to_string(p->mcfg[s].grid);
+            if (!p->kscan[s]) kname = (spec ? jname : std::string(mscan_kernel_name(p->mcfg[s]))) + "_grid" + std::to_string(p->mcfg[s].grid);
         }
         p->word_offset[s] = off;
         off += (int64_t)sp.aggs.size() + 1;
@@ -458,7 +486,7 @@ void run_fused_local(vdl_ctx *c, vdl_plan *p, int64_t *dev_words, bool single_ra
         const bool grouped = s >= ns;
         const bool never = grouped ? p->fused.gscans[s - ns].never : p->fused.scans[s].never;
         int64_t *out = dev_words + (grouped ? p->gword_offset[s - ns] : p->word_offset[s]);
-        const bool kscan = !grouped && use_kscan(p->fused.scans[s]);
+        const bool kscan = !grouped && p->kscan[s];
         const int64_t n = kscan ? p->sargs[s].n : p->mcols[s].n;
         const bool timed = p->profiling && (int)s == p->dominant && !never && n > 0;
         if (kscan) {
@@ -919,7 +947,6 @@ int vdl_plan_jit_check(vdl_ctx *c, vdl_plan *p) {
         const size_t ns = F.scans.size();
         for (size_t s = 0; s < ns + F.gscans.size(); s++) {
             const bool grouped = s >= ns;
-            if (!grouped && use_kscan(F.scans[s])) { p->jit_note += "scan " + std::to_string(s) + ": k_scan (not specialised); "; continue; }
             MScanCols cols;
             auto d = std::make_unique<MScanDesc>();
             int64_t bpr = 0;
