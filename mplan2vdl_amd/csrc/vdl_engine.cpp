@@ -374,6 +374,24 @@ static int64_t bind_vcols(vdl_ctx *c, const std::string &table, const std::vecto
     return n;
 }
 
+// The projection scan's passes specialised for this plan (vdl_plan_set_jit): built at the first run after a catalog change,
+// kept by role ("select", "take", "dim<k>"); nullptr = the precompiled kernel (not asked for, or it did not build: the note says).
+static hipFunction_t front_kernel(vdl_ctx *c, vdl_plan *p, const std::string &role, jit::Kind kind, const MScanCols &cols, const MScanDesc &d) {
+    if (!p->use_jit) return nullptr;
+    vdl_plan::FrontKernel &fk = p->front_jit[role];
+    if (fk.version == c->catalog_version) return fk.k ? fk.k->fn : nullptr;
+    fk.version = c->catalog_version;
+    fk.k = nullptr;
+    jit::Shape sh;
+    sh.nc = cols.ncol; sh.u = 4; sh.vec = kind == jit::SELECT ? project_select_vec(cols) : false; sh.der = true;
+    std::vector<char> code;
+    std::string why;
+    if (jit::compile(jit::scan_source(kind, mscan_args(cols), d, sh), c->arch, code, why)) fk.k = jit::load(code, why, kind);
+    if (fk.k) p->jit_note += role + ": " + jit::entry_name(kind) + "<" + std::to_string(sh.nc) + ">, " + std::to_string(code.size()) + " B of code; ";
+    else p->jit_note += role + ": not specialised (" + why.substr(0, 400) + "); ";
+    return fk.k ? fk.k->fn : nullptr;
+}
+
 // Dimension-side work of scans with derived columns (FusedPlan::prelude): the per-operator executor runs the statements
 // that hold the dimension selections (filters on the dimension table, joins of dimensions with further dimensions) and
 // their validity bitmaps become the lookup tables of the fact scan; LIKE patterns are evaluated once per heap offset.
@@ -432,9 +450,11 @@ void run_prelude_items(vdl_ctx *c, vdl_plan *p, const std::vector<char> &asked) 
         p->prelude_n[k] = n;
         if (it.never || n <= 0) { HIP_CHECK(hipMemsetAsync(p->prelude_buf[k]->p, 0, sizeof(uint64_t) * words, c->stream)); continue; }
         d->out_ptr[0] = (int64_t *)p->prelude_buf[k]->p;           // bitmap only: no positions, no counts
+        d->bitmap_only = 1;
         descs.push_back(dev_alloc(c, sizeof(MScanDesc)));
         HIP_CHECK(hipMemcpyAsync(descs.back()->p, d, sizeof(MScanDesc), hipMemcpyHostToDevice, c->stream));
-        HIP_CHECK(launch_project_select(cols, (const MScanDesc *)descs.back()->p, c->num_cus, c->stream));
+        HIP_CHECK(launch_project_select(cols, (const MScanDesc *)descs.back()->p, c->num_cus, c->stream,
+                                        front_kernel(c, p, "dim" + std::to_string(k), jit::SELECT, cols, *d)));
     }
     if (!host_descs.empty()) HIP_CHECK(hipStreamSynchronize(c->stream));      // the descriptors live on this frame
 }
@@ -666,7 +686,7 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
         sdesc->out_idx = (int64_t *)scratch->p;
         sdesc->out_ptr[0] = (int64_t *)sel->bitmap->p;
         HIP_CHECK(hipMemcpyAsync(sdev->p, sdesc.get(), sizeof(MScanDesc), hipMemcpyHostToDevice, c->stream));
-        HIP_CHECK(launch_project_select(scols, (const MScanDesc *)sdev->p, c->num_cus, c->stream));
+        HIP_CHECK(launch_project_select(scols, (const MScanDesc *)sdev->p, c->num_cus, c->stream, front_kernel(c, p, "select", jit::SELECT, scols, *sdesc)));
         HIP_CHECK(hipMemcpyAsync(offsets->p, counts->p, sizeof(int64_t) * (size_t)ntiles, hipMemcpyDeviceToDevice, c->stream));
         HIP_CHECK(launch_compact_scan((int64_t *)offsets->p, ntiles, c->stream));
         HIP_CHECK(hipMemcpyAsync(&m, (int64_t *)offsets->p + ntiles, sizeof m, hipMemcpyDeviceToHost, c->stream));
@@ -688,7 +708,7 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
         if (m > 0) {
             HIP_CHECK(hipMemcpyAsync(ddev->p, &d, sizeof d, hipMemcpyHostToDevice, c->stream));
             HIP_CHECK(launch_project_take(cols, (const MScanDesc *)ddev->p, scratch->p, (const int64_t *)counts->p, (const int64_t *)offsets->p,
-                                          c->num_cus, c->stream));
+                                          c->num_cus, c->stream, front_kernel(c, p, "take", jit::TAKE, cols, d)));
             HIP_CHECK(hipStreamSynchronize(c->stream));         // `d` lives on this frame
         }
     } else {
@@ -724,6 +744,7 @@ std::string describe_plan(const vdl_plan *p) {
         if (p->use_jit) o << "scan kernels specialised for this plan at first run (hiprtc)" << (p->jit_note.empty() ? "" : ": " + p->jit_note) << "\n";
     } else {
         if (!p->fused.ok) o << describe_fused(p->fused);
+        if (p->use_jit && p->fused.proj.ok) o << "projection / dimension scans specialised for this plan at first run (hiprtc)" << (p->jit_note.empty() ? "" : ": " + p->jit_note) << "\n";
         else o << "fusion disabled\n";
         o << "general: " << p->prog.order.size() << " statement(s), one kernel per operator\n";
         for (int id : p->prog.order) {

@@ -205,6 +205,8 @@ struct vdl_plan {
     bool use_jit = false;                    // vdl_plan_set_jit / VDL_JIT=1: scans specialised for this plan by hiprtc (vdl_jit.cpp)
     bool jit_tune = false, jit_tuned = false;   // ... =2: rows per lane chosen by timing at the first run
     std::vector<std::shared_ptr<vdl::jit::Kernel>> mjit;
+    struct FrontKernel { uint64_t version = 0; std::shared_ptr<vdl::jit::Kernel> k; };
+    std::map<std::string, FrontKernel> front_jit;   // specialised passes of the projection scan / dimension scans, by role
     std::vector<char> kscan;                 // [scan] runs on the single-aggregate k_scan (decided when the plan is bound / tuned)
     std::string jit_note;                    // what was specialised, or why not
     std::vector<BufP> prelude_buf;           // fused join scans: dimension bitmaps / LIKE tables of the current run (FusedPlan::prelude)

@@ -80,7 +80,7 @@ std::map<std::string, std::vector<char>> g_code;        // key (hash + arch) -> 
 }  // namespace
 
 // The descriptor as a constexpr function: only what differs from the defaults is written.
-std::string mscan_source(const MsArgs &C, const MScanDesc &D, const Shape &sh) {
+std::string scan_source(Kind kind, const MsArgs &C, const MScanDesc &D, const Shape &sh) {
     std::ostringstream o;
     o << "#define VDL_SPEC_UNROLL _Pragma(\"unroll\")\n" << kEmbedded << "\nnamespace vdl {\n";
     o << "constexpr MsArgs jit_args() {\n    MsArgs a{};\n";
@@ -115,14 +115,33 @@ std::string mscan_source(const MsArgs &C, const MScanDesc &D, const Shape &sh) {
         for (int k = 0; k < C.ncol; k++)
             if ((a.used >> k) & 1u) o << "    d.agg[" << j << "].fa[" << k << "] = " << lit(a.fa[k]) << "; d.agg[" << j << "].fs[" << k << "] = " << lit(a.fs[k]) << ";\n";
     }
+    if (kind != MSCAN) {
+        o << "    d.take = " << D.take << "u; d.nout = " << D.nout << "; d.bitmap_only = " << D.bitmap_only << ";\n";
+        for (int k = 0; k < D.nout; k++) o << "    d.out_col[" << k << "] = " << D.out_col[k] << ";\n";
+    }
     o << "    return d;\n}\n}  // namespace vdl\n";
-    o << "extern \"C\" __global__ __launch_bounds__(256) void vdl_jit_mscan(const vdl::MsArgs Cr, const vdl::MScanDesc *__restrict__ Dp) {\n"
-         "    constexpr vdl::MsArgs C = vdl::jit_args();\n"
-         "    constexpr vdl::MScanDesc D = vdl::jit_desc();\n"
-         "    vdl::mscan_body<" << sh.nc << ", " << sh.u << ", " << (sh.vec ? "true" : "false") << ", " << (sh.vec ? "true" : "false") << ", "
-      << (sh.grouped ? "true" : "false") << ", " << (sh.der ? "true" : "false") << ">(C, Cr, D, *Dp);\n}\n";
+    const char *b = sh.vec ? "true" : "false";
+    if (kind == MSCAN)
+        o << "extern \"C\" __global__ __launch_bounds__(256) void " << entry_name(kind) << "(const vdl::MsArgs Cr, const vdl::MScanDesc *__restrict__ Dp) {\n"
+             "    constexpr vdl::MsArgs C = vdl::jit_args();\n"
+             "    constexpr vdl::MScanDesc D = vdl::jit_desc();\n"
+             "    vdl::mscan_body<" << sh.nc << ", " << sh.u << ", " << b << ", " << b << ", " << (sh.grouped ? "true" : "false") << ", " << (sh.der ? "true" : "false")
+          << ">(C, Cr, D, *Dp);\n}\n";
+    else if (kind == SELECT)
+        o << "extern \"C\" __global__ __launch_bounds__(256) void " << entry_name(kind) << "(const vdl::MsArgs Cr, const vdl::MScanDesc *__restrict__ Dp) {\n"
+             "    constexpr vdl::MsArgs C = vdl::jit_args();\n"
+             "    constexpr vdl::MScanDesc D = vdl::jit_desc();\n"
+             "    vdl::project_select_body<" << sh.nc << ", vdl::kProjU, " << b << ", " << b << ">(C, Cr, D, *Dp);\n}\n";
+    else
+        o << "extern \"C\" __global__ __launch_bounds__(256) void " << entry_name(kind) << "(const vdl::MsArgs Cr, const vdl::MScanDesc *__restrict__ Dp, const uint16_t *__restrict__ scratch,\n"
+             "        const int64_t *__restrict__ counts, const int64_t *__restrict__ offsets) {\n"
+             "    constexpr vdl::MsArgs C = vdl::jit_args();\n"
+             "    constexpr vdl::MScanDesc D = vdl::jit_desc();\n"
+             "    vdl::project_take_body<" << sh.nc << ">(C, Cr, D, *Dp, scratch, counts, offsets);\n}\n";
     return o.str();
 }
+std::string mscan_source(const MsArgs &C, const MScanDesc &D, const Shape &sh) { return scan_source(MSCAN, C, D, sh); }
+const char *entry_name(Kind kind) { return kind == MSCAN ? "vdl_jit_mscan" : kind == SELECT ? "vdl_jit_project_select" : "vdl_jit_project_take"; }
 
 bool compile(const std::string &src, const std::string &arch, std::vector<char> &code, std::string &log) {
     const std::string key = std::to_string(fnv(src)) + "_" + std::to_string(src.size()) + "_" + arch;
@@ -170,11 +189,11 @@ bool compile(const std::string &src, const std::string &arch, std::vector<char> 
 
 Kernel::~Kernel() { if (mod) (void)hipModuleUnload(mod); }
 
-std::shared_ptr<Kernel> load(const std::vector<char> &code, std::string &why) {
+std::shared_ptr<Kernel> load(const std::vector<char> &code, std::string &why, Kind kind) {
     auto k = std::make_shared<Kernel>();
     hipError_t e = hipModuleLoadData(&k->mod, code.data());
     if (e != hipSuccess) { why = std::string("hipModuleLoadData: ") + hipGetErrorString(e); k->mod = nullptr; return nullptr; }
-    e = hipModuleGetFunction(&k->fn, k->mod, "vdl_jit_mscan");
+    e = hipModuleGetFunction(&k->fn, k->mod, entry_name(kind));
     if (e != hipSuccess) { why = std::string("hipModuleGetFunction: ") + hipGetErrorString(e); return nullptr; }
     return k;
 }

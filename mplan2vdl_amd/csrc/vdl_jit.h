@@ -13,7 +13,12 @@ namespace jit {
 
 struct Shape { int nc = 0, u = 0; bool vec = false, grouped = false, der = false; };
 
-// the translation unit: the embedded device code + this scan's descriptor as constants + the kernel `vdl_jit_mscan`
+// what is specialised: an aggregate scan, or the two passes of the projection scan (fused front; dimension scans are the
+// select pass with bitmap_only set)
+enum Kind : int { MSCAN = 0, SELECT = 1, TAKE = 2 };
+const char *entry_name(Kind kind);
+// the translation unit: the embedded device code + this scan's descriptor as constants + the kernel
+std::string scan_source(Kind kind, const MsArgs &C, const MScanDesc &D, const Shape &sh);
 std::string mscan_source(const MsArgs &C, const MScanDesc &D, const Shape &sh);
 // hiprtc (no GPU needed); cached per process and under $VDL_JIT_CACHE.  false: `log` says why
 bool compile(const std::string &src, const std::string &arch, std::vector<char> &code, std::string &log);
@@ -23,7 +28,7 @@ struct Kernel {
     hipFunction_t fn = nullptr;
     ~Kernel();
 };
-std::shared_ptr<Kernel> load(const std::vector<char> &code, std::string &why);
+std::shared_ptr<Kernel> load(const std::vector<char> &code, std::string &why, Kind kind = MSCAN);
 
 }  // namespace jit
 }  // namespace vdl

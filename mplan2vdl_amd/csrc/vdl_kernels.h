@@ -66,10 +66,11 @@ size_t mscan_lds_bytes(const MScanDesc &d, bool grouped);
 int64_t project_tiles(int64_t n);
 int64_t project_scratch_bytes(int64_t n);
 // d.out_idx = the scratch area (project_scratch_bytes), d.tile_counts = [tiles + 1]
-hipError_t launch_project_select(const MScanCols &cols, const MScanDesc *dev_desc, int num_cus, hipStream_t s);
+hipError_t launch_project_select(const MScanCols &cols, const MScanDesc *dev_desc, int num_cus, hipStream_t s, hipFunction_t jit_fn = nullptr);
+bool project_select_vec(const MScanCols &cols);          // the 16-byte-load form applies (alignment of the deciding columns)
 // d.take = the columns the outputs need, d.out_* = the packed result vectors; counts = survivors per tile, offsets = their prefix
 hipError_t launch_project_take(const MScanCols &cols, const MScanDesc *dev_desc, const void *scratch, const int64_t *counts, const int64_t *offsets,
-                               int num_cus, hipStream_t s);
+                               int num_cus, hipStream_t s, hipFunction_t jit_fn = nullptr);
 // sharded FoldChoose: after the MIN all-reduce of the row-id words, the owning rank substitutes the value, others 0
 hipError_t launch_mscan_resolve_first(const MScanCols &cols, const MScanDesc &d, const MScanDesc *dev_desc, int64_t *table, hipStream_t s);
 

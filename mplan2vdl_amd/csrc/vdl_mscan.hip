@@ -82,124 +82,15 @@ __global__ void k_mscan_first(const MsArgs C, const MScanDesc *__restrict__ Dp, 
     }
 }
 
-// ---- projection scan (ProjPlan, vdl_fuse.h) -----------------------------------------------------------------------------
-// k_project_select: ONE pass over the columns that decide a row's survival (filtered columns and what they are derived from:
-// for Q3 the ship date and the join index, 12 B/row, plus the dimension bitmap looked up through the index).  Per tile it
-// leaves the number of survivors and their positions inside the tile (16 bits each, in row order) in a scratch area.
-// k_project_take: after a prefix sum over the tile counts, one WAVE per tile reads the survivors' positions and, with every
-// lane busy, loads what the rest of the program wants of them -- fact columns at the row, dimension columns through the
-// index -- and writes the packed vectors.  (A second full pass with exec-masked loads for 5 % of the lanes took 4x as long.)
-// Row order inside a tile is (sub-iteration u, wave, lane, row of the lane's pair).
-constexpr int kProjU = 4;
-constexpr int kProjTile = kMsBlock * 2 * kProjU;
-static_assert(kProjTile <= 65536, "positions inside a tile fit 16 bits");
-
+// the projection scan's kernels (bodies in vdl_mscan_body.h)
 template <int NC, int U, bool VEC, bool NT>
 __global__ __launch_bounds__(kMsBlock) void k_project_select(const MsArgs C, const MScanDesc *__restrict__ Dp) {
-    const MScanDesc &D = *Dp;
-    constexpr int BS = kMsBlock, ROWS = 2 * U, TILE = BS * ROWS, NW = BS / kWave;
-    __shared__ int wcnt[U][NW];
-    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-    const int64_t full = C.n / TILE, ntiles = (C.n + TILE - 1) / TILE;
-    uint16_t *__restrict__ scratch = (uint16_t *)D.out_idx;            // [tiles][TILE] positions
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        int64_t v[NC][ROWS];
-        const int64_t base = tile * TILE + (int64_t)tid * 2;
-        if (tile < full) {
-            load_tile<NC, U, VEC, NT>(C, C, base, v, C.lazy);
-        } else {                                           // the partial last tile: clamped scalar loads
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-                if (c < C.ncol && !(((C.derived | C.lazy) >> c) & 1u)) {
-#pragma unroll
-                    for (int r = 0; r < ROWS; r++) {
-                        const int64_t i = base + (int64_t)(r >> 1) * (BS * 2) + (r & 1);
-                        v[c][r] = load_scalar(C.ptr[c], C.width(c), i < C.n ? i : C.n - 1);
-                    }
-                }
-            }
-        }
-        bool alive[ROWS];
-#pragma unroll
-        for (int r = 0; r < ROWS; r++) alive[r] = base + (int64_t)(r >> 1) * (BS * 2) + (r & 1) < C.n;
-        derive<NC, ROWS>(C, C, D, D, v, alive, C.derived & ~C.lazy);      // filters fold into `alive` as they are derived
-        uint64_t m[ROWS];
-#pragma unroll
-        for (int r = 0; r < ROWS; r++) m[r] = __ballot(alive[r]);
-        // the selection's bitmap over the table's rows, for whoever asks the sparse vectors for their validity: lanes 2l, 2l+1
-        // of the two ballots of a sub-iteration are rows 2l, 2l+1 of the wave's 128 -- interleave them into two words
-        if (D.out_ptr[0] && lane < 2 * U) {
-            const int u = lane >> 1, half = lane & 1;
-            uint64_t a = 0, b = 0;
-#pragma unroll
-            for (int uu = 0; uu < U; uu++) if (uu == u) { a = m[2 * uu]; b = m[2 * uu + 1]; }
-            uint64_t x = half ? (a >> 32) : (a & 0xffffffffull), y = half ? (b >> 32) : (b & 0xffffffffull);
-            x = (x | (x << 16)) & 0x0000ffff0000ffffull; x = (x | (x << 8)) & 0x00ff00ff00ff00ffull; x = (x | (x << 4)) & 0x0f0f0f0f0f0f0f0full;
-            x = (x | (x << 2)) & 0x3333333333333333ull; x = (x | (x << 1)) & 0x5555555555555555ull;
-            y = (y | (y << 16)) & 0x0000ffff0000ffffull; y = (y | (y << 8)) & 0x00ff00ff00ff00ffull; y = (y | (y << 4)) & 0x0f0f0f0f0f0f0f0full;
-            y = (y | (y << 2)) & 0x3333333333333333ull; y = (y | (y << 1)) & 0x5555555555555555ull;
-            const int64_t word = (tile * TILE + (int64_t)u * (BS * 2) + (int64_t)wave * 128) / 64 + half;
-            if (word < ((C.n + 63) >> 6)) ((uint64_t *)D.out_ptr[0])[word] = x | (y << 1);
-        }
-        if (!scratch) continue;                            // a dimension scan wants the bitmap only (block-uniform)
-        if (lane == 0) {
-#pragma unroll
-            for (int u = 0; u < U; u++) wcnt[u][wave] = __popcll(m[2 * u]) + __popcll(m[2 * u + 1]);
-        }
-        __syncthreads();
-        int total = 0, mybase[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-#pragma unroll
-            for (int w = 0; w < NW; w++) { if (w == wave) mybase[u] = total; total += wcnt[u][w]; }
-        }
-        if (tid == 0) D.tile_counts[tile] = total;
-        const uint64_t below = (1ull << lane) - 1;
-#pragma unroll
-        for (int r = 0; r < ROWS; r++) {
-            const int u = r >> 1;
-            const int rank = mybase[u] + __popcll(m[2 * u] & below) + __popcll(m[2 * u + 1] & below) + ((r & 1) && alive[2 * u] ? 1 : 0);
-            if (alive[r]) scratch[tile * TILE + rank] = (uint16_t)(tid * 2 + u * (BS * 2) + (r & 1));
-        }
-        __syncthreads();                                   // wcnt is rewritten by the next tile
-    }
+    project_select_body<NC, U, VEC, NT>(C, C, *Dp, *Dp);
 }
-
-// one wave per tile; lane k takes the tile's survivors k, k + 64, ...
 template <int NC>
 __global__ __launch_bounds__(kMsBlock) void k_project_take(const MsArgs C, const MScanDesc *__restrict__ Dp, const uint16_t *__restrict__ scratch,
-                                                           const int64_t *__restrict__ counts /* raw */, const int64_t *__restrict__ offsets /* exclusive prefix */) {
-    const MScanDesc &D = *Dp;
-    constexpr int TILE = kProjTile;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int64_t ntiles = (C.n + TILE - 1) / TILE;
-    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave);
-    for (int64_t tile = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; tile < ntiles; tile += wstride) {
-        const int cnt = (int)counts[tile];
-        const int64_t off = offsets[tile];
-        for (int k0 = 0; k0 < cnt; k0 += kWave) {          // wave-uniform
-            const int k = k0 + lane;
-            const bool on = k < cnt;
-            const int64_t row = tile * TILE + (on ? (int64_t)scratch[tile * TILE + k] : 0);      // idle lanes re-read a row of the tile
-            int64_t v[NC][1];
-            // every table column the outputs need (directly or as a lookup's index), at the row; then the lookups
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-                v[c][0] = 0;
-                if (c < C.ncol && ((D.take >> c) & 1u) && !((C.derived >> c) & 1u)) v[c][0] = load_scalar(C.ptr[c], C.width(c), row < C.n ? row : C.n - 1);
-            }
-            bool alive[1] = {on};
-            derive<NC, 1>(C, C, D, D, v, alive, C.derived & D.take, false);
-            if (on) D.out_idx[off + k] = row;
-            for (int o = 0; o < D.nout; o++) {
-                const int oc = D.out_col[o];
-                int64_t x = 0;
-#pragma unroll
-                for (int c = 0; c < NC; c++) if (c == oc) x = v[c][0];
-                if (on) D.out_ptr[o][off + k] = x;
-            }
-        }
-    }
+                                                           const int64_t *__restrict__ counts, const int64_t *__restrict__ offsets) {
+    project_take_body<NC>(C, C, *Dp, *Dp, scratch, counts, offsets);
 }
 
 typedef void (*mscan_fn)(const MsArgs, const MScanDesc *);
@@ -310,15 +201,23 @@ hipError_t launch_mscan(const MScanCols &cols, const MScanDesc &d, const MScanDe
 int64_t project_tiles(int64_t n) { return (n + kProjTile - 1) / kProjTile; }
 int64_t project_scratch_bytes(int64_t n) { return project_tiles(n) * kProjTile * (int64_t)sizeof(uint16_t); }
 
-hipError_t launch_project_select(const MScanCols &cols, const MScanDesc *dev_desc, int num_cus, hipStream_t s) {
-    (void)hipGetLastError();
-    if (cols.n <= 0) return hipSuccess;
+bool project_select_vec(const MScanCols &cols) {
     bool vec = true;
     for (int c = 0; c < cols.ncol; c++)
         if (cols.kind[c] == VC_DIRECT && !cols.lazy[c] && ((uintptr_t)cols.ptr[c]) % (uintptr_t)(2 * cols.width[c]) != 0) vec = false;
+    return vec;
+}
+hipError_t launch_project_select(const MScanCols &cols, const MScanDesc *dev_desc, int num_cus, hipStream_t s, hipFunction_t jit_fn) {
+    (void)hipGetLastError();
+    if (cols.n <= 0) return hipSuccess;
+    const bool vec = project_select_vec(cols);
     int64_t grid = project_tiles(cols.n);
     if (grid > (int64_t)num_cus * 8) grid = (int64_t)num_cus * 8;
-    const MsArgs a = ms_args(cols);
+    MsArgs a = ms_args(cols);
+    if (jit_fn) {
+        void *params[] = {&a, &dev_desc};
+        return hipModuleLaunchKernel(jit_fn, (unsigned)grid, 1, 1, kMsBlock, 1, 1, 0, s, params, nullptr);
+    }
 #define VDL_PJ(NC) do { if (vec) k_project_select<NC, kProjU, true, true><<<(int)grid, kMsBlock, 0, s>>>(a, dev_desc); \
                         else k_project_select<NC, kProjU, false, false><<<(int)grid, kMsBlock, 0, s>>>(a, dev_desc); } while (0)
     if (cols.ncol <= 4) VDL_PJ(4); else if (cols.ncol <= 8) VDL_PJ(8); else VDL_PJ(kMaxVCols);      // (registers: NC x 8 rows x 64 bits)
@@ -326,11 +225,16 @@ hipError_t launch_project_select(const MScanCols &cols, const MScanDesc *dev_des
     return hipGetLastError();
 }
 hipError_t launch_project_take(const MScanCols &cols, const MScanDesc *dev_desc, const void *scratch, const int64_t *counts, const int64_t *offsets,
-                               int num_cus, hipStream_t s) {
+                               int num_cus, hipStream_t s, hipFunction_t jit_fn) {
     (void)hipGetLastError();
     if (cols.n <= 0) return hipSuccess;
     int64_t grid = (project_tiles(cols.n) + 3) / 4;
     if (grid > (int64_t)num_cus * 16) grid = (int64_t)num_cus * 16;
+    if (jit_fn) {
+        MsArgs a = ms_args(cols);
+        void *params[] = {&a, &dev_desc, &scratch, &counts, &offsets};
+        return hipModuleLaunchKernel(jit_fn, (unsigned)grid, 1, 1, kMsBlock, 1, 1, 0, s, params, nullptr);
+    }
     k_project_take<kMaxVCols><<<(int)grid, kMsBlock, 0, s>>>(ms_args(cols), dev_desc, (const uint16_t *)scratch, counts, offsets);
     return hipGetLastError();
 }

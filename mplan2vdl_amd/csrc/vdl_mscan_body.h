@@ -582,5 +582,124 @@ __device__ __forceinline__ void mscan_body(const MsArgs &C, const MsArgs &Cr, co
     }
 }
 
+// ---- projection scan (ProjPlan, vdl_fuse.h) -----------------------------------------------------------------------------
+// k_project_select: ONE pass over the columns that decide a row's survival (filtered columns and what they are derived from:
+// for Q3 the ship date and the join index, 12 B/row, plus the dimension bitmap looked up through the index).  Per tile it
+// leaves the number of survivors and their positions inside the tile (16 bits each, in row order) in a scratch area.
+// k_project_take: after a prefix sum over the tile counts, one WAVE per tile reads the survivors' positions and, with every
+// lane busy, loads what the rest of the program wants of them -- fact columns at the row, dimension columns through the
+// index -- and writes the packed vectors.  (A second full pass with exec-masked loads for 5 % of the lanes took 4x as long.)
+// Row order inside a tile is (sub-iteration u, wave, lane, row of the lane's pair).
+constexpr int kProjU = 4;
+constexpr int kProjTile = kMsBlock * 2 * kProjU;
+static_assert(kProjTile <= 65536, "positions inside a tile fit 16 bits");
+
+template <int NC, int U, bool VEC, bool NT>
+__device__ __forceinline__ void project_select_body(const MsArgs &C, const MsArgs &Cr, const MScanDesc &D, const MScanDesc &Dr) {
+    constexpr int BS = kMsBlock, ROWS = 2 * U, TILE = BS * ROWS, NW = BS / kWave;
+    __shared__ int wcnt[U][NW];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const int64_t full = Cr.n / TILE, ntiles = (Cr.n + TILE - 1) / TILE;
+    uint16_t *__restrict__ scratch = (uint16_t *)Dr.out_idx;            // [tiles][TILE] positions
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int64_t v[NC][ROWS];
+        const int64_t base = tile * TILE + (int64_t)tid * 2;
+        if (tile < full) {
+            load_tile<NC, U, VEC, NT>(C, Cr, base, v, C.lazy);
+        } else {                                           // the partial last tile: clamped scalar loads
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                if (c < C.ncol && !(((C.derived | C.lazy) >> c) & 1u)) {
+#pragma unroll
+                    for (int r = 0; r < ROWS; r++) {
+                        const int64_t i = base + (int64_t)(r >> 1) * (BS * 2) + (r & 1);
+                        v[c][r] = load_scalar(Cr.ptr[c], C.width(c), i < Cr.n ? i : Cr.n - 1);
+                    }
+                }
+            }
+        }
+        bool alive[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) alive[r] = base + (int64_t)(r >> 1) * (BS * 2) + (r & 1) < Cr.n;
+        derive<NC, ROWS>(C, Cr, D, Dr, v, alive, C.derived & ~C.lazy);      // filters fold into `alive` as they are derived
+        uint64_t m[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) m[r] = __ballot(alive[r]);
+        // the selection's bitmap over the table's rows, for whoever asks the sparse vectors for their validity: lanes 2l, 2l+1
+        // of the two ballots of a sub-iteration are rows 2l, 2l+1 of the wave's 128 -- interleave them into two words
+        if (Dr.out_ptr[0] && lane < 2 * U) {
+            const int u = lane >> 1, half = lane & 1;
+            uint64_t a = 0, b = 0;
+#pragma unroll
+            for (int uu = 0; uu < U; uu++) if (uu == u) { a = m[2 * uu]; b = m[2 * uu + 1]; }
+            uint64_t x = half ? (a >> 32) : (a & 0xffffffffull), y = half ? (b >> 32) : (b & 0xffffffffull);
+            x = (x | (x << 16)) & 0x0000ffff0000ffffull; x = (x | (x << 8)) & 0x00ff00ff00ff00ffull; x = (x | (x << 4)) & 0x0f0f0f0f0f0f0f0full;
+            x = (x | (x << 2)) & 0x3333333333333333ull; x = (x | (x << 1)) & 0x5555555555555555ull;
+            y = (y | (y << 16)) & 0x0000ffff0000ffffull; y = (y | (y << 8)) & 0x00ff00ff00ff00ffull; y = (y | (y << 4)) & 0x0f0f0f0f0f0f0f0full;
+            y = (y | (y << 2)) & 0x3333333333333333ull; y = (y | (y << 1)) & 0x5555555555555555ull;
+            const int64_t word = (tile * TILE + (int64_t)u * (BS * 2) + (int64_t)wave * 128) / 64 + half;
+            if (word < ((Cr.n + 63) >> 6)) ((uint64_t *)Dr.out_ptr[0])[word] = x | (y << 1);
+        }
+        if (D.bitmap_only) continue;                       // a dimension scan wants the bitmap only
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < U; u++) wcnt[u][wave] = __popcll(m[2 * u]) + __popcll(m[2 * u + 1]);
+        }
+        __syncthreads();
+        int total = 0, mybase[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+#pragma unroll
+            for (int w = 0; w < NW; w++) { if (w == wave) mybase[u] = total; total += wcnt[u][w]; }
+        }
+        if (tid == 0) Dr.tile_counts[tile] = total;
+        const uint64_t below = (1ull << lane) - 1;
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            const int u = r >> 1;
+            const int rank = mybase[u] + __popcll(m[2 * u] & below) + __popcll(m[2 * u + 1] & below) + ((r & 1) && alive[2 * u] ? 1 : 0);
+            if (alive[r]) scratch[tile * TILE + rank] = (uint16_t)(tid * 2 + u * (BS * 2) + (r & 1));
+        }
+        __syncthreads();                                   // wcnt is rewritten by the next tile
+    }
+}
+
+// one wave per tile; lane k takes the tile's survivors k, k + 64, ...
+template <int NC>
+__device__ __forceinline__ void project_take_body(const MsArgs &C, const MsArgs &Cr, const MScanDesc &D, const MScanDesc &Dr, const uint16_t *__restrict__ scratch,
+                                                  const int64_t *__restrict__ counts /* raw */, const int64_t *__restrict__ offsets /* exclusive prefix */) {
+    constexpr int TILE = kProjTile;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t ntiles = (Cr.n + TILE - 1) / TILE;
+    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave);
+    for (int64_t tile = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; tile < ntiles; tile += wstride) {
+        const int cnt = (int)counts[tile];
+        const int64_t off = offsets[tile];
+        for (int k0 = 0; k0 < cnt; k0 += kWave) {          // wave-uniform
+            const int k = k0 + lane;
+            const bool on = k < cnt;
+            const int64_t row = tile * TILE + (on ? (int64_t)scratch[tile * TILE + k] : 0);      // idle lanes re-read a row of the tile
+            int64_t v[NC][1];
+            // every table column the outputs need (directly or as a lookup's index), at the row; then the lookups
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                v[c][0] = 0;
+                if (c < C.ncol && ((D.take >> c) & 1u) && !((C.derived >> c) & 1u)) v[c][0] = load_scalar(Cr.ptr[c], C.width(c), row < Cr.n ? row : Cr.n - 1);
+            }
+            bool alive[1] = {on};
+            derive<NC, 1>(C, Cr, D, Dr, v, alive, C.derived & D.take, false);
+            if (on) Dr.out_idx[off + k] = row;
+            VDL_SPEC_UNROLL
+            for (int o = 0; o < D.nout; o++) {
+                const int oc = D.out_col[o];
+                int64_t x = 0;
+#pragma unroll
+                for (int c = 0; c < NC; c++) if (c == oc) x = v[c][0];
+                if (on) Dr.out_ptr[o][off + k] = x;
+            }
+        }
+    }
+}
+
 }  // namespace
 }  // namespace vdl

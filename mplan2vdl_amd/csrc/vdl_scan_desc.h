@@ -120,6 +120,7 @@ struct MScanDesc {                           // lives in device memory, read wit
     int64_t *out_idx = nullptr;              // the surviving rows' slot ids, ascending
     int64_t *tile_counts = nullptr;          // [tiles + 1]: survivors per tile
     uint32_t take = 0;                       // k_project_take: the columns the outputs need (with the columns they are derived from)
+    int bitmap_only = 0;                     // k_project_select: a dimension scan -- the selection's bitmap, no counts, no positions
     int ncomp = 0, key_masked = 0;           // ncomp > 0: the key program is this canonical form
     int64_t key_mask = 0;
     KeyComp comp[kMaxKeyComps];

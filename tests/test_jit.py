@@ -135,3 +135,36 @@ def test_specialised_scans_shard_like_the_precompiled_ones():
 
     for res, note in run_ranks(2, work):
         assert res == want and "k_mscan_specialised<" in note
+
+
+@pytest.mark.gpu
+def test_specialised_fronts_and_dimension_scans_match_the_oracle():
+    """Plans that do not fuse as a whole: the projection scan's two passes and the dimension-side bitmap scans are
+    specialised too (roles select / take / dim<k> in the note)."""
+    for n in (3, 9, 10, 11, 15, 20):
+        text, cols = compiled(n, 2e-3)
+        want = oracle_run(text, cols)
+        e = engine_with(cols)
+        p = e.parse(text)
+        p.set_jit(True)
+        got = p.run()["results"]
+        again = p.run()["results"]
+        note = p.jit_note()
+        e.close()
+        assert got == want and again == want, (n, note)
+        assert "select: vdl_jit_project_select<" in note and "not specialised" not in note, (n, note)
+        assert ("dim" in note) == (n != 15), (n, note)          # Q15's front has no dimension side
+    from test_random_conditions import FrontGen
+    fronts = 0
+    for seed in range(30):
+        text, cols = FrontGen(seed).build()
+        want = oracle_run(text, cols)
+        e = engine_with(cols)
+        p = e.parse(text)
+        p.set_jit(True)
+        got = p.run()["results"]
+        note = p.jit_note()
+        e.close()
+        check_against_oracle("specialised_front", seed, text, cols, got, want)
+        fronts += "vdl_jit_project_select<" in note
+    assert fronts >= 15
