@@ -108,6 +108,8 @@ def secondary_measurements(eng, rows, jit="tune"):
         n_orders = 15000000                       # SF10: 60 M lineitems, 15 M orders, 1.5 M customers
         keep = datagen.register_q3_columns(eng, n_orders)
         q3 = eng.parse(open(os.path.join(ROOT, "tests", "golden", "q3.vdl")).read())
+        if jit != "off":
+            q3.set_jit(True)                      # (its projection / dimension scans; nothing to tune: their tile shape is fixed)
         times = {}
         for dev_out in (True, False):
             q3.set_device_outputs(dev_out)
@@ -120,7 +122,7 @@ def secondary_measurements(eng, rows, jit="tune"):
                                 "ms_per_query_results_left_in_hbm": 1e3 * times[True], "result_rows": int(len(res["tmp110"][".revenue"])),
                                 "path": "fused front (one projection scan of lineitem: ship-date filter + join filter through the orders bitmap, "
                                         "survivors' columns packed) then Partition / Scatter / Fold statement by statement",
-                                "verified_vs_numpy_sql": q3_matches_sql(eng, res)}
+                                "scan_kernels": q3.jit_note(), "verified_vs_numpy_sql": q3_matches_sql(eng, res)}
         q3.close()
         for name in list(keep) + ["customer.c_mktsegment", "orders.o_orderdate", "orders.o_shippriority", "orders.orders_customer",
                                   "lineitem.l_shipdate", "lineitem.l_extendedprice", "lineitem.l_discount"]:

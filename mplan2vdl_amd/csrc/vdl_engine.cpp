@@ -685,10 +685,13 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
         sdesc->tile_counts = (int64_t *)counts->p;
         sdesc->out_idx = (int64_t *)scratch->p;
         sdesc->out_ptr[0] = (int64_t *)sel->bitmap->p;
+        sdesc->out_ptr[1] = (int64_t *)offsets->p;
+        BufP sums = dev_alloc(c, sizeof(int64_t) * (size_t)(prefix_sum_blocks(ntiles + 1) + 1));
         HIP_CHECK(hipMemcpyAsync(sdev->p, sdesc.get(), sizeof(MScanDesc), hipMemcpyHostToDevice, c->stream));
         HIP_CHECK(launch_project_select(scols, (const MScanDesc *)sdev->p, c->num_cus, c->stream, front_kernel(c, p, "select", jit::SELECT, scols, *sdesc)));
-        HIP_CHECK(hipMemcpyAsync(offsets->p, counts->p, sizeof(int64_t) * (size_t)ntiles, hipMemcpyDeviceToDevice, c->stream));
-        HIP_CHECK(launch_compact_scan((int64_t *)offsets->p, ntiles, c->stream));
+        // (the select pass left the counts in `offsets` too, with a 0 behind them: a device-wide exclusive prefix sum over
+        // ntiles + 1 words puts the total there -- Q3 at SF10 has 29 K tiles, a one-block scan took 26 us)
+        HIP_CHECK(launch_prefix_sum((int64_t *)offsets->p, ntiles + 1, (int64_t *)sums->p, c->stream));
         HIP_CHECK(hipMemcpyAsync(&m, (int64_t *)offsets->p + ntiles, sizeof m, hipMemcpyDeviceToHost, c->stream));
         HIP_CHECK(hipStreamSynchronize(c->stream));             // (also: `d` has been read by the first copy)
         sel->idx = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(m, 1));

@@ -652,7 +652,13 @@ __device__ __forceinline__ void project_select_body(const MsArgs &C, const MsArg
 #pragma unroll
             for (int w = 0; w < NW; w++) { if (w == wave) mybase[u] = total; total += wcnt[u][w]; }
         }
-        if (tid == 0) Dr.tile_counts[tile] = total;
+        if (tid == 0) {
+            Dr.tile_counts[tile] = total;
+            if (Dr.out_ptr[1]) {                           // a second copy that the prefix sum overwrites, one longer: the grand total ends up there
+                Dr.out_ptr[1][tile] = total;
+                if (tile == 0) Dr.out_ptr[1][ntiles] = 0;
+            }
+        }
         const uint64_t below = (1ull << lane) - 1;
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {

@@ -160,7 +160,7 @@ bool read_reply(const std::string &path, Reply &r) {
 struct Options {
     int64_t rows = 60175;           // SF0.01 lineitem, /root/reference/tests/tpchnoorder/bounds.csv:59
     uint64_t seed = 0x5EED0006ULL;
-    int device = 0, fuse = 1, profile = 0, describe = 0, gpus = 1;
+    int device = 0, fuse = 1, profile = 0, describe = 0, gpus = 1, jit = 0;
     std::string data_dir, shard = "lineitem";
 };
 
@@ -173,6 +173,7 @@ int run_rank(const Options &o, const std::string &text, int rank, int world, con
     if ((rc = vdl_parse(ctx, text.data(), text.size(), &plan))) return die(ctx, "vdl_parse", rc);
     vdl_plan_set_fusion(plan, o.fuse);
     vdl_plan_set_profiling(plan, o.profile);
+    if (o.jit) vdl_plan_set_jit(plan, o.jit);
     if (o.describe) { std::fputs(vdl_plan_describe(plan), stdout); return 0; }
     int64_t row0 = 0;
     if (!o.data_dir.empty()) {
@@ -228,10 +229,12 @@ int main(int argc, char **argv) {
         else if (a == "--gpus" && i + 1 < argc) o.gpus = std::atoi(argv[++i]);
         else if (a == "--shard" && i + 1 < argc) o.shard = argv[++i];
         else if (a == "--no-fuse") o.fuse = 0;
+        else if (a == "--jit") o.jit = 1;
+        else if (a == "--jit-tune") o.jit = 2;
         else if (a == "--profile") o.profile = 1;
         else if (a == "--describe") o.describe = 1;
         else {
-            std::fprintf(stderr, "usage: vdlrun [--rows N | --data DIR] [--gpus N [--shard TABLE]] [--seed S] [--device D] [--no-fuse] [--profile] [--describe] < program.vdl\n");
+            std::fprintf(stderr, "usage: vdlrun [--rows N | --data DIR] [--gpus N [--shard TABLE]] [--seed S] [--device D] [--no-fuse] [--jit | --jit-tune] [--profile] [--describe] < program.vdl\n");
             return 2;
         }
     }

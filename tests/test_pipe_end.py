@@ -48,8 +48,10 @@ def test_vdlrun_rows_runs_q6_on_generated_lineitem(q6_text, rows, flags):
     assert reply["results"] == oracle_run(q6_text, lineitem(datagen.Q6_COLUMNS, rows))
 
 
-def test_vdlrun_rows_runs_q1_grouped(q1_text):
-    reply = pipe(q1_text, ["--rows", "60175"])
+@pytest.mark.parametrize("flags", [[], ["--jit"], ["--jit-tune"]])
+def test_vdlrun_rows_runs_q1_grouped(q1_text, flags):
+    """(--jit / --jit-tune: the grouped scan specialised for the plan by hiprtc inside the C host, vdl_plan_set_jit)"""
+    reply = pipe(q1_text, ["--rows", "60175"] + flags)
     assert reply["results"] == oracle_run(q1_text, lineitem(datagen.Q1_COLUMNS, 60175))
     golden = json.load(open(os.path.join(ROOT, "tests", "golden", "q1_sf001.json")))
     assert reply["results"] == golden["results"]                # the committed fixture, through the pipe end
