@@ -474,7 +474,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath)).get(args.query, {})
+                late = ",late>" in kernel_label
+                tj = json.load(open(tpath)).get(args.query + ("_late" if late else ""), {})
                 if tj.get("rows") == my_rows:
                     traffic = tj.get("hbm_bytes_per_launch")
                     traffic_source = "committed profile, not measured in this run: " + tj.get("source", "profiles/traffic.json")
@@ -492,7 +493,13 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel_label, "kernel_us": kern_us,
-                         "algorithmic_bytes_per_launch": my_rows * q_bytes},
+                         "algorithmic_bytes_per_launch": my_rows * q_bytes,
+                         # a kernel the tuner chose with late materialisation reads the filter columns of every row and the
+                         # aggregate-only columns in the 64-byte sectors that hold a passing row: it moves fewer bytes than the
+                         # algorithmic figure (all column widths x rows), so `frac` -- defined on that figure --
+                         # can pass 1; `frac_of_traffic` prices the bytes the counters saw instead
+                         "late_materialisation": ",late>" in kernel_label,
+                         "frac_of_traffic": (traffic / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBPS) if (traffic and kern_us) else None},
             "cpu_baseline": cpu_baseline,
             "revenue": (revenue[0] if revenue else None), "verified_bit_exact_vs_cpu": verified,
             "scan_kernels": {"mode": args.jit, "note": plan.jit_note()},

@@ -137,11 +137,33 @@ static std::string jit_name(const jit::Shape &sh) {
            (sh.der ? ",derived" : "") + ">";
 }
 struct Specialised { std::shared_ptr<jit::Kernel> k; int grid = 0, per_cu = 0; size_t code_bytes = 0; std::string name; };
-static bool build_specialised(vdl_ctx *c, vdl_plan *p, size_t s, bool grouped, int u, Specialised &out, std::string &why) {
+// table columns a specialised scan may read late (for passing rows only): aggregate inputs that no filter, derived column or
+// group key looks at
+static uint32_t late_columns(const MScanCols &cols, const MScanDesc &d, bool grouped) {
+    uint32_t late = 0;
+    for (int k = 0; k < cols.ncol; k++) if (cols.kind[k] == VC_DIRECT && !cols.filtered[k]) late |= 1u << k;
+    for (int k = 0; k < cols.ncol; k++) {
+        if (cols.kind[k] == VC_DIRECT) continue;
+        if (cols.kind[k] == VC_FORM) { for (int f = d.dsrc[k]; f < d.dsrc[k] + d.dtests[k]; f++) late &= ~(1u << d.form[f].col); continue; }
+        if (d.dsrc[k] >= 0) late &= ~(1u << d.dsrc[k]);
+        if (d.dsrc2[k] >= 0) late &= ~(1u << d.dsrc2[k]);
+    }
+    if (grouped) {
+        for (int k = 0; k < d.nkey; k++) if (d.key[k].kind == KeyStep::LOAD) late &= ~(1u << d.key[k].col);
+        for (int k = 0; k < d.ncomp; k++) late &= ~(1u << d.comp[k].col);
+    }
+    uint32_t used = 0;
+    for (int j = 0; j < d.nagg; j++) if (d.agg[j].kind != AGG_FIRST) used |= d.agg[j].used;
+    return late & used;
+}
+static bool build_specialised(vdl_ctx *c, vdl_plan *p, size_t s, bool grouped, int u, bool lazy, Specialised &out, std::string &why) {
     jit::Shape sh = jit_shape(p->mcols[s], p->mcfg[s]);
     if (u > 0) sh.u = u;
     std::vector<char> code;
-    if (!jit::compile(jit::mscan_source(mscan_args(p->mcols[s]), p->mdesc[s], sh), c->arch, code, why)) { why = why.substr(0, 400); return false; }
+    MsArgs args = mscan_args(p->mcols[s]);
+    args.lazy = lazy ? late_columns(p->mcols[s], p->mdesc[s], grouped) : 0;
+    if (lazy && !args.lazy) { why = "no column to read late"; return false; }
+    if (!jit::compile(jit::mscan_source(args, p->mdesc[s], sh), c->arch, code, why)) { why = why.substr(0, 400); return false; }
     out.k = jit::load(code, why);
     if (!out.k) return false;
     int per_cu = 0;
@@ -155,12 +177,14 @@ static bool build_specialised(vdl_ctx *c, vdl_plan *p, size_t s, bool grouped, i
     if (grid > p->mcols[s].n / tile) grid = p->mcols[s].n / tile;
     if (grid < 1) grid = 1;
     out.grid = (int)grid; out.per_cu = per_cu; out.code_bytes = code.size(); out.name = jit_name(sh);
+    if (lazy) out.name.insert(out.name.size() - 1, ",late");
     return true;
 }
 static bool specialise_scan(vdl_ctx *c, vdl_plan *p, size_t s, bool grouped, std::string *kname) {
     Specialised sp;
     std::string why;
-    if (!build_specialised(c, p, s, grouped, 0, sp, why)) { p->jit_note += "scan " + std::to_string(s) + ": not specialised (" + why + "); "; return false; }
+    const bool late = getenv("VDL_JIT_LATE") != nullptr;          // (tests: force late materialisation where a column allows it)
+    if (!(late && build_specialised(c, p, s, grouped, 0, true, sp, why)) && !build_specialised(c, p, s, grouped, 0, false, sp, why)) { p->jit_note += "scan " + std::to_string(s) + ": not specialised (" + why + "); "; return false; }
     p->mcfg[s].grid = sp.grid;
     p->mjit[s] = sp.k;
     *kname = sp.name;
@@ -186,11 +210,17 @@ static void tune_specialised(vdl_ctx *c, vdl_plan *p, int64_t *dev_words) {
         Specialised best;
         float best_ms = 0;
         std::string tried;
-        for (int u : {2, 3, 4, 6}) {
-            if ((int64_t)256 * 2 * u > p->mcols[s].n) continue;
+        // rows per lane first; then, at the winner and at 2, the columns that are only aggregate inputs read late
+        std::vector<std::pair<int, bool>> cands = {{2, false}, {3, false}, {4, false}, {6, false}, {0, true}, {2, true}};
+        int best_u = 0;
+        for (auto &cu : cands) {
+            const int u = cu.first ? cu.first : best_u;
+            const bool lazy = cu.second;
+            if (u <= 0 || (int64_t)256 * 2 * u > p->mcols[s].n) continue;
+            if (lazy && cu.first == best_u) continue;
             Specialised cand;
             std::string why;
-            if (!build_specialised(c, p, s, grouped, u, cand, why)) continue;
+            if (!build_specialised(c, p, s, grouped, u, lazy, cand, why)) continue;
             ScanLaunch cfg = p->mcfg[s];
             cfg.grid = cand.grid;
             HIP_CHECK(hipMemcpyAsync(p->mdev[s]->p, &p->mdesc[s], sizeof(MScanDesc), hipMemcpyHostToDevice, c->stream));
@@ -204,8 +234,8 @@ static void tune_specialised(vdl_ctx *c, vdl_plan *p, int64_t *dev_words) {
                 HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
                 if (rep > 0 && t < ms) ms = t;                  // the first launch of a module pays for its load
             }
-            tried += " u=" + std::to_string(u) + ":" + std::to_string((int)(ms * 1000)) + "us";
-            if (!best.k || ms < best_ms) { best = cand; best_ms = ms; }
+            tried += " u=" + std::to_string(u) + (lazy ? ",late:" : ":") + std::to_string((int)(ms * 1000)) + "us";
+            if (!best.k || ms < best_ms) { best = cand; best_ms = ms; if (!lazy) best_u = u; }
         }
         if (!best.k) continue;
         if (!grouped && use_kscan(p->fused.scans[s]) && p->block_partials[s]) {

@@ -82,7 +82,7 @@ std::map<std::string, std::vector<char>> g_code;        // key (hash + arch) -> 
 // The descriptor as a constexpr function: only what differs from the defaults is written.
 std::string scan_source(Kind kind, const MsArgs &C, const MScanDesc &D, const Shape &sh) {
     std::ostringstream o;
-    o << "#define VDL_SPEC_UNROLL _Pragma(\"unroll\")\n" << kEmbedded << "\nnamespace vdl {\n";
+    o << "#define VDL_SPEC_UNROLL _Pragma(\"unroll\")\n#define VDL_SPEC_LAZY 1\n" << kEmbedded << "\nnamespace vdl {\n";
     o << "constexpr MsArgs jit_args() {\n    MsArgs a{};\n";
     o << "    a.ncol = " << C.ncol << "; a.widths = " << C.widths << "ull; a.filtered = " << C.filtered << "u; a.derived = " << C.derived
       << "u; a.lazy = " << C.lazy << "u;\n    return a;\n}\n";

@@ -403,6 +403,20 @@ __device__ __forceinline__ void mscan_body(const MsArgs &C, const MsArgs &Cr, co
         } else {
             eval_pass<NC, RW>(C, D, v, pass);
         }
+#ifdef VDL_SPEC_LAZY
+        // Late materialisation (specialised builds, when the tuner found it quicker): table columns that are only aggregate
+        // inputs are read for the rows that pass, after the filters -- Q14 keeps 1 row in 84, so 16 of its 28 B/row are
+        // touched in one 64-byte sector out of eleven.  Worthless when most rows pass (Q1): it is a tuner candidate, not a rule.
+        if (C.lazy) {
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                if ((C.lazy >> c) & 1u) {
+#pragma unroll
+                    for (int r = 0; r < RW; r++) { v[c][r] = 0; if (pass[r]) v[c][r] = load_scalar(Cr.ptr[c], C.width(c), rowid[r] - Cr.row0); }
+                }
+            }
+        }
+#endif
         int off[RW];
         if (GROUPED) {
             // group key: two-accumulator program (vdl_fuse.h KeyStep)
@@ -516,7 +530,7 @@ __device__ __forceinline__ void mscan_body(const MsArgs &C, const MsArgs &Cr, co
         const int64_t base = tile * TILE + (int64_t)tid * 2;
 #pragma unroll
         for (int u = 0; u < U; u++) { rowid[2 * u] = Cr.row0 + base + (int64_t)u * (BS * 2); rowid[2 * u + 1] = rowid[2 * u] + 1; }
-        load_tile<NC, U, VEC, NT>(C, Cr, base, v);
+        load_tile<NC, U, VEC, NT>(C, Cr, base, v, C.lazy);
         process(IntTag<ROWS>{}, v, rowid, (int64_t)1 << 40);
     }
     if (blockIdx.x == gridDim.x - 1 && ntiles * TILE < Cr.n) {

@@ -91,11 +91,16 @@ def test_specialised_tpch_plans_match_the_oracle(tune):
 
 
 @pytest.mark.gpu
-def test_specialised_random_programs_match_the_oracle():
+@pytest.mark.parametrize("late", [False, True])
+def test_specialised_random_programs_match_the_oracle(late, monkeypatch):
+    """late: columns that are only aggregate inputs are read for the passing rows only (VDL_JIT_LATE forces what the tuner
+    otherwise decides by timing)."""
     from test_random_conditions import Gen as CondGen
     from test_random_fused import Gen as FusedGen
     from test_random_joins import Gen as JoinGen
-    ran = 0
+    if late:
+        monkeypatch.setenv("VDL_JIT_LATE", "1")
+    ran = lates = 0
     for tag, gen in (("fused", FusedGen), ("joins", JoinGen), ("conditions", CondGen)):
         for seed in range(40):
             text, cols = gen(seed).build()
@@ -111,7 +116,8 @@ def test_specialised_random_programs_match_the_oracle():
             e.close()
             check_against_oracle("specialised_random_" + tag, seed, text, cols, got, want)
             ran += "k_mscan_specialised<" in note
-    assert ran >= 60
+            lates += ",late>" in note
+    assert ran >= 60 and (lates >= 30 if late else lates == 0)
 
 
 @pytest.mark.gpu
