@@ -251,6 +251,12 @@ def main():
     import mplan2vdl_amd as m
     from mplan2vdl_amd import datagen
 
+    if args.jit != "off":
+        # code objects of the specialised scans are kept across processes (ranks of one run, the N = 1, 2, 4, 8 runs of a
+        # scaling sweep): the key is a hash of the whole generated source, so a changed kernel or plan never meets a stale one
+        import tempfile
+        os.environ.setdefault("VDL_JIT_CACHE", os.path.join(tempfile.gettempdir(), "vdl_jit_cache_%d" % os.getuid()))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
