@@ -137,33 +137,74 @@ static std::string jit_name(const jit::Shape &sh) {
            (sh.der ? ",derived" : "") + ">";
 }
 struct Specialised { std::shared_ptr<jit::Kernel> k; int grid = 0, per_cu = 0; size_t code_bytes = 0; std::string name; };
-// table columns a specialised scan may read late (for passing rows only): aggregate inputs that no filter, derived column or
-// group key looks at
-static uint32_t late_columns(const MScanCols &cols, const MScanDesc &d, bool grouped) {
-    uint32_t late = 0;
-    for (int k = 0; k < cols.ncol; k++) if (cols.kind[k] == VC_DIRECT && !cols.filtered[k]) late |= 1u << k;
+// fraction of a table column's rows inside [lo, hi], from 16 samples of 4096 rows spread over the column
+static double sampled_selectivity(vdl_ctx *c, const void *dev, int width, int64_t n, int64_t lo, int64_t hi) {
+    if (const char *a = getenv("VDL_JIT_ASSUME_SELECTIVITY")) return atof(a);      // (tests without a GPU: vdl_plan_jit_check of staged builds)
+    if (n <= 0 || !dev || c->device < 0) return 1.0;
+    const int64_t chunk = std::min<int64_t>(4096, n), pieces = std::max<int64_t>(1, std::min<int64_t>(16, n / chunk));
+    std::vector<char> host((size_t)(chunk * width));
+    int64_t in = 0, seen = 0;
+    for (int64_t k = 0; k < pieces; k++) {
+        const int64_t at = pieces > 1 ? (n - chunk) / (pieces - 1) * k : 0;
+        if (hipMemcpy(host.data(), (const char *)dev + at * width, (size_t)(chunk * width), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return 1.0; }
+        for (int64_t i = 0; i < chunk; i++) {
+            const int64_t x = width == 8 ? ((const int64_t *)host.data())[i] : width == 4 ? ((const int32_t *)host.data())[i]
+                            : width == 2 ? ((const int16_t *)host.data())[i] : ((const int8_t *)host.data())[i];
+            in += x >= lo && x <= hi;
+        }
+        seen += chunk;
+    }
+    return seen ? (double)in / (double)seen : 1.0;
+}
+
+// Stages of a specialised scan that reads late (MsArgs::stages): the most selective filter column on table columns comes
+// with the tile, the other filter columns in order of (sampled) selectivity for the rows still in, then the sources of
+// derived columns and of the group key, and last the columns that are only aggregate inputs.  0 = nothing to defer.
+static uint64_t staged_columns(vdl_ctx *c, const MScanCols &cols, const MScanDesc &d, bool grouped, uint32_t *lazy_mask) {
+    uint32_t source = 0, used = 0;
     for (int k = 0; k < cols.ncol; k++) {
         if (cols.kind[k] == VC_DIRECT) continue;
-        if (cols.kind[k] == VC_FORM) { for (int f = d.dsrc[k]; f < d.dsrc[k] + d.dtests[k]; f++) late &= ~(1u << d.form[f].col); continue; }
-        if (d.dsrc[k] >= 0) late &= ~(1u << d.dsrc[k]);
-        if (d.dsrc2[k] >= 0) late &= ~(1u << d.dsrc2[k]);
+        if (cols.kind[k] == VC_FORM) { for (int f = d.dsrc[k]; f < d.dsrc[k] + d.dtests[k]; f++) source |= 1u << d.form[f].col; continue; }
+        if (d.dsrc[k] >= 0) source |= 1u << d.dsrc[k];
+        if (d.dsrc2[k] >= 0) source |= 1u << d.dsrc2[k];
     }
     if (grouped) {
-        for (int k = 0; k < d.nkey; k++) if (d.key[k].kind == KeyStep::LOAD) late &= ~(1u << d.key[k].col);
-        for (int k = 0; k < d.ncomp; k++) late &= ~(1u << d.comp[k].col);
+        for (int k = 0; k < d.nkey; k++) if (d.key[k].kind == KeyStep::LOAD) source |= 1u << d.key[k].col;
+        for (int k = 0; k < d.ncomp; k++) source |= 1u << d.comp[k].col;
     }
-    uint32_t used = 0;
     for (int j = 0; j < d.nagg; j++) if (d.agg[j].kind != AGG_FIRST) used |= d.agg[j].used;
-    return late & used;
+    std::vector<std::pair<double, int>> filters;
+    for (int k = 0; k < cols.ncol; k++)
+        if (cols.kind[k] == VC_DIRECT && cols.filtered[k])
+            filters.push_back({sampled_selectivity(c, cols.ptr[k], cols.width[k], cols.n, cols.lo[k], cols.hi[k]), k});
+    std::sort(filters.begin(), filters.end());
+    uint64_t stages = 0;
+    uint32_t lazy = 0;
+    auto put = [&](int k, int st) { stages |= (uint64_t)st << (4 * k); if (st) lazy |= 1u << k; };
+    const bool selective = !filters.empty() && filters[0].first < 0.6;
+    if (selective)
+        for (size_t i = 1; i < filters.size(); i++) put(filters[i].second, (int)std::min<size_t>(i, 3));
+    for (int k = 0; k < cols.ncol; k++) {
+        if (cols.kind[k] != VC_DIRECT || cols.filtered[k]) continue;
+        if ((source >> k) & 1u) { if (selective) put(k, 14); }
+        else if ((used >> k) & 1u) put(k, 15);
+    }
+    *lazy_mask = lazy;
+    return stages;
 }
 static bool build_specialised(vdl_ctx *c, vdl_plan *p, size_t s, bool grouped, int u, bool lazy, Specialised &out, std::string &why) {
     jit::Shape sh = jit_shape(p->mcols[s], p->mcfg[s]);
     if (u > 0) sh.u = u;
     std::vector<char> code;
     MsArgs args = mscan_args(p->mcols[s]);
-    args.lazy = lazy ? late_columns(p->mcols[s], p->mdesc[s], grouped) : 0;
-    if (lazy && !args.lazy) { why = "no column to read late"; return false; }
+    if (lazy) {
+        args.stages = staged_columns(c, p->mcols[s], p->mdesc[s], grouped, &args.lazy);
+        if (!args.lazy) { why = "no column to read late"; return false; }
+    }
     if (!jit::compile(jit::mscan_source(args, p->mdesc[s], sh), c->arch, code, why)) { why = why.substr(0, 400); return false; }
+    // a specialised scan is 10-25 KB of code; ten times that means the compiler did not fold the descriptor (it then sits in
+    // scratch memory and every descriptor-driven loop stays): such a build is slower than the precompiled kernel
+    if (code.size() > (size_t)96 << 10) { why = "the descriptor did not fold (" + std::to_string(code.size()) + " B of code)"; return false; }
     out.k = jit::load(code, why);
     if (!out.k) return false;
     int per_cu = 0;
@@ -210,8 +251,9 @@ static void tune_specialised(vdl_ctx *c, vdl_plan *p, int64_t *dev_words) {
         Specialised best;
         float best_ms = 0;
         std::string tried;
-        // rows per lane first; then, at the winner and at 2, the columns that are only aggregate inputs read late
-        std::vector<std::pair<int, bool>> cands = {{2, false}, {3, false}, {4, false}, {6, false}, {0, true}, {2, true}};
+        // rows per lane first; then, at the winner, at 2 and at 1, the staged form that reads late (fewer rows per lane suit it:
+        // its loads depend on each other, and what hides them is more waves, not more loads per wave)
+        std::vector<std::pair<int, bool>> cands = {{2, false}, {3, false}, {4, false}, {6, false}, {0, true}, {2, true}, {1, true}};
         int best_u = 0;
         for (auto &cu : cands) {
             const int u = cu.first ? cu.first : best_u;
@@ -1018,9 +1060,11 @@ int vdl_plan_jit_check(vdl_ctx *c, vdl_plan *p) {
             const jit::Shape sh = jit_shape(cols, cfg);
             std::vector<char> code;
             std::string log;
-            if (!jit::compile(jit::mscan_source(mscan_args(cols), *d, sh), c->arch, code, log))
+            MsArgs args = mscan_args(cols);
+            if (getenv("VDL_JIT_LATE")) args.stages = staged_columns(c, cols, *d, grouped, &args.lazy);      // the staged form of the same scan
+            if (!jit::compile(jit::mscan_source(args, *d, sh), c->arch, code, log))
                 throw Error(VDL_ERR_UNSUPPORTED, "scan " + std::to_string(s) + " does not build: " + log.substr(0, 2000));
-            p->jit_note += "scan " + std::to_string(s) + ": " + jit_name(sh) + ", " + std::to_string(code.size()) + " B of code; ";
+            p->jit_note += "scan " + std::to_string(s) + ": " + jit_name(sh) + (args.lazy ? " (late)" : "") + ", " + std::to_string(code.size()) + " B of code; ";
         }
     });
 }

@@ -82,10 +82,33 @@ std::map<std::string, std::vector<char>> g_code;        // key (hash + arch) -> 
 // The descriptor as a constexpr function: only what differs from the defaults is written.
 std::string scan_source(Kind kind, const MsArgs &C, const MScanDesc &D, const Shape &sh) {
     std::ostringstream o;
-    o << "#define VDL_SPEC_UNROLL _Pragma(\"unroll\")\n#define VDL_SPEC_LAZY 1\n" << kEmbedded << "\nnamespace vdl {\n";
+    o << "#define VDL_SPEC_UNROLL _Pragma(\"unroll\")\n";
+    if (kind == MSCAN && C.lazy) {
+        // the stages of a scan that reads late (MsArgs::stages), as straight-line code inside the body's row loop context
+        auto load = [&](int c, const char *mask) {
+            std::ostringstream l;
+            l << " _Pragma(\"unroll\") for (int r = 0; r < RW; r++) { v[" << c << "][r] = 0; if (" << mask << "[r]) v[" << c << "][r] = load_scalar(Cr.ptr[" << c << "], "
+              << C.width(c) << ", rowid[r] - Cr.row0); }";
+            return l.str();
+        };
+        o << "#define VDL_STAGED_PRE";
+        for (int st = 0; st <= 3; st++)
+            for (int c = 0; c < C.ncol; c++) {
+                if (((C.derived >> c) & 1u) || C.stage(c) != st) continue;
+                if (st > 0) o << load(c, "alive");
+                if ((C.filtered >> c) & 1u)
+                    o << " _Pragma(\"unroll\") for (int r = 0; r < RW; r++) alive[r] = alive[r] & (v[" << c << "][r] >= " << lit(D.flo[c]) << ") & (v[" << c << "][r] <= "
+                      << lit(D.fhi[c]) << ");";
+            }
+        for (int c = 0; c < C.ncol; c++) if (!((C.derived >> c) & 1u) && C.stage(c) == 14) o << load(c, "alive");
+        o << "\n#define VDL_STAGED_POST";
+        for (int c = 0; c < C.ncol; c++) if (!((C.derived >> c) & 1u) && C.stage(c) == 15) o << load(c, "pass");
+        o << "\n";
+    }
+    o << kEmbedded << "\nnamespace vdl {\n";
     o << "constexpr MsArgs jit_args() {\n    MsArgs a{};\n";
     o << "    a.ncol = " << C.ncol << "; a.widths = " << C.widths << "ull; a.filtered = " << C.filtered << "u; a.derived = " << C.derived
-      << "u; a.lazy = " << C.lazy << "u;\n    return a;\n}\n";
+      << "u; a.lazy = " << C.lazy << "u; a.stages = " << C.stages << "ull;\n    return a;\n}\n";
     o << "constexpr MScanDesc jit_desc() {\n    MScanDesc d{};\n";
     o << "    d.nagg = " << D.nagg << "; d.nkey = " << D.nkey << "; d.replicas = " << D.replicas << "; d.pmin = " << lit(D.pmin) << "; d.pcount = " << lit(D.pcount) << ";\n";
     int pool = 0;
@@ -126,7 +149,7 @@ std::string scan_source(Kind kind, const MsArgs &C, const MScanDesc &D, const Sh
              "    constexpr vdl::MsArgs C = vdl::jit_args();\n"
              "    constexpr vdl::MScanDesc D = vdl::jit_desc();\n"
              "    vdl::mscan_body<" << sh.nc << ", " << sh.u << ", " << b << ", " << b << ", " << (sh.grouped ? "true" : "false") << ", " << (sh.der ? "true" : "false")
-          << ">(C, Cr, D, *Dp);\n}\n";
+          << ", " << (C.lazy ? "true" : "false") << ">(C, Cr, D, *Dp);\n}\n";
     else if (kind == SELECT)
         o << "extern \"C\" __global__ __launch_bounds__(256) void " << entry_name(kind) << "(const vdl::MsArgs Cr, const vdl::MScanDesc *__restrict__ Dp) {\n"
              "    constexpr vdl::MsArgs C = vdl::jit_args();\n"
@@ -149,6 +172,10 @@ bool compile(const std::string &src, const std::string &arch, std::vector<char> 
         std::lock_guard<std::mutex> g(g_mu);
         auto it = g_code.find(key);
         if (it != g_code.end()) { code = it->second; return true; }
+    }
+    if (const char *dump = getenv("VDL_JIT_DUMP")) {           // debugging: the generated translation unit as a file
+        std::ofstream f(std::string(dump) + "/vdl_" + key + ".hip");
+        f << src;
     }
     const char *dir = getenv("VDL_JIT_CACHE");
     std::string path;

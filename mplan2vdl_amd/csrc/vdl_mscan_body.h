@@ -355,7 +355,7 @@ __device__ __forceinline__ void eval_term(const MAggDesc &d, const int64_t (&v)[
 // is only known at launch (column bases, row counts, lookup-table sizes, the partials area).  The precompiled kernels pass the
 // same objects for both; a kernel specialised for one plan (vdl_jit.cpp) passes compile-time constants for C and D, and the
 // compiler folds every descriptor-driven branch and loop of this body away.
-template <int NC, int U, bool VEC, bool NT, bool GROUPED, bool DER>
+template <int NC, int U, bool VEC, bool NT, bool GROUPED, bool DER, bool STAGED = false>
 __device__ __forceinline__ void mscan_body(const MsArgs &C, const MsArgs &Cr, const MScanDesc &D, const MScanDesc &Dr) {
     extern __shared__ int64_t lds[];
     constexpr int BS = kMsBlock, TILE = BS * 2 * U, ROWS = 2 * U;
@@ -390,33 +390,36 @@ __device__ __forceinline__ void mscan_body(const MsArgs &C, const MsArgs &Cr, co
     auto process = [&](auto rows_tag, int64_t (&v)[NC][decltype(rows_tag)::value], const int64_t (&rowid)[decltype(rows_tag)::value], int64_t rows_left) {
         constexpr int RW = decltype(rows_tag)::value;
         bool pass[RW];
-        if (DER) {
-            // (scans with derived columns run their last, partial tile through this same code: rows past the end are
-            // switched off here -- `rows_left` counts from the lane's first row)
-            bool alive[RW];
+        // Staged reads (STAGED: specialised builds, when the tuner found them quicker): only the most selective filter column comes
+        // with the tile; each further filter column is read for the rows still in (masked 8-byte loads: a 64-byte sector
+        // without a live row is never touched), then what derived columns and the group key need, and last the columns that
+        // are only aggregate inputs, for the rows that passed everything.  Q6 keeps 1.9 % of its rows and moves ~13 of its
+        // 28 B/row this way; Q14 (1 row in 84 passes the date filter) ~6 of 28.  Worthless when most rows pass (Q1).
+        constexpr bool staged = STAGED;
+        bool alive[RW];
 #pragma unroll
-            for (int r = 0; r < RW; r++) alive[r] = (int64_t)((r >> 1) * (BS * 2) + (r & 1)) < rows_left;
-            derive<NC, RW>(C, Cr, D, Dr, v, alive, C.derived);
-            eval_pass<NC, RW>(C, D, v, pass);
+        for (int r = 0; r < RW; r++) alive[r] = !DER || (int64_t)((r >> 1) * (BS * 2) + (r & 1)) < rows_left;
+        // (the stages arrive as generated straight-line code -- VDL_STAGED_PRE / _POST, vdl_jit.cpp: written as loops over
+        // columns and stages with the stage numbers read from C, the compiler no longer folded the descriptor: 235 KB of code)
+#ifdef VDL_STAGED_PRE
+        if (staged) { VDL_STAGED_PRE }
+#endif
+        // (scans with derived columns run their last, partial tile through this same code: rows past the end were switched off
+        // above -- `rows_left` counts from the lane's first row.  Staged: the filters on table columns are already in `alive`.)
+        if (DER) derive<NC, RW>(C, Cr, D, Dr, v, alive, C.derived, !staged);
+        if (staged) {
 #pragma unroll
-            for (int r = 0; r < RW; r++) pass[r] = pass[r] & alive[r];
+            for (int r = 0; r < RW; r++) pass[r] = alive[r];
+#ifdef VDL_STAGED_POST
+            VDL_STAGED_POST
+#endif
         } else {
             eval_pass<NC, RW>(C, D, v, pass);
-        }
-#ifdef VDL_SPEC_LAZY
-        // Late materialisation (specialised builds, when the tuner found it quicker): table columns that are only aggregate
-        // inputs are read for the rows that pass, after the filters -- Q14 keeps 1 row in 84, so 16 of its 28 B/row are
-        // touched in one 64-byte sector out of eleven.  Worthless when most rows pass (Q1): it is a tuner candidate, not a rule.
-        if (C.lazy) {
+            if (DER) {
 #pragma unroll
-            for (int c = 0; c < NC; c++) {
-                if ((C.lazy >> c) & 1u) {
-#pragma unroll
-                    for (int r = 0; r < RW; r++) { v[c][r] = 0; if (pass[r]) v[c][r] = load_scalar(Cr.ptr[c], C.width(c), rowid[r] - Cr.row0); }
-                }
+                for (int r = 0; r < RW; r++) pass[r] = pass[r] & alive[r];
             }
         }
-#endif
         int off[RW];
         if (GROUPED) {
             // group key: two-accumulator program (vdl_fuse.h KeyStep)
@@ -530,7 +533,7 @@ __device__ __forceinline__ void mscan_body(const MsArgs &C, const MsArgs &Cr, co
         const int64_t base = tile * TILE + (int64_t)tid * 2;
 #pragma unroll
         for (int u = 0; u < U; u++) { rowid[2 * u] = Cr.row0 + base + (int64_t)u * (BS * 2); rowid[2 * u + 1] = rowid[2 * u] + 1; }
-        load_tile<NC, U, VEC, NT>(C, Cr, base, v, C.lazy);
+        load_tile<NC, U, VEC, NT>(C, Cr, base, v, STAGED ? C.lazy : 0u);
         process(IntTag<ROWS>{}, v, rowid, (int64_t)1 << 40);
     }
     if (blockIdx.x == gridDim.x - 1 && ntiles * TILE < Cr.n) {

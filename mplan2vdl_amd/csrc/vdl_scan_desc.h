@@ -137,7 +137,12 @@ struct MsArgs {
     uint64_t widths = 0;                     // 4 bits per column: bytes
     uint32_t filtered = 0;                   // bit c: column c has a range filter (MScanDesc::flo / fhi)
     uint32_t derived = 0;                    // bit c: column c is derived from earlier columns (MScanDesc::dkind ...), ptr[c] = its table
-    uint32_t lazy = 0;                       // bit c (projection scan): needed for surviving rows only
+    uint32_t lazy = 0;                       // bit c: not read with the tile (projection scan: needed for surviving rows only; staged scans: below)
+    // specialised aggregate scans that read late (vdl_jit.cpp): 4 bits per table column -- 0: read with the tile; 1..3: a filter
+    // column read for the rows that passed the earlier stages; 14: a source of derived columns / of the group key, read for
+    // the rows that passed every filter on table columns; 15: an aggregate input only, read for the rows that passed everything
+    uint64_t stages = 0;
+    VDL_SD constexpr int stage(int c) const { return (int)((stages >> (4 * c)) & 15u); }
     int64_t n = 0, row0 = 0;
     const void *ptr[kMaxVCols] = {};
     VDL_SD constexpr int width(int c) const { return (int)((widths >> (4 * c)) & 15u); }

@@ -30,6 +30,11 @@ def host_engine_with_declared(cols):
     return e
 
 
+def code_bytes(note):
+    import re
+    return [int(x) for x in re.findall(r"(\d+) B of code", note)]
+
+
 @pytest.mark.parametrize("n", FUSED_PLANS)
 def test_specialised_kernels_of_the_tpch_plans_build_without_a_gpu(n, tmp_path, monkeypatch):
     monkeypatch.setenv("VDL_JIT_CACHE", str(tmp_path))
@@ -38,6 +43,16 @@ def test_specialised_kernels_of_the_tpch_plans_build_without_a_gpu(n, tmp_path, 
     p = e.parse(text)
     note = p.jit_check()
     assert "k_mscan_specialised<" in note and "B of code" in note, note
+    # the descriptor folded: straight-line code of 10-25 KB (a build in which it did not -- the descriptor then lives in scratch
+    # memory and every loop over it stays -- was 230-360 KB and slower than the precompiled kernel)
+    assert code_bytes(note) and max(code_bytes(note)) < 64 << 10, note
+    # ... and the form that reads late, with the filter columns staged (the tuner's other candidate)
+    monkeypatch.setenv("VDL_JIT_LATE", "1")
+    monkeypatch.setenv("VDL_JIT_ASSUME_SELECTIVITY", "0.2")
+    late = p.jit_check()
+    assert "(late)" in late and max(code_bytes(late)) < 64 << 10, late
+    monkeypatch.delenv("VDL_JIT_LATE")
+    monkeypatch.delenv("VDL_JIT_ASSUME_SELECTIVITY")
     assert ("derived" in note) == (n != 1)                      # the join scans carry looked-up / condition columns
     assert [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]          # the code object is kept for the next process
     assert p.jit_check() == note                                # ... and for this one (no second compile: same text, same key)
