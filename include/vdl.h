@@ -99,7 +99,11 @@ int  vdl_download_column(vdl_ctx *ctx, const char *name, void *host_ptr, size_t 
 /* Parse the VDL text, check it, and build the execution plan (operator fusion included).
  * Needs no device.  Both output formats of the compiler are accepted: the default VDL lines
  * (/root/reference/src/Vdl.hs:410-453) and the --vliteformat lines (Vdl.hs:370-408,455-475; recognised by
- * their Output statements). */
+ * their Output statements).
+ * One point where a program's meaning is narrower than its text: Scatter(src, fold, pos) with the SAME position twice
+ * leaves one of the two values there, which one is unspecified (the oracle keeps the later slot's, the kernels whichever
+ * store lands last).  Every Scatter the compiler emits has unique positions -- Partition ranks, filtered row ids
+ * (/root/reference/src/Vlite.hs:508,1058-1059,1267-1275) -- and the parity tests only build such programs. */
 int  vdl_parse(vdl_ctx *ctx, const char *vdl_text, size_t len, vdl_plan **out);
 void vdl_plan_free(vdl_plan *plan);
 
