@@ -205,7 +205,7 @@ static bool build_specialised(vdl_ctx *c, vdl_plan *p, size_t s, bool grouped, i
     // a specialised scan is 10-25 KB of code; ten times that means the compiler did not fold the descriptor (it then sits in
     // scratch memory and every descriptor-driven loop stays): such a build is slower than the precompiled kernel
     if (code.size() > (size_t)96 << 10) { why = "the descriptor did not fold (" + std::to_string(code.size()) + " B of code)"; return false; }
-    out.k = jit::load(code, why);
+    out.k = jit::load(code, why, jit::entry_name(jit::MSCAN, args, p->mdesc[s], sh));
     if (!out.k) return false;
     int per_cu = 0;
     if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, out.k->fn, 256, mscan_lds_bytes(p->mdesc[s], grouped)) != hipSuccess || per_cu < 1) {
@@ -458,7 +458,7 @@ static hipFunction_t front_kernel(vdl_ctx *c, vdl_plan *p, const std::string &ro
     sh.nc = cols.ncol; sh.u = 4; sh.vec = kind == jit::SELECT ? project_select_vec(cols) : false; sh.der = true;
     std::vector<char> code;
     std::string why;
-    if (jit::compile(jit::scan_source(kind, mscan_args(cols), d, sh), c->arch, code, why)) fk.k = jit::load(code, why, kind);
+    if (jit::compile(jit::scan_source(kind, mscan_args(cols), d, sh), c->arch, code, why)) fk.k = jit::load(code, why, jit::entry_name(kind));
     if (fk.k) p->jit_note += role + ": " + jit::entry_name(kind) + "<" + std::to_string(sh.nc) + ">, " + std::to_string(code.size()) + " B of code; ";
     else p->jit_note += role + ": not specialised (" + why.substr(0, 400) + "); ";
     return fk.k ? fk.k->fn : nullptr;

@@ -79,33 +79,10 @@ std::map<std::string, std::vector<char>> g_code;        // key (hash + arch) -> 
 
 }  // namespace
 
-// The descriptor as a constexpr function: only what differs from the defaults is written.
-std::string scan_source(Kind kind, const MsArgs &C, const MScanDesc &D, const Shape &sh) {
+// the descriptor as constexpr functions: only what differs from the defaults is written
+static std::string desc_text(Kind kind, const MsArgs &C, const MScanDesc &D) {
     std::ostringstream o;
-    o << "#define VDL_SPEC_UNROLL _Pragma(\"unroll\")\n";
-    if (kind == MSCAN && C.lazy) {
-        // the stages of a scan that reads late (MsArgs::stages), as straight-line code inside the body's row loop context
-        auto load = [&](int c, const char *mask) {
-            std::ostringstream l;
-            l << " _Pragma(\"unroll\") for (int r = 0; r < RW; r++) { v[" << c << "][r] = 0; if (" << mask << "[r]) v[" << c << "][r] = load_scalar(Cr.ptr[" << c << "], "
-              << C.width(c) << ", rowid[r] - Cr.row0); }";
-            return l.str();
-        };
-        o << "#define VDL_STAGED_PRE";
-        for (int st = 0; st <= 3; st++)
-            for (int c = 0; c < C.ncol; c++) {
-                if (((C.derived >> c) & 1u) || C.stage(c) != st) continue;
-                if (st > 0) o << load(c, "alive");
-                if ((C.filtered >> c) & 1u)
-                    o << " _Pragma(\"unroll\") for (int r = 0; r < RW; r++) alive[r] = alive[r] & (v[" << c << "][r] >= " << lit(D.flo[c]) << ") & (v[" << c << "][r] <= "
-                      << lit(D.fhi[c]) << ");";
-            }
-        for (int c = 0; c < C.ncol; c++) if (!((C.derived >> c) & 1u) && C.stage(c) == 14) o << load(c, "alive");
-        o << "\n#define VDL_STAGED_POST";
-        for (int c = 0; c < C.ncol; c++) if (!((C.derived >> c) & 1u) && C.stage(c) == 15) o << load(c, "pass");
-        o << "\n";
-    }
-    o << kEmbedded << "\nnamespace vdl {\n";
+    o << "namespace vdl {\n";
     o << "constexpr MsArgs jit_args() {\n    MsArgs a{};\n";
     o << "    a.ncol = " << C.ncol << "; a.widths = " << C.widths << "ull; a.filtered = " << C.filtered << "u; a.derived = " << C.derived
       << "u; a.lazy = " << C.lazy << "u; a.stages = " << C.stages << "ull;\n    return a;\n}\n";
@@ -143,9 +120,38 @@ std::string scan_source(Kind kind, const MsArgs &C, const MScanDesc &D, const Sh
         for (int k = 0; k < D.nout; k++) o << "    d.out_col[" << k << "] = " << D.out_col[k] << ";\n";
     }
     o << "    return d;\n}\n}  // namespace vdl\n";
+    return o.str();
+}
+
+std::string scan_source(Kind kind, const MsArgs &C, const MScanDesc &D, const Shape &sh) {
+    std::ostringstream o;
+    o << "#define VDL_SPEC_UNROLL _Pragma(\"unroll\")\n";
+    if (kind == MSCAN && C.lazy) {
+        // the stages of a scan that reads late (MsArgs::stages), as straight-line code inside the body's row loop context
+        auto load = [&](int c, const char *mask) {
+            std::ostringstream l;
+            l << " _Pragma(\"unroll\") for (int r = 0; r < RW; r++) { v[" << c << "][r] = 0; if (" << mask << "[r]) v[" << c << "][r] = load_scalar(Cr.ptr[" << c << "], "
+              << C.width(c) << ", rowid[r] - Cr.row0); }";
+            return l.str();
+        };
+        o << "#define VDL_STAGED_PRE";
+        for (int st = 0; st <= 3; st++)
+            for (int c = 0; c < C.ncol; c++) {
+                if (((C.derived >> c) & 1u) || C.stage(c) != st) continue;
+                if (st > 0) o << load(c, "alive");
+                if ((C.filtered >> c) & 1u)
+                    o << " _Pragma(\"unroll\") for (int r = 0; r < RW; r++) alive[r] = alive[r] & (v[" << c << "][r] >= " << lit(D.flo[c]) << ") & (v[" << c << "][r] <= "
+                      << lit(D.fhi[c]) << ");";
+            }
+        for (int c = 0; c < C.ncol; c++) if (!((C.derived >> c) & 1u) && C.stage(c) == 14) o << load(c, "alive");
+        o << "\n#define VDL_STAGED_POST";
+        for (int c = 0; c < C.ncol; c++) if (!((C.derived >> c) & 1u) && C.stage(c) == 15) o << load(c, "pass");
+        o << "\n";
+    }
+    o << kEmbedded << "\n" << desc_text(kind, C, D);
     const char *b = sh.vec ? "true" : "false";
     if (kind == MSCAN)
-        o << "extern \"C\" __global__ __launch_bounds__(256) void " << entry_name(kind) << "(const vdl::MsArgs Cr, const vdl::MScanDesc *__restrict__ Dp) {\n"
+        o << "extern \"C\" __global__ __launch_bounds__(256) void " << entry_name(kind, C, D, sh) << "(const vdl::MsArgs Cr, const vdl::MScanDesc *__restrict__ Dp) {\n"
              "    constexpr vdl::MsArgs C = vdl::jit_args();\n"
              "    constexpr vdl::MScanDesc D = vdl::jit_desc();\n"
              "    vdl::mscan_body<" << sh.nc << ", " << sh.u << ", " << b << ", " << b << ", " << (sh.grouped ? "true" : "false") << ", " << (sh.der ? "true" : "false")
@@ -165,6 +171,13 @@ std::string scan_source(Kind kind, const MsArgs &C, const MScanDesc &D, const Sh
 }
 std::string mscan_source(const MsArgs &C, const MScanDesc &D, const Shape &sh) { return scan_source(MSCAN, C, D, sh); }
 const char *entry_name(Kind kind) { return kind == MSCAN ? "vdl_jit_mscan" : kind == SELECT ? "vdl_jit_project_select" : "vdl_jit_project_take"; }
+// aggregate scans carry their shape in the kernel's name, so that a profile of a tuned run lists the tuner's candidates apart
+std::string entry_name(Kind kind, const MsArgs &C, const MScanDesc &D, const Shape &sh) {
+    if (kind != MSCAN) return entry_name(kind);
+    char tag[16];
+    snprintf(tag, sizeof tag, "%06llx", (unsigned long long)(fnv(desc_text(kind, C, D)) & 0xffffffull));      // which plan's scan
+    return std::string("vdl_jit_mscan_") + (sh.grouped ? "grouped_" : "") + "u" + std::to_string(sh.u) + (C.lazy ? "_staged_" : "_") + tag;
+}
 
 bool compile(const std::string &src, const std::string &arch, std::vector<char> &code, std::string &log) {
     const std::string key = std::to_string(fnv(src)) + "_" + std::to_string(src.size()) + "_" + arch;
@@ -216,11 +229,11 @@ bool compile(const std::string &src, const std::string &arch, std::vector<char> 
 
 Kernel::~Kernel() { if (mod) (void)hipModuleUnload(mod); }
 
-std::shared_ptr<Kernel> load(const std::vector<char> &code, std::string &why, Kind kind) {
+std::shared_ptr<Kernel> load(const std::vector<char> &code, std::string &why, const std::string &entry) {
     auto k = std::make_shared<Kernel>();
     hipError_t e = hipModuleLoadData(&k->mod, code.data());
     if (e != hipSuccess) { why = std::string("hipModuleLoadData: ") + hipGetErrorString(e); k->mod = nullptr; return nullptr; }
-    e = hipModuleGetFunction(&k->fn, k->mod, entry_name(kind));
+    e = hipModuleGetFunction(&k->fn, k->mod, entry.c_str());
     if (e != hipSuccess) { why = std::string("hipModuleGetFunction: ") + hipGetErrorString(e); return nullptr; }
     return k;
 }

@@ -17,6 +17,7 @@ struct Shape { int nc = 0, u = 0; bool vec = false, grouped = false, der = false
 // select pass with bitmap_only set)
 enum Kind : int { MSCAN = 0, SELECT = 1, TAKE = 2 };
 const char *entry_name(Kind kind);
+std::string entry_name(Kind kind, const MsArgs &C, const MScanDesc &D, const Shape &sh);
 // the translation unit: the embedded device code + this scan's descriptor as constants + the kernel
 std::string scan_source(Kind kind, const MsArgs &C, const MScanDesc &D, const Shape &sh);
 std::string mscan_source(const MsArgs &C, const MScanDesc &D, const Shape &sh);
@@ -28,7 +29,7 @@ struct Kernel {
     hipFunction_t fn = nullptr;
     ~Kernel();
 };
-std::shared_ptr<Kernel> load(const std::vector<char> &code, std::string &why, Kind kind = MSCAN);
+std::shared_ptr<Kernel> load(const std::vector<char> &code, std::string &why, const std::string &entry);
 
 }  // namespace jit
 }  // namespace vdl

@@ -20,6 +20,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/q1 -- python3 $ROOT
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/q6_fetch -- python3 $ROOT/bench.py --jit off --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-secondary --latency-steps 0 > $OUT/q6_fetch.json 2> $OUT/q6_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/q6_write -- python3 $ROOT/bench.py --jit off --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-secondary --latency-steps 0 > $OUT/q6_write.json 2> $OUT/q6_write.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/q1_fetch -- python3 $ROOT/bench.py --jit on --query q1 --steps 3 --warmup 1 --no-cpu-baseline --no-verify --latency-steps 0 > $OUT/q1_fetch.json 2> $OUT/q1_fetch.err
+# the plain command (default --jit tune, secondary measurements included): the tuner's candidates show up as kernels of their
+# own (vdl_jit_mscan_u<pairs>[_staged]), the winner's average is the one bench.py reports
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/default -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/default_bench.json 2> $OUT/default.err
+cp $(ls $OUT/default/*/*kernel_stats.csv | head -n 1) $OUT/default_kernel_stats.csv
 for q in q6 q6late q1; do
   f=$(ls $OUT/$q/*/*kernel_stats.csv | head -n 1); cp $f $OUT/${q}_kernel_stats.csv
   echo "== $q"; head -n 6 $f | cut -c1-160; tail -n 1 $OUT/${q}_bench.json | cut -c1-300
