@@ -480,7 +480,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                late = ",late>" in kernel_label
+                late = ",late" in kernel_label
                 tj = json.load(open(tpath)).get(args.query + ("_late" if late else ""), {})
                 if tj.get("rows") == my_rows:
                     traffic = tj.get("hbm_bytes_per_launch")
@@ -504,7 +504,7 @@ def main():
                          # aggregate-only columns in the 64-byte sectors that hold a passing row: it moves fewer bytes than the
                          # algorithmic figure (all column widths x rows), so `frac` -- defined on that figure --
                          # can pass 1; `frac_of_traffic` prices the bytes the counters saw instead
-                         "late_materialisation": ",late>" in kernel_label,
+                         "late_materialisation": ",late" in kernel_label,
                          "frac_of_traffic": (traffic / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBPS) if (traffic and kern_us) else None},
             "cpu_baseline": cpu_baseline,
             "revenue": (revenue[0] if revenue else None), "verified_bit_exact_vs_cpu": verified,

@@ -160,7 +160,7 @@ static double sampled_selectivity(vdl_ctx *c, const void *dev, int width, int64_
 // Stages of a specialised scan that reads late (MsArgs::stages): the most selective filter column on table columns comes
 // with the tile, the other filter columns in order of (sampled) selectivity for the rows still in, then the sources of
 // derived columns and of the group key, and last the columns that are only aggregate inputs.  0 = nothing to defer.
-static uint64_t staged_columns(vdl_ctx *c, const MScanCols &cols, const MScanDesc &d, bool grouped, uint32_t *lazy_mask) {
+static uint64_t staged_columns(vdl_ctx *c, const MScanCols &cols, const MScanDesc &d, bool grouped, uint32_t *lazy_mask, int eager_filters = 1) {
     uint32_t source = 0, used = 0;
     for (int k = 0; k < cols.ncol; k++) {
         if (cols.kind[k] == VC_DIRECT) continue;
@@ -182,8 +182,10 @@ static uint64_t staged_columns(vdl_ctx *c, const MScanCols &cols, const MScanDes
     uint32_t lazy = 0;
     auto put = [&](int k, int st) { stages |= (uint64_t)st << (4 * k); if (st) lazy |= 1u << k; };
     const bool selective = !filters.empty() && filters[0].first < 0.6;
+    // (eager_filters = 2: the second most selective filter column comes with the tile as well -- when the first leaves 14 % of
+    // the rows, 71 % of the second's sectors are touched anyway and 16-byte streaming loads beat masked 8-byte ones)
     if (selective)
-        for (size_t i = 1; i < filters.size(); i++) put(filters[i].second, (int)std::min<size_t>(i, 3));
+        for (size_t i = (size_t)std::max(eager_filters, 1); i < filters.size(); i++) put(filters[i].second, (int)std::min<size_t>(i - (size_t)std::max(eager_filters, 1) + 1, 3));
     for (int k = 0; k < cols.ncol; k++) {
         if (cols.kind[k] != VC_DIRECT || cols.filtered[k]) continue;
         if ((source >> k) & 1u) { if (selective) put(k, 14); }
@@ -192,13 +194,13 @@ static uint64_t staged_columns(vdl_ctx *c, const MScanCols &cols, const MScanDes
     *lazy_mask = lazy;
     return stages;
 }
-static bool build_specialised(vdl_ctx *c, vdl_plan *p, size_t s, bool grouped, int u, bool lazy, Specialised &out, std::string &why) {
+static bool build_specialised(vdl_ctx *c, vdl_plan *p, size_t s, bool grouped, int u, int lazy /* 0 | eager filter columns of the staged form */, Specialised &out, std::string &why) {
     jit::Shape sh = jit_shape(p->mcols[s], p->mcfg[s]);
     if (u > 0) sh.u = u;
     std::vector<char> code;
     MsArgs args = mscan_args(p->mcols[s]);
     if (lazy) {
-        args.stages = staged_columns(c, p->mcols[s], p->mdesc[s], grouped, &args.lazy);
+        args.stages = staged_columns(c, p->mcols[s], p->mdesc[s], grouped, &args.lazy, lazy);
         if (!args.lazy) { why = "no column to read late"; return false; }
     }
     if (!jit::compile(jit::mscan_source(args, p->mdesc[s], sh), c->arch, code, why)) { why = why.substr(0, 400); return false; }
@@ -218,14 +220,15 @@ static bool build_specialised(vdl_ctx *c, vdl_plan *p, size_t s, bool grouped, i
     if (grid > p->mcols[s].n / tile) grid = p->mcols[s].n / tile;
     if (grid < 1) grid = 1;
     out.grid = (int)grid; out.per_cu = per_cu; out.code_bytes = code.size(); out.name = jit_name(sh);
-    if (lazy) out.name.insert(out.name.size() - 1, ",late");
+    if (lazy) out.name.insert(out.name.size() - 1, lazy > 1 ? ",late2" : ",late");
     return true;
 }
 static bool specialise_scan(vdl_ctx *c, vdl_plan *p, size_t s, bool grouped, std::string *kname) {
     Specialised sp;
     std::string why;
-    const bool late = getenv("VDL_JIT_LATE") != nullptr;          // (tests: force late materialisation where a column allows it)
-    if (!(late && build_specialised(c, p, s, grouped, 0, true, sp, why)) && !build_specialised(c, p, s, grouped, 0, false, sp, why)) { p->jit_note += "scan " + std::to_string(s) + ": not specialised (" + why + "); "; return false; }
+    // (tests, profiles: VDL_JIT_LATE=1|2 forces the staged form -- with that many filter columns read with the tile -- where a column allows it)
+    const int late = getenv("VDL_JIT_LATE") ? std::max(1, atoi(getenv("VDL_JIT_LATE"))) : 0;
+    if (!(late && build_specialised(c, p, s, grouped, 0, late, sp, why)) && !build_specialised(c, p, s, grouped, 0, 0, sp, why)) { p->jit_note += "scan " + std::to_string(s) + ": not specialised (" + why + "); "; return false; }
     p->mcfg[s].grid = sp.grid;
     p->mjit[s] = sp.k;
     *kname = sp.name;
@@ -253,13 +256,13 @@ static void tune_specialised(vdl_ctx *c, vdl_plan *p, int64_t *dev_words) {
         std::string tried;
         // rows per lane first; then, at the winner, at 2 and at 1, the staged form that reads late (fewer rows per lane suit it:
         // its loads depend on each other, and what hides them is more waves, not more loads per wave)
-        std::vector<std::pair<int, bool>> cands = {{2, false}, {3, false}, {4, false}, {6, false}, {0, true}, {2, true}, {1, true}};
+        std::vector<std::pair<int, int>> cands = {{2, 0}, {3, 0}, {4, 0}, {6, 0}, {0, 1}, {2, 1}, {1, 1}, {2, 2}, {4, 2}};
         int best_u = 0;
         for (auto &cu : cands) {
             const int u = cu.first ? cu.first : best_u;
-            const bool lazy = cu.second;
+            const int lazy = cu.second;
             if (u <= 0 || (int64_t)256 * 2 * u > p->mcols[s].n) continue;
-            if (lazy && cu.first == best_u) continue;
+            if (lazy == 1 && cu.first == best_u) continue;
             Specialised cand;
             std::string why;
             if (!build_specialised(c, p, s, grouped, u, lazy, cand, why)) continue;
@@ -276,7 +279,7 @@ static void tune_specialised(vdl_ctx *c, vdl_plan *p, int64_t *dev_words) {
                 HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
                 if (rep > 0 && t < ms) ms = t;                  // the first launch of a module pays for its load
             }
-            tried += " u=" + std::to_string(u) + (lazy ? ",late:" : ":") + std::to_string((int)(ms * 1000)) + "us";
+            tried += " u=" + std::to_string(u) + (lazy > 1 ? ",late2:" : lazy ? ",late:" : ":") + std::to_string((int)(ms * 1000)) + "us";
             if (!best.k || ms < best_ms) { best = cand; best_ms = ms; if (!lazy) best_u = u; }
         }
         if (!best.k) continue;
