@@ -756,15 +756,20 @@ struct GenExec {
         o.perm = !data.valid;                                   // every slot gets a rank: a permutation of 0 .. n-1
         o.ranks = true;                                         // in any case the valid slots get the ranks 0 .. m-1
         o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(o.n, 1));
+        int64_t max_bucket = -1;
         if (o.n > 1 && !data.valid && partition_passes(pcount) > 1 && !getenv("VDL_NO_SORTED_SHORTCUT")) {
             // data already in order (lineitems are clustered by order key: the group keys of Q3 / Q18 arrive sorted)?
             // bucket = clamp(data - min) is monotone, so the stable ranks are then 0, 1, 2, ... without a single radix pass
-            BufP flag = dev_alloc(c, sizeof(int64_t));
-            HIP_CHECK(hipMemsetAsync(flag->p, 0, sizeof(int64_t), s));
+            BufP flag = dev_alloc(c, 2 * sizeof(int64_t));
+            const int64_t init[2] = {0, INT64_MIN};
+            HIP_CHECK(hipMemcpyAsync(flag->p, init, sizeof init, hipMemcpyHostToDevice, s));
             HIP_CHECK(launch_sorted_check(src_of(data), o.n, (int64_t *)flag->p, s));
-            int64_t descends = 0;
-            HIP_CHECK(hipMemcpyAsync(&descends, flag->p, sizeof descends, hipMemcpyDeviceToHost, s));
+            int64_t seen[2] = {0, 0};
+            HIP_CHECK(hipMemcpyAsync(seen, flag->p, sizeof seen, hipMemcpyDeviceToHost, s));
             HIP_CHECK(hipStreamSynchronize(s));
+            const int64_t descends = seen[0];
+            // the largest bucket that occurs (bucket = clamp(data - min, 0, cnt) is monotone in the data)
+            max_bucket = seen[1] <= pmin ? 0 : ((int64_t)((uint64_t)seen[1] - (uint64_t)pmin) < 0 ? pcount : std::min<int64_t>((int64_t)((uint64_t)seen[1] - (uint64_t)pmin), pcount));
             if (!descends) {
                 Src zero; zero.kind = SRC_RANGE; zero.from = 0; zero.step = 0;
                 HIP_CHECK(launch_binary(B_ADD, iota_src(), zero, (int64_t *)o.data->p, o.n, s));
@@ -786,7 +791,7 @@ struct GenExec {
             HIP_CHECK(launch_partition(src_of(data), vp(data), o.n, pmin, pcount, (int64_t *)hist->p, (int64_t *)scr->p,
                                        ka ? (uint64_t *)ka->p : nullptr, sa ? (int64_t *)sa->p : nullptr,
                                        kb ? (uint64_t *)kb->p : nullptr, sb ? (int64_t *)sb->p : nullptr,
-                                       (int64_t *)nvalid->p, (int64_t *)o.data->p, s));
+                                       (int64_t *)nvalid->p, (int64_t *)o.data->p, s, max_bucket));
         }
         return o;
     }

@@ -204,7 +204,7 @@ int partition_passes(int64_t pcount);
 hipError_t launch_sorted_check(Src d, int64_t n, int64_t *flag, hipStream_t s);
 hipError_t launch_partition(Src data, const uint64_t *valid, int64_t n, int64_t pmin, int64_t pcount, int64_t *hist,
                             int64_t *scan_scratch, uint64_t *keys_a, int64_t *slots_a, uint64_t *keys_b, int64_t *slots_b,
-                            int64_t *n_valid_dev, int64_t *pos_out, hipStream_t s);
+                            int64_t *n_valid_dev, int64_t *pos_out, hipStream_t s, int64_t max_bucket = -1 /* largest bucket known to occur */);
 
 // Fold over a general control vector; kind 0 sum, 1 min, 2 max, 3 count, 4 choose
 // heads: nwords uint64; wordhd: nwords + maxscan_blocks(nwords) int64

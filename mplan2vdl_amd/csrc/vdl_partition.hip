@@ -2,6 +2,8 @@
 // Partition.
 #include "vdl_device.h"
 
+#include <cstdlib>
+
 namespace vdl {
 
 // ------------------------------------------------------------------------------------------
@@ -72,6 +74,8 @@ struct PartIn {
     const int64_t *n_dev;        // later passes: number of elements (device scalar)
     int64_t n;                   // first pass: number of slots; later: upper bound for the grid
     int shift;
+    int slot_bits;               // > 0: packed form -- a pair travels as ONE word (bucket << slot_bits) | slot, `slots` is unused:
+                                 // every later pass moves 8 instead of 16 bytes per row (taken when bits(pcount) + bits(n) <= 64)
 };
 
 // A wave's share of a tile: kPartSteps x 64 consecutive slots starting at a multiple of 64, fetched with every load
@@ -102,7 +106,15 @@ __device__ __forceinline__ void part_fetch_share(const PartIn &in, int64_t n, in
             const int64_t x = (int64_t)keys[st];
             int64_t b = 0;
             if (x > in.pmin) { b = (int64_t)((uint64_t)x - (uint64_t)in.pmin); if (b < 0 || b > in.pcount) b = in.pcount; }
-            keys[st] = (uint64_t)b;
+            keys[st] = in.slot_bits ? (((uint64_t)b << in.slot_bits) | (uint64_t)slots[st]) : (uint64_t)b;
+        }
+    } else if (in.slot_bits) {
+#pragma unroll
+        for (int st = 0; st < kPartSteps; st++) {
+            const int64_t i = share0 + st * kWave + lane;
+            oks[st] = i < n;
+            keys[st] = in.keys[oks[st] ? i : 0];
+            slots[st] = (int64_t)(keys[st] & ((1ull << in.slot_bits) - 1));
         }
     } else {
 #pragma unroll
@@ -238,6 +250,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(PartIn in, int64_t 
             keys_out[dest[k]] = key;
         }
     }
+    if (in.slot_bits) return;                                  // packed: the slot travelled inside the key word
     __syncthreads();
 #pragma unroll
     for (int st = 0; st < kPartSteps; st++)
@@ -251,14 +264,24 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(PartIn in, int64_t 
 // Is the (fully valid) data already in non-decreasing order?  Then its stable partition ranks are 0, 1, 2, ... and none of
 // the radix passes is needed: TPC-H lineitems are clustered by order key, so the composite group keys of Q3 / Q18 arrive
 // sorted.  flag[0] (pre-zeroed) is set when a descent is found.
+// (flag[1], pre-zeroed, receives the largest value: when the data is not in order, the radix passes only have to cover the
+// buckets that occur, not the whole declared domain -- and a smaller bucket range may let a pair travel as one word)
 __global__ __launch_bounds__(256) void k_sorted_check(Src d, int64_t n, int64_t *flag) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     bool bad = false;
+    int64_t mx = INT64_MIN;
     by_kind(d.kind, [&](auto kd) {
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i + 1 < n; i += stride)
-            bad |= ldk<decltype(kd)::value>(d, i) > ldk<decltype(kd)::value>(d, i + 1);
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+            const int64_t x = ldk<decltype(kd)::value>(d, i);
+            if (i + 1 < n) bad |= x > ldk<decltype(kd)::value>(d, i + 1);
+            mx = x > mx ? x : mx;
+        }
     });
     if (__ballot(bad) != 0 && (threadIdx.x & (kWave - 1)) == 0) flag[0] = 1;
+    mx = wave_reduce(mx, R_MAX);
+    // (a plain look first: after the first few waves hardly any has a new maximum, and tens of thousands of atomics on one
+    // word would cost more than the scan)
+    if ((threadIdx.x & (kWave - 1)) == 0 && mx > *(volatile int64_t *)&flag[1]) atomicMax((long long *)&flag[1], (long long)mx);
 }
 hipError_t launch_sorted_check(Src d, int64_t n, int64_t *flag, hipStream_t s) {
     (void)hipGetLastError();
@@ -271,19 +294,23 @@ hipError_t launch_sorted_check(Src d, int64_t n, int64_t *flag, hipStream_t s) {
 hipError_t launch_partition(Src data, const uint64_t *valid, int64_t n, int64_t pmin, int64_t pcount,
                             int64_t *hist /* 256*ntiles + 1 */, int64_t *scan_scratch /* prefix_sum_blocks(256*ntiles)+1 */,
                             uint64_t *keys_a, int64_t *slots_a, uint64_t *keys_b, int64_t *slots_b /* n each, or null if one pass */,
-                            int64_t *n_valid_dev /* 1 word */, int64_t *pos_out, hipStream_t s) {
+                            int64_t *n_valid_dev /* 1 word */, int64_t *pos_out, hipStream_t s, int64_t max_bucket) {
     (void)hipGetLastError();   // see launch_status()
     if (n <= 0) return hipSuccess;
     int bits = 0;
-    while (bits < 63 && ((uint64_t)pcount >> bits) != 0) bits++;       // buckets 0..pcount
+    const int64_t top = (max_bucket >= 0 && max_bucket < pcount) ? max_bucket : pcount;      // buckets 0..pcount, or those known to occur
+    while (bits < 63 && ((uint64_t)top >> bits) != 0) bits++;
     const int passes = bits <= 8 ? 1 : (bits + 7) / 8;
     const int64_t ntiles = partition_tiles(n);
     const int64_t hn = (int64_t)kRadix * ntiles;
     PartIn in{};
     in.data = data; in.valid = valid; in.pmin = pmin; in.pcount = pcount; in.n = n; in.n_dev = n_valid_dev;
+    int nbits = 1;
+    while (nbits < 63 && ((uint64_t)(n - 1) >> nbits) != 0) nbits++;    // slots 0..n-1
+    in.slot_bits = (passes > 1 && bits + nbits <= 64 && !getenv("VDL_NO_PACKED_PARTITION")) ? nbits : 0;
     uint64_t *kin = nullptr, *kout = keys_a; int64_t *sin = nullptr, *sout = slots_a;
     for (int p = 0; p < passes; p++) {
-        in.shift = 8 * p; in.keys = kin; in.slots = sin;
+        in.shift = 8 * p + in.slot_bits; in.keys = kin; in.slots = sin;
         const bool first = p == 0, last = p == passes - 1;
         if (first) k_part_hist<true><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist);
         else k_part_hist<false><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist);
