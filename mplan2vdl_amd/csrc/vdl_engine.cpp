@@ -683,14 +683,22 @@ namespace eng {
 // The fused front of a plan that does not fuse as a whole (ProjPlan, vdl_fuse.h): one scan over the fact table -- two
 // passes: count per tile, then write -- produces the statements of `proj.nodes` as SPARSE vectors on one shared selection;
 // the per-operator executor starts from them (`over`).  false: the plan has no such front (or it is switched off).
-bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
+// What is known of the fused front before anything runs: the columns of both passes (the select pass sees only the columns
+// that decide a row's survival, renumbered), which columns the take pass needs and which it writes.  Pointers and sizes of
+// the prelude's tables are patched in by the caller once they exist (patch_front).
+struct FrontBound {
+    MScanCols cols, scols;
+    std::unique_ptr<MScanDesc> d = std::make_unique<MScanDesc>(), sdesc = std::make_unique<MScanDesc>();
+    std::vector<int> renum, distinct;
+    std::vector<char> wanted;
+    int64_t n = 0;
+};
+static void bind_front(vdl_ctx *c, vdl_plan *p, FrontBound &b) {
     const ProjPlan &J = p->fused.proj;
-    if (!J.ok || (p->use_fusion && p->fused.ok) || !p->use_fusion || getenv("VDL_NO_PROJECTION")) return false;
-    MScanCols cols;
-    auto desc = std::make_unique<MScanDesc>();
-    MScanDesc &d = *desc;
-    std::vector<char> wanted(p->fused.prelude.size(), 0);
-    const int64_t n = bind_vcols(c, J.table, J.cols, cols, d, wanted);
+    MScanCols &cols = b.cols;
+    MScanDesc &d = *b.d;
+    b.wanted.assign(p->fused.prelude.size(), 0);
+    b.n = bind_vcols(c, J.table, J.cols, cols, d, b.wanted);
     // columns that decide a row's survival: the filtered ones and what they are derived from; a lookup whose range check is
     // done by another deciding column through the same index (the dimension bitmap, an INRANGE) decides nothing itself.
     // Everything else is read for the surviving rows only, in the write pass.
@@ -713,6 +721,62 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
         }
         for (int k = 0; k < cols.ncol; k++) cols.lazy[k] = decides[(size_t)k] ? 0 : 1;
     }
+    // the select pass: deciding columns only, renumbered (its register use grows with the column count)
+    MScanCols &scols = b.scols;
+    MScanDesc *sdesc = b.sdesc.get();
+    b.renum.assign((size_t)cols.ncol, -1);
+    std::vector<int> &renum = b.renum;
+    for (int k = 0; k < cols.ncol; k++) {
+        if (cols.lazy[k]) continue;
+        const int j = scols.ncol++;
+        renum[(size_t)k] = j;
+        scols.ptr[j] = cols.ptr[k]; scols.width[j] = cols.width[k]; scols.filtered[j] = cols.filtered[k];
+        scols.lo[j] = cols.lo[k]; scols.hi[j] = cols.hi[k]; scols.kind[j] = cols.kind[k];
+        sdesc->flo[j] = d.flo[k]; sdesc->fhi[j] = d.fhi[k]; sdesc->dkind[j] = d.dkind[k]; sdesc->dn[j] = d.dn[k]; sdesc->dtests[j] = d.dtests[k];
+        if (d.dkind[k] == VC_FORM) {                          // its steps stay where they are in the pool; the tests' columns are
+            sdesc->dsrc[j] = d.dsrc[k]; sdesc->dsrc2[j] = d.dsrc2[k];      // renumbered (monotonic: they stay sorted by column)
+            for (int f = d.dsrc[k]; f < d.dsrc[k] + d.dsrc2[k]; f++) {
+                sdesc->form[f] = d.form[f];
+                if (d.form[f].op == FormStep::LEAF) sdesc->form[f].col = renum[(size_t)d.form[f].col];
+            }
+            continue;
+        }
+        sdesc->dsrc[j] = d.dsrc[k] >= 0 ? renum[(size_t)d.dsrc[k]] : -1;
+        sdesc->dsrc2[j] = d.dsrc2[k] >= 0 ? renum[(size_t)d.dsrc2[k]] : -1;
+    }
+    scols.n = b.n;
+    // the take pass: one packed vector per produced column (statements that are the same column share it), and what those
+    // columns are derived from
+    for (int oc : J.node_col) if (oc >= 0 && std::find(b.distinct.begin(), b.distinct.end(), oc) == b.distinct.end()) b.distinct.push_back(oc);
+    d.nout = (int)b.distinct.size();
+    d.take = 0;
+    for (size_t o = 0; o < b.distinct.size(); o++) { d.out_col[o] = b.distinct[o]; d.take |= 1u << b.distinct[o]; }
+    for (int k = cols.ncol - 1; k >= 0; k--) {
+        if (!((d.take >> k) & 1u)) continue;
+        for (int src : J.cols[(size_t)k].sources()) d.take |= 1u << src;
+    }
+}
+// the prelude's tables of this run, in both passes' arguments
+static void patch_front(const vdl_plan *p, FrontBound &b) {
+    patch_prelude(p, p->fused.proj.cols, b.cols, *b.d);
+    for (int k = 0; k < b.cols.ncol; k++) {
+        if (b.renum[(size_t)k] < 0) continue;
+        b.scols.ptr[b.renum[(size_t)k]] = b.cols.ptr[k];
+        b.sdesc->dn[b.renum[(size_t)k]] = b.d->dn[k];
+    }
+}
+
+bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
+    const ProjPlan &J = p->fused.proj;
+    if (!J.ok || (p->use_fusion && p->fused.ok) || !p->use_fusion || getenv("VDL_NO_PROJECTION")) return false;
+    FrontBound fb;
+    bind_front(c, p, fb);
+    MScanCols &cols = fb.cols, &scols = fb.scols;
+    MScanDesc &d = *fb.d;
+    std::unique_ptr<MScanDesc> &sdesc = fb.sdesc;
+    const std::vector<char> &wanted = fb.wanted;
+    const std::vector<int> &distinct = fb.distinct;
+    const int64_t n = fb.n;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (p->profiling) {
         if (!p->stmt_ev[1]) { HIP_CHECK(hipEventCreate(&p->stmt_ev[0])); HIP_CHECK(hipEventCreate(&p->stmt_ev[1])); }
@@ -720,10 +784,7 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
         HIP_CHECK(hipEventRecord(e0, c->stream));
     }
     run_prelude_items(c, p, wanted);
-    patch_prelude(p, J.cols, cols, d);
-    // produced columns: one packed vector each (statements that are the same column share it)
-    std::vector<int> distinct;
-    for (int oc : J.node_col) if (oc >= 0 && std::find(distinct.begin(), distinct.end(), oc) == distinct.end()) distinct.push_back(oc);
+    patch_front(p, fb);
     SelP sel = std::make_shared<Sel>();
     sel->n = n;
     const int64_t ntiles = project_tiles(n);
@@ -733,29 +794,6 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
         BufP counts = dev_alloc(c, sizeof(int64_t) * (size_t)(ntiles + 1)), offsets = dev_alloc(c, sizeof(int64_t) * (size_t)(ntiles + 1));
         BufP scratch = dev_alloc(c, (size_t)project_scratch_bytes(n));
         BufP ddev = dev_alloc(c, sizeof(MScanDesc)), sdev = dev_alloc(c, sizeof(MScanDesc));
-        // the select pass sees only the columns that decide survival, renumbered (its register use grows with the column count)
-        MScanCols scols;
-        auto sdesc = std::make_unique<MScanDesc>();
-        std::vector<int> renum((size_t)cols.ncol, -1);
-        for (int k = 0; k < cols.ncol; k++) {
-            if (cols.lazy[k]) continue;
-            const int j = scols.ncol++;
-            renum[(size_t)k] = j;
-            scols.ptr[j] = cols.ptr[k]; scols.width[j] = cols.width[k]; scols.filtered[j] = cols.filtered[k];
-            scols.lo[j] = cols.lo[k]; scols.hi[j] = cols.hi[k]; scols.kind[j] = cols.kind[k];
-            sdesc->flo[j] = d.flo[k]; sdesc->fhi[j] = d.fhi[k]; sdesc->dkind[j] = d.dkind[k]; sdesc->dn[j] = d.dn[k]; sdesc->dtests[j] = d.dtests[k];
-            if (d.dkind[k] == VC_FORM) {                          // its steps stay where they are in the pool; the tests' columns are
-                sdesc->dsrc[j] = d.dsrc[k]; sdesc->dsrc2[j] = d.dsrc2[k];      // renumbered (monotonic: they stay sorted by column)
-                for (int f = d.dsrc[k]; f < d.dsrc[k] + d.dsrc2[k]; f++) {
-                    sdesc->form[f] = d.form[f];
-                    if (d.form[f].op == FormStep::LEAF) sdesc->form[f].col = renum[(size_t)d.form[f].col];
-                }
-                continue;
-            }
-            sdesc->dsrc[j] = d.dsrc[k] >= 0 ? renum[(size_t)d.dsrc[k]] : -1;
-            sdesc->dsrc2[j] = d.dsrc2[k] >= 0 ? renum[(size_t)d.dsrc2[k]] : -1;
-        }
-        scols.n = n;
         sel->bitmap = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>((n + 63) >> 6, 1));
         sdesc->tile_counts = (int64_t *)counts->p;
         sdesc->out_idx = (int64_t *)scratch->p;
@@ -771,17 +809,9 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
         HIP_CHECK(hipStreamSynchronize(c->stream));             // (also: `d` has been read by the first copy)
         sel->idx = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(m, 1));
         d.out_idx = (int64_t *)sel->idx->p;
-        d.nout = (int)distinct.size();
-        d.take = 0;
         for (size_t o = 0; o < distinct.size(); o++) {
             outs[o] = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(m, 1));
-            d.out_col[o] = distinct[o];
             d.out_ptr[o] = (int64_t *)outs[o]->p;
-            d.take |= 1u << distinct[o];
-        }
-        for (int k = cols.ncol - 1; k >= 0; k--) {               // ... and what they are derived from
-            if (!((d.take >> k) & 1u)) continue;
-            for (int src : J.cols[(size_t)k].sources()) d.take |= 1u << src;
         }
         if (m > 0) {
             HIP_CHECK(hipMemcpyAsync(ddev->p, &d, sizeof d, hipMemcpyHostToDevice, c->stream));
@@ -1041,6 +1071,34 @@ int vdl_plan_jit_check(vdl_ctx *c, vdl_plan *p) {
     if (!c || !p) return VDL_ERR_ARG;
     return guard(c, [&] {
         p->jit_note.clear();
+        if (!p->fused.ok && p->fused.proj.ok) {
+            // the fused front of a plan that does not fuse as a whole: both passes of the projection scan, and the dimension
+            // scans its prelude holds
+            auto build = [&](const std::string &role, jit::Kind kind, const MScanCols &cols, const MScanDesc &d) {
+                jit::Shape sh;
+                sh.nc = cols.ncol; sh.u = 4; sh.vec = kind == jit::SELECT ? project_select_vec(cols) : false; sh.der = true;
+                std::vector<char> code;
+                std::string log;
+                if (!jit::compile(jit::scan_source(kind, mscan_args(cols), d, sh), c->arch, code, log))
+                    throw Error(VDL_ERR_UNSUPPORTED, role + " does not build: " + log.substr(0, 2000));
+                p->jit_note += role + ": " + jit::entry_name(kind) + "<" + std::to_string(sh.nc) + ">, " + std::to_string(code.size()) + " B of code; ";
+            };
+            const FusedPlan &F = p->fused;
+            for (size_t k = 0; k < F.prelude.size(); k++) {
+                if (F.prelude[k].kind != PreludeItem::DIM_BITMAP || !F.prelude[k].scan) continue;
+                MScanCols cols;
+                auto d = std::make_unique<MScanDesc>();
+                std::vector<char> unused(F.prelude.size(), 0);
+                bind_vcols(c, F.prelude[k].table, F.prelude[k].cols, cols, *d, unused);
+                d->bitmap_only = 1;
+                build("dim" + std::to_string(k), jit::SELECT, cols, *d);
+            }
+            FrontBound fb;
+            bind_front(c, p, fb);
+            build("select", jit::SELECT, fb.scols, *fb.sdesc);
+            build("take", jit::TAKE, fb.cols, *fb.d);
+            return;
+        }
         if (!p->fused.ok) throw Error(VDL_ERR_UNSUPPORTED, "the plan has no fused scans: " + p->fused.why_not);
         const FusedPlan &F = p->fused;
         const size_t ns = F.scans.size();

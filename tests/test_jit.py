@@ -75,8 +75,20 @@ def test_specialised_kernels_of_random_programs_build_without_a_gpu():
     assert built >= 6
 
 
+@pytest.mark.parametrize("n", [3, 9, 10, 11, 15, 20])
+def test_specialised_fronts_build_without_a_gpu(n):
+    """Plans with a fused front: the projection scan's select and take passes and the dimension scans of the prelude."""
+    text, cols = compiled(n, 1e-4)
+    e = host_engine_with_declared(cols)
+    p = e.parse(text)
+    note = p.jit_check()
+    assert "select: vdl_jit_project_select<" in note and "take: vdl_jit_project_take<" in note, note
+    assert ("dim" in note) == (n != 15), note
+    assert max(code_bytes(note)) < 64 << 10, note
+
+
 def test_a_plan_without_fused_scans_is_refused():
-    text, cols = compiled(3, 1e-4)
+    text, cols = compiled(4, 1e-4)                             # Q4: neither fused nor a fused front
     e = host_engine_with_declared(cols)
     p = e.parse(text)
     with pytest.raises(m.VdlError, match="no fused scans"):
