@@ -771,6 +771,7 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
     if (!J.ok || (p->use_fusion && p->fused.ok) || !p->use_fusion || getenv("VDL_NO_PROJECTION")) return false;
     FrontBound fb;
     bind_front(c, p, fb);
+    if (fb.scols.ncol > kMaxSelectCols) return false;          // more deciding columns than the select pass takes: statement by statement
     MScanCols &cols = fb.cols, &scols = fb.scols;
     MScanDesc &d = *fb.d;
     std::unique_ptr<MScanDesc> &sdesc = fb.sdesc;

@@ -713,7 +713,7 @@ struct VCols {
         bool never = cl.never;
         if (!inner.lower_filters(cl, never)) return;
         tidy_columns(dc, {});
-        if ((int)dc.size() > kMaxProjCols) return;
+        if ((int)dc.size() > kMaxSelectCols) return;
         bool direct = false;
         for (const ScanColumn &c : dc) direct |= c.kind == VC_DIRECT && c.name.compare(0, S.table.size() + 1, S.table + ".") == 0;
         if (!direct) return;
@@ -896,6 +896,7 @@ int64_t eval_scalar(const Scalar &s, const int64_t *agg) {
     }
 }
 
+static void show_col(const ScanColumn &c, size_t k, std::ostringstream &o);
 // ProjPlan (vdl_fuse.h): the selection of the program's Partition key, and the atom statements living on it that the
 // rest of the program reads.
 static void build_projection(const Program &P, Builder &B, FusedPlan &F) {
@@ -945,7 +946,13 @@ static void build_projection(const Program &P, Builder &B, FusedPlan &F) {
         const std::vector<int> map = VCols::tidy_columns(J.cols, J.node_col);
         for (int &nc : J.node_col) if (nc >= 0) nc = map[(size_t)nc];
     }
-    if ((int)J.cols.size() > kMaxProjCols) { J.why = "more than " + std::to_string(kMaxProjCols) + " columns"; return; }
+    if ((int)J.cols.size() > kMaxProjCols) {
+        std::ostringstream o;
+        o << "more than " << kMaxProjCols << " columns (" << J.cols.size() << "):";
+        for (size_t k = 0; k < J.cols.size(); k++) { std::ostringstream one; show_col(J.cols[k], k, one); std::string t = one.str(); o << " |" << t.substr(0, t.size() - 1); }
+        J.why = o.str();
+        return;
+    }
     bool direct = false;
     for (const ScanColumn &c : J.cols) direct |= c.kind == VC_DIRECT && c.name.compare(0, J.table.size() + 1, J.table + ".") == 0;
     if (!direct) { J.why = "no column of the table itself (row count unknown)"; return; }

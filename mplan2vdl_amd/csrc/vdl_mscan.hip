@@ -220,7 +220,8 @@ hipError_t launch_project_select(const MScanCols &cols, const MScanDesc *dev_des
     }
 #define VDL_PJ(NC) do { if (vec) k_project_select<NC, kProjU, true, true><<<(int)grid, kMsBlock, 0, s>>>(a, dev_desc); \
                         else k_project_select<NC, kProjU, false, false><<<(int)grid, kMsBlock, 0, s>>>(a, dev_desc); } while (0)
-    if (cols.ncol <= 4) VDL_PJ(4); else if (cols.ncol <= 8) VDL_PJ(8); else VDL_PJ(kMaxVCols);      // (registers: NC x 8 rows x 64 bits)
+    if (cols.ncol > kMaxSelectCols) return hipErrorInvalidValue;
+    if (cols.ncol <= 4) VDL_PJ(4); else if (cols.ncol <= 8) VDL_PJ(8); else VDL_PJ(kMaxSelectCols);      // (registers: NC x 8 rows x 64 bits)
 #undef VDL_PJ
     return hipGetLastError();
 }
@@ -235,7 +236,8 @@ hipError_t launch_project_take(const MScanCols &cols, const MScanDesc *dev_desc,
         void *params[] = {&a, &dev_desc, &scratch, &counts, &offsets};
         return hipModuleLaunchKernel(jit_fn, (unsigned)grid, 1, 1, kMsBlock, 1, 1, 0, s, params, nullptr);
     }
-    k_project_take<kMaxVCols><<<(int)grid, kMsBlock, 0, s>>>(ms_args(cols), dev_desc, (const uint16_t *)scratch, counts, offsets);
+    if (cols.ncol <= 12) k_project_take<12><<<(int)grid, kMsBlock, 0, s>>>(ms_args(cols), dev_desc, (const uint16_t *)scratch, counts, offsets);
+    else k_project_take<kMaxVCols><<<(int)grid, kMsBlock, 0, s>>>(ms_args(cols), dev_desc, (const uint16_t *)scratch, counts, offsets);
     return hipGetLastError();
 }
 

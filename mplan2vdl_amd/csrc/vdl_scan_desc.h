@@ -81,10 +81,12 @@ struct KeyStep {
 // interpreted step by step (KeyStep).
 constexpr int kMaxKeyComps = 4;
 struct KeyComp { int col = 0, rsh = 0, lsh = 0, pad = 0; int64_t sub = 0; };
-constexpr int kMaxProjCols = 12, kMaxProjOuts = 10;
+// (the projection scan's take pass handles up to 16 columns; its select pass sees only the columns that decide a row's survival,
+// at most kMaxSelectCols of them)
+constexpr int kMaxProjCols = 16, kMaxSelectCols = 12, kMaxProjOuts = 10;
 
 constexpr int kMaxGroupAggs = 16;
-constexpr int kMaxVCols = kMaxProjCols;      // columns of a scan descriptor: 8 for plain aggregate scans, up to 12 with derived columns / for the projection scan
+constexpr int kMaxVCols = kMaxProjCols;      // columns of a scan descriptor: 8 for plain aggregate scans, up to 12 with derived columns, 16 for the projection scan
 static_assert(kMaxVCols >= kMaxScanCols && kMaxVCols >= kMaxJoinScanCols, "the aggregate scans' columns fit the descriptor");
 struct MScanCols {                           // host-side description of a scan's columns
     int ncol = 0;
