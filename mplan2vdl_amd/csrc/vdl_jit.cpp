@@ -49,7 +49,8 @@ Rtc &rtc() {
     static std::once_flag once;
     std::call_once(once, [] {
         const char *names[] = {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"};
-        for (const char *n : names) if ((r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+        if (const char *forced = getenv("VDL_HIPRTC_LIB")) r.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);      // (this one or none)
+        else for (const char *n : names) if ((r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
         if (!r.lib) { r.why = "libhiprtc not found"; return; }
         auto sym = [&](const char *n) { void *p = dlsym(r.lib, n); if (!p) r.why = std::string("libhiprtc lacks ") + n; return p; };
         r.create = (decltype(r.create))sym("hiprtcCreateProgram");

@@ -201,3 +201,21 @@ def test_specialised_fronts_and_dimension_scans_match_the_oracle():
         check_against_oracle("specialised_front", seed, text, cols, got, want)
         fronts += "vdl_jit_project_select<" in note
     assert fronts >= 15
+
+
+@pytest.mark.gpu
+def test_without_hiprtc_the_precompiled_kernels_run_and_the_note_says_so():
+    """vdlrun --jit in a process that cannot load libhiprtc (VDL_HIPRTC_LIB names nothing): same answer, through the
+    precompiled kernels; the library says why in the plan's note (printed by --describe-after-run on stderr)."""
+    import json
+    import subprocess
+    from helpers import lineitem
+    from mplan2vdl_amd import datagen
+    text = open(os.path.join(ROOT, "tests", "golden", "q1.vdl")).read()
+    vdlrun = os.path.join(ROOT, "mplan2vdl_amd", "bin", "vdlrun")
+    env = dict(os.environ, VDL_HIPRTC_LIB="/nonexistent/libhiprtc.so")
+    r = subprocess.run([vdlrun, "--rows", "60175", "--jit", "--profile"], input=text.encode(), capture_output=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    reply = json.loads(r.stdout)
+    assert reply["results"] == oracle_run(text, lineitem(datagen.Q1_COLUMNS, 60175))
+    assert any("k_mscan<" in k for k in reply["timings"]), reply["timings"]          # the precompiled grouped scan ran
