@@ -244,9 +244,13 @@ static int max_scan_grid(const vdl_ctx *c, const vdl_plan *p, int chosen) { retu
 // 4.13 / 4.04 / 4.30 / 3.96 ms for 2 / 3 / 4 / 6.
 static void tune_specialised(vdl_ctx *c, vdl_plan *p, int64_t *dev_words) {
     const size_t ns = p->fused.scans.size(), ng = p->fused.gscans.size();
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    HIP_CHECK(hipEventCreate(&e0));
-    HIP_CHECK(hipEventCreate(&e1));
+    struct Events {                                            // (destroyed on every way out, also a throwing HIP_CHECK)
+        hipEvent_t a = nullptr, b = nullptr;
+        ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } ev;
+    HIP_CHECK(hipEventCreate(&ev.a));
+    HIP_CHECK(hipEventCreate(&ev.b));
+    const hipEvent_t e0 = ev.a, e1 = ev.b;
     for (size_t s = 0; s < ns + ng; s++) {
         if (!p->mjit[s]) continue;
         const bool grouped = s >= ns;
@@ -311,8 +315,6 @@ static void tune_specialised(vdl_ctx *c, vdl_plan *p, int64_t *dev_words) {
         if ((int)s == p->dominant)
             p->dominant_kernel = best.name + "_grid" + std::to_string(best.grid) + (grouped ? "_rep" + std::to_string(p->mdesc[s].replicas) : "");
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     p->description = describe_plan(p);
 }
 
@@ -455,6 +457,10 @@ static hipFunction_t front_kernel(vdl_ctx *c, vdl_plan *p, const std::string &ro
     if (!p->use_jit) return nullptr;
     vdl_plan::FrontKernel &fk = p->front_jit[role];
     if (fk.version == c->catalog_version) return fk.k ? fk.k->fn : nullptr;
+    {   // a rebuild after a catalog change: this role's old line leaves the note
+        const size_t at = p->jit_note.find(role + ": ");
+        if (at != std::string::npos) { const size_t end = p->jit_note.find("; ", at); p->jit_note.erase(at, end == std::string::npos ? std::string::npos : end + 2 - at); }
+    }
     fk.version = c->catalog_version;
     fk.k = nullptr;
     jit::Shape sh;
