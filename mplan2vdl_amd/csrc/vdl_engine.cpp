@@ -516,12 +516,14 @@ void run_prelude_items(vdl_ctx *c, vdl_plan *p, const std::vector<char> &asked) 
     }
     // dimension scans, in order: an item only looks up earlier ones
     std::vector<BufP> descs;
-    std::vector<std::unique_ptr<MScanDesc>> host_descs;
+    // (host copies of the descriptors stay alive in the plan until its next run: the copies to the device are asynchronous)
+    std::vector<std::shared_ptr<MScanDesc>> &host_descs = p->host_descs;
+    host_descs.clear();
     for (size_t k = 0; scans && k < F.prelude.size(); k++) {
         const PreludeItem &it = F.prelude[k];
         if (!wanted[k] || it.kind != PreludeItem::DIM_BITMAP || !it.scan) continue;
         MScanCols cols;
-        host_descs.push_back(std::make_unique<MScanDesc>());
+        host_descs.push_back(std::make_shared<MScanDesc>());
         MScanDesc *d = host_descs.back().get();
         std::vector<char> unused(F.prelude.size(), 0);
         const int64_t n = bind_vcols(c, it.table, it.cols, cols, *d, unused);
@@ -537,7 +539,6 @@ void run_prelude_items(vdl_ctx *c, vdl_plan *p, const std::vector<char> &asked) 
         HIP_CHECK(launch_project_select(cols, (const MScanDesc *)descs.back()->p, c->num_cus, c->stream,
                                         front_kernel(c, p, "dim" + std::to_string(k), jit::SELECT, cols, *d)));
     }
-    if (!host_descs.empty()) HIP_CHECK(hipStreamSynchronize(c->stream));      // the descriptors live on this frame
 }
 // hand the tables to a scan that looks them up
 void patch_prelude(const vdl_plan *p, const std::vector<ScanColumn> &sc, MScanCols &cols, MScanDesc &d) {
@@ -775,9 +776,11 @@ static void patch_front(const vdl_plan *p, FrontBound &b) {
 bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
     const ProjPlan &J = p->fused.proj;
     if (!J.ok || (p->use_fusion && p->fused.ok) || !p->use_fusion || getenv("VDL_NO_PROJECTION")) return false;
-    FrontBound fb;
+    auto fbp = std::make_shared<FrontBound>();                 // (kept by the plan until its next run: its descriptors are copied asynchronously)
+    FrontBound &fb = *fbp;
     bind_front(c, p, fb);
     if (fb.scols.ncol > kMaxSelectCols) return false;          // more deciding columns than the select pass takes: statement by statement
+    p->front_keep = fbp;
     MScanCols &cols = fb.cols, &scols = fb.scols;
     MScanDesc &d = *fb.d;
     std::unique_ptr<MScanDesc> &sdesc = fb.sdesc;
@@ -824,7 +827,6 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
             HIP_CHECK(hipMemcpyAsync(ddev->p, &d, sizeof d, hipMemcpyHostToDevice, c->stream));
             HIP_CHECK(launch_project_take(cols, (const MScanDesc *)ddev->p, scratch->p, (const int64_t *)counts->p, (const int64_t *)offsets->p,
                                           c->num_cus, c->stream, front_kernel(c, p, "take", jit::TAKE, cols, d)));
-            HIP_CHECK(hipStreamSynchronize(c->stream));         // `d` lives on this frame
         }
     } else {
         sel->idx = dev_alloc(c, sizeof(int64_t));

@@ -207,6 +207,8 @@ struct vdl_plan {
     std::vector<std::shared_ptr<vdl::jit::Kernel>> mjit;
     struct FrontKernel { uint64_t version = 0; std::shared_ptr<vdl::jit::Kernel> k; };
     std::map<std::string, FrontKernel> front_jit;   // specialised passes of the projection scan / dimension scans, by role
+    std::vector<std::shared_ptr<vdl::MScanDesc>> host_descs;     // dimension scans of the current run (copied to the device asynchronously)
+    std::shared_ptr<void> front_keep;                        // the fused front's bound descriptors of the current run, likewise
     std::vector<char> kscan;                 // [scan] runs on the single-aggregate k_scan (decided when the plan is bound / tuned)
     std::string jit_note;                    // what was specialised, or why not
     std::vector<BufP> prelude_buf;           // fused join scans: dimension bitmaps / LIKE tables of the current run (FusedPlan::prelude)
