@@ -18,7 +18,19 @@ for fmt in ("vdl", "vlite"):
     for n in (1, 3, 4, 5, 6, 9, 10, 11, 12, 14, 15, 16, 18, 19, 20):
         open(os.path.join(out, "q%02d.%s" % (n, fmt)), "w").write(frontend.compile_plan(open(os.path.join(meta, "%02d.sql.mplan" % n)).read(), cfg))
 PY
-$OUT/parse_fuse $HERE/tests/golden/q6.vdl $HERE/tests/golden/q1.vdl $HERE/tests/golden/q3.vdl $OUT/q*.vdl $OUT/q*.vlite
+# ... and the random join / condition / front programs of the parity tests (round 2: condition columns, column ordering, dimension scans)
+mkdir -p $OUT/rand
+PYTHONPATH=$HERE:$HERE/tests python3 - $OUT/rand <<'PY'
+import sys
+from test_random_conditions import Gen, FrontGen
+from test_random_joins import Gen as JoinGen
+from test_random_fused import Gen as FusedGen
+k = 0
+for G in (Gen, FrontGen, JoinGen, FusedGen):
+    for seed in range(120):
+        open("%s/p%04d.vdl" % (sys.argv[1], k), "w").write(G(seed).build()[0]); k += 1
+PY
+$OUT/parse_fuse $HERE/tests/golden/q6.vdl $HERE/tests/golden/q1.vdl $HERE/tests/golden/q3.vdl $OUT/q*.vdl $OUT/q*.vlite $OUT/rand/*.vdl
 gcc -std=c11 -g -O1 -fsanitize=address,undefined -fno-omit-frame-pointer -fopenmp -shared -fPIC $HERE/oracle/vdl_oracle.c -o $OUT/libvdl_oracle_asan.so
 echo "oracle ASan build ok: $OUT/libvdl_oracle_asan.so"
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0 VDL_ORACLE_SO=$OUT/libvdl_oracle_asan.so \
