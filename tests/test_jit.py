@@ -119,15 +119,17 @@ def test_specialised_tpch_plans_match_the_oracle(tune, scale):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("late", [False, True])
+@pytest.mark.parametrize("late", [0, 1, 2])
 def test_specialised_random_programs_match_the_oracle(late, monkeypatch):
-    """late: columns that are only aggregate inputs are read for the passing rows only (VDL_JIT_LATE forces what the tuner
-    otherwise decides by timing)."""
+    """late: staged reads -- that many filter columns with the tile, the other table columns for the rows still in
+    (VDL_JIT_LATE forces what the tuner otherwise decides by timing)."""
     from test_random_conditions import Gen as CondGen
     from test_random_fused import Gen as FusedGen
     from test_random_joins import Gen as JoinGen
     if late:
-        monkeypatch.setenv("VDL_JIT_LATE", "1")
+        monkeypatch.setenv("VDL_JIT_LATE", str(late))
+        monkeypatch.setenv("VDL_JIT_ASSUME_SELECTIVITY", "0.3")      # every filter counts as selective: the staged-filter code runs wherever a scan has two
+
     ran = lates = 0
     for tag, gen in (("fused", FusedGen), ("joins", JoinGen), ("conditions", CondGen)):
         for seed in range(40):
@@ -144,7 +146,7 @@ def test_specialised_random_programs_match_the_oracle(late, monkeypatch):
             e.close()
             check_against_oracle("specialised_random_" + tag, seed, text, cols, got, want)
             ran += "k_mscan_specialised<" in note
-            lates += ",late>" in note
+            lates += ",late" in note
     assert ran >= 60 and (lates >= 30 if late else lates == 0)
 
 
