@@ -239,9 +239,11 @@ static bool specialise_scan(vdl_ctx *c, vdl_plan *p, size_t s, bool grouped, std
 static int max_scan_grid(const vdl_ctx *c, const vdl_plan *p, int chosen) { return p->use_jit ? std::max(chosen, c->num_cus * 8) : chosen; }
 
 // vdl_plan_set_jit(plan, 2): at the first run, with the real columns and lookup tables in place, every specialised scan is
-// built with 2, 3, 4 and 6 row pairs per lane (a second each) and the quickest of three timed launches stays.  Which one
-// wins depends on the registers the specialised code needs and on how its blocks fill the CUs: Q1 at SF100 measured
-// 4.13 / 4.04 / 4.30 / 3.96 ms for 2 / 3 / 4 / 6.
+// built in up to nine forms (a second each) -- 2, 3, 4, 6 row pairs per lane, then the staged forms that read late (one or two
+// filter columns with the tile) at the winner's and at smaller shapes -- and the quickest of three timed launches stays; for a
+// single-aggregate scan the hand-tuned k_scan is timed as well.  Which one wins depends on the registers the specialised
+// code needs, on how its blocks fill the CUs and on the filters' selectivity: Q1 at SF100 measured 4.13 / 4.04 / 4.30 /
+// 3.96 ms for 2 / 3 / 4 / 6 pairs (staged: 4.1-4.2), Q6 2.7 / 2.5 / 2.4 / 2.5 ms eager, 1.63 staged, 2.38 on k_scan.
 static void tune_specialised(vdl_ctx *c, vdl_plan *p, int64_t *dev_words) {
     const size_t ns = p->fused.scans.size(), ng = p->fused.gscans.size();
     struct Events {                                            // (destroyed on every way out, also a throwing HIP_CHECK)
