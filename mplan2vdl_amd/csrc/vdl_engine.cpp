@@ -136,7 +136,21 @@ static std::string jit_name(const jit::Shape &sh) {
     return "k_mscan_specialised<" + std::to_string(sh.nc) + "," + std::to_string(sh.u) + "," + (sh.vec ? "vec" : "novec") + "," + (sh.grouped ? "grouped" : "global") +
            (sh.der ? ",derived" : "") + ">";
 }
-struct Specialised { std::shared_ptr<jit::Kernel> k; int grid = 0, per_cu = 0; size_t code_bytes = 0; std::string name; };
+struct Specialised { std::shared_ptr<jit::Kernel> k; int grid = 0, per_cu = 0; size_t code_bytes = 0; std::string name, stages; };
+// "l_discount@1 l_quantity@2 l_extendedprice@last": which table columns a staged scan reads when (MsArgs::stages)
+static std::string stages_text(const vdl_plan *p, size_t s, const MsArgs &args) {
+    const size_t ns = p->fused.scans.size();
+    const std::vector<ScanColumn> &sc = s < ns ? p->fused.scans[s].cols : p->fused.gscans[s - ns].cols;
+    std::string o;
+    for (int k = 0; k < args.ncol && k < (int)sc.size(); k++) {
+        const int st = args.stage(k);
+        if (!st) continue;
+        const std::string &name = sc[(size_t)k].name;
+        o += (o.empty() ? "" : " ") + name.substr(name.find('.') == std::string::npos ? 0 : name.find('.') + 1) + "@" +
+             (st == 15 ? std::string("last") : st == 14 ? std::string("lookups") : std::to_string(st));
+    }
+    return o;
+}
 // fraction of a table column's rows inside [lo, hi], from 16 samples of 4096 rows spread over the column
 static double sampled_selectivity(vdl_ctx *c, const void *dev, int width, int64_t n, int64_t lo, int64_t hi) {
     if (const char *a = getenv("VDL_JIT_ASSUME_SELECTIVITY")) return atof(a);      // (tests without a GPU: vdl_plan_jit_check of staged builds)
@@ -221,6 +235,7 @@ static bool build_specialised(vdl_ctx *c, vdl_plan *p, size_t s, bool grouped, i
     if (grid < 1) grid = 1;
     out.grid = (int)grid; out.per_cu = per_cu; out.code_bytes = code.size(); out.name = jit_name(sh);
     if (lazy) out.name.insert(out.name.size() - 1, lazy > 1 ? ",late2" : ",late");
+    if (lazy) out.stages = stages_text(p, s, args);
     return true;
 }
 static bool specialise_scan(vdl_ctx *c, vdl_plan *p, size_t s, bool grouped, std::string *kname) {
@@ -232,7 +247,8 @@ static bool specialise_scan(vdl_ctx *c, vdl_plan *p, size_t s, bool grouped, std
     p->mcfg[s].grid = sp.grid;
     p->mjit[s] = sp.k;
     *kname = sp.name;
-    p->jit_note += "scan " + std::to_string(s) + ": " + sp.name + ", " + std::to_string(sp.code_bytes) + " B of code, " + std::to_string(sp.per_cu) + " blocks/CU; ";
+    p->jit_note += "scan " + std::to_string(s) + ": " + sp.name + ", " + std::to_string(sp.code_bytes) + " B of code, " + std::to_string(sp.per_cu) + " blocks/CU" +
+                   (sp.stages.empty() ? "" : ", read late: " + sp.stages) + "; ";
     return true;
 }
 // blocks a specialised scan may be launched with, whatever rows-per-lane the tuner settles on: the partials area is sized for it
@@ -313,7 +329,7 @@ static void tune_specialised(vdl_ctx *c, vdl_plan *p, int64_t *dev_words) {
         }
         p->mjit[s] = best.k;
         p->mcfg[s].grid = best.grid;
-        p->jit_note += "scan " + std::to_string(s) + " tuned:" + tried + " -> " + best.name + "; ";
+        p->jit_note += "scan " + std::to_string(s) + " tuned:" + tried + " -> " + best.name + (best.stages.empty() ? "" : " (read late: " + best.stages + ")") + "; ";
         if ((int)s == p->dominant)
             p->dominant_kernel = best.name + "_grid" + std::to_string(best.grid) + (grouped ? "_rep" + std::to_string(p->mdesc[s].replicas) : "");
     }
