@@ -129,10 +129,23 @@ std::string scan_source(Kind kind, const MsArgs &C, const MScanDesc &D, const Sh
     o << "#define VDL_SPEC_UNROLL _Pragma(\"unroll\")\n";
     if (kind == MSCAN && C.lazy) {
         // the stages of a scan that reads late (MsArgs::stages), as straight-line code inside the body's row loop context
+        // a lane's rows come in adjacent pairs (2u, 2u + 1): with aligned columns a pair of which a row is still in is ONE
+        // 16-byte (int64) / 8-byte (int32) load instead of two masked scalar ones; the one-row tail and unaligned columns
+        // take the scalar form
+        const bool pairs = sh.vec && !getenv("VDL_JIT_NO_PAIR_LOADS");
         auto load = [&](int c, const char *mask) {
             std::ostringstream l;
+            const int w = C.width(c);
+            if (pairs && (w == 8 || w == 4)) {
+                const char *vt = w == 8 ? "ll2" : "i32x2";
+                l << " if (RW % 2 == 0) { _Pragma(\"unroll\") for (int r = 0; r < RW; r += 2) { const int r1 = r + 1 < RW ? r + 1 : r; v[" << c << "][r] = 0; v[" << c
+                  << "][r1] = 0; if (" << mask << "[r] | " << mask << "[r1]) { const int64_t i0 = rowid[r] - Cr.row0; if (i0 + 1 < Cr.n) { const " << vt << " x = *(const " << vt
+                  << " *)((const char *)Cr.ptr[" << c << "] + i0 * " << w << "); v[" << c << "][r] = x.x; v[" << c << "][r1] = x.y; } else if (" << mask << "[r]) v[" << c
+                  << "][r] = load_scalar(Cr.ptr[" << c << "], " << w << ", i0); } } } else {";   /* (the table's last row has no partner) */
+            }
             l << " _Pragma(\"unroll\") for (int r = 0; r < RW; r++) { v[" << c << "][r] = 0; if (" << mask << "[r]) v[" << c << "][r] = load_scalar(Cr.ptr[" << c << "], "
-              << C.width(c) << ", rowid[r] - Cr.row0); }";
+              << w << ", rowid[r] - Cr.row0); }";
+            if (pairs && (w == 8 || w == 4)) l << " }";
             return l.str();
         };
         o << "#define VDL_STAGED_PRE";
