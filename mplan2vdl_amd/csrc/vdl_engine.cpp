@@ -255,7 +255,7 @@ static bool specialise_scan(vdl_ctx *c, vdl_plan *p, size_t s, bool grouped, std
 static int max_scan_grid(const vdl_ctx *c, const vdl_plan *p, int chosen) { return p->use_jit ? std::max(chosen, c->num_cus * 8) : chosen; }
 
 // vdl_plan_set_jit(plan, 2): at the first run, with the real columns and lookup tables in place, every specialised scan is
-// built in up to nine forms (a second each) -- 2, 3, 4, 6 row pairs per lane, then the staged forms that read late (one or two
+// built in up to eleven forms (a second each) -- 2, 3, 4, 6 row pairs per lane, then the staged forms that read late (one or two
 // filter columns with the tile) at the winner's and at smaller shapes -- and the quickest of three timed launches stays; for a
 // single-aggregate scan the hand-tuned k_scan is timed as well.  Which one wins depends on the registers the specialised
 // code needs, on how its blocks fill the CUs and on the filters' selectivity: Q1 at SF100 measured 4.13 / 4.04 / 4.30 /
@@ -278,7 +278,7 @@ static void tune_specialised(vdl_ctx *c, vdl_plan *p, int64_t *dev_words) {
         std::string tried;
         // rows per lane first; then, at the winner, at 2 and at 1, the staged form that reads late (fewer rows per lane suit it:
         // its loads depend on each other, and what hides them is more waves, not more loads per wave)
-        std::vector<std::pair<int, int>> cands = {{2, 0}, {3, 0}, {4, 0}, {6, 0}, {0, 1}, {2, 1}, {1, 1}, {2, 2}, {4, 2}};
+        std::vector<std::pair<int, int>> cands = {{2, 0}, {3, 0}, {4, 0}, {6, 0}, {0, 1}, {3, 1}, {2, 1}, {1, 1}, {3, 2}, {2, 2}, {4, 2}};
         int best_u = 0;
         for (auto &cu : cands) {
             const int u = cu.first ? cu.first : best_u;
