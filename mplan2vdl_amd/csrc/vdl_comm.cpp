@@ -376,6 +376,15 @@ int vdl_run_sharded_end(vdl_ctx *c, vdl_plan *p, int slot) {
 
 int vdl_run_sharded(vdl_ctx *c, vdl_plan *p) {
     if (!c || !p) return VDL_ERR_ARG;
+    if (p->use_fusion && p->fused.ok) {                       // a fused plan with a semi-join set has no sharded route: one rank runs it whole
+        bool semi = false;
+        for (const PreludeItem &it : p->fused.prelude) semi |= it.kind == PreludeItem::SEMI_BITMAP;
+        if (semi) {
+            if (!c->comm || c->comm->world == 1) return vdl_run(c, p);
+            c->err = "this fused plan builds a semi-join set from every row of a table: it has no sharded route";
+            return VDL_ERR_UNSUPPORTED;
+        }
+    }
     int rc = guard(c, [&] {
         if (fold_route(c, p)) sharded_begin(c, p, 0);
         else sharded_exchange(c, p);

@@ -37,6 +37,9 @@ int64_t plan_words(const vdl_plan *p, std::vector<int32_t> *ops, bool *shardable
         if (ops) ops->push_back(VDL_REDUCE_SUM);                              // out-of-domain key count
         off += gp.pcount * ((int64_t)gp.aggs.size() + 1) + 1;
     }
+    // a semi-join set is built from ALL selected rows of its source table: a rank that holds a shard of either table would test
+    // (or build) a partial set
+    if (shardable) for (const PreludeItem &it : p->fused.prelude) if (it.kind == PreludeItem::SEMI_BITMAP) *shardable = false;
     return off;
 }
 
@@ -537,15 +540,36 @@ void run_prelude_items(vdl_ctx *c, vdl_plan *p, const std::vector<char> &asked) 
     // (host copies of the descriptors stay alive in the plan until its next run: the copies to the device are asynchronous)
     std::vector<std::shared_ptr<MScanDesc>> &host_descs = p->host_descs;
     host_descs.clear();
-    for (size_t k = 0; scans && k < F.prelude.size(); k++) {
+    for (size_t k = 0; k < F.prelude.size(); k++) {
         const PreludeItem &it = F.prelude[k];
-        if (!wanted[k] || it.kind != PreludeItem::DIM_BITMAP || !it.scan) continue;
+        const bool semi = it.kind == PreludeItem::SEMI_BITMAP;
+        if (!wanted[k] || !it.scan || !(semi || (scans && it.kind == PreludeItem::DIM_BITMAP))) continue;
         MScanCols cols;
         host_descs.push_back(std::make_shared<MScanDesc>());
         MScanDesc *d = host_descs.back().get();
         std::vector<char> unused(F.prelude.size(), 0);
         const int64_t n = bind_vcols(c, it.table, it.cols, cols, *d, unused);
         patch_prelude(p, it.cols, cols, *d);
+        if (semi) {
+            // the set of rows of another table that a selected row of this one points at: one scan, atomic ORs
+            const int64_t nbits = find_col(c, it.bits_of).n;
+            if (it.modulus > 0 && nbits > it.modulus)
+                throw NeedGeneralPath("the semi-join's positions are taken mod " + std::to_string(it.modulus) + " but the table they index has " + std::to_string(nbits) + " rows");
+            const size_t words = (size_t)std::max<int64_t>((nbits + 63) >> 6, 1);
+            p->prelude_buf[k] = dev_alloc(c, sizeof(uint64_t) * words);
+            p->prelude_n[k] = nbits;
+            HIP_CHECK(hipMemsetAsync(p->prelude_buf[k]->p, 0, sizeof(uint64_t) * words, c->stream));
+            if (it.never || n <= 0) continue;
+            d->bitmap_only = 2;
+            d->nout = 1; d->out_col[0] = it.index_col;
+            d->dn[it.index_col] = nbits;
+            d->out_ptr[0] = (int64_t *)p->prelude_buf[k]->p;
+            descs.push_back(dev_alloc(c, sizeof(MScanDesc)));
+            HIP_CHECK(hipMemcpyAsync(descs.back()->p, d, sizeof(MScanDesc), hipMemcpyHostToDevice, c->stream));
+            HIP_CHECK(launch_project_select(cols, (const MScanDesc *)descs.back()->p, c->num_cus, c->stream,
+                                            front_kernel(c, p, "semi" + std::to_string(k), jit::SELECT, cols, *d)));
+            continue;
+        }
         const size_t words = (size_t)std::max<int64_t>((n + 63) >> 6, 1);
         p->prelude_buf[k] = dev_alloc(c, sizeof(uint64_t) * words);
         p->prelude_n[k] = n;
@@ -1259,6 +1283,10 @@ int vdl_plan_partial_spec(const vdl_plan *p, int64_t *n_words, const int32_t **r
     q->reduce_ops.clear();
     bool shardable = true;
     const int64_t off = plan_words(p, &q->reduce_ops, &shardable);
+    if (!shardable) {
+        if (p->ctx) p->ctx->err = "this fused plan builds a semi-join set from every row of a table: it has no sharded route";
+        return VDL_ERR_UNSUPPORTED;
+    }
     if (n_words) *n_words = off;
     if (reduce_ops) *reduce_ops = q->reduce_ops.data();
     return VDL_OK;
@@ -1269,6 +1297,9 @@ int vdl_run_local(vdl_ctx *c, vdl_plan *p, void *dev_partials) {
     return guard(c, [&] {
         need_device(c);
         if (!(p->use_fusion && p->fused.ok)) { general_run_local(c, p, (int64_t *)dev_partials); return; }
+        bool shardable = true;
+        plan_words(p, nullptr, &shardable);
+        if (!shardable) throw Error(VDL_ERR_UNSUPPORTED, "this fused plan builds a semi-join set from every row of a table: it has no sharded route");
         run_fused_local(c, p, (int64_t *)dev_partials, false);
     });
 }

@@ -75,7 +75,7 @@ std::string row_key(const RowP &e) { std::string o; row_key(e, o); return o; }
 bool is_atom(const RowP &e) {
     switch (e->k) {
     case Row::COL: return true;
-    case Row::VIA: return is_atom(e->l) && (e->r->k == Row::COL || is_const(e->r, 1));
+    case Row::VIA: return (is_atom(e->l) || (e->l->k == Row::IOTA && e->l->c0 == 0 && e->l->c1 == 1 && is_const(e->r, 1))) && (e->r->k == Row::COL || is_const(e->r, 1));
     case Row::LIKE: return is_atom(e->l);
     case Row::BIN: return e->bin == B_SUB && is_atom(e->l) && is_atom(e->r);
     default: return false;
@@ -99,7 +99,10 @@ struct Sym {
     //  PART   : Partition(ROW key, RangeC min cnt 1) -- positions that sort the selected rows by key
     //  SORTED : Scatter(ROW x, _, PART) -- x in key order
     //  GFOLD  : Fold(SORTED key, SORTED x) -- one value per distinct key = per group
-    enum Kind { NONE, ROW, FOLD, RANGEC, PART, SORTED, GFOLD } kind = NONE;
+    //  POSSET : Scatter(constant, _, index [mod N]) over the selected rows of `table` -- a set of positions P (a vector holding
+    //           the constant at p in P, EPS elsewhere); r_step = 1: RangeV 0 1 / FoldSelect of it (p at p in P).  e = the index
+    //           atom, r_count = N (0: no mod), sel = the source rows.  Only ever consumed as Gather positions: a semi-join.
+    enum Kind { NONE, ROW, FOLD, RANGEC, PART, SORTED, GFOLD, POSSET } kind = NONE;
     std::string table;
     int sel = 0;       // ROW/SORTED/PART: selection index (0 = every row); FOLD: selection of the control vector
     RowP e;            // ROW, SORTED (source expression), PART (key expression)
@@ -306,6 +309,14 @@ struct Builder {
 
     std::map<std::string, int> sel_intern;                     // canonical conjunct set -> selection index
     std::map<int, int> witness;                                // selection -> first statement whose vector is EPS exactly outside it
+    struct SemiSet { std::string table; int sel; RowP index; int64_t modulus; };
+    std::vector<SemiSet> semis;                                // position sets consumed as semi-joins: VIA::dsel = -(k + 1)
+    int semi_for(const Sym &ps) {
+        for (size_t k = 0; k < semis.size(); k++)
+            if (semis[k].table == ps.table && semis[k].sel == ps.sel && semis[k].modulus == ps.r_count && row_equal(semis[k].index, ps.e)) return (int)k;
+        semis.push_back({ps.table, ps.sel, ps.e, ps.r_count});
+        return (int)semis.size() - 1;
+    }
     std::map<std::string, std::string> table_col;              // table -> one of its columns (for the table's length)
 
     // A selection is a SET of conjuncts: two routes to the same filter (the emitter gathers every column of a join
@@ -387,6 +398,20 @@ struct Builder {
             // sorted keys / sorted aggregate inputs, Vlite.hs:1058-1059
             const Sym &src = S(n.a), &fold = S(n.b), &pos = S(n.c);
             if (src.kind == Sym::ROW && pos.kind == Sym::ROW && fold.kind == Sym::ROW && src.table == pos.table && fold.table == pos.table &&
+                src.e->k == Row::CONST && src.e->c0 != 0) {
+                // a constant scattered by an index (mod N): duplicates write the same value -- the set of positions (semi-join,
+                // Vlite.hs:1212-1222)
+                RowP index = pos.e;
+                int64_t modulus = 0;
+                if (index->k == Row::BIN && index->bin == B_MOD && index->r->k == Row::CONST && index->r->c0 > 0) { modulus = index->r->c0; index = index->l; }
+                if (is_atom(index)) {
+                    out.kind = Sym::POSSET; out.table = src.table; out.e = index;
+                    out.sel = combine_sel(src.table, src.sel, pos.sel);
+                    out.r_from = src.e->c0; out.r_count = modulus; out.r_step = 0;
+                    return out;
+                }
+            }
+            if (src.kind == Sym::ROW && pos.kind == Sym::ROW && fold.kind == Sym::ROW && src.table == pos.table && fold.table == pos.table &&
                 pos.e->k == Row::IOTA && pos.e->c0 == 0 && pos.e->c1 == 1) {
                 // positions = the slots' own ids (the dimension side of a join scatters ones / row ids back by
                 // Gather(rowids, FoldSelect(..)), Vlite.hs:1268-1275): the source, restricted to those slots
@@ -408,6 +433,8 @@ struct Builder {
             } else if ((r.kind == Sym::FOLD || r.kind == Sym::GFOLD) && n.imm1 == 0) {
                 out = r;
                 auto s = std::make_shared<Scalar>(); s->k = Scalar::CONST; s->c = n.imm0; out.sc = s;
+            } else if (r.kind == Sym::POSSET && n.imm0 == 0 && n.imm1 == 1) {
+                out = r; out.r_step = 1;                                // the positions themselves
             }
             return out;
         }
@@ -425,6 +452,11 @@ struct Builder {
         }
         case Op::FoldSelect: {
             const Sym &ctl = S(n.a), &d = S(n.b);
+            if (ctl.kind == Sym::POSSET && d.kind == Sym::POSSET && ctl.r_step == 1 && d.r_step == 0 && d.r_from != 0 && ctl.table == d.table &&
+                ctl.sel == d.sel && ctl.r_count == d.r_count && row_equal(ctl.e, d.e)) {
+                out = ctl;                                              // FoldSelect(RangeV 0 1 set, set): p where the set holds its (non-zero) constant
+                return out;
+            }
             if (ctl.kind != Sym::ROW || d.kind != Sym::ROW || ctl.table != d.table) return out;
             if (ctl.e->k != Row::IOTA || ctl.e->c1 == 0) return out;      // runs of length one only
             int base = combine_sel(d.table, ctl.sel, d.sel);
@@ -453,6 +485,16 @@ struct Builder {
         }
         case Op::Gather: {
             const Sym &src = S(n.a), &pos = S(n.b);
+            if (src.kind == Sym::ROW && pos.kind == Sym::POSSET && pos.r_step == 1 && table_col.count(src.table)) {
+                // src[p] for p in the set: the rows of src's table that some selected row of the other table points at -- a
+                // semi-join.  (The result has the other table's length; its slots beyond src's rows are EPS and nothing but
+                // folds and compactions ever looks at it.)  As a row expression of src's table: src, restricted to the rows
+                // whose own id is in the set.
+                const int k = semi_for(pos);
+                out.kind = Sym::ROW; out.table = src.table; out.e = src.e;
+                out.sel = combine_sel(src.table, src.sel, new_sel(src.table, mk_via(mk_iota(0, 1), mk_const(1), "#semi" + std::to_string(k), -(k + 1), table_col.at(src.table))));
+                return out;
+            }
             if (src.kind != Sym::ROW || pos.kind != Sym::ROW) return out;
             if (src.table != pos.table) {
                 // a lookup into another table's vector through an index expression: the FK-join lowering seen from the fact
@@ -745,7 +787,7 @@ struct VCols {
         auto cost = [&](size_t k) {
             switch (cols[k].kind) {
             case VC_DIRECT: return 0;
-            case VC_SUB: case VC_FORM: return 1;
+            case VC_SUB: case VC_FORM: case VC_ROWID: return 1;
             case VC_BITS: case VC_INRANGE: return 2;
             default: return 3;
             }
@@ -778,6 +820,30 @@ struct VCols {
         cols = out;
         return map;
     }
+    // the position set B.semis[k] as a scan of its table (PreludeItem::SEMI_BITMAP)
+    int prelude_semi(int k, const std::string &bits_of) {
+        const Builder::SemiSet &S = B.semis[(size_t)k];
+        PreludeItem it; it.kind = PreludeItem::SEMI_BITMAP; it.scan = true; it.table = S.table; it.modulus = S.modulus; it.bits_of = bits_of;
+        it.witness = -(k + 1);
+        for (size_t j = 0; j < F.prelude.size(); j++)
+            if (F.prelude[j].kind == PreludeItem::SEMI_BITMAP && F.prelude[j].witness == it.witness && F.prelude[j].bits_of == bits_of) return (int)j;
+        Clause cl;
+        if (!to_clause(B.pred_of(S.sel), cl)) { why = "the semi-join's source selection is not a conjunction of ranges / conditions"; return -1; }
+        std::string inner_why;
+        VCols inner{it.cols, F, B, inner_why, {}};
+        it.never = cl.never;
+        if (!inner.lower_filters(cl, it.never)) { why = "semi-join source: " + inner_why; return -1; }
+        int index = inner(S.index);
+        if (index < 0) { why = "semi-join index: " + inner_why; return -1; }
+        const std::vector<int> map = tidy_columns(it.cols, {index});
+        it.index_col = map[(size_t)index];
+        if ((int)it.cols.size() > kMaxSelectCols) { why = "semi-join source scan needs more than " + std::to_string(kMaxSelectCols) + " columns"; return -1; }
+        bool direct = false;
+        for (const ScanColumn &c : it.cols) direct |= c.kind == VC_DIRECT && c.name.compare(0, S.table.size() + 1, S.table + ".") == 0;
+        if (!direct) { why = "semi-join source scan touches no column of its table"; return -1; }
+        F.prelude.push_back(it);
+        return (int)F.prelude.size() - 1;
+    }
     int prelude_lut(const std::string &heap, const std::string &pattern) {
         for (size_t k = 0; k < F.prelude.size(); k++)
             if (F.prelude[k].kind == PreludeItem::LIKE_LUT && F.prelude[k].heap == heap && F.prelude[k].pattern == pattern) return (int)k;
@@ -792,9 +858,15 @@ struct VCols {
         ScanColumn c;
         switch (atom->k) {
         case Row::COL: c.kind = VC_DIRECT; c.name = atom->col; break;
+        case Row::IOTA: c.kind = VC_ROWID; break;          // the row's own id (index of a semi-join bit: is_atom)
         case Row::VIA: {
             c.idx = (*this)(atom->l);
             if (c.idx < 0) return -1;
+            if (atom->dsel < 0) {                           // bit `own row id` of a position set built by a scan of another table
+                c.kind = VC_BITS; c.prelude = prelude_semi(-atom->dsel - 1, atom->col);
+                if (c.prelude < 0) return -1;
+                break;
+            }
             if (atom->r->k == Row::COL && atom->dsel == 0) { c.kind = VC_GATHER; c.name = atom->r->col; }
             else if (is_const(atom->r, 1) && atom->dsel == 0) { c.kind = VC_INRANGE; c.name = atom->col; }
             else if (is_const(atom->r, 1)) { c.kind = VC_BITS; c.prelude = prelude_bitmap(atom->dsel); if (c.prelude < 0) return -1; }
@@ -1095,6 +1167,7 @@ static void show_col(const ScanColumn &c, size_t k, std::ostringstream &o) {
     case VC_BITS: o << "prelude" << c.prelude << ".bit[col" << c.idx << "]"; break;
     case VC_LUT: o << "prelude" << c.prelude << ".lut[col" << c.idx << "]"; break;
     case VC_INRANGE: o << "inrange(col" << c.idx << ", rows of " << c.name << ")"; break;
+    case VC_ROWID: o << "row id"; break;
     case VC_FORM:
         o << "cond(";
         for (size_t i = 0; i < c.form.size(); i++) {
@@ -1126,6 +1199,14 @@ static void show_prelude(const FusedPlan &F, std::ostringstream &o) {
     for (size_t k = 0; k < F.prelude.size(); k++) {
         const PreludeItem &it = F.prelude[k];
         if (it.kind == PreludeItem::LIKE_LUT) { o << "prelude " << k << ": LIKE '" << it.pattern << "' over every offset of " << it.heap << "\n"; continue; }
+        if (it.kind == PreludeItem::SEMI_BITMAP) {
+            o << "prelude " << k << ": semi-join set over the rows of " << it.bits_of.substr(0, it.bits_of.find('.')) << ": one scan of " << it.table << (it.never ? " [never]" : "")
+              << " sets bit col" << it.index_col;
+            if (it.modulus) o << " (emitted mod " << it.modulus << ": exact while the table has no more rows)";
+            o << "\n";
+            for (size_t c = 0; c < it.cols.size(); c++) show_col(it.cols[c], c, o);
+            continue;
+        }
         o << "prelude " << k << ": bitmap of the dimension-side selection held by statement " << it.witness;
         if (!it.scan) { o << " (per-operator executor)\n"; continue; }
         o << ": one scan of " << it.table << (it.never ? " [never]" : "") << "\n";

@@ -36,7 +36,7 @@ struct ScanColumn {
 // selection (the validity of a `witness` statement, run by the per-operator executor: dimension filters, joins of
 // dimensions with further dimensions), or the 0 / 1 table of a LIKE pattern over every offset of a string heap.
 struct PreludeItem {
-    enum Kind : int { DIM_BITMAP = 0, LIKE_LUT = 1 } kind = DIM_BITMAP;
+    enum Kind : int { DIM_BITMAP = 0, LIKE_LUT = 1, SEMI_BITMAP = 2 } kind = DIM_BITMAP;
     int witness = 0;           // DIM_BITMAP: statement whose vector is EPS exactly where the dimension selection rejects the row
     std::string heap, pattern; // LIKE_LUT
     // DIM_BITMAP whose selection is itself a conjunction of range filters over columns of the dimension table and lookups
@@ -47,6 +47,14 @@ struct PreludeItem {
     std::string table;
     std::vector<ScanColumn> cols;
     bool never = false;
+    // SEMI_BITMAP: the set {index(r) : r a selected row of `table`} as a bitmap over the rows of another table -- the semi-join the
+    // compiler writes as Scatter(ones, fk mod N) + FoldSelect (LeftSemi with the dimension on the left, /root/reference/src/Vlite.hs:
+    // 1212-1222; TPC-H Q4's EXISTS).  One scan of `table` (`cols`: its filters and the index atom, column `index_col`) sets the
+    // bits with atomic ORs; the scan of the other table tests the bit of its own row id (VC_ROWID -> VC_BITS).  `modulus` is the N of
+    // the emitted `mod`: exact only while the other table has at most N rows (checked when the plan is bound; else statement by statement)
+    int index_col = -1;
+    int64_t modulus = 0;
+    std::string bits_of;       // a column of the table whose rows the bits stand for (its length)
 };
 
 struct ScanFactor {            // (a + s * column[col])

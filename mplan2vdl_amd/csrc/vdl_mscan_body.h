@@ -164,7 +164,8 @@ __device__ __forceinline__ void eval_pass(const MsArgs &C, const MScanDesc &D, c
 // seen from the fact table (Vlite.hs:1199-1282).  `alive` starts as "the direct range filters pass", so rows a cheap
 // filter already rejects do no lookups (Q14 keeps 1 row in 84); a lookup out of range makes the row EPS (alive = false).
 template <int NC, int RW>
-__device__ __forceinline__ void derive(const MsArgs &C, const MsArgs &Cr, const MScanDesc &D, const MScanDesc &Dr, int64_t (&v)[NC][RW], bool (&alive)[RW], uint32_t only, bool direct_filters = true) {
+__device__ __forceinline__ void derive(const MsArgs &C, const MsArgs &Cr, const MScanDesc &D, const MScanDesc &Dr, int64_t (&v)[NC][RW], bool (&alive)[RW], uint32_t only,
+                                       const int64_t (&rowid)[RW] /* global row ids: Cr.row0 + index */, bool direct_filters = true) {
     if (direct_filters) {
 #pragma unroll
         for (int c = 0; c < NC; c++) {
@@ -179,6 +180,11 @@ __device__ __forceinline__ void derive(const MsArgs &C, const MsArgs &Cr, const 
     for (int c = 1; c < NC; c++) {
         if ((only >> c) & 1u) {                            // wave-uniform
             const int kind = D.dkind[c], a = D.dsrc[c], b = D.dsrc2[c];
+            if (kind == VC_ROWID) {
+#pragma unroll
+                for (int r = 0; r < RW; r++) v[c][r] = rowid[r] - Cr.row0;
+                continue;
+            }
             if (kind == VC_FORM) {
                 // A boolean formula over range tests of earlier columns.  Descriptor layout (bind_forms, vdl_engine.cpp): D.dtests[c]
                 // tests sorted by column -- so each column's tests run with the column index a compile-time constant, no
@@ -406,7 +412,7 @@ __device__ __forceinline__ void mscan_body(const MsArgs &C, const MsArgs &Cr, co
 #endif
         // (scans with derived columns run their last, partial tile through this same code: rows past the end were switched off
         // above -- `rows_left` counts from the lane's first row.  Staged: the filters on table columns are already in `alive`.)
-        if (DER) derive<NC, RW>(C, Cr, D, Dr, v, alive, C.derived, !staged);
+        if (DER) derive<NC, RW>(C, Cr, D, Dr, v, alive, C.derived, rowid, !staged);
         if (staged) {
 #pragma unroll
             for (int r = 0; r < RW; r++) pass[r] = alive[r];
@@ -638,7 +644,26 @@ __device__ __forceinline__ void project_select_body(const MsArgs &C, const MsArg
         bool alive[ROWS];
 #pragma unroll
         for (int r = 0; r < ROWS; r++) alive[r] = base + (int64_t)(r >> 1) * (BS * 2) + (r & 1) < Cr.n;
-        derive<NC, ROWS>(C, Cr, D, Dr, v, alive, C.derived & ~C.lazy);      // filters fold into `alive` as they are derived
+        int64_t rid[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) rid[r] = Cr.row0 + base + (int64_t)(r >> 1) * (BS * 2) + (r & 1);
+        derive<NC, ROWS>(C, Cr, D, Dr, v, alive, C.derived & ~C.lazy, rid);      // filters fold into `alive` as they are derived
+        if (D.bitmap_only == 2) {
+            // a semi-join scan: every selected row sets the bit of its index in the set (many rows share a bit: atomic OR)
+            unsigned long long *set = (unsigned long long *)Dr.out_ptr[0];
+            const int64_t nbits = Dr.dn[D.out_col[0]];
+#pragma unroll
+            for (int k = 0; k < NC; k++) {
+                if (k == D.out_col[0]) {
+#pragma unroll
+                    for (int r = 0; r < ROWS; r++) {
+                        const int64_t x = v[k][r];
+                        if (alive[r] && x >= 0 && x < nbits) atomicOr(&set[x >> 6], 1ull << (x & 63));
+                    }
+                }
+            }
+            continue;
+        }
         uint64_t m[ROWS];
 #pragma unroll
         for (int r = 0; r < ROWS; r++) m[r] = __ballot(alive[r]);
@@ -710,7 +735,8 @@ __device__ __forceinline__ void project_take_body(const MsArgs &C, const MsArgs 
                 if (c < C.ncol && ((D.take >> c) & 1u) && !((C.derived >> c) & 1u)) v[c][0] = load_scalar(Cr.ptr[c], C.width(c), row < Cr.n ? row : Cr.n - 1);
             }
             bool alive[1] = {on};
-            derive<NC, 1>(C, Cr, D, Dr, v, alive, C.derived & D.take, false);
+            const int64_t rid[1] = {Cr.row0 + row};
+            derive<NC, 1>(C, Cr, D, Dr, v, alive, C.derived & D.take, rid, false);
             if (on) Dr.out_idx[off + k] = row;
             VDL_SPEC_UNROLL
             for (int o = 0; o < D.nout; o++) {

@@ -49,6 +49,8 @@ enum VColKind : int {
     VC_LUT = 3,      // value = prelude[prelude] (a lookup table) at v[idx]; outside the table -> 0 (Like over heap offsets)
     VC_INRANGE = 4,  // value = 1; the row is EPS unless 0 <= v[idx] < rows of column `name` (a Gather out of an unfiltered table)
     VC_SUB = 5,      // value = v[idx] - v[idx2] (column against column comparisons become a range filter on the difference)
+    VC_ROWID = 7,    // value = the row's own index in the scanned table (the index of a lookup into a set built over this table's rows:
+                     // the semi-join bitmap of PreludeItem::SEMI_BITMAP)
     VC_FORM = 6      // value = 0 / 1: a boolean formula over range tests of earlier columns (ScanColumn::form) -- IN lists, disjunctions
                      // across columns (Q19), CASE WHEN conditions used as aggregate inputs (Q12, Q14)
 };
@@ -122,7 +124,8 @@ struct MScanDesc {                           // lives in device memory, read wit
     int64_t *out_idx = nullptr;              // the surviving rows' slot ids, ascending
     int64_t *tile_counts = nullptr;          // [tiles + 1]: survivors per tile
     uint32_t take = 0;                       // k_project_take: the columns the outputs need (with the columns they are derived from)
-    int bitmap_only = 0;                     // k_project_select: a dimension scan -- the selection's bitmap, no counts, no positions
+    int bitmap_only = 0;                     // k_project_select: 1 = a dimension scan -- the selection's bitmap, no counts, no positions;
+                                             // 2 = a semi-join scan: for every selected row, bit v[out_col[0]] of the set out_ptr[0] (dn[out_col[0]] bits) is set
     int ncomp = 0, key_masked = 0;           // ncomp > 0: the key program is this canonical form
     int64_t key_mask = 0;
     KeyComp comp[kMaxKeyComps];

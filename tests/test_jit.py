@@ -13,7 +13,7 @@ from conftest import ROOT
 from helpers import check_against_oracle, engine_with, oracle_run
 
 META = os.path.join(ROOT, "tests", "golden", "tpch10noorder")
-FUSED_PLANS = [1, 12, 14, 19]                 # multi-aggregate scans (Q6's single-aggregate scan runs on k_scan, which is not specialised)
+FUSED_PLANS = [1, 4, 12, 14, 19]              # multi-aggregate scans (Q6's single-aggregate scan runs on k_scan, which is not specialised)
 
 
 def compiled(n, scale, seed=3):
@@ -88,7 +88,7 @@ def test_specialised_fronts_build_without_a_gpu(n):
 
 
 def test_a_plan_without_fused_scans_is_refused():
-    text, cols = compiled(4, 1e-4)                             # Q4: neither fused nor a fused front
+    text, cols = compiled(18, 1e-4)                            # Q18: neither fused nor a fused front
     e = host_engine_with_declared(cols)
     p = e.parse(text)
     with pytest.raises(m.VdlError, match="no fused scans"):

@@ -198,10 +198,11 @@ def test_which_plans_have_a_fused_front(cfg):
     dims = {}
     for n in PLANS:
         d = e.parse(frontend.compile_plan(open(os.path.join(META, "%02d.sql.mplan" % n)).read(), cfg)).describe()
-        tables = [l.split("one scan of ")[1].strip() for l in d.split("\n") if l.startswith("prelude") and "one scan of" in l]
+        tables = [l.split("one scan of ")[1].split(" sets bit")[0].strip() + ("*" if "semi-join" in l else "") for l in d.split("\n") if l.startswith("prelude") and "one scan of" in l]
         if tables:
             dims[n] = tables
-    assert dims == {3: ["customer", "orders"], 5: ["orders", "region"], 9: ["part"], 10: ["orders"], 11: ["nation", "supplier"], 19: ["part"], 20: ["part", "partsupp"]}
+    # (* = a semi-join set: Q4's EXISTS as a lineitem scan setting bits of orders rows)
+    assert dims == {3: ["customer", "orders"], 4: ["orders", "lineitem*"], 5: ["orders", "region"], 9: ["part"], 10: ["orders"], 11: ["nation", "supplier"], 19: ["part"], 20: ["part", "partsupp"]}
     q3 = e.parse(open(os.path.join(ROOT, "tests", "golden", "q3.vdl")).read()).describe()
     assert "\nfused front: one scan of lineitem" in q3 and "orders.o_orderdate[col1]" in q3 and "prelude0.bit[col1] in [1,1]" in q3
 
@@ -224,9 +225,16 @@ def test_which_plans_have_a_sharded_route(cfg):
             verdict[n] = str(ex)
     # fused JOIN scans: Q14 (lineitem with part looked up through the join index), Q12 (orders' priority looked up, IN lists and
     # CASE conditions as condition columns), Q19 (a disjunction across lineitem and part columns as one condition column)
-    assert sorted(n for n, v in verdict.items() if v == "fused") == [1, 6, 12, 14, 19]
+    # ... and Q4: its EXISTS as a semi-join set (a lineitem scan setting bits of orders rows) + a grouped orders scan
+    assert sorted(n for n, v in verdict.items() if v == "fused") == [1, 4, 6, 12, 14, 19]
     assert sorted(n for n, v in verdict.items() if v == "exchange") == [3, 5, 9, 10, 20]
-    assert "more than one Partition" in verdict[18] and "below the Partition" in verdict[4]
+    assert "more than one Partition" in verdict[18]
+    q4 = e.parse(frontend.compile_plan(open(os.path.join(META, "04.sql.mplan")).read(), cfg))
+    with pytest.raises(m.VdlError, match="semi-join set"):     # built from every row of lineitem: fused, it has no sharded route
+        q4.partial_spec()
+    q4.set_fusion(False)
+    with pytest.raises(m.VdlError, match="below the Partition"):
+        q4.exchange_columns("lineitem")
     for n in (12, 19):                                         # ... and the routes they take with fusion off
         p = e.parse(frontend.compile_plan(open(os.path.join(META, "%02d.sql.mplan" % n)).read(), cfg))
         p.set_fusion(False)
