@@ -25,8 +25,9 @@ import sys
 from test_random_conditions import Gen, FrontGen
 from test_random_joins import Gen as JoinGen
 from test_random_fused import Gen as FusedGen
+from test_random_semijoins import Gen as SemiGen
 k = 0
-for G in (Gen, FrontGen, JoinGen, FusedGen):
+for G in (Gen, FrontGen, JoinGen, FusedGen, SemiGen):
     for seed in range(120):
         open("%s/p%04d.vdl" % (sys.argv[1], k), "w").write(G(seed).build()[0]); k += 1
 PY
