@@ -561,6 +561,7 @@ void run_prelude_items(vdl_ctx *c, vdl_plan *p, const std::vector<char> &asked) 
             HIP_CHECK(hipMemsetAsync(p->prelude_buf[k]->p, 0, sizeof(uint64_t) * words, c->stream));
             if (it.never || n <= 0) continue;
             d->bitmap_only = 2;
+            d->pmin = it.modulus;
             d->nout = 1; d->out_col[0] = it.index_col;
             d->dn[it.index_col] = nbits;
             d->out_ptr[0] = (int64_t *)p->prelude_buf[k]->p;

@@ -657,7 +657,8 @@ __device__ __forceinline__ void project_select_body(const MsArgs &C, const MsArg
                 if (k == D.out_col[0]) {
 #pragma unroll
                     for (int r = 0; r < ROWS; r++) {
-                        const int64_t x = v[k][r];
+                        int64_t x = v[k][r];
+                        if (D.pmin > 0) x = x % D.pmin;            // the emitted `mod N` (sign of the dividend, like the element-wise operator)
                         if (alive[r] && x >= 0 && x < nbits) atomicOr(&set[x >> 6], 1ull << (x & 63));
                     }
                 }

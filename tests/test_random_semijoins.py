@@ -58,7 +58,9 @@ class Gen:
             pred = self.bin("Greater", c["t.a"], c["t.b"]) if r.random() < 0.4 else self.bin("Greater", c["t.b"], self.const(int(r.integers(0, 25)), c["t.b"]))
             st = self.select(pred)
             fk = self.gather(fk, self.gather(self.pos(c["t.t_pkey"]), st))
-        hit = self.gather(idmap, fk)                                                            # the dimension row id, EPS where there is none
+        # the dimension row id, EPS where there is none -- or (not what the compiler emits, but legal text) the raw join index:
+        # negative ones are never scattered, those beyond N wrap around
+        hit = self.gather(idmap, fk) if r.random() < 0.75 else fk
         ones = self.const(1, hit)
         n_mod = self.nu + int(r.integers(0, 50)) if not self.wrap else max(1, self.nu - int(r.integers(1, 5)))
         where = self.bin("Modulo", hit, self.const(n_mod, hit))
