@@ -224,6 +224,16 @@ bool to_clause_strict(const RowP &p, Clause &out) {
     if (p->k != Row::BIN) return false;
     RowP atom; IvSet set;
     if (leaf_cmp(*p, atom, set)) { clause_and(out, atom, set); return true; }
+    // `k - row id` read as a truth value: every row but row k.  (What the reference's anti-join comes to: `ones - selectmask` with
+    // selectmask re-bound to a vector of positions, /root/reference/src/Vlite.hs:1199-1229 -- SURVEY.md section 10; TPC-H Q16.)
+    if (p->bin == B_SUB && p->l->k == Row::CONST && p->r->k == Row::IOTA && p->r->c0 == 0 && p->r->c1 == 1) {
+        const int64_t k = p->l->c0;
+        IvSet others;
+        if (k > INT64_MIN) others.push_back({INT64_MIN, k - 1});
+        if (k < INT64_MAX) others.push_back({k + 1, INT64_MAX});
+        clause_and(out, p->r, others);
+        return true;
+    }
     if (p->bin == B_LAND) return to_clause_strict(p->l, out) && to_clause_strict(p->r, out);
     if (p->bin == B_LOR) {
         // only a disjunction of conditions on ONE column stays a per-column filter
@@ -999,7 +1009,12 @@ static void build_projection(const Program &P, Builder &B, FusedPlan &F) {
         for (int opnd : {n.a, n.b, n.c}) if (opnd > 0) needed[(size_t)opnd] = 1;
     }
     Clause cl;
-    if (!to_clause(B.pred_of(pt.sel), cl)) { J.why = "the selection is not a conjunction of per-column ranges"; return; }
+    if (!to_clause(B.pred_of(pt.sel), cl)) {
+        std::ostringstream o; o << "the selection is not a conjunction of per-column ranges / conditions: ";
+        show_row(B.pred_of(pt.sel), o);
+        J.why = o.str().substr(0, 600);
+        return;
+    }
     J.never = cl.never;
     VCols vc{J.cols, F, B, J.why, {}};
     if (!vc.lower_filters(cl, J.never)) return;

@@ -75,7 +75,7 @@ def test_specialised_kernels_of_random_programs_build_without_a_gpu():
     assert built >= 6
 
 
-@pytest.mark.parametrize("n", [3, 5, 9, 10, 11, 15, 20])
+@pytest.mark.parametrize("n", [3, 5, 9, 10, 11, 15, 16, 20])
 def test_specialised_fronts_build_without_a_gpu(n):
     """Plans with a fused front: the projection scan's select and take passes and the dimension scans of the prelude."""
     text, cols = compiled(n, 1e-4)
@@ -177,7 +177,7 @@ def test_specialised_scans_shard_like_the_precompiled_ones():
 def test_specialised_fronts_and_dimension_scans_match_the_oracle():
     """Plans that do not fuse as a whole: the projection scan's two passes and the dimension-side bitmap scans are
     specialised too (roles select / take / dim<k> in the note)."""
-    for n in (3, 5, 9, 10, 11, 15, 20):
+    for n in (3, 5, 9, 10, 11, 15, 16, 20):
         text, cols = compiled(n, 2e-3)
         want = oracle_run(text, cols)
         e = engine_with(cols)

@@ -193,7 +193,7 @@ def test_which_plans_have_a_fused_front(cfg):
         d = e.parse(frontend.compile_plan(open(os.path.join(META, "%02d.sql.mplan" % n)).read(), cfg)).describe()
         if "\nfused front:" in d:
             front.append(n)
-    assert front == [3, 5, 9, 10, 11, 15, 20]            # (Q5: 13 columns -- the take pass handles 16, the select pass sees 10 of them)
+    assert front == [3, 5, 9, 10, 11, 15, 16, 20]            # (Q5: 13 columns -- the take pass handles 16, the select pass sees 10 of them)
     # ... and whose dimension-side selections are scans of the dimension table themselves (PreludeItem::scan)
     dims = {}
     for n in PLANS:
@@ -202,7 +202,7 @@ def test_which_plans_have_a_fused_front(cfg):
         if tables:
             dims[n] = tables
     # (* = a semi-join set: Q4's EXISTS as a lineitem scan setting bits of orders rows)
-    assert dims == {3: ["customer", "orders"], 4: ["orders", "lineitem*"], 5: ["orders", "region"], 9: ["part"], 10: ["orders"], 11: ["nation", "supplier"], 19: ["part"], 20: ["part", "partsupp"]}
+    assert dims == {3: ["customer", "orders"], 4: ["orders", "lineitem*"], 5: ["orders", "region"], 9: ["part"], 10: ["orders"], 11: ["nation", "supplier"], 16: ["part", "supplier"], 19: ["part"], 20: ["part", "partsupp"]}
     q3 = e.parse(open(os.path.join(ROOT, "tests", "golden", "q3.vdl")).read()).describe()
     assert "\nfused front: one scan of lineitem" in q3 and "orders.o_orderdate[col1]" in q3 and "prelude0.bit[col1] in [1,1]" in q3
 
