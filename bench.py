@@ -253,9 +253,11 @@ def main():
 
     if args.jit != "off":
         # code objects of the specialised scans are kept across processes (ranks of one run, the N = 1, 2, 4, 8 runs of a
-        # scaling sweep): the key is a hash of the whole generated source, so a changed kernel or plan never meets a stale one
-        import tempfile
-        os.environ.setdefault("VDL_JIT_CACHE", os.path.join(tempfile.gettempdir(), "vdl_jit_cache_%d" % os.getuid()))
+        # scaling sweep): the key is a hash of the whole generated source, so a changed kernel or plan never meets a stale one.
+        # The directory is private to this user (libvdl creates it 0700 and refuses one that anybody else could write:
+        # csrc/vdl_jit.cpp "the on-disk cache"); no usable home directory = no cache, every process compiles for itself.
+        base = os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache")
+        os.environ.setdefault("VDL_JIT_CACHE", os.path.join(base, "vdl-mi355x", "jit"))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

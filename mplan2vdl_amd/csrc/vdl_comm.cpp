@@ -107,11 +107,17 @@ struct CommState {
 };
 
 // per-plan buffers of the sharded fold route (two slots: pipelined callers)
+// A rank's block in the all-gather is 2 * n_words + 1 int64: the words raw, the words with FoldChoose entries resolved, and the
+// STATUS of its local phase (VDL_OK or the error code).  A rank whose local phase failed still takes part in the collective
+// (zeroed words, its status) -- otherwise its peers would wait in ncclAllGather / the host transport for ever -- and every
+// rank reports the failure: the failing rank at once with its own message, the others when they collect the answer.
 struct ShardState {
     int64_t n_words = 0;
     bool any_first = false;
     BufP ops;                    // int32 per word on the device
-    BufP send[2], recv[2], merged[2];
+    BufP send[2], recv[2], merged[2], status[2];
+    int64_t *status_host = nullptr;       // pinned: 2 slots x {status, rank}
+    ~ShardState() { if (status_host) (void)hipHostFree(status_host); }
 };
 
 static CommState &comm_of(vdl_ctx *c) {
@@ -195,7 +201,7 @@ static ShardState &shard_state(vdl_ctx *c, vdl_plan *p, const CommState &m) {
     if (!p->shard) p->shard = std::make_shared<ShardState>();
     ShardState &st = *p->shard;
     const size_t words = (size_t)std::max<int64_t>(nw, 1);
-    if (st.n_words != nw || !st.ops || !st.recv[0] || st.recv[0]->cls < sizeof(int64_t) * 2 * words * (size_t)m.world) {
+    if (st.n_words != nw || !st.ops || !st.recv[0] || st.recv[0]->cls < sizeof(int64_t) * (2 * words + 1) * (size_t)m.world) {
         st.n_words = nw;
         st.any_first = false;
         for (int64_t i = 0; i < nw; i++) st.any_first |= ops[i] == VDL_REDUCE_FIRST;
@@ -203,10 +209,13 @@ static ShardState &shard_state(vdl_ctx *c, vdl_plan *p, const CommState &m) {
         if (nw) HIP_CHECK(hipMemcpyAsync(st.ops->p, ops, sizeof(int32_t) * (size_t)nw, hipMemcpyHostToDevice, c->stream));
         HIP_CHECK(hipStreamSynchronize(c->stream));                    // `ops` belongs to the plan and may be rewritten by the next spec call
         for (int k = 0; k < 2; k++) {
-            st.send[k] = dev_alloc(c, sizeof(int64_t) * 2 * words);
-            st.recv[k] = dev_alloc(c, sizeof(int64_t) * 2 * words * (size_t)m.world);
+            st.send[k] = dev_alloc(c, sizeof(int64_t) * (2 * words + 1));
+            st.recv[k] = dev_alloc(c, sizeof(int64_t) * (2 * words + 1) * (size_t)m.world);
             st.merged[k] = dev_alloc(c, sizeof(int64_t) * words);
+            st.status[k] = dev_alloc(c, sizeof(int64_t) * 2);
         }
+        if (!st.status_host) HIP_CHECK(hipHostMalloc((void **)&st.status_host, sizeof(int64_t) * 4, hipHostMallocDefault));
+        for (int k = 0; k < 4; k++) st.status_host[k] = 0;
     }
     return st;
 }
@@ -221,8 +230,10 @@ static void sharded_begin(vdl_ctx *c, vdl_plan *p, int slot) {
     const bool overlap = m.kind == CommState::RCCL;
     hipStream_t cs = overlap ? m.stream : c->stream;
     if (overlap && m.ev_merged[slot]) HIP_CHECK(hipStreamWaitEvent(c->stream, m.ev_merged[slot], 0));    // the previous query of this slot has left the send buffer
-    if (vdl_run_local(c, p, send) != VDL_OK) throw Error(VDL_ERR_DEVICE, c->err);
-    p->ev_buf[p->last_ev] = st.merged[slot]->p;            // the scan's timing is claimed by the finalisation of the MERGED words
+    // the local phase; its outcome travels with the words (ShardState)
+    int64_t local_rc = vdl_run_local(c, p, send);
+    std::string local_error = local_rc != VDL_OK ? c->err : std::string();
+    if (local_rc == VDL_OK) p->ev_buf[p->last_ev] = st.merged[slot]->p;            // the scan's timing is claimed by the finalisation of the MERGED words
     if (overlap) {
         if (!m.ev_local[slot]) {
             HIP_CHECK(hipEventCreateWithFlags(&m.ev_local[slot], hipEventDisableTiming));
@@ -233,17 +244,41 @@ static void sharded_begin(vdl_ctx *c, vdl_plan *p, int slot) {
     }
     StreamSwap on_comm(c, cs);
     // second half of the send buffer: the words again, FoldChoose words resolved to the value at this rank's own row id
-    if (nw) HIP_CHECK(hipMemcpyAsync(send + nw, send, sizeof(int64_t) * (size_t)nw, hipMemcpyDeviceToDevice, cs));
-    if (st.any_first && vdl_resolve_first(c, p, send + nw) != VDL_OK) throw Error(VDL_ERR_DEVICE, c->err);
+    if (local_rc == VDL_OK) {
+        if (nw) HIP_CHECK(hipMemcpyAsync(send + nw, send, sizeof(int64_t) * (size_t)nw, hipMemcpyDeviceToDevice, cs));
+        if (st.any_first && vdl_resolve_first(c, p, send + nw) != VDL_OK) { local_rc = VDL_ERR_DEVICE; local_error = c->err; }
+    }
+    if (local_rc != VDL_OK && nw) HIP_CHECK(hipMemsetAsync(send, 0, sizeof(int64_t) * 2 * (size_t)nw, cs));
+    int64_t *slot_status = st.status_host + 2 * slot;
+    slot_status[0] = local_rc;                 // (pinned: read by the copy below when the stream gets there; this slot's previous
+    slot_status[1] = m.rank;                   //  query has been collected -- _end -- before the slot is begun again)
+    HIP_CHECK(hipMemcpyAsync(send + 2 * nw, slot_status, sizeof(int64_t), hipMemcpyHostToDevice, cs));
     int64_t *merged = (int64_t *)st.merged[slot]->p;
+    const int64_t stride = 2 * nw + 1;
     if (m.world > 1) {
-        all_gather(c, send, st.recv[slot]->p, sizeof(int64_t) * 2 * (size_t)nw, cs);
-        HIP_CHECK(launch_merge_words((const int64_t *)st.recv[slot]->p, m.world, nw, (const int32_t *)st.ops->p, merged, cs));
-    } else if (nw) {
-        HIP_CHECK(launch_merge_words(send, 1, nw, (const int32_t *)st.ops->p, merged, cs));
+        all_gather(c, send, st.recv[slot]->p, sizeof(int64_t) * (size_t)stride, cs);
+        HIP_CHECK(launch_merge_words((const int64_t *)st.recv[slot]->p, m.world, nw, stride, (const int32_t *)st.ops->p, merged, (int64_t *)st.status[slot]->p, cs));
+    } else {
+        HIP_CHECK(launch_merge_words(send, 1, nw, stride, (const int32_t *)st.ops->p, merged, (int64_t *)st.status[slot]->p, cs));
     }
     if (overlap) HIP_CHECK(hipEventRecord(m.ev_merged[slot], cs));
+    if (local_rc != VDL_OK) {
+        // this rank has done its part of the collective; it reports its own failure now
+        HIP_CHECK(hipStreamSynchronize(cs));
+        throw Error((int)local_rc, local_error);
+    }
+    HIP_CHECK(hipMemcpyAsync(slot_status, st.status[slot]->p, sizeof(int64_t) * 2, hipMemcpyDeviceToHost, cs));   // ahead of the words: same event
     if (vdl_finalize_begin(c, p, merged, slot) != VDL_OK) throw Error(VDL_ERR_DEVICE, c->err);
+    if (!(p->use_fusion && p->fused.ok)) HIP_CHECK(hipStreamSynchronize(cs));     // (fold records: finalised at once, no slot event for _end to wait on)
+}
+
+// after vdl_finalize_end has waited for the slot: did every rank's local phase succeed?
+static void sharded_check_status(vdl_plan *p, int slot) {
+    if (!p->shard || !p->shard->status_host || slot < 0 || slot > 1) return;
+    const int64_t *s = p->shard->status_host + 2 * slot;
+    if (s[0] != VDL_OK)
+        throw Error(VDL_ERR_UNSUPPORTED, "sharded run: the local phase failed on rank " + std::to_string(s[1]) + " (status " + std::to_string(s[0]) +
+                                         "); the merged words are not an answer");
 }
 
 static void sharded_exchange(vdl_ctx *c, vdl_plan *p) {
@@ -371,7 +406,9 @@ int vdl_run_sharded_begin(vdl_ctx *c, vdl_plan *p, int slot) {
 
 int vdl_run_sharded_end(vdl_ctx *c, vdl_plan *p, int slot) {
     if (!c || !p) return VDL_ERR_ARG;
-    return vdl_finalize_end(c, p, slot);
+    const int rc = vdl_finalize_end(c, p, slot);
+    const int rs = guard(c, [&] { sharded_check_status(p, slot); });      // (a failed peer outranks whatever the merged zeros gave)
+    return rs != VDL_OK ? rs : rc;
 }
 
 int vdl_run_sharded(vdl_ctx *c, vdl_plan *p) {
@@ -390,14 +427,14 @@ int vdl_run_sharded(vdl_ctx *c, vdl_plan *p) {
         else sharded_exchange(c, p);
     });
     if (rc != VDL_OK) return rc;
-    return fold_route(c, p) ? vdl_finalize_end(c, p, 0) : VDL_OK;
+    return fold_route(c, p) ? vdl_run_sharded_end(c, p, 0) : VDL_OK;
 }
 
 /* The merge of the gathered partial words on the HOST: the same per-word rule the device kernel applies (merge_word,
  * vdl_kernels.h), exported so that hosts and CPU tests can check a transport without a GPU. */
 int vdl_comm_merge_host(int world, int64_t n_words, const int32_t *ops, const int64_t *gathered, int64_t *out) {
     if (world < 1 || n_words < 0 || (n_words && (!ops || !gathered || !out))) return VDL_ERR_ARG;
-    for (int64_t i = 0; i < n_words; i++) out[i] = merge_word(gathered, world, n_words, ops[i], i);
+    for (int64_t i = 0; i < n_words; i++) out[i] = merge_word(gathered, world, n_words, ops[i], i, 2 * n_words);
     return VDL_OK;
 }
 

@@ -563,7 +563,10 @@ void run_prelude_items(vdl_ctx *c, vdl_plan *p, const std::vector<char> &asked) 
             d->bitmap_only = 2;
             d->pmin = it.modulus;
             d->nout = 1; d->out_col[0] = it.index_col;
-            d->dn[it.index_col] = nbits;
+            // the Scatter this set stands for writes into a vector as long as ITS table (the fold operand, Vlite.hs:1212-1222):
+            // positions at or beyond that length are dropped like any out-of-range Scatter position, also when the indexed
+            // table is the longer one
+            d->dn[it.index_col] = std::min(nbits, n);
             d->out_ptr[0] = (int64_t *)p->prelude_buf[k]->p;
             descs.push_back(dev_alloc(c, sizeof(MScanDesc)));
             HIP_CHECK(hipMemcpyAsync(descs.back()->p, d, sizeof(MScanDesc), hipMemcpyHostToDevice, c->stream));
@@ -836,7 +839,15 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
         e0 = p->stmt_ev[0]; e1 = p->stmt_ev[1];
         HIP_CHECK(hipEventRecord(e0, c->stream));
     }
-    run_prelude_items(c, p, wanted);
+    try {
+        run_prelude_items(c, p, wanted);
+    } catch (const NeedGeneralPath &e) {
+        // an assumption of a set the front looks up does not hold for this catalog (a semi-join's modulus smaller than its
+        // table): no front for this run -- the statements run one by one, which is exact for any data
+        p->front_keep.reset();
+        p->fallback_note = e.what();
+        return false;
+    }
     patch_front(p, fb);
     SelP sel = std::make_shared<Sel>();
     sel->n = n;

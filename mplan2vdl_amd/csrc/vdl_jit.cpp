@@ -12,9 +12,11 @@
 #include "vdl_jit.h"
 
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -42,6 +44,7 @@ struct Rtc {
     int (*code_size)(void *, size_t *) = nullptr;
     int (*code)(void *, char *) = nullptr;
     int (*destroy)(void **) = nullptr;
+    int (*version)(int *, int *) = nullptr;      // optional
     std::string why;
 };
 Rtc &rtc() {
@@ -60,6 +63,7 @@ Rtc &rtc() {
         r.code_size = (decltype(r.code_size))sym("hiprtcGetCodeSize");
         r.code = (decltype(r.code))sym("hiprtcGetCode");
         r.destroy = (decltype(r.destroy))sym("hiprtcDestroyProgram");
+        r.version = (decltype(r.version))dlsym(r.lib, "hiprtcVersion");
     });
     return r;
 }
@@ -75,8 +79,98 @@ uint64_t fnv(const std::string &s) {
     return h;
 }
 
+// a second, unrelated 64-bit hash of the source: a cache entry must match both (and the length) before its code is loaded
+uint64_t mix64(const std::string &s) {
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    for (unsigned char ch : s) {
+        h += ch + 0x9E3779B97F4A7C15ull;
+        h = (h ^ (h >> 30)) * 0xBF58476D1CE4E5B9ull;
+        h = (h ^ (h >> 27)) * 0x94D049BB133111EBull;
+        h ^= h >> 31;
+    }
+    return h;
+}
+
 std::mutex g_mu;
 std::map<std::string, std::vector<char>> g_code;        // key (hash + arch) -> code object, per process
+
+// ---- the on-disk cache ---------------------------------------------------------------------------------------------------
+// Code objects are device code that runs against this process's GPU memory, so a cache entry is only ever read from a
+// directory that belongs to the caller and that nobody else can write: the directory (created 0700, parents included when
+// missing) must be a real directory -- not a symbolic link -- owned by the effective user and closed to group and others;
+// entries are regular files of the same owner opened with O_NOFOLLOW, and carry a header {magic, both hashes and the length
+// of the source they were built from, code length} that must match the source about to be compiled.  The key holds the
+// hiprtc version, so a toolchain upgrade does not meet stale code.  Anything that does not check out is ignored (and said on
+// stderr once): the scan is compiled again, never loaded from there.
+struct CacheHeader { char magic[8]; uint64_t h1, h2, src_len, code_len; };
+const char kCacheMagic[8] = {'V', 'D', 'L', 'J', 'I', 'T', '2', 0};
+
+bool make_private_dirs(const std::string &dir) {
+    struct stat st;
+    if (lstat(dir.c_str(), &st) == 0) return true;
+    const size_t cut = dir.find_last_of('/');
+    if (cut != std::string::npos && cut > 0 && !make_private_dirs(dir.substr(0, cut))) return false;
+    return mkdir(dir.c_str(), 0700) == 0 || errno == EEXIST;
+}
+// "" when the directory cannot be trusted (why: on stderr, once per directory)
+std::string trusted_cache_dir() {
+    const char *dir = getenv("VDL_JIT_CACHE");
+    if (!dir || !*dir) return "";
+    static std::mutex mu;
+    static std::map<std::string, bool> verdicts;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = verdicts.find(dir);
+    if (it != verdicts.end()) return it->second ? dir : "";
+    std::string why;
+    struct stat st;
+    if (!make_private_dirs(dir)) why = "cannot be created";
+    else if (lstat(dir, &st) != 0) why = "cannot be examined";
+    else if (!S_ISDIR(st.st_mode)) why = "is not a directory (symbolic links are not followed)";
+    else if (st.st_uid != geteuid()) why = "belongs to another user";
+    else if (st.st_mode & (S_IWGRP | S_IWOTH)) why = "is writable by group or others";
+    verdicts[dir] = why.empty();
+    if (!why.empty()) fprintf(stderr, "vdl: VDL_JIT_CACHE=%s %s: not used, specialised scans are compiled in this process\n", dir, why.c_str());
+    return why.empty() ? dir : "";
+}
+bool cache_read(const std::string &path, const std::string &src, std::vector<char> &code) {
+    const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    if (fd < 0) return false;
+    bool ok = false;
+    struct stat st;
+    CacheHeader h;
+    if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == geteuid() && !(st.st_mode & (S_IWGRP | S_IWOTH)) &&
+        read(fd, &h, sizeof h) == (ssize_t)sizeof h && memcmp(h.magic, kCacheMagic, 8) == 0 && h.h1 == fnv(src) && h.h2 == mix64(src) &&
+        h.src_len == src.size() && h.code_len > 0 && (off_t)(sizeof h + h.code_len) == st.st_size) {
+        code.resize(h.code_len);
+        size_t got = 0;
+        while (got < code.size()) {
+            const ssize_t k = read(fd, code.data() + got, code.size() - got);
+            if (k <= 0) break;
+            got += (size_t)k;
+        }
+        ok = got == code.size();
+    }
+    close(fd);
+    if (!ok) code.clear();
+    return ok;
+}
+void cache_write(const std::string &path, const std::string &src, const std::vector<char> &code) {
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+    if (fd < 0) return;
+    CacheHeader h;
+    memcpy(h.magic, kCacheMagic, 8);
+    h.h1 = fnv(src); h.h2 = mix64(src); h.src_len = src.size(); h.code_len = code.size();
+    bool ok = write(fd, &h, sizeof h) == (ssize_t)sizeof h;
+    size_t put = 0;
+    while (ok && put < code.size()) {
+        const ssize_t k = write(fd, code.data() + put, code.size() - put);
+        if (k <= 0) ok = false; else put += (size_t)k;
+    }
+    ok = (close(fd) == 0) && ok;
+    if (ok) ok = rename(tmp.c_str(), path.c_str()) == 0;
+    if (!ok) unlink(tmp.c_str());
+}
 
 }  // namespace
 
@@ -194,7 +288,12 @@ std::string entry_name(Kind kind, const MsArgs &C, const MScanDesc &D, const Sha
 }
 
 bool compile(const std::string &src, const std::string &arch, std::vector<char> &code, std::string &log) {
-    const std::string key = std::to_string(fnv(src)) + "_" + std::to_string(src.size()) + "_" + arch;
+    std::string key = std::to_string(fnv(src)) + "_" + std::to_string(src.size()) + "_" + arch;
+    {
+        Rtc &r0 = rtc();
+        int major = 0, minor = 0;
+        if (r0.lib && r0.version && r0.version(&major, &minor) == 0) key += "_rtc" + std::to_string(major) + "." + std::to_string(minor);
+    }
     {
         std::lock_guard<std::mutex> g(g_mu);
         auto it = g_code.find(key);
@@ -204,15 +303,11 @@ bool compile(const std::string &src, const std::string &arch, std::vector<char> 
         std::ofstream f(std::string(dump) + "/vdl_" + key + ".hip");
         f << src;
     }
-    const char *dir = getenv("VDL_JIT_CACHE");
+    const std::string dir = trusted_cache_dir();
     std::string path;
-    if (dir && *dir) {
-        path = std::string(dir) + "/vdl_" + key + ".hsaco";
-        std::ifstream f(path, std::ios::binary);
-        if (f) {
-            code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
-            if (!code.empty()) { std::lock_guard<std::mutex> g(g_mu); g_code[key] = code; return true; }
-        }
+    if (!dir.empty()) {
+        path = dir + "/vdl_" + key + ".vdlco";
+        if (cache_read(path, src, code)) { std::lock_guard<std::mutex> g(g_mu); g_code[key] = code; return true; }
     }
     Rtc &r = rtc();
     if (!r.lib || !r.why.empty()) { log = r.why.empty() ? "libhiprtc not usable" : r.why; return false; }
@@ -230,12 +325,7 @@ bool compile(const std::string &src, const std::string &arch, std::vector<char> 
     r.code(prog, code.data());
     r.destroy(&prog);
     if (code.empty()) { log = "hiprtc produced no code"; return false; }
-    if (!path.empty()) {
-        mkdir(dir, 0777);
-        const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
-        std::ofstream f(tmp, std::ios::binary);
-        if (f && f.write(code.data(), (std::streamsize)code.size()) && (f.close(), true)) rename(tmp.c_str(), path.c_str());
-    }
+    if (!path.empty()) cache_write(path, src, code);
     std::lock_guard<std::mutex> g(g_mu);
     g_code[key] = code;
     return true;

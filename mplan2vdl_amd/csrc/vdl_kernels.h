@@ -118,8 +118,9 @@ hipError_t launch_pred(const PredProg &prog, const uint64_t *valid, uint64_t *ou
 #else
 #define VDL_HD
 #endif
-VDL_HD inline int64_t merge_word(const int64_t *g, int world, int64_t n_words, int op, int64_t i) {
-    const int64_t stride = 2 * n_words;
+// (`stride`: int64 words per rank in `g`: 2 * n_words, plus whatever the caller keeps behind them -- the status word of the
+// sharded fold route)
+VDL_HD inline int64_t merge_word(const int64_t *g, int world, int64_t n_words, int op, int64_t i, int64_t stride) {
     if (op == 4 /* VDL_REDUCE_FIRST */) {
         int64_t best = INT64_MAX, val = 0;
         for (int r = 0; r < world; r++) {
@@ -137,7 +138,11 @@ VDL_HD inline int64_t merge_word(const int64_t *g, int world, int64_t n_words, i
     }
     return acc;
 }
-hipError_t launch_merge_words(const int64_t *gathered, int world, int64_t n_words, const int32_t *ops, int64_t *out, hipStream_t s);
+// gathered: `stride` words per rank = n_words raw, n_words resolved, then (stride > 2 * n_words) the rank's status word.
+// status_out (may be null; needs that word): [0] = the first non-zero status over the ranks (0 = every rank's local phase
+// succeeded), [1] = that rank.
+hipError_t launch_merge_words(const int64_t *gathered, int world, int64_t n_words, int64_t stride, const int32_t *ops, int64_t *out,
+                              int64_t *status_out, hipStream_t s);
 hipError_t launch_fold_words(const int64_t *rec, int reduce, int64_t row0, int64_t *out, hipStream_t s);
 hipError_t launch_fold_record(const int64_t *words, int64_t *rec, hipStream_t s);
 // Gather out of a sparse vector without densifying it: counts[w] = popcount of bitmap word w (the caller turns them into

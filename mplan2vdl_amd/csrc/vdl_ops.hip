@@ -494,14 +494,23 @@ hipError_t launch_fold_record(const int64_t *words, int64_t *rec, hipStream_t s)
     k_fold_record<<<1, 1, 0, s>>>(words, rec);
     return launch_status();
 }
-__global__ void k_merge_words(const int64_t *g, int world, int64_t n_words, const int32_t *ops, int64_t *out) {
+__global__ void k_merge_words(const int64_t *g, int world, int64_t n_words, int64_t stride, const int32_t *ops, int64_t *out, int64_t *status_out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_words) out[i] = merge_word(g, world, n_words, ops[i], i);
+    if (i < n_words) out[i] = merge_word(g, world, n_words, ops[i], i, stride);
+    if (i == 0 && status_out) {
+        int64_t st = 0, who = -1;
+        for (int r = world - 1; r >= 0; r--) {
+            const int64_t x = g[(int64_t)r * stride + 2 * n_words];
+            if (x != 0) { st = x; who = r; }
+        }
+        status_out[0] = st; status_out[1] = who;
+    }
 }
-hipError_t launch_merge_words(const int64_t *gathered, int world, int64_t n_words, const int32_t *ops, int64_t *out, hipStream_t s) {
+hipError_t launch_merge_words(const int64_t *gathered, int world, int64_t n_words, int64_t stride, const int32_t *ops, int64_t *out,
+                              int64_t *status_out, hipStream_t s) {
     (void)hipGetLastError();
-    if (n_words <= 0) return hipSuccess;
-    k_merge_words<<<(int)((n_words + 255) / 256), 256, 0, s>>>(gathered, world, n_words, ops, out);
+    if (n_words <= 0 && !status_out) return hipSuccess;
+    k_merge_words<<<(int)((std::max<int64_t>(n_words, 1) + 255) / 256), 256, 0, s>>>(gathered, world, n_words, stride, ops, out, status_out);
     return launch_status();
 }
 __global__ void k_onehot_dense(const int64_t *oh, int64_t *out, uint64_t *valid, int64_t n) {

@@ -194,6 +194,46 @@ def test_a_failure_on_one_rank_is_reported_on_every_rank():
     assert any("outside the pivots" in msg for _, msg in errors) and any("failed on rank 1" in msg for _, msg in errors)
 
 
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_a_failed_local_phase_on_the_fold_route_reaches_every_rank(pipelined):
+    """The fold route (one all-gather of the partial words): a rank whose local phase fails -- here its catalog lacks a column --
+    still takes part in the collective with its status, so its peer is not left waiting; the failing rank reports its own error,
+    the other one names the rank.  The next query on the same communicator, with the catalog repaired, runs normally."""
+    text = golden("q6.vdl")
+    n = 100003
+    whole = lineitem(datagen.Q6_COLUMNS, n)
+    want = oracle_run(text, whole)
+    shards = [(lo, {k: v[lo:hi] for k, v in whole.items()}) for lo, hi in (shard_rows(n, r, 2) for r in range(2))]
+    errors, after = [], [None, None]
+
+    def work(rank, rv):
+        r0, cols = shards[rank]
+        e = engine_with(cols)
+        e.comm_init_host(rank, 2, *rv.transport(rank))
+        p = e.parse(text)
+        p.set_row_offset(r0)
+        if rank == 1:
+            e.drop("lineitem.l_discount")
+        try:
+            if pipelined:
+                p.run_sharded_begin(0)
+                p.run_sharded_end(0)
+            else:
+                p.run_sharded()
+        except m.VdlError as exc:
+            errors.append((rank, str(exc)))
+        if rank == 1:
+            e.upload("lineitem.l_discount", cols["lineitem.l_discount"])
+        after[rank] = p.run_sharded()["results"]
+        e.close()
+
+    run_ranks(2, work)
+    assert sorted(r for r, _ in errors) == [0, 1], errors
+    assert any(r == 0 and "failed on rank 1" in msg for r, msg in errors), errors
+    assert any(r == 1 and "l_discount" in msg for r, msg in errors), errors
+    assert after == [want, want]
+
+
 def test_rccl_communicator_of_one_rank_runs_both_routes(q6_text):
     """Real RCCL on this box's one GPU: ncclGetUniqueId, ncclCommInitRank, the fold route and the exchange route."""
     n = 100003

@@ -54,8 +54,59 @@ def test_specialised_kernels_of_the_tpch_plans_build_without_a_gpu(n, tmp_path, 
     monkeypatch.delenv("VDL_JIT_LATE")
     monkeypatch.delenv("VDL_JIT_ASSUME_SELECTIVITY")
     assert ("derived" in note) == (n != 1)                      # the join scans carry looked-up / condition columns
-    assert [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]          # the code object is kept for the next process
+    kept = [f for f in os.listdir(tmp_path) if f.endswith(".vdlco")]           # the code object is kept for the next process
+    assert kept and all(os.stat(os.path.join(tmp_path, f)).st_mode & 0o777 == 0o600 for f in kept)
     assert p.jit_check() == note                                # ... and for this one (no second compile: same text, same key)
+
+
+def test_the_code_object_cache_is_only_used_when_nobody_else_can_write_it(tmp_path):
+    """Cached code objects run against the process's GPU memory: a directory that another user could have prepared (group- or
+    world-writable, reached through a symbolic link, not ours) is never read or written; missing directories are created 0700;
+    an entry whose header does not match the source about to be compiled is ignored and replaced.  Every build runs in a
+    process of its own (a process keeps what it built in memory and would not look at the disk twice)."""
+    import subprocess
+    import sys
+
+    code = ("import os, sys; sys.path.insert(0, %r); sys.path.insert(0, %r); os.environ['VDL_JIT_CACHE'] = sys.argv[1]; os.environ['VDL_JIT_GROUP_U'] = sys.argv[2];"
+            "import test_jit as t; tx, c = t.compiled(1, 1e-4); e = t.host_engine_with_declared(c); n = e.parse(tx).jit_check();"
+            "assert 'k_mscan_specialised<' in n, n") % (ROOT, os.path.join(ROOT, "tests"))
+
+    def build(cache, u="2"):
+        r = subprocess.run([sys.executable, "-c", code, str(cache), u], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        return sorted(os.listdir(cache)), r.stderr
+
+    shared = tmp_path / "shared"
+    shared.mkdir()
+    os.chmod(shared, 0o777)
+    files, err = build(shared)
+    assert files == [] and "writable by group or others" in err            # built, nothing written there
+    real, link = tmp_path / "real", tmp_path / "link"
+    real.mkdir(mode=0o700)
+    os.symlink(real, link)
+    files, err = build(link)
+    assert files == [] and "symbolic links are not followed" in err
+    fresh = tmp_path / "a" / "b" / "cache"
+    (name,), err = build(fresh)
+    assert name.endswith(".vdlco") and "not used" not in err
+    for d in (tmp_path / "a", tmp_path / "a" / "b", fresh):
+        assert os.stat(d).st_mode & 0o777 == 0o700
+    good = open(fresh / name, "rb").read()
+    (other,), _ = build(tmp_path / "other", u="3")                         # a valid entry -- of another kernel
+    planted = open(tmp_path / "other" / other, "rb").read()
+    assert other != name and planted != good
+    victim = tmp_path / "victim"
+    victim.mkdir(mode=0o700)
+    with open(victim / name, "wb") as f:
+        f.write(planted)
+    os.chmod(victim / name, 0o600)
+    build(victim)
+    assert open(victim / name, "rb").read() == good                        # not loaded: compiled again and replaced
+    with open(victim / name, "wb") as f:                                   # an entry somebody else could rewrite is not read either
+        f.write(planted)
+    os.chmod(victim / name, 0o666)
+    build(victim)
+    assert open(victim / name, "rb").read() == good and os.stat(victim / name).st_mode & 0o777 == 0o600
 
 
 def test_specialised_kernels_of_random_programs_build_without_a_gpu():

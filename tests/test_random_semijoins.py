@@ -14,12 +14,14 @@ from helpers import check_against_oracle, engine_with, oracle_run, prog
 
 
 class Gen:
-    def __init__(self, seed, wrap=False):
+    def __init__(self, seed, wrap=False, short_fact=False, sparse_domain=False):
         self.rng = r = np.random.default_rng(seed)
         self.lines, self.nid = [], 0
-        nu = int(r.integers(1, 3000))
-        nt = int(r.integers(max(nu, 2), 30000))              # the scattered vector has the fact table's length: at least as long as the dimension
-        self.nu, self.wrap = nu, wrap
+        nu = int(r.integers(2 if short_fact else 1, 3000))
+        # the scattered vector has the fact table's length: normally at least as long as the dimension; with short_fact it is
+        # shorter, so positions in [nt, nu) fall off its end and those dimension rows are NOT selected
+        nt = int(r.integers(1, nu)) if short_fact else int(r.integers(max(nu, 2), 30000))
+        self.nu, self.wrap, self.sparse_domain = nu, wrap, sparse_domain
         self.cols = {"t.a": r.integers(-50, 50, nt).astype(np.int64), "t.b": r.integers(0, 30, nt).astype(np.int32),
                      "t.t_pkey": np.zeros(nt, np.int64),
                      "t.t_u": r.integers(-1 if seed % 3 == 0 else 0, nu + (2 if seed % 3 == 0 else 0), nt).astype(np.int64),
@@ -68,8 +70,9 @@ class Gen:
         sel = self.select(marks)
         x, y = self.gather(ucols["x"], sel), self.gather(ucols["y"], sel)
         outs = []
-        if r.random() < 0.5:
-            part = self.emit("Partition,val,Id %d,val,Id %d,val" % (y, self.emit("RangeC,val,0,8,1")))
+        if r.random() < 0.5 or self.sparse_domain:
+            # (a sparse pivot domain keeps the plan from fusing as a whole: the semi-join set then belongs to a fused FRONT)
+            part = self.emit("Partition,val,Id %d,val,Id %d,val" % (y, self.emit("RangeC,val,0,%d,1" % (1 << 30 if self.sparse_domain else 8))))
             sy = self.emit("Scatter,Id %d,Id %d,val,Id %d,val" % (y, self.pos(y), part))
             outs.append(self.emit("FoldChoose,val,Id %d,val,Id %d,val" % (sy, sy)))
             for kind in [str(k) for k in r.choice(["FoldSum", "FoldMin", "FoldMax", "FoldCount"], int(r.integers(1, 3)))]:
@@ -133,3 +136,43 @@ def test_a_modulus_smaller_than_the_dimension_is_noticed_at_run_time():
         check_against_oracle("random_semijoin_wrapping", seed, text, cols, out["results"], want)
         abandoned += any("fusedPlanAbandoned" in k and "semi-join" in k for k in out["timings"])
     assert abandoned >= 10
+
+
+@pytest.mark.gpu
+def test_a_wrapping_modulus_under_a_fused_front_falls_back_to_statements():
+    """the same with a sparse Partition domain above the semi-join: the plan does not fuse as a whole, the set belongs to the
+    fused front (run_projection), and a wrapping modulus must abandon the front for that run -- not fail the run"""
+    abandoned = fronts = 0
+    for seed in range(30):
+        text, cols = Gen(seed, wrap=True, sparse_domain=True).build()
+        want = oracle_run(text, cols)
+        e = engine_with(cols)
+        p = e.parse(text)
+        fronts += (not p.is_fused) and "semi-join set" in p.describe()
+        out = p.run()
+        e.close()
+        check_against_oracle("random_semijoin_wrapping_front", seed, text, cols, out["results"], want)
+        abandoned += any("fusedPlanAbandoned" in k and "semi-join" in k for k in out["timings"])
+    assert fronts >= 10 and abandoned >= 10, (fronts, abandoned)
+
+
+@pytest.mark.gpu
+def test_a_fact_table_shorter_than_the_dimension_drops_positions_beyond_it():
+    """Scatter(ones, pos(ones), fk mod N) is as long as the FACT table: with fewer fact rows than dimension rows the positions in
+    [n_fact, n_dim) fall off its end (oracle/vdl_oracle.c Scatter; the statement-by-statement path), so the fused set must not
+    hold them either"""
+    fused = 0
+    for seed in range(120):
+        for sparse in (False, True):
+            text, cols = Gen(seed, short_fact=True, sparse_domain=sparse).build()
+            want = oracle_run(text, cols)
+            e = engine_with(cols)
+            p = e.parse(text)
+            fused += p.is_fused
+            got = p.run()["results"]
+            p.set_fusion(False)
+            unfused = p.run()["results"]
+            e.close()
+            check_against_oracle("random_semijoin_short_fact_as_planned", seed, text, cols, got, want)
+            check_against_oracle("random_semijoin_short_fact_statement_by_statement", seed, text, cols, unfused, want)
+    assert fused >= 80
