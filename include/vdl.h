@@ -165,6 +165,13 @@ int  vdl_plan_set_profiling(vdl_plan *plan, int enabled);
 /* Rows scanned and algorithmic bytes read by the dominant (fused scan) kernel of the last
  * run, and its device time in microseconds (0 if profiling was off). */
 int  vdl_plan_scan_stats(const vdl_plan *plan, int64_t *rows, int64_t *algo_bytes, double *usec);
+/* HBM bytes ONE launch of that kernel moves over the columns registered now (measurement; call after a run, outside any
+ * timed region).  A scan that reads every column with the tile moves its algorithmic bytes.  A scan specialised to read
+ * late (vdl_plan_set_jit: staged reads) moves the eager columns in full plus 128 bytes for every cache line of a late
+ * column in which some row was still in when the column was read -- the memory side fetches whole 128-byte lines
+ * (tools/ubench/fetch_calib.hip) -- and that number is COUNTED: a census build of the same kernel form runs once.
+ * `detail` (may be null): "column=bytes ..." text, valid until the next call. */
+int  vdl_plan_scan_traffic(vdl_ctx *ctx, vdl_plan *plan, int64_t *bytes_moved, const char **detail);
 
 /* ---- sharded execution: one process per GPU, columns sharded by row range --------
  * A plan whose outputs are global folds keeps its mergeable state in `n_words` int64

@@ -139,7 +139,7 @@ static std::string jit_name(const jit::Shape &sh) {
     return "k_mscan_specialised<" + std::to_string(sh.nc) + "," + std::to_string(sh.u) + "," + (sh.vec ? "vec" : "novec") + "," + (sh.grouped ? "grouped" : "global") +
            (sh.der ? ",derived" : "") + ">";
 }
-struct Specialised { std::shared_ptr<jit::Kernel> k; int grid = 0, per_cu = 0; size_t code_bytes = 0; std::string name, stages; };
+struct Specialised { std::shared_ptr<jit::Kernel> k; int grid = 0, per_cu = 0, u = 0, lazy = 0; size_t code_bytes = 0; std::string name, stages; };
 // "l_discount@1 l_quantity@2 l_extendedprice@last": which table columns a staged scan reads when (MsArgs::stages)
 static std::string stages_text(const vdl_plan *p, size_t s, const MsArgs &args) {
     const size_t ns = p->fused.scans.size();
@@ -211,9 +211,11 @@ static uint64_t staged_columns(vdl_ctx *c, const MScanCols &cols, const MScanDes
     *lazy_mask = lazy;
     return stages;
 }
-static bool build_specialised(vdl_ctx *c, vdl_plan *p, size_t s, bool grouped, int u, int lazy /* 0 | eager filter columns of the staged form */, Specialised &out, std::string &why) {
+static bool build_specialised(vdl_ctx *c, vdl_plan *p, size_t s, bool grouped, int u, int lazy /* 0 | eager filter columns of the staged form */, Specialised &out, std::string &why,
+                              bool census = false) {
     jit::Shape sh = jit_shape(p->mcols[s], p->mcfg[s]);
     if (u > 0) sh.u = u;
+    sh.census = census;
     std::vector<char> code;
     MsArgs args = mscan_args(p->mcols[s]);
     if (lazy) {
@@ -236,7 +238,7 @@ static bool build_specialised(vdl_ctx *c, vdl_plan *p, size_t s, bool grouped, i
     int64_t grid = (int64_t)c->num_cus * per_cu;
     if (grid > p->mcols[s].n / tile) grid = p->mcols[s].n / tile;
     if (grid < 1) grid = 1;
-    out.grid = (int)grid; out.per_cu = per_cu; out.code_bytes = code.size(); out.name = jit_name(sh);
+    out.grid = (int)grid; out.per_cu = per_cu; out.code_bytes = code.size(); out.name = jit_name(sh); out.u = sh.u; out.lazy = lazy;
     if (lazy) out.name.insert(out.name.size() - 1, lazy > 1 ? ",late2" : ",late");
     if (lazy) out.stages = stages_text(p, s, args);
     return true;
@@ -249,6 +251,7 @@ static bool specialise_scan(vdl_ctx *c, vdl_plan *p, size_t s, bool grouped, std
     if (!(late && build_specialised(c, p, s, grouped, 0, late, sp, why)) && !build_specialised(c, p, s, grouped, 0, 0, sp, why)) { p->jit_note += "scan " + std::to_string(s) + ": not specialised (" + why + "); "; return false; }
     p->mcfg[s].grid = sp.grid;
     p->mjit[s] = sp.k;
+    p->mjit_form[s].u = sp.u; p->mjit_form[s].lazy = sp.lazy;
     *kname = sp.name;
     p->jit_note += "scan " + std::to_string(s) + ": " + sp.name + ", " + std::to_string(sp.code_bytes) + " B of code, " + std::to_string(sp.per_cu) + " blocks/CU" +
                    (sp.stages.empty() ? "" : ", read late: " + sp.stages) + "; ";
@@ -282,6 +285,16 @@ static void tune_specialised(vdl_ctx *c, vdl_plan *p, int64_t *dev_words) {
         // rows per lane first; then, at the winner, at 2 and at 1, the staged form that reads late (fewer rows per lane suit it:
         // its loads depend on each other, and what hides them is more waves, not more loads per wave)
         std::vector<std::pair<int, int>> cands = {{2, 0}, {3, 0}, {4, 0}, {6, 0}, {0, 1}, {3, 1}, {2, 1}, {1, 1}, {3, 2}, {2, 2}, {4, 2}};
+        // VDL_JIT_PIN="u=3,late=2" (profiles: tools/profile_bench.sh runs the form a plain run chose, and nothing else): one candidate
+        int pin_u = 0, pin_late = -1;
+        if (const char *pin = getenv("VDL_JIT_PIN")) {
+            if (const char *q = strstr(pin, "u=")) pin_u = atoi(q + 2);
+            if (const char *q = strstr(pin, "late=")) pin_late = atoi(q + 5);
+            if (pin_u > 0) cands = {{pin_u, std::max(pin_late, 0)}};
+        }
+        // a candidate's time is the MEDIAN of five launches after the module's first, and a later candidate only replaces the one
+        // in hand when it is more than 2 % quicker: forms within the noise of each other no longer swap places from run to run
+        auto median_of = [](std::vector<float> &t) { std::sort(t.begin(), t.end()); return t[t.size() / 2]; };
         int best_u = 0;
         for (auto &cu : cands) {
             const int u = cu.first ? cu.first : best_u;
@@ -294,24 +307,27 @@ static void tune_specialised(vdl_ctx *c, vdl_plan *p, int64_t *dev_words) {
             ScanLaunch cfg = p->mcfg[s];
             cfg.grid = cand.grid;
             HIP_CHECK(hipMemcpyAsync(p->mdev[s]->p, &p->mdesc[s], sizeof(MScanDesc), hipMemcpyHostToDevice, c->stream));
-            float ms = 1e30f;
-            for (int rep = 0; rep < 4; rep++) {
+            std::vector<float> times;
+            for (int rep = 0; rep < 6; rep++) {
                 HIP_CHECK(hipEventRecord(e0, c->stream));
                 HIP_CHECK(launch_mscan(p->mcols[s], p->mdesc[s], (const MScanDesc *)p->mdev[s]->p, cfg, grouped, false, out, false, c->stream, cand.k->fn));
                 HIP_CHECK(hipEventRecord(e1, c->stream));
                 HIP_CHECK(hipEventSynchronize(e1));
                 float t = 0;
                 HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
-                if (rep > 0 && t < ms) ms = t;                  // the first launch of a module pays for its load
+                if (rep > 0) times.push_back(t);                // the first launch of a module pays for its load
             }
+            const float ms = median_of(times);
             tried += " u=" + std::to_string(u) + (lazy > 1 ? ",late2:" : lazy ? ",late:" : ":") + std::to_string((int)(ms * 1000)) + "us";
-            if (!best.k || ms < best_ms) { best = cand; best_ms = ms; if (!lazy) best_u = u; }
+            if (!best.k || ms < best_ms * 0.98f) { best = cand; best_ms = ms; }
+            if (!lazy && (best_u == 0 || cand.k == best.k)) best_u = u;       // the staged forms start from the quickest eager shape
         }
         if (!best.k) continue;
-        if (!grouped && use_kscan(p->fused.scans[s]) && p->block_partials[s]) {
+        if (!grouped && use_kscan(p->fused.scans[s]) && p->block_partials[s] && pin_u <= 0) {
             // the hand-tuned single-aggregate kernel is a candidate too
             float ms = 1e30f;
-            for (int rep = 0; rep < 4; rep++) {
+            std::vector<float> times;
+            for (int rep = 0; rep < 6; rep++) {
                 HIP_CHECK(hipEventRecord(e0, c->stream));
                 HIP_CHECK(launch_scan(p->sargs[s], p->scfg[s], c->stream));
                 HIP_CHECK(launch_scan_finish(p->sargs[s].block_partials, p->scfg[s].grid, p->sargs[s].nagg, nullptr, p->sargs[s], out, c->stream));
@@ -319,10 +335,11 @@ static void tune_specialised(vdl_ctx *c, vdl_plan *p, int64_t *dev_words) {
                 HIP_CHECK(hipEventSynchronize(e1));
                 float t = 0;
                 HIP_CHECK(hipEventElapsedTime(&t, e0, e1));
-                if (rep > 0 && t < ms) ms = t;
+                if (rep > 0) times.push_back(t);
             }
+            ms = median_of(times);
             tried += std::string(" k_scan:") + std::to_string((int)(ms * 1000)) + "us";
-            if (ms <= best_ms) {
+            if (ms < best_ms * 0.98f) {
                 p->kscan[s] = 1;
                 p->mjit[s] = nullptr;
                 p->jit_note += "scan " + std::to_string(s) + " tuned:" + tried + " -> " + scan_kernel_name(p->scfg[s]) + "; ";
@@ -332,11 +349,63 @@ static void tune_specialised(vdl_ctx *c, vdl_plan *p, int64_t *dev_words) {
         }
         p->mjit[s] = best.k;
         p->mcfg[s].grid = best.grid;
+        p->mjit_form[s].u = best.u; p->mjit_form[s].lazy = best.lazy;
         p->jit_note += "scan " + std::to_string(s) + " tuned:" + tried + " -> " + best.name + (best.stages.empty() ? "" : " (read late: " + best.stages + ")") + "; ";
         if ((int)s == p->dominant)
             p->dominant_kernel = best.name + "_grid" + std::to_string(best.grid) + (grouped ? "_rep" + std::to_string(p->mdesc[s].replicas) : "");
     }
     p->description = describe_plan(p);
+}
+
+// HBM bytes one launch of the dominant scan moves, counted rather than modelled.  The memory side fetches whole 128-byte lines,
+// one request per line, whatever part of the line the lanes ask for (tools/ubench/fetch_calib: TCC_EA0_RDREQ = lines touched
+// for streaming, every-other-sector and random masked 16-byte loads alike; FETCH_SIZE = 64 B per request).  A scan that reads
+// every column with the tile moves its algorithmic bytes.  A staged scan (late materialisation) moves the eager columns in
+// full plus, per late column, 128 B for every line in which some row was still in when the column was read: a CENSUS build of
+// the very form that ran (same rows per lane, same stages; vdl_jit.cpp VDL_CENSUS) counts those lines in one untimed launch
+// over the real columns.  detail: "column=bytes ..." for the note.
+static int64_t scan_bytes_moved(vdl_ctx *c, vdl_plan *p, std::string &detail) {
+    if (!p->bound || p->dominant < 0) throw Error(VDL_ERR_ARG, "vdl_plan_scan_traffic: run the (fused) plan first");
+    const size_t s = (size_t)p->dominant, ns = p->fused.scans.size();
+    const bool grouped = s >= ns;
+    const std::vector<ScanColumn> &sc = grouped ? p->fused.gscans[s - ns].cols : p->fused.scans[s].cols;
+    const MScanCols &cols = p->mcols[s];
+    auto short_name = [&](int k) { const std::string &n = sc[(size_t)k].name; return n.substr(n.find('.') == std::string::npos ? 0 : n.find('.') + 1); };
+    const bool staged = !(!grouped && p->kscan[s]) && p->mjit[s] && p->mjit_form[s].lazy > 0;
+    int64_t total = 0;
+    if (!staged) {
+        for (int k = 0; k < cols.ncol; k++)
+            if (cols.kind[k] == VC_DIRECT) { total += cols.n * cols.width[k]; detail += short_name(k) + "=" + std::to_string(cols.n * cols.width[k]) + " "; }
+        detail += "(every column read with the tile)";
+        return total;
+    }
+    Specialised cen;
+    std::string why;
+    if (!build_specialised(c, p, s, grouped, p->mjit_form[s].u, p->mjit_form[s].lazy, cen, why, true)) throw Error(VDL_ERR_UNSUPPORTED, "the census build of the staged scan failed: " + why);
+    BufP counts = dev_alloc(c, sizeof(unsigned long long) * kMaxVCols);
+    BufP words = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(p->n_words, 1));
+    HIP_CHECK(hipMemsetAsync(counts->p, 0, sizeof(unsigned long long) * kMaxVCols, c->stream));
+    MScanDesc d = p->mdesc[s];
+    d.census = (unsigned long long *)counts->p;
+    BufP ddev = dev_alloc(c, sizeof(MScanDesc));
+    HIP_CHECK(hipMemcpyAsync(ddev->p, &d, sizeof d, hipMemcpyHostToDevice, c->stream));
+    ScanLaunch cfg = p->mcfg[s];
+    cfg.grid = cen.grid;
+    int64_t *out = (int64_t *)words->p + (grouped ? p->gword_offset[s - ns] : p->word_offset[s]);
+    HIP_CHECK(launch_mscan(cols, d, (const MScanDesc *)ddev->p, cfg, grouped, false, out, false, c->stream, cen.k->fn));
+    unsigned long long lines[kMaxVCols] = {};
+    HIP_CHECK(hipMemcpyAsync(lines, counts->p, sizeof lines, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    const MsArgs args = [&] { MsArgs a = mscan_args(cols); uint32_t lz = 0; a.stages = staged_columns(c, cols, p->mdesc[s], grouped, &lz, p->mjit_form[s].lazy); a.lazy = lz; return a; }();
+    for (int k = 0; k < cols.ncol; k++) {
+        if (cols.kind[k] != VC_DIRECT) continue;
+        const bool late = (args.lazy >> k) & 1u;
+        const int64_t b = late ? (int64_t)lines[k] * 128 : cols.n * cols.width[k];
+        total += b;
+        detail += short_name(k) + "=" + std::to_string(b) + (late ? "(late: " + std::to_string(lines[k]) + " lines of " + std::to_string((cols.n * cols.width[k] + 127) / 128) + ") " : " ");
+    }
+    detail += "(census of " + cen.name + ", full tiles)";
+    return total;
 }
 
 void bind_fused(vdl_ctx *c, vdl_plan *p) {
@@ -352,6 +421,7 @@ void bind_fused(vdl_ctx *c, vdl_plan *p) {
     p->mparts.assign(ns + ng, nullptr);
     p->mdev.resize(ns + ng);
     p->mjit.assign(ns + ng, nullptr);
+    p->mjit_form.assign(ns + ng, vdl_plan::JitForm{});
     p->kscan.assign(ns + ng, 0);
     p->jit_note.clear();
     p->jit_tuned = false;
@@ -1181,7 +1251,8 @@ int vdl_plan_jit_check(vdl_ctx *c, vdl_plan *p) {
             }
             const ScanLaunch cfg = mscan_launch_config(cols, *d, grouped, c->num_cus);
             if (cfg.variant < 0) throw Error(VDL_ERR_UNSUPPORTED, "no scan kernel variant for this shape");
-            const jit::Shape sh = jit_shape(cols, cfg);
+            jit::Shape sh = jit_shape(cols, cfg);
+            if (getenv("VDL_JIT_CENSUS")) sh.census = true;              // (tests: the measurement build of a staged scan compiles too)
             std::vector<char> code;
             std::string log;
             MsArgs args = mscan_args(cols);
@@ -1275,6 +1346,18 @@ int vdl_plan_scan_stats(const vdl_plan *p, int64_t *rows, int64_t *algo_bytes, d
     if (algo_bytes) *algo_bytes = p->scan_bytes;
     if (usec) *usec = p->scan_usec;
     return VDL_OK;
+}
+
+int vdl_plan_scan_traffic(vdl_ctx *c, vdl_plan *p, int64_t *bytes_moved, const char **detail) {
+    if (!c || !p) return VDL_ERR_ARG;
+    return guard(c, [&] {
+        need_device(c);
+        if (!(p->use_fusion && p->fused.ok)) throw Error(VDL_ERR_UNSUPPORTED, "vdl_plan_scan_traffic serves fused plans");
+        p->traffic_detail.clear();
+        const int64_t b = scan_bytes_moved(c, p, p->traffic_detail);
+        if (bytes_moved) *bytes_moved = b;
+        if (detail) *detail = p->traffic_detail.c_str();
+    });
 }
 
 int vdl_plan_partial_spec(const vdl_plan *p, int64_t *n_words, const int32_t **reduce_ops) {

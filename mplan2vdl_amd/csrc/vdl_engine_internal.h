@@ -205,6 +205,8 @@ struct vdl_plan {
     bool use_jit = false;                    // vdl_plan_set_jit / VDL_JIT=1: scans specialised for this plan by hiprtc (vdl_jit.cpp)
     bool jit_tune = false, jit_tuned = false;   // ... =2: rows per lane chosen by timing at the first run
     std::vector<std::shared_ptr<vdl::jit::Kernel>> mjit;
+    struct JitForm { int u = 0, lazy = 0; };     // rows per lane / filter columns read with the tile (0 = not staged) of mjit[s]
+    std::vector<JitForm> mjit_form;
     struct FrontKernel { uint64_t version = 0; std::shared_ptr<vdl::jit::Kernel> k; };
     std::map<std::string, FrontKernel> front_jit;   // specialised passes of the projection scan / dimension scans, by role
     std::vector<std::shared_ptr<vdl::MScanDesc>> host_descs;     // dimension scans of the current run (copied to the device asynchronously)
@@ -216,6 +218,7 @@ struct vdl_plan {
     std::vector<int64_t> gword_offset;
     int dominant = -1;
     std::string dominant_kernel;
+    std::string traffic_detail;            // vdl_plan_scan_traffic: per-column bytes of the last census
     int64_t n_words = 0;
     int64_t row_offset = 0;                  // global index of this rank's first row (sharded FoldChoose)
     // sharded Partition exchange (vdl_exchange_*)

@@ -221,19 +221,31 @@ static std::string desc_text(Kind kind, const MsArgs &C, const MScanDesc &D) {
 std::string scan_source(Kind kind, const MsArgs &C, const MScanDesc &D, const Shape &sh) {
     std::ostringstream o;
     o << "#define VDL_SPEC_UNROLL _Pragma(\"unroll\")\n";
+    if (kind == MSCAN && sh.census) o << "#define VDL_CENSUS 1\n";
     if (kind == MSCAN && C.lazy) {
         // the stages of a scan that reads late (MsArgs::stages), as straight-line code inside the body's row loop context
         // a lane's rows come in adjacent pairs (2u, 2u + 1): with aligned columns a pair of which a row is still in is ONE
         // 16-byte (int64) / 8-byte (int32) load instead of two masked scalar ones; the one-row tail and unaligned columns
         // take the scalar form
         const bool pairs = sh.vec && !getenv("VDL_JIT_NO_PAIR_LOADS");
+        // census builds: the wave's lanes hold consecutive addresses (stride 2 w), so a lane is the first asker of its line when no
+        // lower active lane lies in the same 128 bytes -- the lanes [lane - (a % 128) / (2 w), lane)
+        auto census = [&](int c, int w, const char *on) {
+            std::ostringstream l;
+            if (!sh.census) return std::string();
+            l << " { const uint64_t m_ = __ballot(" << on << "); const uint64_t a_ = (uint64_t)Cr.ptr[" << c << "] + (uint64_t)(rowid[r] - Cr.row0) * " << w << "ull;"
+              << " const int ln_ = (int)(threadIdx.x & 63u); int lo_ = ln_ - (int)((a_ & 127ull) / " << 2 * w << "ull); if (lo_ < 0) lo_ = 0;"
+              << " const bool first_ = (" << on << ") && ((m_ >> lo_) & ((1ull << (ln_ - lo_)) - 1ull)) == 0ull;"
+              << " const uint64_t f_ = __ballot(first_); if (ln_ == 0) census_cnt[" << c << "] += (unsigned long long)__popcll(f_); }";
+            return l.str();
+        };
         auto load = [&](int c, const char *mask) {
             std::ostringstream l;
             const int w = C.width(c);
             if (pairs && (w == 8 || w == 4)) {
                 const char *vt = w == 8 ? "ll2" : "i32x2";
                 l << " if (RW % 2 == 0) { _Pragma(\"unroll\") for (int r = 0; r < RW; r += 2) { const int r1 = r + 1 < RW ? r + 1 : r; v[" << c << "][r] = 0; v[" << c
-                  << "][r1] = 0; if (" << mask << "[r] | " << mask << "[r1]) { const int64_t i0 = rowid[r] - Cr.row0; if (i0 + 1 < Cr.n) { const " << vt << " x = *(const " << vt
+                  << "][r1] = 0;" << census(c, w, (std::string(mask) + "[r] | " + mask + "[r1]").c_str()) << " if (" << mask << "[r] | " << mask << "[r1]) { const int64_t i0 = rowid[r] - Cr.row0; if (i0 + 1 < Cr.n) { const " << vt << " x = *(const " << vt
                   << " *)((const char *)Cr.ptr[" << c << "] + i0 * " << w << "); v[" << c << "][r] = x.x; v[" << c << "][r1] = x.y; } else if (" << mask << "[r]) v[" << c
                   << "][r] = load_scalar(Cr.ptr[" << c << "], " << w << ", i0); } } } else {";   /* (the table's last row has no partner) */
             }
@@ -284,7 +296,11 @@ std::string entry_name(Kind kind, const MsArgs &C, const MScanDesc &D, const Sha
     if (kind != MSCAN) return entry_name(kind);
     char tag[16];
     snprintf(tag, sizeof tag, "%06llx", (unsigned long long)(fnv(desc_text(kind, C, D)) & 0xffffffull));      // which plan's scan
-    return std::string("vdl_jit_mscan_") + (sh.grouped ? "grouped_" : "") + "u" + std::to_string(sh.u) + (C.lazy ? "_staged_" : "_") + tag;
+    // (staged: how many filter columns come with the tile is part of the name too -- the profiles tell the forms apart by it)
+    int eager_filters = 0;
+    for (int c = 0; c < C.ncol; c++) eager_filters += ((C.filtered >> c) & 1u) && !((C.derived >> c) & 1u) && C.stage(c) == 0;
+    return std::string("vdl_jit_mscan_") + (sh.grouped ? "grouped_" : "") + "u" + std::to_string(sh.u) + (C.lazy ? "_staged" + std::to_string(eager_filters) + "_" : "_") +
+           (sh.census ? "census_" : "") + tag;
 }
 
 bool compile(const std::string &src, const std::string &arch, std::vector<char> &code, std::string &log) {

@@ -11,7 +11,8 @@
 namespace vdl {
 namespace jit {
 
-struct Shape { int nc = 0, u = 0; bool vec = false, grouped = false, der = false; };
+struct Shape { int nc = 0, u = 0; bool vec = false, grouped = false, der = false;
+               bool census = false; };     // census: a staged scan's late loads also count the 128-byte lines they ask for (measurement builds)
 
 // what is specialised: an aggregate scan, or the two passes of the projection scan (fused front; dimension scans are the
 // select pass with bitmap_only set)

@@ -376,6 +376,13 @@ __device__ __forceinline__ void mscan_body(const MsArgs &C, const MsArgs &Cr, co
     int64_t cnt = 0, oob = 0;
     int64_t *mytab = lds;
     int trash = 0;
+#ifdef VDL_CENSUS
+    // a census build (measurement, never timed): the generated late loads count, per column, the distinct 128-byte lines they
+    // ask for -- the memory side fetches whole lines (tools/ubench/fetch_calib) -- in lane 0's registers
+    unsigned long long census_cnt[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) census_cnt[c] = 0;
+#endif
     if (GROUPED) {
         for (int r = 0; r < R; r++)
             for (int64_t i = tid; i < words; i += BS) {
@@ -574,6 +581,12 @@ __device__ __forceinline__ void mscan_body(const MsArgs &C, const MsArgs &Cr, co
     __syncthreads();
     __shared__ int64_t red[kMsBlock / kWave];
     const int lane = tid & (kWave - 1), wave = tid / kWave;
+#ifdef VDL_CENSUS
+    if (lane == 0 && Dr.census) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) if (census_cnt[c]) atomicAdd(&Dr.census[c], census_cnt[c]);
+    }
+#endif
     if (GROUPED) {
         int64_t *dst = Dr.block_partials + (int64_t)blockIdx.x * (words + 1);
         for (int64_t i = tid; i < words; i += BS) {

@@ -131,6 +131,9 @@ struct MScanDesc {                           // lives in device memory, read wit
     KeyComp comp[kMaxKeyComps];
     MAggDesc agg[kMaxGroupAggs];
     KeyStep key[kMaxKeySteps];
+    // census builds of a staged scan (vdl_jit.cpp, VDL_CENSUS; measurement only, never the timed kernel): [column] = number of
+    // distinct 128-byte lines the late loads of that column asked for
+    unsigned long long *census = nullptr;
 };
 
 // What the scan kernels take by value: column bases (kept in the global address space), the widths and the

@@ -208,6 +208,13 @@ class Plan:
         self._e._check(self._e._L.vdl_plan_scan_stats(self._h, ctypes.byref(rows), ctypes.byref(nbytes), ctypes.byref(us)))
         return rows.value, nbytes.value, us.value
 
+    def scan_traffic(self):
+        """(HBM bytes one launch of the dominant fused scan moves, per-column detail): vdl_plan_scan_traffic -- measurement,
+        call after a run and outside timed regions (a staged scan's late columns are counted by a census launch)."""
+        b, detail = ctypes.c_int64(), ctypes.c_char_p()
+        self._e._check(self._e._L.vdl_plan_scan_traffic(self._e._c, self._h, ctypes.byref(b), ctypes.byref(detail)))
+        return b.value, (detail.value or b"").decode()
+
 
 class Engine:
     """One context = one GPU (``device=None``: host-only, can parse/describe but not run)."""

@@ -51,6 +51,11 @@ def test_specialised_kernels_of_the_tpch_plans_build_without_a_gpu(n, tmp_path, 
     monkeypatch.setenv("VDL_JIT_ASSUME_SELECTIVITY", "0.2")
     late = p.jit_check()
     assert "(late)" in late and max(code_bytes(late)) < 64 << 10, late
+    # ... and its census build (vdl_plan_scan_traffic: the same form counting the 128-byte lines its late loads ask for)
+    monkeypatch.setenv("VDL_JIT_CENSUS", "1")
+    census = p.jit_check()
+    assert "(late)" in census and code_bytes(census) != code_bytes(late) and max(code_bytes(census)) < 96 << 10, census
+    monkeypatch.delenv("VDL_JIT_CENSUS")
     monkeypatch.delenv("VDL_JIT_LATE")
     monkeypatch.delenv("VDL_JIT_ASSUME_SELECTIVITY")
     assert ("derived" in note) == (n != 1)                      # the join scans carry looked-up / condition columns
@@ -199,6 +204,39 @@ def test_specialised_random_programs_match_the_oracle(late, monkeypatch):
             ran += "k_mscan_specialised<" in note
             lates += ",late" in note
     assert ran >= 60 and (lates >= 30 if late else lates == 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("late", [0, 1, 2])
+def test_scan_traffic_counts_the_lines_a_staged_scan_asks_for(late, monkeypatch, q6_text):
+    """vdl_plan_scan_traffic (bench.py's `roofline.achieved` is built on it): a scan that reads everything moves its algorithmic
+    bytes; a staged scan moves the eager columns plus 128 B per line of a late column in which a row was still in -- the census
+    build's count equals a numpy count over the same columns, line by line (16 int64 rows per line)."""
+    from mplan2vdl_amd import datagen
+    from helpers import lineitem
+    monkeypatch.setenv("VDL_JIT_U", "2")
+    n = 1024 * 301                                               # whole tiles of 256 lanes x 2 rows x 2
+    cols = lineitem(datagen.Q6_COLUMNS, n)
+    e = engine_with(cols)
+    p = e.parse(q6_text)
+    if late:
+        monkeypatch.setenv("VDL_JIT_LATE", str(late))
+        p.set_jit(True)
+    assert p.run()["results"] == oracle_run(q6_text, cols)
+    moved, detail = p.scan_traffic()
+    assert p.run()["results"] == oracle_run(q6_text, cols)       # the census launch leaves the plan as it was
+    e.close()
+    if not late:
+        assert moved == 28 * n and "every column read with the tile" in detail, detail
+        return
+    d, disc, q, x = (cols["lineitem." + c] for c in ("l_shipdate", "l_discount", "l_quantity", "l_extendedprice"))
+    lines = lambda alive: int(alive.reshape(-1, 16).any(axis=1).sum())
+    a0 = (d >= 728294) & (d <= 728658)                           # 1994-01-01 <= shipdate < 1995-01-01 (tests/golden/q6.vdl:5-11)
+    a1 = a0 & (disc >= 5) & (disc <= 7)
+    a2 = a1 & (q < 2400)
+    want = 4 * n + (8 * n if late == 2 else 128 * lines(a0)) + 128 * lines(a1) + 128 * lines(a2)
+    assert moved == want, (moved, want, detail)
+    assert want < 28 * n and "late:" in detail
 
 
 @pytest.mark.gpu

@@ -7,7 +7,7 @@ and prints, per configuration, the counter against the bytes of the 16-B lanes, 
 import csv, sys
 table, pmc = sys.argv[1], sys.argv[2]
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-rows = [l.split() for l in open(table) if l.strip() and not l.startswith("#")]
+rows = [l.split() for l in open(table) if l.strip() and l.split()[0].isdigit() and len(l.split()) == 12]
 disp = {}
 for r in csv.DictReader(open(pmc)):
     if "k_calib" not in r["Kernel_Name"]:
