@@ -8,9 +8,11 @@ all-reduce of the partial words), finalisation and the 8-byte answer copied to t
 N > 1 shards the SF100 rows by contiguous row range, one process per GPU (strong scaling,
 as BASELINE.json config "Q6 SF100 row-range sharded across 8xMI355X").
 
-Prints ONE JSON line (rank 0).  `value` = rows/s over all GPUs; `roofline.achieved` =
-28 B/row x rows per launch / mean fused-scan kernel time (HIP events on the launch stream,
-recorded by libvdl around the kernel, inside the timed region).
+Prints ONE JSON line (rank 0).  `value` = rows/s over all GPUs; kernel time = mean fused-scan
+time from HIP events on the launch stream, recorded by libvdl around the kernel inside the
+timed region.  `roofline.achieved` / `frac` are on the bytes the kernel MOVED
+(vdl_plan_scan_traffic: counted, never above the peak); the 28 B/row figure of SURVEY.md 8(d) is `algorithmic_equivalent_GBps`,
+and `read_everything_kernel` is the kernel that moves exactly those bytes, timed in the same run.
 """
 import argparse
 import json
@@ -72,6 +74,98 @@ def q3_matches_sql(eng, res):
     return bool(np.array_equal(got[np.argsort(got[:, 0])], want[np.argsort(want[:, 0])]))
 
 
+Q3_ORDERS = {"sf0.01": 15000, "sf1": 1500000, "sf10": 15000000, "sf100": 150000000}      # lineitem = 4 x orders (datagen.register_q3_columns), customer = orders / 10
+
+
+def q3_program(n_orders):
+    """Q3's VDL for a catalog of that size: the committed fixture up to SF10 (compiled from 03.sql.mplan against the reference's SF10
+    metadata: 2^38 group-key domain); beyond it the same plan compiled by the front-end restatement against those bounds scaled
+    like TPC-H scales (2^42 at SF100), as `./tpchrun` over an SF100 export would print it."""
+    if n_orders <= 15000000:
+        return open(os.path.join(ROOT, "tests", "golden", "q3.vdl")).read()
+    from mplan2vdl_amd import catalog, frontend
+    meta = os.path.join(ROOT, "tests", "golden", "tpch10noorder")
+    factor = -(-n_orders // 15000000)
+    return frontend.compile_plan(open(os.path.join(meta, "03.sql.mplan")).read(), catalog.tpch_scaled_config(frontend.load_metadata(meta), factor))
+
+
+def q3_outputs(res):
+    """the four result columns of a Q3 reply by field name (statement numbers differ between compilations)"""
+    flat = {list(v.keys())[0][1:]: list(v.values())[0] for v in res.values()}
+    return (flat["l_orderkey__lineitem__l_orderkey"], flat["revenue"], flat["o_orderdate__orders__o_orderdate"], flat["o_shippriority__orders__o_shippriority"])
+
+
+def q3_checksums_torch(eng, dev):
+    """Q3's SQL (tests/golden/tpch10noorder/03.sql.mplan:1-19) over THIS rank's columns as they lie in HBM, evaluated with plain
+    torch tensor operations (a checker: nothing of libvdl's kernels; outside every timed region).  Returns int64 checksums of
+    the grouped result -- groups, sum of revenue, sum of order keys, sum of order dates, sum of key x revenue (wrapping) -- that
+    add up over ranks when no order's lineitems are split between two of them (shard boundaries are multiples of 4 rows)."""
+    import torch
+    col = lambda name: torch.as_tensor(eng.column_device(name), device=dev)
+    order_ok = (col("orders.o_orderdate") < 728732) & (col("customer.c_mktsegment")[col("orders.orders_customer")] == 16)       # date '1995-03-15', 'BUILDING'
+    l_ord = col("lineitem.lineitem_orders")
+    rows = torch.nonzero((col("lineitem.l_shipdate") > 728732) & order_ok[l_ord]).reshape(-1)
+    del order_ok
+    okey = col("lineitem.l_orderkey")[rows].to(torch.int64)
+    uniq, inv = torch.unique(okey, return_inverse=True)
+    rev = torch.zeros(len(uniq), dtype=torch.int64, device=dev)
+    rev.index_add_(0, inv, col("lineitem.l_extendedprice")[rows] * (100 - col("lineitem.l_discount")[rows]))
+    date = torch.zeros(len(uniq), dtype=torch.int64, device=dev)
+    date.scatter_(0, inv, col("orders.o_orderdate")[l_ord[rows]].to(torch.int64))             # (every row of a group carries its order's date)
+    return [int(len(uniq)), int(rev.sum()), int(uniq.sum()), int(date.sum()), int((uniq * rev).sum())]
+
+
+def q3_checksums_of_result(plan_result, dev):
+    import torch
+    okey, rev, date, prio = (torch.as_tensor(x, device=dev) if not isinstance(x, list) else torch.tensor(x, dtype=torch.int64, device=dev) for x in q3_outputs(plan_result))
+    assert int(prio.abs().sum()) == 0 if len(prio) else True
+    return [int(len(okey)), int(rev.sum()), int(okey.sum()), int(date.sum()), int((okey * rev).sum())]
+
+
+def q3_measure(eng, dev, n_orders, li_range, world, steps, warmup, jit, dist=None, sharded=False):
+    """Q3 over the columns register_q3_columns builds in place: `steps` executions with the four result columns left in HBM
+    (vdl_plan_set_device_outputs), wall time per query; then the same with the results copied to the host (N = 1 only).
+    sharded: vdl_run_sharded -- local phase on this rank's lineitem rows (orders co-partitioned), ONE count all-gather, ONE grouped
+    send/receive of the surviving rows by key range over RCCL, tail on the received rows."""
+    import torch
+    from mplan2vdl_amd import datagen
+
+    keep = datagen.register_q3_columns(eng, n_orders, li_range, device=dev, copartition=world > 1)
+    plan = eng.parse(q3_program(n_orders))
+    if jit != "off":
+        plan.set_jit(True)                        # (its projection / dimension scans; nothing to tune: their tile shape is fixed)
+    plan.set_device_outputs(True)
+    if sharded:
+        plan.set_sharded_table("lineitem")
+    go = plan.execute_sharded if sharded else plan.execute
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(warmup, 1)):
+        go()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        go()
+    sync()
+    elapsed = time.perf_counter() - t0
+    res = plan.collect()["results"]
+    got = q3_checksums_of_result(res, dev)
+    want = q3_checksums_torch(eng, dev)
+    host_ms = None
+    if not sharded:
+        plan.set_device_outputs(False)
+        wall = []
+        for _ in range(5):
+            torch.cuda.synchronize(); t1 = time.perf_counter(); plan.execute(); torch.cuda.synchronize(); wall.append(time.perf_counter() - t1)
+        host_ms = 1e3 * sum(wall[2:]) / len(wall[2:])
+    return {"plan": plan, "keep": keep, "elapsed": elapsed, "got": got, "want": want, "host_ms": host_ms, "note": plan.jit_note()}
+
+
 def secondary_measurements(eng, rows, jit="tune"):
     """Not the headline metric: the other two single-GPU configurations of BASELINE.json on the same box, measured
     after the timed region (Q1 grouped fused scan over the same lineitem rows; Q3 at SF10 through the statement-by-
@@ -94,9 +188,11 @@ def secondary_measurements(eng, rows, jit="tune"):
             torch.cuda.synchronize(); t0 = time.perf_counter(); r = q1.run(); wall.append(time.perf_counter() - t0)
             us.append(next(v for lbl, v in r["timings"].items() if "FusedScan" in lbl))
         k_us = sum(us[2:]) / len(us[2:])
+        moved, _ = q1.scan_traffic()              # bytes the kernel form that ran moves (counted: vdl_plan_scan_traffic)
         also["tpch_q1_same_rows"] = {"rows": rows, "ms_per_query": 1e3 * sum(wall[2:]) / len(wall[2:]), "rows_per_s": rows / (sum(wall[2:]) / len(wall[2:])),
-                                     "kernel_us": k_us, "bytes_per_row": datagen.Q1_BYTES_PER_ROW,
-                                     "roofline_frac": rows * datagen.Q1_BYTES_PER_ROW / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                     "kernel_us": k_us, "bytes_per_row": datagen.Q1_BYTES_PER_ROW, "bytes_moved_per_launch": moved,
+                                     "roofline_frac": moved / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                     "algorithmic_equivalent_frac": rows * datagen.Q1_BYTES_PER_ROW / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                                      "groups": len(r["results"]["tmp101"][".count_order"]), "scan_kernels": q1.jit_note(),
                                      "verified_bit_exact_vs_cpu": q1_matches_sql(r["results"], rows, max(1, min(os.cpu_count() or 1, 64)))}
         q1.close()
@@ -153,9 +249,11 @@ def secondary_measurements(eng, rows, jit="tune"):
         promo_off = {o for o in set(t["part.p_type"].tolist()) if heap[o:o + 5] == b"PROMO"}
         promo = np.isin(t["part.p_type"][t["lineitem.lineitem_part"][sel]], sorted(promo_off))
         want = int(rev[promo].sum()) * 10000 // int(rev.sum())
+        moved, _ = q14.scan_traffic()             # lineitem columns only: the part side (p_type, the LIKE table) stays in the caches
         also["tpch_q14_sf10"] = {"lineitem_rows": n_li, "ms_per_query": 1e3 * sum(wall[2:]) / len(wall[2:]), "kernel_us": k_us,
-                                 "bytes_per_row": datagen.Q14_BYTES_PER_ROW,
-                                 "roofline_frac": n_li * datagen.Q14_BYTES_PER_ROW / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                 "bytes_per_row": datagen.Q14_BYTES_PER_ROW, "bytes_moved_per_launch": moved,
+                                 "roofline_frac": moved / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                 "algorithmic_equivalent_frac": n_li * datagen.Q14_BYTES_PER_ROW / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                                  "path": "fused JOIN scan: lineitem columns + part.p_type looked up through the join index + a LIKE table, one pass",
                                  "scan_kernels": q14.jit_note(),
                                  "verified_vs_numpy_sql": r["results"]["tmp65"][".promo_revenue"] == [want]}
@@ -163,6 +261,18 @@ def secondary_measurements(eng, rows, jit="tune"):
         del keep
     except Exception as exc:                      # noqa: BLE001
         also["tpch_q14_sf10"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    if rows >= datagen.LINEITEM_ROWS["sf100"]:
+        # BASELINE.json config 5's table sizes on ONE GPU (600 M lineitems, 150 M orders, 15 M customers: it fits), program compiled
+        # for the SF100 bounds; `bench.py --query q3 --gpus N` is the same query with the Partition exchange over RCCL
+        try:
+            n_orders = Q3_ORDERS["sf100"]
+            r = q3_measure(eng, "cuda:%d" % torch.cuda.current_device(), n_orders, (0, 4 * n_orders), 1, 5, 2, jit)
+            also["tpch_q3_sf100"] = {"lineitem_rows": 4 * n_orders, "ms_per_query_results_left_in_hbm": 1e3 * r["elapsed"] / 5,
+                                     "lineitem_rows_per_s": 4 * n_orders / (r["elapsed"] / 5), "ms_per_query": r["host_ms"], "result_rows": r["got"][0],
+                                     "scan_kernels": r["note"], "verified_vs_torch_sql_checksums": r["got"] == r["want"]}
+            r["plan"].close()
+        except Exception as exc:                  # noqa: BLE001
+            also["tpch_q3_sf100"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     return also
 
 
@@ -217,6 +327,90 @@ def dry_run(args, world, rank):
     return 0 if ok else 1
 
 
+def main_q3(args):
+    """--query q3: BASELINE.json config 5 (Q3: lineitem joined to orders and customer through join indices, sparse-domain GROUP BY).
+    N = 1: fused front (dimension scans, projection scan of lineitem) + the group-by tail, whole table on one GPU.  N > 1: lineitem
+    sharded by rows, orders co-partitioned, customer replicated; the surviving rows travel by key range in ONE grouped RCCL
+    send/receive inside libvdl (vdl_run_sharded) -- the all-to-all of the north star -- and every rank ends with the groups of its
+    key range.  value = lineitem rows per second over all GPUs with the four result columns left in HBM."""
+    import torch
+    import torch.distributed as dist
+
+    import mplan2vdl_amd as m
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = 0 if os.environ.get("VDL_BENCH_SHARE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    comm_mode = os.environ.get("VDL_BENCH_COMM", "native")
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    n_orders = (args.rows // 4) if args.rows else Q3_ORDERS[args.sf]
+    n_li = 4 * n_orders
+    lo, hi = m.shard_rows(n_li, rank, world)
+    lo, hi = lo - lo % 4, (hi - hi % 4 if rank < world - 1 else n_li)          # an order's lineitems stay on one rank
+    eng = m.Engine(device=local_rank)
+    eng.use_torch_stream()
+    transport = "none (single GPU)"
+    if world > 1:
+        if comm_mode == "host":                   # rehearsal on a box with fewer GPUs than ranks: libvdl's host transport over gloo
+            def gloo_all_gather(send):
+                t = torch.frombuffer(bytearray(send), dtype=torch.uint8)
+                parts = [torch.empty_like(t) for _ in range(world)]
+                dist.all_gather(parts, t)
+                return [bytes(x.numpy()) for x in parts]
+
+            def gloo_all_to_all(pieces):
+                box = [None] * world
+                dist.all_gather_object(box, pieces)
+                return [box[src][rank] for src in range(world)]
+
+            eng.comm_init_host(rank, world, gloo_all_gather, gloo_all_to_all)
+        else:
+            box = [eng.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            eng.comm_init_rccl(rank, world, box[0])
+        _, n_ranks, name = eng.comm_info()
+        if n_ranks != args.gpus:
+            print("bench.py: the communicator has %d rank(s), --gpus asked for %d" % (n_ranks, args.gpus), file=sys.stderr)
+            sys.exit(2)
+        transport = {"rccl": "RCCL inside libvdl: one count all-gather + ONE ncclGroupStart..End of sends/receives (rows by key range) per query",
+                     "host": "libvdl host transport over gloo (REHEARSAL)"}[name]
+    r = q3_measure(eng, dev, n_orders, (lo, hi), world, args.steps, args.warmup, args.jit, dist if world > 1 else None, sharded=world > 1)
+    elapsed = r["elapsed"]
+    sums = torch.tensor([r["got"], r["want"]], dtype=torch.int64)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    verified = bool((sums[0] == sums[1]).all())
+    if rank == 0:
+        out = {"metric": "lineitem rows/s, TPC-H Q3 %s (join-index gathers + sparse GROUP BY; N > 1: RCCL all-to-all Partition)" % args.sf.upper(),
+               "value": n_li / (elapsed / args.steps), "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+               "config": {"workload": "tpch_q3_%s" % (args.sf if not args.rows else "rows%d" % n_li), "lineitem_rows": n_li, "orders_rows": n_orders,
+                          "customer_rows": max(n_orders // 10, 1), "sharding": "lineitem by rows, orders co-partitioned, customer replicated" if world > 1 else "single GPU",
+                          "exchange": transport, "results": "left in HBM (4 columns)"},
+               "roofline": None,                  # random access through join indices: rows/s only (SURVEY.md 8(d))
+               "cpu_baseline": None,
+               "result_rows_all_ranks": int(sums[0][0]), "ms_per_query_results_copied_to_host": r["host_ms"],
+               "verified_vs_torch_sql_checksums": verified,
+               "checksums": {"groups, sum(revenue), sum(orderkey), sum(orderdate), sum(orderkey*revenue) mod 2^64": [int(x) for x in sums[0]]},
+               "scan_kernels": r["note"]}
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not verified:
+        print("VERIFICATION FAILED (q3): engine %s vs torch %s" % (sums[0].tolist(), sums[1].tolist()), file=sys.stderr)
+        sys.exit(1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -228,8 +422,9 @@ def main():
     ap.add_argument("--cpu-sample-rows", type=int, default=59986052, help="rows of the CPU-baseline sample (default SF10)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the Q1 / Q3 numbers reported under \"also\" (N=1 only)")
     ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--query", default="q6", choices=["q6", "q1"],
-                    help="q6 (default, BASELINE.json's metric) or q1 (grouped fused scan; secondary measurement)")
+    ap.add_argument("--query", default="q6", choices=["q6", "q1", "q3"],
+                    help="q6 (default, BASELINE.json's metric), q1 (grouped fused scan; secondary measurement) or q3 (join + sparse GROUP BY; "
+                         "N > 1: the Partition exchange over RCCL -- BASELINE.json config 5)")
     ap.add_argument("--jit", default="tune", choices=["off", "on", "tune"],
                     help="scan kernels specialised for the plan by hiprtc at the first (untimed) run: off = the precompiled kernels, on = specialised with the "
                          "precompiled variant's rows per lane, tune (default) = rows per lane chosen by timing at that run, the precompiled kernel staying if it wins")
@@ -244,6 +439,11 @@ def main():
         sys.exit(2)
     if args.dry_run:
         sys.exit(dry_run(args, int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))))
+    if args.query == "q3":
+        if args.jit != "off":
+            base = os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache")
+            os.environ.setdefault("VDL_JIT_CACHE", os.path.join(base, "vdl-mi355x", "jit"))
+        return main_q3(args)
 
     import torch
     import torch.distributed as dist
@@ -433,7 +633,6 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     rows_per_s = total_rows / (elapsed / args.steps)
     kern_us = sum(scan_us) / len(scan_us)
-    achieved = my_rows * q_bytes / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
 
     out = None
     if rank == 0:
@@ -475,20 +674,41 @@ def main():
                             "fused_sql_loop_rows_per_s_1core": n_s / f1,
                             "fused_sql_loop_rows_per_s_allcores": n_s / fn, "allcores": nt,
                             "interpreter_matches_sql_loop": ok}
-        # HBM bytes per launch from the PMC counters cannot be collected from inside this process: the figure is the one
-        # of the committed rocprofv3 --pmc FETCH_SIZE pass of this same command (tools/profile_bench.sh ->
-        # profiles/traffic.json), used only when it was taken for the same kernel over the same number of rows
+        # ---- bytes the timed kernel MOVED (roofline.achieved is built on them, so frac <= 1 by construction) ------------------------
+        # libvdl counts them for the kernel form that ran (vdl_plan_scan_traffic): a scan that reads everything moves its algorithmic
+        # bytes; a staged scan (late materialisation) moves the eager columns plus 128 B per cache line of a late column that still
+        # held a live row -- counted by a census build of the same form in one untimed launch.  Whole 128-byte lines are what the
+        # memory side fetches: tools/ubench/fetch_calib.hip, profiles/r03/fetch_calib.txt.  `traffic` is the independent figure:
+        # FETCH_SIZE x 2 of the committed rocprofv3 --pmc pass, used only when it was taken for EXACTLY this kernel (name with
+        # rows per lane, stages, grid) over the same number of rows (tools/profile_bench.sh -> profiles/traffic.json).
+        moved, moved_detail = plan.scan_traffic()
+        achieved = moved / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                late = ",late" in kernel_label
-                tj = json.load(open(tpath)).get(args.query + ("_late" if late else ""), {})
-                if tj.get("rows") == my_rows:
+                tj = json.load(open(tpath)).get(kernel_label, {})
+                if tj.get("rows") == my_rows and tj.get("query") == args.query:
                     traffic = tj.get("hbm_bytes_per_launch")
-                    traffic_source = "committed profile, not measured in this run: " + tj.get("source", "profiles/traffic.json")
+                    traffic_source = "committed profile of this kernel, not measured in this run: " + tj.get("source", "profiles/traffic.json")
             except Exception:
                 traffic = None
+        # the kernel that reads every byte (precompiled k_scan / k_mscan), timed in this same run after the timed region: its
+        # fraction is the plain "algorithmic bytes / time" figure of SURVEY.md 8(d)
+        read_everything = None
+        if world == 1 and args.jit != "off" and not args.no_secondary:
+            try:
+                plan.set_jit(False)
+                us = []
+                for _ in range(12):
+                    plan.run()
+                    us.append(plan.scan_stats()[2])
+                r_label = next((k.replace("timeInMicrosecondsForFusedScan_", "") for k in plan.run()["timings"] if "FusedScan" in k), "?")
+                k_us = sum(us[2:]) / len(us[2:])
+                read_everything = {"kernel": r_label, "kernel_us": k_us, "bytes_per_launch": my_rows * q_bytes,
+                                   "achieved": my_rows * q_bytes / (k_us * 1e-6) / 1e9, "frac": my_rows * q_bytes / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBPS}
+            except Exception as exc:              # noqa: BLE001
+                read_everything = {"error": "%s: %s" % (type(exc).__name__, exc)}
         out = {
             "metric": "rows/s, TPC-H %s %s (fused VDL scan), + achieved HBM GB/s in roofline" % (args.query.upper(), args.sf.upper()),
             "value": rows_per_s, "unit": "rows/s", "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup,
@@ -501,13 +721,14 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel_label, "kernel_us": kern_us,
+                         "bytes_moved_per_launch": moved,
+                         "bytes_moved_source": "vdl_plan_scan_traffic: " + moved_detail,
                          "algorithmic_bytes_per_launch": my_rows * q_bytes,
-                         # a kernel the tuner chose with late materialisation reads the filter columns of every row and the
-                         # aggregate-only columns in the 64-byte sectors that hold a passing row: it moves fewer bytes than the
-                         # algorithmic figure (all column widths x rows), so `frac` -- defined on that figure --
-                         # can pass 1; `frac_of_traffic` prices the bytes the counters saw instead
-                         "late_materialisation": ",late" in kernel_label,
-                         "frac_of_traffic": (traffic / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBPS) if (traffic and kern_us) else None},
+                         # what the same time means in SURVEY.md 8(d)'s terms (every column of every row counted once): above the
+                         # HBM peak when the kernel reads late -- it evaluates the same rows, it does not move those bytes
+                         "algorithmic_equivalent_GBps": my_rows * q_bytes / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0,
+                         "late_materialisation": moved < my_rows * q_bytes,
+                         "read_everything_kernel": read_everything},
             "cpu_baseline": cpu_baseline,
             "revenue": (revenue[0] if revenue else None), "verified_bit_exact_vs_cpu": verified,
             "scan_kernels": {"mode": args.jit, "note": plan.jit_note()},

@@ -189,6 +189,10 @@ class Plan:
         self._e._check(self._e._L.vdl_run_sharded(self._e._c, self._h))
         return self._collect(as_numpy)
 
+    def execute_sharded(self):
+        """vdl_run_sharded only: the outputs stay in the plan (`collect()` converts them)."""
+        self._e._check(self._e._L.vdl_run_sharded(self._e._c, self._h))
+
     def run_sharded_begin(self, slot):
         self._e._check(self._e._L.vdl_run_sharded_begin(self._e._c, self._h, int(slot)))
 
@@ -354,6 +358,17 @@ class Engine:
         out = np.empty(n.value, dtype={1: np.int8, 2: np.int16, 4: np.int32, 8: np.int64}[w.value])
         self._check(self._L.vdl_download_column(self._c, name.encode(), out.ctypes.data_as(ctypes.c_void_p), out.nbytes))
         return out
+
+    def column_device(self, name):
+        """A registered / generated column as it lies in HBM: `DeviceValues`-like object with `__cuda_array_interface__`
+        (`torch.as_tensor(x, device=...)` wraps it without a copy; checkers use it to read the very bytes the engine scans)."""
+        w, n, ptr = ctypes.c_int(), ctypes.c_int64(), ctypes.c_void_p()
+        self._check(self._L.vdl_column_info(self._c, name.encode(), ctypes.byref(w), ctypes.byref(n), ctypes.byref(ptr)))
+
+        class _Column:
+            __cuda_array_interface__ = {"shape": (n.value,), "typestr": "<i%d" % w.value, "data": (ptr.value or 0, True), "version": 3, "strides": None}
+            owner = self
+        return _Column()
 
     def drop(self, name):
         self._keep.pop(name, None)
