@@ -683,6 +683,7 @@ def main():
         # rows per lane, stages, grid) over the same number of rows (tools/profile_bench.sh -> profiles/traffic.json).
         moved, moved_detail = plan.scan_traffic()
         achieved = moved / (kern_us * 1e-6) / 1e9 if kern_us > 0 else 0.0
+        tuner_note = plan.jit_note()                  # (before the read-everything run below switches the specialisation off)
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -731,7 +732,7 @@ def main():
                          "read_everything_kernel": read_everything},
             "cpu_baseline": cpu_baseline,
             "revenue": (revenue[0] if revenue else None), "verified_bit_exact_vs_cpu": verified,
-            "scan_kernels": {"mode": args.jit, "note": plan.jit_note()},
+            "scan_kernels": {"mode": args.jit, "note": tuner_note},
         }
         if world == 1 and args.query == "q6" and not args.no_secondary:
             out["also"] = secondary_measurements(eng, total_rows, args.jit)

@@ -177,8 +177,8 @@ __device__ __forceinline__ void derive(const MsArgs &C, const MsArgs &Cr, const 
         }
     }
 #pragma unroll
-    for (int c = 1; c < NC; c++) {
-        if ((only >> c) & 1u) {                            // wave-uniform
+    for (int c = 0; c < NC; c++) {                         // (from 0: a row-id column has no source and may come first -- the select pass of a front
+        if ((only >> c) & 1u) {                            //  whose only deciding columns are the row id and the set it is looked up in; wave-uniform)
             const int kind = D.dkind[c], a = D.dsrc[c], b = D.dsrc2[c];
             if (kind == VC_ROWID) {
 #pragma unroll

@@ -366,7 +366,7 @@ class Engine:
         self._check(self._L.vdl_column_info(self._c, name.encode(), ctypes.byref(w), ctypes.byref(n), ctypes.byref(ptr)))
 
         class _Column:
-            __cuda_array_interface__ = {"shape": (n.value,), "typestr": "<i%d" % w.value, "data": (ptr.value or 0, True), "version": 3, "strides": None}
+            __cuda_array_interface__ = {"shape": (n.value,), "typestr": "<i%d" % w.value, "data": (ptr.value or 0, False), "version": 3, "strides": None}
             owner = self
         return _Column()
 
