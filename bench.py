@@ -389,7 +389,7 @@ def main_q3(args):
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
     verified = bool((sums[0] == sums[1]).all())
     if rank == 0:
-        out = {"metric": "lineitem rows/s, TPC-H Q3 %s (join-index gathers + sparse GROUP BY; N > 1: RCCL all-to-all Partition)" % args.sf.upper(),
+        out = {"metric": "lineitem rows/s, TPC-H Q3 %s (join-index gathers + sparse GROUP BY; N > 1: RCCL all-to-all Partition)" % (args.sf.upper() if not args.rows else "%d lineitems" % n_li),
                "value": n_li / (elapsed / args.steps), "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
                "config": {"workload": "tpch_q3_%s" % (args.sf if not args.rows else "rows%d" % n_li), "lineitem_rows": n_li, "orders_rows": n_orders,

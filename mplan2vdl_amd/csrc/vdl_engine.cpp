@@ -373,6 +373,12 @@ static int64_t scan_bytes_moved(vdl_ctx *c, vdl_plan *p, std::string &detail) {
     auto short_name = [&](int k) { const std::string &n = sc[(size_t)k].name; return n.substr(n.find('.') == std::string::npos ? 0 : n.find('.') + 1); };
     const bool staged = !(!grouped && p->kscan[s]) && p->mjit[s] && p->mjit_form[s].lazy > 0;
     int64_t total = 0;
+    if (!grouped && p->kscan[s]) {                             // the hand-tuned single-aggregate kernel: its own argument block
+        const ScanArgs &a = p->sargs[s];
+        for (int k = 0; k < a.ncol; k++) { total += a.n * a.width[k]; detail += short_name(k) + "=" + std::to_string(a.n * a.width[k]) + " "; }
+        detail += "(every column read with the tile)";
+        return total;
+    }
     if (!staged) {
         for (int k = 0; k < cols.ncol; k++)
             if (cols.kind[k] == VC_DIRECT) { total += cols.n * cols.width[k]; detail += short_name(k) + "=" + std::to_string(cols.n * cols.width[k]) + " "; }
