@@ -121,8 +121,10 @@ def _fk_graph(cfg):
     return out
 
 
-def synth_columns(meta_dir, cfg, vdl_text, scale=2e-4, seed=1, extra=()):
-    """{column key path: numpy array} for every Load of `vdl_text` (and every path in `extra`)."""
+def synth_columns(meta_dir, cfg, vdl_text, scale=2e-4, seed=1, extra=(), clustered=()):
+    """{column key path: numpy array} for every Load of `vdl_text` (and every path in `extra`).
+    clustered: join-index columns (e.g. "lineitem.lineitem_orders") whose rows come in the dimension's order, as dbgen writes
+    lineitem clustered by order -- the same random draw, sorted: keys derived through it (l_orderkey) are then non-decreasing."""
     codes = _per_column_codes(meta_dir)
     patterns = _like_patterns(vdl_text)
     info = {name: ci for name, ci in cfg.colinfo.to_list()}
@@ -173,6 +175,8 @@ def synth_columns(meta_dir, cfg, vdl_text, scale=2e-4, seed=1, extra=()):
             v = a if idx == mine[0] else (i // n0 + a * 7) % n1
         else:
             v = _rng(seed, "%s.%s" % key).integers(0, rows[dim], n)
+            if "%s.%s" % key in clustered:
+                v = np.sort(v)
         memo[key] = np.asarray(v, dtype=np.int64)
         return memo[key]
 

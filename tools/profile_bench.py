@@ -83,6 +83,11 @@ for query in ("q6", "q1"):
     pin = pin_of(label)
     print(query, "plain run chose", label, "-> pin", pin, flush=True)
     runs = [("tuned", ["--jit", "tune"], {"VDL_JIT_PIN": pin} if pin else {}, label)] if pin else []
+    # the staged form's sibling (one / two filter columns read with the tile: within a per cent or two of each other, so either
+    # may be what another box's tuner keeps): profiled too, so that traffic.json has an entry for whichever a run reports
+    if pin and "late=" in pin and not pin.endswith("late=0"):
+        other = pin[:-1] + ("1" if pin.endswith("2") else "2")
+        runs.append(("sibling", ["--jit", "tune"], {"VDL_JIT_PIN": other}, None))
     runs.append(("everything", ["--jit", "off"], {}, None))
     for name, jit, env, want in runs:
         tag = "%s_%s" % (query, name)

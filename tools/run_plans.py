@@ -2,7 +2,8 @@
 """Every TPC-H plan the front end compiles, on the GPU over a synthetic catalog at a chosen scale
 (fraction of the SF10 catalog the metadata describes): wall time per query, summed per-statement kernel
 time, the slowest statements, and the oracle's single-core time on the same columns for comparison.
-    python tools/run_plans.py [scale=0.05] [plans...]"""
+    python tools/run_plans.py [scale=0.05] [plans...]
+RUN_PLANS_CLUSTERED=1: lineitem comes clustered by order (its join index into orders is non-decreasing), as dbgen writes it."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -17,7 +18,7 @@ cfg = frontend.load_metadata(META)
 print("scale %g of SF10: lineitem %d rows" % (scale, catalog.scaled_rows(59986052, scale)))
 for n in plans:
     text = frontend.compile_plan(open(os.path.join(META, "%02d.sql.mplan" % n)).read(), cfg)
-    cols = catalog.synth_columns(META, cfg, text, scale=scale)
+    cols = catalog.synth_columns(META, cfg, text, scale=scale, clustered=("lineitem.lineitem_orders",) if os.environ.get("RUN_PLANS_CLUSTERED") == "1" else ())
     in_bytes = sum(v.nbytes for v in cols.values())
     e = m.Engine(0)
     for k, v in cols.items():
