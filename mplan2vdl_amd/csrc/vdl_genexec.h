@@ -152,6 +152,14 @@ struct GenExec {
         return sel->first_slot;
     }
     struct RunHeads { BufP ctl, heads, wordhd, offsets; int64_t count = 0; SelP sel, child; };
+    // run heads a Partition's sortedness pass left behind (partition_positions): when the key turns out to be in order, the folds of
+    // the GROUP BY run over that very buffer and need neither a head pass nor a count of their own
+    struct SortedHeads { BufP key, heads, offsets; int64_t count = 0; };
+    std::map<const void *, SortedHeads> sorted_heads;           // key entries buffer -> (kept alive by the entry)
+    bool group_batch_on = !getenv("VDL_NO_GROUP_BATCH");        // all folds of one GROUP BY in one launch (launch_group_fold)
+    std::vector<char> done;                                     // statements executed ahead of their turn (ensure)
+    const std::map<int, DVec> *cur_over = nullptr;
+    std::vector<char> needed_now;
     std::map<std::pair<const void *, const void *>, RunHeads> heads_of;   // (control entries buffer, its selection) -> run heads (both kept alive by the entry)
     struct DenseHeads { BufP ctl, ctlv, heads, wordhd; };
     std::map<std::pair<const void *, const void *>, DenseHeads> dense_heads;    // (control data, its validity) of a stored control vector -> run heads
@@ -760,13 +768,25 @@ struct GenExec {
         if (o.n > 1 && !data.valid && partition_passes(pcount) > 1 && !getenv("VDL_NO_SORTED_SHORTCUT")) {
             // data already in order (lineitems are clustered by order key: the group keys of Q3 / Q18 arrive sorted)?
             // bucket = clamp(data - min) is monotone, so the stable ranks are then 0, 1, 2, ... without a single radix pass
-            BufP flag = dev_alloc(c, 2 * sizeof(int64_t));
-            const int64_t init[2] = {0, INT64_MIN};
+            BufP flag = dev_alloc(c, 3 * sizeof(int64_t));
+            const int64_t init[3] = {0, INT64_MIN, 0};
             HIP_CHECK(hipMemcpyAsync(flag->p, init, sizeof init, hipMemcpyHostToDevice, s));
-            HIP_CHECK(launch_sorted_check(src_of(data), o.n, (int64_t *)flag->p, s));
-            int64_t seen[2] = {0, 0};
+            // (the same pass leaves the run heads: if the data is in order the folds over it need no head pass and no count of
+            // their own -- and their number comes back with the verdict, in this one round trip)
+            BufP heads = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(o.n), 1));
+            HIP_CHECK(launch_sorted_heads(src_of(data), o.n, (uint64_t *)heads->p, (int64_t *)flag->p, s));
+            const int64_t nb = (o.n + compact_tile() - 1) / compact_tile();
+            BufP counts = dev_alloc(c, sizeof(int64_t) * (size_t)(nb + 1));
+            HIP_CHECK(launch_compact_count((const uint64_t *)heads->p, o.n, (int64_t *)counts->p, s));
+            HIP_CHECK(launch_compact_scan((int64_t *)counts->p, nb, s));
+            int64_t seen[2] = {0, 0}, nheads = 0;
             HIP_CHECK(hipMemcpyAsync(seen, flag->p, sizeof seen, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipMemcpyAsync(&nheads, (int64_t *)counts->p + nb, sizeof nheads, hipMemcpyDeviceToHost, s));
             HIP_CHECK(hipStreamSynchronize(s));
+            if (!seen[0] && data.kind == DVec::DENSE && data.data) {
+                SortedHeads &sh = sorted_heads[data.data->p];
+                sh.key = data.data; sh.heads = heads; sh.offsets = counts; sh.count = nheads;
+            }
             const int64_t descends = seen[0];
             // the largest bucket that occurs (bucket = clamp(data - min, 0, cnt) is monotone in the data)
             max_bucket = seen[1] <= pmin ? 0 : ((int64_t)((uint64_t)seen[1] - (uint64_t)pmin) < 0 ? pcount : std::min<int64_t>((int64_t)((uint64_t)seen[1] - (uint64_t)pmin), pcount));
@@ -794,6 +814,18 @@ struct GenExec {
                                        (int64_t *)nvalid->p, (int64_t *)o.data->p, s, max_bucket));
         }
         return o;
+    }
+
+    // a statement (and what it depends on) ahead of its turn: statements are pure, so order does not matter; the main loop skips it
+    void ensure(int id) {
+        if (id <= 0 || done[(size_t)id] || vec[(size_t)id].kind != DVec::NONE) return;
+        if (cur_over && cur_over->count(id)) { vec[(size_t)id] = cur_over->at(id); done[(size_t)id] = 1; return; }
+        const Node &n = p->prog.at(id);
+        if (!column_filter(n))
+            for (int opnd : {n.a, n.b, n.c}) ensure(opnd);
+        vec[(size_t)id] = exec(n);
+        done[(size_t)id] = 1;
+        if (p->tracing) snapshot(n, vec[(size_t)id]);
     }
 
     DVec exec(const Node &n) {
@@ -984,6 +1016,7 @@ struct GenExec {
             if (src.n != pos.n) throw Error(VDL_ERR_SHAPE, "Scatter (Id " + std::to_string(n.id) + "): source and position lengths differ");
             o.kind = DVec::DENSE; o.n = fold.n;
             o.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(o.n, 1));
+            if (pos.perm && pos.iota && !pos.valid && src.n == o.n) return src;   // the identity (the partitioned data was in order): nothing moves
             if (pos.perm && !pos.valid && !src.valid && src.n == o.n) {      // a permutation of all slots: every slot is written
                 HIP_CHECK(launch_scatter(src_of(src), nullptr, src_of(pos), nullptr, src.n, o.n, (int64_t *)o.data->p, nullptr, s));
                 return o;
@@ -1037,11 +1070,62 @@ struct GenExec {
                 if (!rh.heads) {
                     const size_t nw = (size_t)std::max<int64_t>(nwords(m), 1);
                     rh.ctl = sc.data; rh.sel = sel;
-                    rh.heads = dev_alloc(c, sizeof(uint64_t) * nw);
+                    auto known = sorted_heads.find(sc.data->p);
+                    if (group_batch_on && known != sorted_heads.end()) {
+                        // the Partition found this key in order and left its run heads and their count (partition_positions)
+                        rh.heads = known->second.heads; rh.offsets = known->second.offsets; rh.count = known->second.count;
+                    } else {
+                        rh.heads = dev_alloc(c, sizeof(uint64_t) * nw);
+                        rh.wordhd = dev_alloc(c, sizeof(int64_t) * (nw + (size_t)maxscan_blocks((int64_t)nw) + 1));
+                        HIP_CHECK(launch_fold_heads(i64_src(sc.data), nullptr, m, (uint64_t *)rh.heads->p, (int64_t *)rh.wordhd->p, s));
+                        rh.count = popcount(rh.heads, m, &rh.offsets);
+                    }
+                    rh.child = child_selection(sel, rh.heads, rh.count, rh.offsets);
+                }
+                if (group_batch_on) {
+                    // every fold of this GROUP BY in one launch: the folds over the same control statement whose data can be had
+                    // now (their operand statements are run ahead of their turn: statements are pure) join this one
+                    std::vector<int> members{n.id};
+                    std::vector<Src> srcs{dsrc};
+                    std::vector<BufP> hold;
+                    for (int id : p->prog.order) {
+                        const Node &f = p->prog.at(id);
+                        if (id == n.id || f.a != n.a || (size_t)id >= needed_now.size() || !needed_now[(size_t)id] || done[(size_t)id]) continue;
+                        if (f.op != Op::FoldSum && f.op != Op::FoldMin && f.op != Op::FoldMax && f.op != Op::FoldCount && f.op != Op::FoldChoose) continue;
+                        if (cur_over && cur_over->count(id)) continue;
+                        ensure(f.b);
+                        const DVec &fd = V(f.b);
+                        if (fd.kind == DVec::SPARSE && fd.sel == sel) srcs.push_back(i64_src(fd.data));
+                        else if (fd.kind == DVec::RANGE && fd.step == 0 && fd.n == sc.n && subset(bitmap_of(sel), fd.valid)) srcs.push_back(src_of(fd));
+                        else continue;
+                        members.push_back(id);
+                    }
+                    std::vector<BufP> outs(members.size());
+                    const int64_t G = rh.count;
+                    for (size_t at = 0; at < members.size(); at += kMaxGroupFolds) {
+                        GroupFoldArgs ga;
+                        for (size_t k = at; k < members.size() && k < at + kMaxGroupFolds; k++) {
+                            const Op fop = p->prog.at(members[k]).op;
+                            const int fk = fop == Op::FoldSum ? 0 : fop == Op::FoldMin ? 1 : fop == Op::FoldMax ? 2 : fop == Op::FoldCount ? 3 : 4;
+                            outs[k] = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(G, 1));
+                            if (fk != 4 && G > 0)
+                                HIP_CHECK(launch_fill_words((uint64_t *)outs[k]->p, fk == 1 ? (uint64_t)INT64_MAX : fk == 2 ? (uint64_t)INT64_MIN : 0ull, G, s));
+                            ga.kind[ga.nfold] = fk; ga.data[ga.nfold] = srcs[k]; ga.out[ga.nfold] = (int64_t *)outs[k]->p;
+                            ga.nfold++;
+                        }
+                        if (G > 0) HIP_CHECK(launch_group_fold(ga, (const uint64_t *)rh.heads->p, m, (const int64_t *)rh.offsets->p, s));
+                    }
+                    for (size_t k = 1; k < members.size(); k++) {
+                        vec[(size_t)members[k]] = make_sparse(rh.child, outs[k]);
+                        done[(size_t)members[k]] = 1;
+                        if (p->tracing) snapshot(p->prog.at(members[k]), vec[(size_t)members[k]]);
+                    }
+                    return make_sparse(rh.child, outs[0]);
+                }
+                if (!rh.wordhd) {                                   // (heads adopted from the Partition, batch switched off meanwhile: never both)
+                    const size_t nw = (size_t)std::max<int64_t>(nwords(m), 1);
                     rh.wordhd = dev_alloc(c, sizeof(int64_t) * (nw + (size_t)maxscan_blocks((int64_t)nw) + 1));
                     HIP_CHECK(launch_fold_heads(i64_src(sc.data), nullptr, m, (uint64_t *)rh.heads->p, (int64_t *)rh.wordhd->p, s));
-                    rh.count = popcount(rh.heads, m, &rh.offsets);
-                    rh.child = child_selection(sel, rh.heads, rh.count, rh.offsets);
                 }
                 // FoldChoose takes a run's first element, and here every entry holds one: the values at the run heads, i.e. one
                 // compaction by the head bitmap (every output column of a GROUP BY is such a fold, Vlite.hs:1056-1060)
@@ -1230,6 +1314,8 @@ struct GenExec {
     void run_nodes(const std::vector<int> &targets, const std::map<int, DVec> *overrides) {
         const Program &P = p->prog;
         std::vector<char> needed(P.nodes.size(), 0);
+        done.assign(P.nodes.size(), 0);
+        cur_over = overrides;
         for (int id : targets) needed[(size_t)id] = 1;
         for (auto it = P.order.rbegin(); it != P.order.rend(); ++it) {
             const Node &n = P.at(*it);
@@ -1292,6 +1378,7 @@ struct GenExec {
             }
             if (rv >= 0 && fs >= 0 && P.at(fs).a == rv && readers[(size_t)rv].size() == 1 && n_uses[(size_t)rv] == 1) lazy_pred_ok[(size_t)id] = 1;
         }
+        needed_now = needed;
         p->outs.clear();
         p->timings.clear();
         if (p->profiling && !p->stmt_ev[1]) { HIP_CHECK(hipEventCreate(&p->stmt_ev[0])); HIP_CHECK(hipEventCreate(&p->stmt_ev[1])); }
@@ -1301,6 +1388,11 @@ struct GenExec {
             const Node &n = P.at(P.order[k]);
             if (!needed[(size_t)n.id]) continue;
             if (overrides && overrides->count(n.id)) { vec[(size_t)n.id] = overrides->at(n.id); continue; }
+            if (done[(size_t)n.id]) {                              // ran ahead of its turn (ensure): only its operands' lifetimes end here
+                for (int opnd : {n.a, n.b, n.c})
+                    if (opnd > 0 && last_use[(size_t)opnd] == (int)k) vec[(size_t)opnd] = DVec{};
+                continue;
+            }
             if (p->profiling) HIP_CHECK(hipEventRecord(e0, s));
             vec[(size_t)n.id] = exec(n);
             if (p->tracing) snapshot(n, vec[(size_t)n.id]);

@@ -647,6 +647,88 @@ hipError_t launch_compact_write(Src v, const uint64_t *valid, int64_t n, const i
     return launch_status();
 }
 
+// ---- every fold of one GROUP BY in one launch, results packed per run ---------------------------------------------------------
+// (the tail of a plan whose front is fused: Partition -> Scatter x k -> Fold x k over the survivors, Vlite.hs:1056-1060,1082-1098.
+// Statement by statement that is a head pass, a count, a compaction per FoldChoose and fill + segmented fold + compaction per
+// aggregate -- a dozen launches of a few microseconds of work each; here: one pass over the entries for all of them.)
+// A block owns one compaction tile (64 head words = 4096 entries), a wave walks words of it, lane l holds entry 64 w + l.  Group of
+// an entry = heads before the tile (offsets) + heads before its word inside the tile + heads at or before its lane - 1.  Values are
+// folded along the lanes with a segmented shuffle scan bounded by the head word; the last lane of a segment hands the partial to
+// out[group]: a plain store when the run begins and ends inside the word (nobody else adds to it), an atomic otherwise.
+__device__ __forceinline__ void atomic_combine(int rk, int64_t *addr, int64_t v);
+__global__ __launch_bounds__(256) void k_group_fold(GroupFoldArgs a, const uint64_t *heads, int64_t m, const int64_t *offsets) {
+    __shared__ int wprefix[kCompactWords];
+    __shared__ uint64_t wmask[kCompactWords];
+    const int64_t nw = (m + 63) >> 6;
+    const int64_t w0 = (int64_t)blockIdx.x * kCompactWords;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    if (tid < kCompactWords) {
+        const int64_t w = w0 + tid;
+        const uint64_t hm = w < nw ? heads[w] : 0ull;             // (bits past m are clear: launch_sorted_heads / k_seg_heads)
+        wmask[tid] = hm;
+        const int cnt = __popcll(hm);
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) { const int y = __shfl_up(incl, off, kWave); if (lane >= off) incl += y; }
+        wprefix[tid] = incl - cnt;
+    }
+    __syncthreads();
+    const int64_t base = offsets[blockIdx.x];
+    constexpr int U = 4, NW = 256 / kWave;
+    const uint64_t upto = lane == 63 ? ~0ull : ((2ull << lane) - 1);        // lanes at or before mine
+    for (int j = 0; j < a.nfold; j++) {                                     // wave-uniform
+        const int kind = a.kind[j];
+        const Src d = a.data[j];
+        int64_t *out = a.out[j];
+        const int rk = kind == 1 ? R_MIN : kind == 2 ? R_MAX : R_SUM;
+        by_kind(d.kind, [&](auto kv) {
+            for (int k0 = wave * U; k0 < kCompactWords; k0 += NW * U) {
+                int64_t x[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int64_t i = ((w0 + k0 + u) << 6) + lane;
+                    x[u] = kind == 3 ? 1 : ldk<decltype(kv)::value>(d, i < m ? i : 0);
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int64_t i = ((w0 + k0 + u) << 6) + lane;
+                    if (((w0 + k0 + u) << 6) >= m) break;                   // wave-uniform: past the last word
+                    const uint64_t hw = wmask[k0 + u];
+                    const bool in = i < m;
+                    const uint64_t hm = hw & upto;
+                    const int64_t g = base + wprefix[k0 + u] + __popcll(hm) - 1;
+                    if (kind == 4) {                                        // FoldChoose: the run's first value
+                        if (in && ((hw >> lane) & 1ull)) out[g] = x[u];
+                        continue;
+                    }
+                    const int seg0 = hm ? 63 - __clzll((long long)hm) : 0;  // first lane of my segment in this word
+                    int64_t v = in ? x[u] : r_identity(rk);
+#pragma unroll
+                    for (int off = 1; off < kWave; off <<= 1) {
+                        const int64_t y = __shfl_up(v, off, kWave);
+                        if (lane - off >= seg0) v = r_combine(rk, v, y);
+                    }
+                    const bool last_in = i + 1 >= m;                        // the vector ends here
+                    const bool tail = in && (lane == kWave - 1 || last_in || ((hw >> (lane + 1)) & 1ull));
+                    if (tail) {
+                        // the whole run lies in this word: it begins here (a head at or before me) and ends before the word does
+                        const bool whole = hm != 0 && (lane < kWave - 1 || last_in);
+                        if (whole) out[g] = v; else atomic_combine(rk, &out[g], v);
+                    }
+                }
+            }
+        });
+    }
+}
+hipError_t launch_group_fold(const GroupFoldArgs &a, const uint64_t *heads, int64_t m, const int64_t *offsets, hipStream_t s) {
+    (void)hipGetLastError();
+    const int64_t nb = (m + compact_tile() - 1) / compact_tile();
+    if (nb <= 0 || a.nfold <= 0) return hipSuccess;
+    if (a.nfold > kMaxGroupFolds) return hipErrorInvalidValue;
+    k_group_fold<<<(int)nb, 256, 0, s>>>(a, heads, m, offsets);
+    return launch_status();
+}
+
 // ---- FoldSelect over general runs (never emitted by mplan2vdl, whose six call sites use unit runs: Vlite.hs:702-1228) ----
 __global__ __launch_bounds__(256) void k_run_heads(const int64_t *ctl, int64_t m, int64_t *flags, int64_t *flags_copy) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;

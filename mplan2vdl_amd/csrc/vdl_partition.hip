@@ -290,6 +290,37 @@ hipError_t launch_sorted_check(Src d, int64_t n, int64_t *flag, hipStream_t s) {
     return launch_status();
 }
 
+// One wave per 64 entries: neighbour compare through a shuffle (lane 0 reads its predecessor), heads word by ballot.
+__global__ __launch_bounds__(256) void k_sorted_heads(Src d, int64_t n, uint64_t *heads, int64_t *flag) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t nw = (n + 63) >> 6;
+    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave);
+    bool bad = false;
+    int64_t mx = INT64_MIN;
+    by_kind(d.kind, [&](auto kd) {
+        for (int64_t w = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; w < nw; w += wstride) {
+            const int64_t i = (w << 6) + lane;
+            const bool in = i < n;
+            const int64_t x = ldk<decltype(kd)::value>(d, in ? i : n - 1);
+            int64_t prev = __shfl_up(x, 1, kWave);
+            if (lane == 0) prev = i > 0 ? ldk<decltype(kd)::value>(d, i - 1) : x;
+            bad |= in && x < prev;
+            mx = in && x > mx ? x : mx;
+            const uint64_t hm = __ballot(in && (i == 0 || x != prev));
+            if (lane == 0) heads[w] = hm;
+        }
+    });
+    if (__ballot(bad) != 0 && lane == 0) flag[0] = 1;
+    mx = wave_reduce(mx, R_MAX);
+    if (lane == 0 && mx > *(volatile int64_t *)&flag[1]) atomicMax((long long *)&flag[1], (long long)mx);
+}
+hipError_t launch_sorted_heads(Src d, int64_t n, uint64_t *heads, int64_t *flag, hipStream_t s) {
+    (void)hipGetLastError();
+    if (n <= 0) return hipSuccess;
+    k_sorted_heads<<<grid_for(n, 256, 4), 256, 0, s>>>(d, n, heads, flag);
+    return launch_status();
+}
+
 // scratch layout is owned by the caller (vdl_engine.cpp); see launch_partition's arguments.
 hipError_t launch_partition(Src data, const uint64_t *valid, int64_t n, int64_t pmin, int64_t pcount,
                             int64_t *hist /* 256*ntiles + 1 */, int64_t *scan_scratch /* prefix_sum_blocks(256*ntiles)+1 */,

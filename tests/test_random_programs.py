@@ -123,7 +123,7 @@ def test_generator_produces_programs_the_oracle_accepts():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [None, "VDL_SPARSE_ALWAYS", "VDL_NO_SPARSE", "VDL_NO_EXPR_FUSION", "VDL_NO_FILTER_FUSION"])
+@pytest.mark.parametrize("mode", [None, "VDL_SPARSE_ALWAYS", "VDL_NO_SPARSE", "VDL_NO_EXPR_FUSION", "VDL_NO_FILTER_FUSION", "VDL_NO_GROUP_BATCH"])
 def test_random_programs_match_the_oracle(monkeypatch, mode):
     if mode:
         monkeypatch.setenv(mode, "1")

@@ -74,7 +74,7 @@ def test_q16_as_written_differs_from_what_the_reference_compiles(cfg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [None, "VDL_SPARSE_ALWAYS", "VDL_NO_SPARSE", "VDL_NO_PROJECTION"])
+@pytest.mark.parametrize("mode", [None, "VDL_SPARSE_ALWAYS", "VDL_NO_SPARSE", "VDL_NO_PROJECTION", "VDL_NO_GROUP_BATCH"])
 @pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-5] for p in FIXTURES])
 def test_engine_reproduces_the_committed_fixtures(cfg, monkeypatch, path, mode):
     if mode:

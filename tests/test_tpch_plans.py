@@ -3,6 +3,7 @@ the reference's own `error` calls, tests/test_frontend.py) runs end to end over 
 respects the catalog metadata (mplan2vdl_amd/catalog.py): oracle on the CPU, engine on the GPU, bit-exact."""
 import os
 
+import numpy as np
 import pytest
 
 from mplan2vdl_amd import catalog, frontend
@@ -159,7 +160,7 @@ def test_engine_matches_oracle_on_the_vlite_dialect(cfg, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["VDL_SPARSE_ALWAYS", "VDL_NO_SPARSE", "VDL_NO_EXPR_FUSION", "VDL_NO_FILTER_FUSION", "VDL_NO_PROJECTION", "VDL_NO_DIM_SCAN"])
+@pytest.mark.parametrize("mode", ["VDL_SPARSE_ALWAYS", "VDL_NO_SPARSE", "VDL_NO_EXPR_FUSION", "VDL_NO_FILTER_FUSION", "VDL_NO_PROJECTION", "VDL_NO_DIM_SCAN", "VDL_NO_GROUP_BATCH"])
 def test_sparse_vector_routes_agree(cfg, monkeypatch, mode):
     """The general executor keeps vectors that only hold values on a selection in compact form after selective
     filters, and runs chains of single-reader element-wise operators as one fused kernel.  Sparse forced on for
@@ -180,6 +181,27 @@ def test_sparse_vector_routes_agree(cfg, monkeypatch, mode):
         got = e.run_vdl(text)["results"]
         e.close()
         assert got == want, (mode, "hierarchical", n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [None, "VDL_NO_GROUP_BATCH", "VDL_NO_SPARSE", "VDL_NO_PROJECTION", "VDL_NO_SORTED_SHORTCUT"])
+def test_plans_over_lineitem_clustered_by_order(cfg, monkeypatch, mode):
+    """dbgen writes lineitem clustered by order: the join index into orders -- and every group key built from the order key
+    (Q3, Q10, Q18) -- is then non-decreasing, the Partition's sortedness pass finds that, hands out identity ranks AND the run
+    heads, and the folds of the GROUP BY run as one launch over them (launch_group_fold).  Every switch that takes another route
+    gives the same answers, and all of them the oracle's."""
+    if mode:
+        monkeypatch.setenv(mode, "1")
+    for n in (3, 5, 9, 10, 18, 20):
+        text = frontend.compile_plan(open(os.path.join(META, "%02d.sql.mplan" % n)).read(), cfg)
+        cols = catalog.synth_columns(META, cfg, text, scale=5e-4, seed=3, clustered=("lineitem.lineitem_orders",))
+        assert (np.diff(cols["lineitem.lineitem_orders"]) >= 0).all()
+        want = oracle_run(text, cols)
+        e = engine_with(cols)
+        got = e.run_vdl(text)["results"]
+        e.close()
+        assert got == want, (mode, n)
+        assert any(len(list(v.values())[0]) for v in want.values()) or n == 18, n
 
 
 def test_which_plans_have_a_fused_front(cfg):
