@@ -945,8 +945,10 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
         // (the select pass left the counts in `offsets` too, with a 0 behind them: a device-wide exclusive prefix sum over
         // ntiles + 1 words puts the total there -- Q3 at SF10 has 29 K tiles, a one-block scan took 26 us)
         HIP_CHECK(launch_prefix_sum((int64_t *)offsets->p, ntiles + 1, (int64_t *)sums->p, c->stream));
-        HIP_CHECK(hipMemcpyAsync(&m, (int64_t *)offsets->p + ntiles, sizeof m, hipMemcpyDeviceToHost, c->stream));
+        int64_t *back = c->pinned(1) ? c->pinned(1) : &m;          // (pinned: a pageable destination is staged and costs a second round trip)
+        HIP_CHECK(hipMemcpyAsync(back, (int64_t *)offsets->p + ntiles, sizeof m, hipMemcpyDeviceToHost, c->stream));
         HIP_CHECK(hipStreamSynchronize(c->stream));             // (also: `d` has been read by the first copy)
+        m = *back;
         sel->idx = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(m, 1));
         d.out_idx = (int64_t *)sel->idx->p;
         for (size_t o = 0; o < distinct.size(); o++) {

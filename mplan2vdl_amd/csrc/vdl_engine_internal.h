@@ -176,6 +176,14 @@ struct vdl_ctx {
     std::shared_ptr<Pool> pool = std::make_shared<Pool>();
     std::shared_ptr<CommState> comm;       // vdl_comm_init / vdl_comm_init_host
     std::string err;
+    // a few words of PINNED host memory for the round trips of the executors (survivor counts, sortedness verdicts): a copy
+    // into pageable memory is staged by the runtime and cost 20-30 us of idle GPU each (Q3 at SF10: three of them per query)
+    int64_t *pinned_words = nullptr;
+    int64_t *pinned(int words) {
+        if (!pinned_words && hipHostMalloc((void **)&pinned_words, sizeof(int64_t) * 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); pinned_words = nullptr; }
+        return words <= 64 ? pinned_words : nullptr;
+    }
+    ~vdl_ctx() { if (pinned_words) (void)hipHostFree(pinned_words); }
 };
 
 struct vdl_plan {

@@ -223,6 +223,8 @@ struct GenExec {
     // ---- fused element-wise trees -------------------------------------------------------------------------
     bool fuse_on = !getenv("VDL_NO_EXPR_FUSION");
     std::vector<int> n_uses;                 // readers of each statement in this run (targets count as one more)
+    std::vector<int> value_uses;             // ... of its VALUES: RangeV readers, which only want its shape, left out
+    std::vector<char> value_read_by_binary_only;
     std::vector<char> read_by_binary_only;
     static bool leafable(const DVec &v) { return v.kind == DVec::DENSE || v.kind == DVec::COLUMN || v.kind == DVec::RANGE; }
     std::shared_ptr<ExprNode> expr_of(const DVec &v) {
@@ -473,7 +475,9 @@ struct GenExec {
         };
         std::shared_ptr<ExprNode> el, er;
         if (!node_of(a, el) || !node_of(b, er)) return false;
-        const bool lazy = n_uses[(size_t)n.id] == 1 && read_by_binary_only[(size_t)n.id];
+        // (RangeV readers want the shape of a vector, not its values -- exec(RangeV) serves them from the selection -- so they do not
+        // end a chain: Q3's composite key, whose every step also feeds a constant-making RangeV, is ONE kernel over the survivors)
+        const bool lazy = value_uses[(size_t)n.id] == 1 && value_read_by_binary_only[(size_t)n.id];
         if (!lazy && el->bin < 0 && er->bin < 0) return false;                // a lone operator: the plain kernel
         auto t = std::make_shared<ExprNode>();
         t->bin = n.bin; t->l = el; t->r = er;
@@ -768,21 +772,20 @@ struct GenExec {
         if (o.n > 1 && !data.valid && partition_passes(pcount) > 1 && !getenv("VDL_NO_SORTED_SHORTCUT")) {
             // data already in order (lineitems are clustered by order key: the group keys of Q3 / Q18 arrive sorted)?
             // bucket = clamp(data - min) is monotone, so the stable ranks are then 0, 1, 2, ... without a single radix pass
-            BufP flag = dev_alloc(c, 3 * sizeof(int64_t));
-            const int64_t init[3] = {0, INT64_MIN, 0};
-            HIP_CHECK(hipMemcpyAsync(flag->p, init, sizeof init, hipMemcpyHostToDevice, s));
             // (the same pass leaves the run heads: if the data is in order the folds over it need no head pass and no count of
-            // their own -- and their number comes back with the verdict, in this one round trip)
-            BufP heads = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(o.n), 1));
-            HIP_CHECK(launch_sorted_heads(src_of(data), o.n, (uint64_t *)heads->p, (int64_t *)flag->p, s));
+            // their own -- and their number comes back with the verdict, in this one round trip through pinned memory)
             const int64_t nb = (o.n + compact_tile() - 1) / compact_tile();
-            BufP counts = dev_alloc(c, sizeof(int64_t) * (size_t)(nb + 1));
+            BufP counts = dev_alloc(c, sizeof(int64_t) * (size_t)(nb + 3));                 // tile counts, their total, then {descends, max}
+            int64_t *flag = (int64_t *)counts->p + nb + 1;
+            BufP heads = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(o.n), 1));
+            HIP_CHECK(launch_sorted_heads(src_of(data), o.n, (uint64_t *)heads->p, flag, s));     // (sets the two flag words itself)
             HIP_CHECK(launch_compact_count((const uint64_t *)heads->p, o.n, (int64_t *)counts->p, s));
             HIP_CHECK(launch_compact_scan((int64_t *)counts->p, nb, s));
-            int64_t seen[2] = {0, 0}, nheads = 0;
-            HIP_CHECK(hipMemcpyAsync(seen, flag->p, sizeof seen, hipMemcpyDeviceToHost, s));
-            HIP_CHECK(hipMemcpyAsync(&nheads, (int64_t *)counts->p + nb, sizeof nheads, hipMemcpyDeviceToHost, s));
+            int64_t stack[3] = {0, 0, 0};
+            int64_t *back = c->pinned(3) ? c->pinned(3) : stack;
+            HIP_CHECK(hipMemcpyAsync(back, (int64_t *)counts->p + nb, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
             HIP_CHECK(hipStreamSynchronize(s));
+            const int64_t nheads = back[0], seen[2] = {back[1], back[2]};
             if (!seen[0] && data.kind == DVec::DENSE && data.data) {
                 SortedHeads &sh = sorted_heads[data.data->p];
                 sh.key = data.data; sh.heads = heads; sh.offsets = counts; sh.count = nheads;
@@ -845,6 +848,10 @@ struct GenExec {
                 if (n.imm1 == 0) { o.kind = DVec::OHCONST; o.n = r.n; o.data = r.data; o.from = n.imm0; return o; }
                 DVec d = densify(r);
                 o.kind = DVec::RANGE; o.n = d.n; o.from = n.imm0; o.step = n.imm1; o.valid = d.valid;
+                return o;
+            }
+            if (r.kind == DVec::EXPR && r.sel) {               // a pending chain over the entries of a selection: values exactly there
+                o.kind = DVec::RANGE; o.n = r.n; o.from = n.imm0; o.step = n.imm1; o.valid = bitmap_of(r.sel);
                 return o;
             }
             if (r.kind == DVec::EXPR) {
@@ -1332,6 +1339,8 @@ struct GenExec {
         for (int id : targets) last_use[(size_t)id] = 1 << 30;      // targets stay alive for the caller
         n_uses.assign(P.nodes.size(), 0);
         read_by_binary_only.assign(P.nodes.size(), 1);
+        value_uses.assign(P.nodes.size(), 0);
+        value_read_by_binary_only.assign(P.nodes.size(), 1);
         std::vector<std::vector<std::pair<int, int>>> readers(P.nodes.size());      // (reader id, operand slot)
         for (size_t k = 0; k < P.order.size(); k++) {
             const Node &n = P.at(P.order[k]);
@@ -1341,13 +1350,17 @@ struct GenExec {
                 if (opnd > 0) {
                     n_uses[(size_t)opnd]++;
                     if (n.op != Op::Binary) read_by_binary_only[(size_t)opnd] = 0;
+                    if (n.op != Op::RangeV) {                      // (RangeV reads the shape only)
+                        value_uses[(size_t)opnd]++;
+                        if (n.op != Op::Binary) value_read_by_binary_only[(size_t)opnd] = 0;
+                    }
                     readers[(size_t)opnd].push_back({n.id, slot});
                 }
                 slot++;
             }
-            if (n.op == Op::Binary && n.a == n.b && n.a > 0) n_uses[(size_t)n.a]--;       // x op x: both operands are one reader
+            if (n.op == Op::Binary && n.a == n.b && n.a > 0) { n_uses[(size_t)n.a]--; value_uses[(size_t)n.a]--; }       // x op x: both operands are one reader
         }
-        for (int id : targets) n_uses[(size_t)id] += 2;
+        for (int id : targets) { n_uses[(size_t)id] += 2; value_uses[(size_t)id] += 2; }
         lazy_gather_ok.assign(P.nodes.size(), 0);
         for (int id : P.order) {
             const Node &g = P.at(id);

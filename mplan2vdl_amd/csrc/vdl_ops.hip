@@ -656,6 +656,8 @@ hipError_t launch_compact_write(Src v, const uint64_t *valid, int64_t n, const i
 // folded along the lanes with a segmented shuffle scan bounded by the head word; the last lane of a segment hands the partial to
 // out[group]: a plain store when the run begins and ends inside the word (nobody else adds to it), an atomic otherwise.
 __device__ __forceinline__ void atomic_combine(int rk, int64_t *addr, int64_t v);
+// NF = folds handled per trip over the tile (their loads are issued together: 2 words x NF values in flight per lane)
+template <int NF>
 __global__ __launch_bounds__(256) void k_group_fold(GroupFoldArgs a, const uint64_t *heads, int64_t m, const int64_t *offsets) {
     __shared__ int wprefix[kCompactWords];
     __shared__ uint64_t wmask[kCompactWords];
@@ -674,50 +676,56 @@ __global__ __launch_bounds__(256) void k_group_fold(GroupFoldArgs a, const uint6
     }
     __syncthreads();
     const int64_t base = offsets[blockIdx.x];
-    constexpr int U = 4, NW = 256 / kWave;
+    constexpr int U = 2, NW = 256 / kWave;
     const uint64_t upto = lane == 63 ? ~0ull : ((2ull << lane) - 1);        // lanes at or before mine
-    for (int j = 0; j < a.nfold; j++) {                                     // wave-uniform
-        const int kind = a.kind[j];
-        const Src d = a.data[j];
-        int64_t *out = a.out[j];
-        const int rk = kind == 1 ? R_MIN : kind == 2 ? R_MAX : R_SUM;
-        by_kind(d.kind, [&](auto kv) {
-            for (int k0 = wave * U; k0 < kCompactWords; k0 += NW * U) {
-                int64_t x[U];
+    for (int j0 = 0; j0 < a.nfold; j0 += NF) {                              // wave-uniform
+        for (int k0 = wave * U; k0 < kCompactWords; k0 += NW * U) {
+            if (((w0 + k0) << 6) >= m) break;                               // wave-uniform: past the last word
+            int64_t x[NF][U];
+#pragma unroll
+            for (int f = 0; f < NF; f++) {
+                if (j0 + f >= a.nfold) break;
+                const Src d = a.data[j0 + f];
+                const int kind = a.kind[j0 + f];
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     const int64_t i = ((w0 + k0 + u) << 6) + lane;
-                    x[u] = kind == 3 ? 1 : ldk<decltype(kv)::value>(d, i < m ? i : 0);
+                    x[f][u] = kind == 3 ? 1 : ld(d, i < m ? i : 0);
                 }
+            }
 #pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const int64_t i = ((w0 + k0 + u) << 6) + lane;
-                    if (((w0 + k0 + u) << 6) >= m) break;                   // wave-uniform: past the last word
-                    const uint64_t hw = wmask[k0 + u];
-                    const bool in = i < m;
-                    const uint64_t hm = hw & upto;
-                    const int64_t g = base + wprefix[k0 + u] + __popcll(hm) - 1;
+            for (int u = 0; u < U; u++) {
+                const int64_t i = ((w0 + k0 + u) << 6) + lane;
+                if (((w0 + k0 + u) << 6) >= m) break;                       // wave-uniform
+                const uint64_t hw = wmask[k0 + u];
+                const bool in = i < m;
+                const uint64_t hm = hw & upto;
+                const int64_t g = base + wprefix[k0 + u] + __popcll(hm) - 1;
+                const int seg0 = hm ? 63 - __clzll((long long)hm) : 0;      // first lane of my segment in this word
+                const bool last_in = i + 1 >= m;                            // the vector ends here
+                const bool tail = in && (lane == kWave - 1 || last_in || ((hw >> (lane + 1)) & 1ull));
+                // the whole run lies in this word: it begins here (a head at or before me) and ends before the word does
+                const bool whole = hm != 0 && (lane < kWave - 1 || last_in);
+#pragma unroll
+                for (int f = 0; f < NF; f++) {
+                    if (j0 + f >= a.nfold) break;
+                    const int kind = a.kind[j0 + f];
+                    int64_t *out = a.out[j0 + f];
                     if (kind == 4) {                                        // FoldChoose: the run's first value
-                        if (in && ((hw >> lane) & 1ull)) out[g] = x[u];
+                        if (in && ((hw >> lane) & 1ull)) out[g] = x[f][u];
                         continue;
                     }
-                    const int seg0 = hm ? 63 - __clzll((long long)hm) : 0;  // first lane of my segment in this word
-                    int64_t v = in ? x[u] : r_identity(rk);
+                    const int rk = kind == 1 ? R_MIN : kind == 2 ? R_MAX : R_SUM;
+                    int64_t v = in ? x[f][u] : r_identity(rk);
 #pragma unroll
                     for (int off = 1; off < kWave; off <<= 1) {
                         const int64_t y = __shfl_up(v, off, kWave);
                         if (lane - off >= seg0) v = r_combine(rk, v, y);
                     }
-                    const bool last_in = i + 1 >= m;                        // the vector ends here
-                    const bool tail = in && (lane == kWave - 1 || last_in || ((hw >> (lane + 1)) & 1ull));
-                    if (tail) {
-                        // the whole run lies in this word: it begins here (a head at or before me) and ends before the word does
-                        const bool whole = hm != 0 && (lane < kWave - 1 || last_in);
-                        if (whole) out[g] = v; else atomic_combine(rk, &out[g], v);
-                    }
+                    if (tail) { if (whole) out[g] = v; else atomic_combine(rk, &out[g], v); }
                 }
             }
-        });
+        }
     }
 }
 hipError_t launch_group_fold(const GroupFoldArgs &a, const uint64_t *heads, int64_t m, const int64_t *offsets, hipStream_t s) {
@@ -725,7 +733,8 @@ hipError_t launch_group_fold(const GroupFoldArgs &a, const uint64_t *heads, int6
     const int64_t nb = (m + compact_tile() - 1) / compact_tile();
     if (nb <= 0 || a.nfold <= 0) return hipSuccess;
     if (a.nfold > kMaxGroupFolds) return hipErrorInvalidValue;
-    k_group_fold<<<(int)nb, 256, 0, s>>>(a, heads, m, offsets);
+    if (a.nfold <= 2) k_group_fold<2><<<(int)nb, 256, 0, s>>>(a, heads, m, offsets);
+    else k_group_fold<4><<<(int)nb, 256, 0, s>>>(a, heads, m, offsets);
     return launch_status();
 }
 

@@ -279,9 +279,14 @@ __global__ __launch_bounds__(256) void k_sorted_check(Src d, int64_t n, int64_t 
     });
     if (__ballot(bad) != 0 && (threadIdx.x & (kWave - 1)) == 0) flag[0] = 1;
     mx = wave_reduce(mx, R_MAX);
-    // (a plain look first: after the first few waves hardly any has a new maximum, and tens of thousands of atomics on one
-    // word would cost more than the scan)
-    if ((threadIdx.x & (kWave - 1)) == 0 && mx > *(volatile int64_t *)&flag[1]) atomicMax((long long *)&flag[1], (long long)mx);
+    // (one atomic per block, after a plain look: in ascending data every wave holds a new maximum)
+    __shared__ int64_t wmax[256 / kWave];
+    if ((threadIdx.x & (kWave - 1)) == 0) wmax[threadIdx.x / kWave] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 256 / kWave; w++) mx = wmax[w] > mx ? wmax[w] : mx;
+        if (mx > *(volatile int64_t *)&flag[1]) atomicMax((long long *)&flag[1], (long long)mx);
+    }
 }
 hipError_t launch_sorted_check(Src d, int64_t n, int64_t *flag, hipStream_t s) {
     (void)hipGetLastError();
@@ -290,15 +295,20 @@ hipError_t launch_sorted_check(Src d, int64_t n, int64_t *flag, hipStream_t s) {
     return launch_status();
 }
 
-// One wave per 64 entries: neighbour compare through a shuffle (lane 0 reads its predecessor), heads word by ballot.
+// One wave per 64 entries: neighbour compare through a shuffle (lane 0 reads its predecessor), heads word by ballot.  flag[0] /
+// flag[1] are initialised by a first tiny launch (no host copy).  One atomic per BLOCK for the maximum: data in ascending order
+// -- the case this pass exists for -- gives every wave a new maximum, and 50 K atomics on one word took 80 us (3 M entries).
+__global__ void k_sorted_init(int64_t *flag) { flag[0] = 0; flag[1] = INT64_MIN; }
 __global__ __launch_bounds__(256) void k_sorted_heads(Src d, int64_t n, uint64_t *heads, int64_t *flag) {
-    const int lane = threadIdx.x & (kWave - 1);
+    __shared__ int64_t wmax[256 / kWave];
+    __shared__ int wbad[256 / kWave];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const int64_t nw = (n + 63) >> 6;
     const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave);
     bool bad = false;
     int64_t mx = INT64_MIN;
     by_kind(d.kind, [&](auto kd) {
-        for (int64_t w = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; w < nw; w += wstride) {
+        for (int64_t w = (int64_t)blockIdx.x * (blockDim.x / kWave) + wave; w < nw; w += wstride) {
             const int64_t i = (w << 6) + lane;
             const bool in = i < n;
             const int64_t x = ldk<decltype(kd)::value>(d, in ? i : n - 1);
@@ -310,14 +320,25 @@ __global__ __launch_bounds__(256) void k_sorted_heads(Src d, int64_t n, uint64_t
             if (lane == 0) heads[w] = hm;
         }
     });
-    if (__ballot(bad) != 0 && lane == 0) flag[0] = 1;
+    const bool anybad = __ballot(bad) != 0;
     mx = wave_reduce(mx, R_MAX);
-    if (lane == 0 && mx > *(volatile int64_t *)&flag[1]) atomicMax((long long *)&flag[1], (long long)mx);
+    if (lane == 0) { wmax[wave] = mx; wbad[wave] = anybad ? 1 : 0; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t m = wmax[0];
+        int b = wbad[0];
+        for (int w = 1; w < 256 / kWave; w++) { m = wmax[w] > m ? wmax[w] : m; b |= wbad[w]; }
+        if (b) flag[0] = 1;
+        if (m > *(volatile int64_t *)&flag[1]) atomicMax((long long *)&flag[1], (long long)m);
+    }
 }
 hipError_t launch_sorted_heads(Src d, int64_t n, uint64_t *heads, int64_t *flag, hipStream_t s) {
     (void)hipGetLastError();
-    if (n <= 0) return hipSuccess;
-    k_sorted_heads<<<grid_for(n, 256, 4), 256, 0, s>>>(d, n, heads, flag);
+    k_sorted_init<<<1, 1, 0, s>>>(flag);
+    if (n <= 0) return launch_status();
+    int grid = grid_for(n, 256, 4);
+    if (grid > 2048) grid = 2048;
+    k_sorted_heads<<<grid, 256, 0, s>>>(d, n, heads, flag);
     return launch_status();
 }
 
