@@ -30,7 +30,7 @@ for n in plans:
     plan.set_profiling(True)
     prof = plan.run()
     kern = sum(prof["timings"].values()) / 1e3
-    top = sorted(prof["timings"].items(), key=lambda kv: -kv[1])[:3]
+    top = sorted(prof["timings"].items(), key=lambda kv: -kv[1])[:int(os.environ.get("RUN_PLANS_TOP", "3"))]
     line = "Q%02d %3d stmts fused=%d in=%7.1f MB  wall %8.2f ms  kernels %8.2f ms  out rows %d" % (
         n, len(text.splitlines()), plan.is_fused, in_bytes / 1e6, best * 1e3, kern, max(len(list(v.values())[0]) for v in out["results"].values()))
     if check:
