@@ -819,6 +819,88 @@ struct GenExec {
         return o;
     }
 
+    // Fold `n` over m ENTRIES (every one holds a value, entry 0 starts the first run): control values at ctl, this fold's data at
+    // dsrc.  sel = the selection the entries sit on (a prefix selection for vectors scattered into key order, or all n slots).
+    // Results: SPARSE on the child selection of the run heads, packed.  Every fold of one GROUP BY shares the heads; with the
+    // batch on they also share ONE launch (launch_group_fold) -- the sibling folds' operands are run ahead of their turn.
+    DVec fold_entries(const Node &n, const SelP &sel, Src ctl_src, const void *ctl_key, const BufP &ctl_keep, Src dsrc, int64_t m, int64_t nslots) {
+        auto V = [&](int id) -> const DVec & { return vec[(size_t)id]; };
+        const int kind = n.op == Op::FoldSum ? 0 : n.op == Op::FoldMin ? 1 : n.op == Op::FoldMax ? 2 : n.op == Op::FoldCount ? 3 : 4;
+        // every entry holds a datum, so each run yields a result at its head: the run heads of this control
+        // vector -- and the selection they form -- are computed once and shared by all folds over it
+        // (a GROUP BY folds every aggregate over the same sorted key, Vlite.hs:1056-1060)
+        RunHeads &rh = heads_of[std::make_pair(ctl_key, (const void *)sel.get())];
+        const size_t nw = (size_t)std::max<int64_t>(nwords(m), 1);
+        if (!rh.heads) {
+            rh.ctl = ctl_keep; rh.sel = sel;
+            auto known = sorted_heads.find(ctl_key);
+            if (group_batch_on && known != sorted_heads.end()) {
+                // the Partition found this key in order and left its run heads and their count (partition_positions)
+                rh.heads = known->second.heads; rh.offsets = known->second.offsets; rh.count = known->second.count;
+            } else {
+                rh.heads = dev_alloc(c, sizeof(uint64_t) * nw);
+                rh.wordhd = dev_alloc(c, sizeof(int64_t) * (nw + (size_t)maxscan_blocks((int64_t)nw) + 1));
+                HIP_CHECK(launch_fold_heads(ctl_src, nullptr, m, (uint64_t *)rh.heads->p, (int64_t *)rh.wordhd->p, s));
+                rh.count = popcount(rh.heads, m, &rh.offsets);
+            }
+            rh.child = child_selection(sel, rh.heads, rh.count, rh.offsets);
+        }
+        // one launch for all folds pays when runs are short (a partial per run and word, atomics where a run crosses words): with a
+        // handful of long runs every word would add to the same few addresses -- k_seg_fold, which carries a run along a wave's
+        // words, is the kernel for those
+        if (group_batch_on && (rh.count * 64 >= m || m <= (1 << 16))) {
+            std::vector<int> members{n.id};
+            std::vector<Src> srcs{dsrc};
+            for (int id : p->prog.order) {
+                const Node &f = p->prog.at(id);
+                if (id == n.id || f.a != n.a || (size_t)id >= needed_now.size() || !needed_now[(size_t)id] || done[(size_t)id]) continue;
+                if (f.op != Op::FoldSum && f.op != Op::FoldMin && f.op != Op::FoldMax && f.op != Op::FoldCount && f.op != Op::FoldChoose) continue;
+                if (cur_over && cur_over->count(id)) continue;
+                ensure(f.b);
+                DVec fd = V(f.b);
+                if (!sel->idx && sel->m == sel->n && fd.kind == DVec::EXPR && !fd.sel) { fd = expr_force(fd); vec[(size_t)f.b] = fd; }
+                if (fd.kind == DVec::SPARSE && fd.sel == sel) srcs.push_back(i64_src(fd.data));
+                else if (fd.kind == DVec::RANGE && fd.step == 0 && fd.n == nslots && (sel->m == sel->n ? !fd.valid : subset(bitmap_of(sel), fd.valid))) srcs.push_back(src_of(fd));
+                else if (!sel->idx && sel->m == sel->n && (fd.kind == DVec::DENSE || fd.kind == DVec::COLUMN) && !fd.valid && fd.n == nslots) srcs.push_back(src_of(fd));
+                else continue;
+                members.push_back(id);
+            }
+            std::vector<BufP> outs(members.size());
+            const int64_t G = rh.count;
+            for (size_t at = 0; at < members.size(); at += kMaxGroupFolds) {
+                GroupFoldArgs ga;
+                for (size_t k = at; k < members.size() && k < at + kMaxGroupFolds; k++) {
+                    const Op fop = p->prog.at(members[k]).op;
+                    const int fk = fop == Op::FoldSum ? 0 : fop == Op::FoldMin ? 1 : fop == Op::FoldMax ? 2 : fop == Op::FoldCount ? 3 : 4;
+                    outs[k] = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(G, 1));
+                    if (fk != 4 && G > 0)
+                        HIP_CHECK(launch_fill_words((uint64_t *)outs[k]->p, fk == 1 ? (uint64_t)INT64_MAX : fk == 2 ? (uint64_t)INT64_MIN : 0ull, G, s));
+                    ga.kind[ga.nfold] = fk; ga.data[ga.nfold] = srcs[k]; ga.out[ga.nfold] = (int64_t *)outs[k]->p;
+                    ga.nfold++;
+                }
+                if (G > 0) HIP_CHECK(launch_group_fold(ga, (const uint64_t *)rh.heads->p, m, (const int64_t *)rh.offsets->p, s));
+            }
+            for (size_t k = 1; k < members.size(); k++) {
+                vec[(size_t)members[k]] = make_sparse(rh.child, outs[k]);
+                done[(size_t)members[k]] = 1;
+                if (p->tracing) snapshot(p->prog.at(members[k]), vec[(size_t)members[k]]);
+            }
+            return make_sparse(rh.child, outs[0]);
+        }
+        if (!rh.wordhd) {                                   // (heads adopted from the Partition: the per-word lookup k_seg_fold wants)
+            rh.wordhd = dev_alloc(c, sizeof(int64_t) * (nw + (size_t)maxscan_blocks((int64_t)nw) + 1));
+            HIP_CHECK(launch_fold_heads(ctl_src, nullptr, m, (uint64_t *)rh.heads->p, (int64_t *)rh.wordhd->p, s));
+        }
+        // FoldChoose takes a run's first element, and here every entry holds one: the values at the run heads, i.e. one
+        // compaction by the head bitmap (every output column of a GROUP BY is such a fold, Vlite.hs:1056-1060)
+        if (kind == 4) return make_sparse(rh.child, compact_write(dsrc, rh.heads, m, rh.offsets, rh.count));
+        BufP data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(m, 1));
+        BufP vout = zero_bitmap(m);
+        HIP_CHECK(launch_fold_runs(kind, dsrc, nullptr, nullptr, (const uint64_t *)rh.heads->p, (const int64_t *)rh.wordhd->p, m,
+                                   (int64_t *)data->p, (uint64_t *)vout->p, s));
+        return make_sparse(rh.child, compact_write(i64_src(data), rh.heads, m, rh.offsets, rh.count));
+    }
+
     // a statement (and what it depends on) ahead of its turn: statements are pure, so order does not matter; the main loop skips it
     void ensure(int id) {
         if (id <= 0 || done[(size_t)id] || vec[(size_t)id].kind != DVec::NONE) return;
@@ -1066,82 +1148,23 @@ struct GenExec {
             if (sparse_on && data_on_sel && first_slot_of(V(n.a).sel) == 0) {
                 // runs skip EPS slots, so folding the m entries gives the same runs; results sit at run-first entries
                 const DVec &sc = V(n.a), &sd = V(n.b);
-                const SelP &sel = sc.sel;
+                const SelP sel = sc.sel;
                 Src dsrc = sd.kind == DVec::SPARSE ? i64_src(sd.data) : src_of(sd);
-                const int64_t m = sel->m;
-                const int kind = n.op == Op::FoldSum ? 0 : n.op == Op::FoldMin ? 1 : n.op == Op::FoldMax ? 2 : n.op == Op::FoldCount ? 3 : 4;
-                // every entry holds a datum, so each run yields a result at its head: the run heads of this control
-                // vector -- and the selection they form -- are computed once and shared by all folds over it
-                // (a GROUP BY folds every aggregate over the same sorted key, Vlite.hs:1056-1060)
-                RunHeads &rh = heads_of[std::make_pair((const void *)sc.data->p, (const void *)sel.get())];
-                if (!rh.heads) {
-                    const size_t nw = (size_t)std::max<int64_t>(nwords(m), 1);
-                    rh.ctl = sc.data; rh.sel = sel;
-                    auto known = sorted_heads.find(sc.data->p);
-                    if (group_batch_on && known != sorted_heads.end()) {
-                        // the Partition found this key in order and left its run heads and their count (partition_positions)
-                        rh.heads = known->second.heads; rh.offsets = known->second.offsets; rh.count = known->second.count;
-                    } else {
-                        rh.heads = dev_alloc(c, sizeof(uint64_t) * nw);
-                        rh.wordhd = dev_alloc(c, sizeof(int64_t) * (nw + (size_t)maxscan_blocks((int64_t)nw) + 1));
-                        HIP_CHECK(launch_fold_heads(i64_src(sc.data), nullptr, m, (uint64_t *)rh.heads->p, (int64_t *)rh.wordhd->p, s));
-                        rh.count = popcount(rh.heads, m, &rh.offsets);
-                    }
-                    rh.child = child_selection(sel, rh.heads, rh.count, rh.offsets);
+                return fold_entries(n, sel, i64_src(sc.data), sc.data->p, sc.data, dsrc, sel->m, sc.n);
+            }
+            // The same for a control vector that holds a value in EVERY slot (the key of a GROUP BY over an unfiltered table: Q18
+            // groups all lineitems by order): its n slots are the entries, the results live on the selection of the run heads.
+            // Only with the batch on and many short runs (fold_entries decides): a handful of long runs is what k_seg_fold is for.
+            if (sparse_on && group_batch_on && V(n.a).n > 0 && (V(n.a).kind == DVec::DENSE || V(n.a).kind == DVec::COLUMN) && !V(n.a).valid) {
+                const DVec &dc = V(n.a);
+                DVec dd = V(n.b);
+                if (dd.kind == DVec::EXPR && !dd.sel) dd = expr_force(dd);
+                const bool plain = (dd.kind == DVec::DENSE || dd.kind == DVec::COLUMN || (dd.kind == DVec::RANGE && dd.step == 0)) && !dd.valid && dd.n == dc.n;
+                if (plain && sorted_heads.count(dc.kind == DVec::DENSE ? dc.data->p : dc.ptr)) {      // (the Partition saw it in order and counted its runs)
+                    const SortedHeads &sh = sorted_heads[dc.kind == DVec::DENSE ? dc.data->p : dc.ptr];
+                    if (sh.count * 64 >= dc.n)
+                        return fold_entries(n, prefix_selection(dc.n, dc.n), src_of(dc), dc.kind == DVec::DENSE ? dc.data->p : dc.ptr, dc.data, src_of(dd), dc.n, dc.n);
                 }
-                if (group_batch_on) {
-                    // every fold of this GROUP BY in one launch: the folds over the same control statement whose data can be had
-                    // now (their operand statements are run ahead of their turn: statements are pure) join this one
-                    std::vector<int> members{n.id};
-                    std::vector<Src> srcs{dsrc};
-                    std::vector<BufP> hold;
-                    for (int id : p->prog.order) {
-                        const Node &f = p->prog.at(id);
-                        if (id == n.id || f.a != n.a || (size_t)id >= needed_now.size() || !needed_now[(size_t)id] || done[(size_t)id]) continue;
-                        if (f.op != Op::FoldSum && f.op != Op::FoldMin && f.op != Op::FoldMax && f.op != Op::FoldCount && f.op != Op::FoldChoose) continue;
-                        if (cur_over && cur_over->count(id)) continue;
-                        ensure(f.b);
-                        const DVec &fd = V(f.b);
-                        if (fd.kind == DVec::SPARSE && fd.sel == sel) srcs.push_back(i64_src(fd.data));
-                        else if (fd.kind == DVec::RANGE && fd.step == 0 && fd.n == sc.n && subset(bitmap_of(sel), fd.valid)) srcs.push_back(src_of(fd));
-                        else continue;
-                        members.push_back(id);
-                    }
-                    std::vector<BufP> outs(members.size());
-                    const int64_t G = rh.count;
-                    for (size_t at = 0; at < members.size(); at += kMaxGroupFolds) {
-                        GroupFoldArgs ga;
-                        for (size_t k = at; k < members.size() && k < at + kMaxGroupFolds; k++) {
-                            const Op fop = p->prog.at(members[k]).op;
-                            const int fk = fop == Op::FoldSum ? 0 : fop == Op::FoldMin ? 1 : fop == Op::FoldMax ? 2 : fop == Op::FoldCount ? 3 : 4;
-                            outs[k] = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(G, 1));
-                            if (fk != 4 && G > 0)
-                                HIP_CHECK(launch_fill_words((uint64_t *)outs[k]->p, fk == 1 ? (uint64_t)INT64_MAX : fk == 2 ? (uint64_t)INT64_MIN : 0ull, G, s));
-                            ga.kind[ga.nfold] = fk; ga.data[ga.nfold] = srcs[k]; ga.out[ga.nfold] = (int64_t *)outs[k]->p;
-                            ga.nfold++;
-                        }
-                        if (G > 0) HIP_CHECK(launch_group_fold(ga, (const uint64_t *)rh.heads->p, m, (const int64_t *)rh.offsets->p, s));
-                    }
-                    for (size_t k = 1; k < members.size(); k++) {
-                        vec[(size_t)members[k]] = make_sparse(rh.child, outs[k]);
-                        done[(size_t)members[k]] = 1;
-                        if (p->tracing) snapshot(p->prog.at(members[k]), vec[(size_t)members[k]]);
-                    }
-                    return make_sparse(rh.child, outs[0]);
-                }
-                if (!rh.wordhd) {                                   // (heads adopted from the Partition, batch switched off meanwhile: never both)
-                    const size_t nw = (size_t)std::max<int64_t>(nwords(m), 1);
-                    rh.wordhd = dev_alloc(c, sizeof(int64_t) * (nw + (size_t)maxscan_blocks((int64_t)nw) + 1));
-                    HIP_CHECK(launch_fold_heads(i64_src(sc.data), nullptr, m, (uint64_t *)rh.heads->p, (int64_t *)rh.wordhd->p, s));
-                }
-                // FoldChoose takes a run's first element, and here every entry holds one: the values at the run heads, i.e. one
-                // compaction by the head bitmap (every output column of a GROUP BY is such a fold, Vlite.hs:1056-1060)
-                if (kind == 4) return make_sparse(rh.child, compact_write(dsrc, rh.heads, m, rh.offsets, rh.count));
-                BufP data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(m, 1));
-                BufP vout = zero_bitmap(m);
-                HIP_CHECK(launch_fold_runs(kind, dsrc, nullptr, nullptr, (const uint64_t *)rh.heads->p, (const int64_t *)rh.wordhd->p, m,
-                                           (int64_t *)data->p, (uint64_t *)vout->p, s));
-                return make_sparse(rh.child, compact_write(i64_src(data), rh.heads, m, rh.offsets, rh.count));
             }
             DVec ctl = densify(V(n.a)), d = densify(V(n.b));
             if (ctl.n != d.n) throw Error(VDL_ERR_SHAPE, std::string(op_name(n.op, -1)) + " (Id " + std::to_string(n.id) + "): operand lengths differ");
