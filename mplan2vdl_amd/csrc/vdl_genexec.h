@@ -175,6 +175,12 @@ struct GenExec {
         ch->n = ps->n; ch->parent = ps; ch->m = count;
         ch->idx = compact_write(idx_src(*ps), flags, ps->m, offsets, count);
         ch->ppos = compact_write(iota_src(), flags, ps->m, offsets, count);
+        if (!ps->idx && ps->m == ps->n && flags && !sel_of_bitmap.count(flags->p)) {
+            // the parent is ALL n slots: the flags over its entries are the child's bitmap over the slots as they stand
+            ch->bitmap = flags;
+            keep_alive.push_back(flags);
+            sel_of_bitmap[flags->p] = ch;
+        }
         return ch;                                              // its n-bit bitmap is built when somebody asks (bitmap_of)
     }
     // SPARSE vectors hold a value in every entry: entries that turned EPS (a gather out of range / from an EPS

@@ -684,7 +684,11 @@ __global__ __launch_bounds__(256) void k_group_fold(GroupFoldArgs a, const uint6
     constexpr int U = 2, NW = 256 / kWave, PW = kCompactWords / kGroupSplit;   // words of this block's part
     static_assert(PW % (U * NW) == 0, "each wave takes whole groups of U words of its block's part");
     const uint64_t upto = lane == 63 ? ~0ull : ((2ull << lane) - 1);        // lanes at or before mine
-    for (int j0 = 0; j0 < a.nfold; j0 += NF) {                              // wave-uniform
+    // (unrolled: every index into the argument block is then a constant and its fields are scalar loads from the kernel
+    // arguments -- indexed with a run-time j0 the compiler copied the whole block to scratch memory: 200 us for 18 M entries)
+#pragma unroll
+    for (int j0 = 0; j0 < kMaxGroupFolds; j0 += NF) {
+        if (j0 >= a.nfold) break;                                           // wave-uniform
         for (int k0 = part * PW + wave * U; k0 < (part + 1) * PW; k0 += NW * U) {
             if (((w0 + k0) << 6) >= m) break;                               // wave-uniform: past the last word
             int64_t x[NF][U];
