@@ -250,6 +250,7 @@ int  vdl_exchange_finish(vdl_ctx *ctx, vdl_plan *plan, const void *dev_recv, int
  *   plans with a Partition (vdl_plan_set_sharded_table names the row-sharded table): local phase -> ONE all-gather of
  *   {status, rows per destination} -> ONE grouped send / receive of all columns -> local tail; rank r ends with the
  *   groups of key range r, and the ranks' outputs concatenate in rank order to the unsharded result.
+ * (more routes: below, at vdl_plan_sharded_route)
  * vdl_run_sharded_begin / _end split the fold route for pipelined callers (slots 0 / 1): `begin` queues the scan on the
  * engine stream and merge + copy-out behind it on the communication stream and returns; `end` waits for that slot's copy
  * only, so the collective of query k hides behind the scan of query k+1. */
@@ -266,6 +267,13 @@ int  vdl_comm_init(vdl_ctx *ctx, int rank, int world, const void *id /* VDL_COMM
 int  vdl_comm_init_host(vdl_ctx *ctx, int rank, int world, const vdl_comm_host *transport);
 int  vdl_comm_info(const vdl_ctx *ctx, int *rank, int *world, const char **transport /* "rccl" | "host" */);
 void vdl_comm_free(vdl_ctx *ctx);                       /* also done by vdl_close */
+/* A third route:
+ *   fused plans with a semi-join set (EXISTS / IN, TPC-H Q4) whose source table is the sharded one and whose scans read replicated
+ *   tables: every rank builds the set from its rows -> ONE all-gather of the sets -> OR kernel -> the scans run everywhere
+ *   against the complete set; every rank ends with the full result.
+ * vdl_plan_sharded_route tells which of the three a plan takes ("fold" | "set" | "exchange") and whether every rank ends with
+ * the whole answer (replicated = 1) or with its slice (0: concatenate the ranks' outputs in rank order). */
+int  vdl_plan_sharded_route(vdl_ctx *ctx, vdl_plan *plan, const char **route, int *replicated);
 int  vdl_run_sharded(vdl_ctx *ctx, vdl_plan *plan);     /* results through vdl_output as after vdl_run */
 int  vdl_run_sharded_begin(vdl_ctx *ctx, vdl_plan *plan, int slot);
 int  vdl_run_sharded_end(vdl_ctx *ctx, vdl_plan *plan, int slot);

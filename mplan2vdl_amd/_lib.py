@@ -72,6 +72,7 @@ def load():
         "vdl_plan_scan_stats": (i32, [vp, P(i64), P(i64), P(ctypes.c_double)]),
         "vdl_plan_scan_traffic": (i32, [vp, vp, P(i64), P(ctypes.c_char_p)]),
         "vdl_plan_partial_spec": (i32, [vp, P(i64), P(P(ctypes.c_int32))]),
+        "vdl_plan_sharded_route": (i32, [vp, vp, P(ctypes.c_char_p), P(i32)]),
         "vdl_run_local": (i32, [vp, vp, vp]),
         "vdl_finalize": (i32, [vp, vp, vp]),
         "vdl_plan_set_row_offset": (i32, [vp, i64]),
@@ -108,7 +109,7 @@ ABI_SYMBOLS = [
     "vdl_upload_column", "vdl_generate_column", "vdl_drop_column", "vdl_column_info", "vdl_download_column",
     "vdl_parse", "vdl_plan_free", "vdl_plan_describe", "vdl_plan_is_fused", "vdl_plan_set_fusion",
     "vdl_plan_set_profiling", "vdl_plan_set_jit", "vdl_plan_jit_note", "vdl_plan_jit_check", "vdl_plan_set_trace", "vdl_n_traced", "vdl_traced", "vdl_run", "vdl_n_outputs", "vdl_output", "vdl_plan_set_device_outputs", "vdl_output_device", "vdl_n_timings", "vdl_timing",
-    "vdl_plan_scan_stats", "vdl_plan_scan_traffic", "vdl_plan_partial_spec", "vdl_run_local", "vdl_finalize", "vdl_finalize_begin", "vdl_finalize_end", "vdl_plan_set_row_offset", "vdl_plan_set_sharded_table", "vdl_resolve_first", "vdl_exchange_spec", "vdl_exchange_begin", "vdl_exchange_pack",
+    "vdl_plan_scan_stats", "vdl_plan_scan_traffic", "vdl_plan_partial_spec", "vdl_plan_sharded_route", "vdl_run_local", "vdl_finalize", "vdl_finalize_begin", "vdl_finalize_end", "vdl_plan_set_row_offset", "vdl_plan_set_sharded_table", "vdl_resolve_first", "vdl_exchange_spec", "vdl_exchange_begin", "vdl_exchange_pack",
     "vdl_exchange_finish", "vdl_comm_unique_id", "vdl_comm_init", "vdl_comm_init_host", "vdl_comm_info", "vdl_comm_free", "vdl_run_sharded",
     "vdl_run_sharded_begin", "vdl_run_sharded_end", "vdl_comm_merge_host",
 ]

@@ -328,6 +328,52 @@ static void sharded_exchange(vdl_ctx *c, vdl_plan *p) {
     p->shard_keep.reset();
 }
 
+// A fused plan with a semi-join set (EXISTS / IN with the dimension on the left: TPC-H Q4, Vlite.hs:1212-1222) when the set's SOURCE
+// table is the row-sharded one and every table the scans read is replicated: each rank builds the set from its rows, ONE all-gather
+// moves the sets (150 M bits = 19 MB per rank at SF100), a kernel ORs them and clips the union at the source table's global
+// length, and every rank then runs the scans of the replicated tables against the complete set: every rank ends with the whole
+// answer.  "" = this plan and placement qualify, else why not.
+static std::string semi_route_refusal(const vdl_plan *p) {
+    if (!(p->use_fusion && p->fused.ok)) return "the plan is not fused";
+    const std::string &t = p->sharded_table;
+    if (t.empty()) return "name the row-sharded table first (vdl_plan_set_sharded_table)";
+    bool any = false;
+    for (const PreludeItem &it : p->fused.prelude) {
+        if (it.kind == PreludeItem::SEMI_BITMAP) {
+            if (it.table != t) return "the semi-join set is built from table '" + it.table + "', which is not the sharded one";
+            any = true;
+        } else if (it.kind == PreludeItem::DIM_BITMAP && it.table == t) return "a dimension selection is taken over the sharded table";
+    }
+    if (!any) return "the plan builds no semi-join set";
+    for (const ScanPlan &sp : p->fused.scans) if (sp.table == t) return "a scan reads the sharded table itself";
+    for (const GroupScanPlan &gp : p->fused.gscans) if (gp.table == t) return "a scan reads the sharded table itself";
+    return "";
+}
+static void sharded_semi(vdl_ctx *c, vdl_plan *p) {
+    need_device(c);
+    CommState &m = comm_of(c);
+    struct Restore { vdl_plan *p; ~Restore() { p->after_prelude = nullptr; p->semi_unclamped = false; } } restore{p};
+    p->semi_unclamped = true;
+    p->after_prelude = [&m](vdl_ctx *cc, vdl_plan *pp) {
+        const FusedPlan &F = pp->fused;
+        for (size_t k = 0; k < F.prelude.size(); k++) {
+            if (F.prelude[k].kind != PreludeItem::SEMI_BITMAP || !pp->prelude_buf[k]) continue;
+            const int64_t words = std::max<int64_t>((pp->prelude_n[k] + 63) >> 6, 1);
+            BufP send = dev_alloc(cc, sizeof(uint64_t) * (size_t)(words + 1)), recv = dev_alloc(cc, sizeof(uint64_t) * (size_t)(words + 1) * (size_t)m.world);
+            HIP_CHECK(hipMemcpyAsync(send->p, pp->prelude_buf[k]->p, sizeof(uint64_t) * (size_t)words, hipMemcpyDeviceToDevice, cc->stream));
+            const int64_t rows = pp->prelude_rows[k];
+            HIP_CHECK(hipMemcpyAsync((uint64_t *)send->p + words, &rows, sizeof rows, hipMemcpyHostToDevice, cc->stream));
+            HIP_CHECK(hipStreamSynchronize(cc->stream));                          // (`rows` is a local)
+            all_gather(cc, send->p, recv->p, sizeof(uint64_t) * (size_t)(words + 1), cc->stream);
+            HIP_CHECK(launch_or_sets((const uint64_t *)recv->p, m.world, words, (uint64_t *)pp->prelude_buf[k]->p, cc->stream));
+        }
+    };
+    if (vdl_run(c, p) != VDL_OK) throw Error(VDL_ERR_DEVICE, c->err);
+    for (const Timing &t : p->timings)
+        if (t.label.find("fusedPlanAbandoned") != std::string::npos)
+            throw Error(VDL_ERR_UNSUPPORTED, "sharded run: the fused plan does not hold for this data (" + t.label + "), and statement by statement the plan has no sharded route");
+}
+
 static bool fold_route(vdl_ctx *c, vdl_plan *p) {
     int64_t nw = 0;
     const int32_t *ops = nullptr;
@@ -395,6 +441,32 @@ void vdl_comm_free(vdl_ctx *c) {
     c->comm.reset();
 }
 
+/* which route vdl_run_sharded takes for this plan and placement: "fold" (partial words merged: every rank ends with the whole
+ * answer), "set" (a semi-join set merged, scans over replicated tables: every rank ends with the whole answer), "exchange" (rows
+ * travel by key range: the ranks' outputs concatenate in rank order); VDL_ERR_UNSUPPORTED with the reason when there is none */
+int vdl_plan_sharded_route(vdl_ctx *c, vdl_plan *p, const char **route, int *replicated) {
+    if (!c || !p) return VDL_ERR_ARG;
+    const char *name = nullptr;
+    bool semi = false;
+    if (p->use_fusion && p->fused.ok) for (const PreludeItem &it : p->fused.prelude) semi |= it.kind == PreludeItem::SEMI_BITMAP;
+    if (semi) {
+        const std::string why = semi_route_refusal(p);
+        if (!why.empty()) { c->err = "no sharded route: " + why; return VDL_ERR_UNSUPPORTED; }
+        name = "set";
+    } else if (fold_route(c, p)) {
+        name = "fold";
+    } else {
+        int ncols = 0;
+        if (p->sharded_table.empty()) { c->err = "name the row-sharded table first (vdl_plan_set_sharded_table)"; return VDL_ERR_ARG; }
+        const int rc = vdl_exchange_spec(p, p->sharded_table.c_str(), &ncols);
+        if (rc != VDL_OK) return rc;
+        name = "exchange";
+    }
+    if (route) *route = name;
+    if (replicated) *replicated = std::strcmp(name, "exchange") != 0;
+    return VDL_OK;
+}
+
 int vdl_run_sharded_begin(vdl_ctx *c, vdl_plan *p, int slot) {
     if (!c || !p) return VDL_ERR_ARG;
     return guard(c, [&] {
@@ -413,13 +485,14 @@ int vdl_run_sharded_end(vdl_ctx *c, vdl_plan *p, int slot) {
 
 int vdl_run_sharded(vdl_ctx *c, vdl_plan *p) {
     if (!c || !p) return VDL_ERR_ARG;
-    if (p->use_fusion && p->fused.ok) {                       // a fused plan with a semi-join set has no sharded route: one rank runs it whole
+    if (p->use_fusion && p->fused.ok) {                       // a fused plan with a semi-join set: the sets are merged across the ranks
         bool semi = false;
         for (const PreludeItem &it : p->fused.prelude) semi |= it.kind == PreludeItem::SEMI_BITMAP;
         if (semi) {
             if (!c->comm || c->comm->world == 1) return vdl_run(c, p);
-            c->err = "this fused plan builds a semi-join set from every row of a table: it has no sharded route";
-            return VDL_ERR_UNSUPPORTED;
+            const std::string why = semi_route_refusal(p);
+            if (!why.empty()) { c->err = "this fused plan builds a semi-join set and has no sharded route here: " + why; return VDL_ERR_UNSUPPORTED; }
+            return guard(c, [&] { sharded_semi(c, p); });
         }
     }
     int rc = guard(c, [&] {

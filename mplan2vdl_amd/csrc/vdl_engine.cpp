@@ -578,6 +578,7 @@ void run_prelude_items(vdl_ctx *c, vdl_plan *p, const std::vector<char> &asked) 
     const FusedPlan &F = p->fused;
     p->prelude_buf.assign(F.prelude.size(), nullptr);
     p->prelude_n.assign(F.prelude.size(), 0);
+    p->prelude_rows.assign(F.prelude.size(), 0);
     std::vector<char> wanted(asked);
     for (size_t k = F.prelude.size(); k-- > 0;)                 // what a wanted dimension scan looks up itself (earlier items)
         if (wanted[k] && F.prelude[k].scan)
@@ -635,6 +636,7 @@ void run_prelude_items(vdl_ctx *c, vdl_plan *p, const std::vector<char> &asked) 
             p->prelude_buf[k] = dev_alloc(c, sizeof(uint64_t) * words);
             p->prelude_n[k] = nbits;
             HIP_CHECK(hipMemsetAsync(p->prelude_buf[k]->p, 0, sizeof(uint64_t) * words, c->stream));
+            p->prelude_rows[k] = std::max<int64_t>(n, 0);
             if (it.never || n <= 0) continue;
             d->bitmap_only = 2;
             d->pmin = it.modulus;
@@ -642,7 +644,9 @@ void run_prelude_items(vdl_ctx *c, vdl_plan *p, const std::vector<char> &asked) 
             // the Scatter this set stands for writes into a vector as long as ITS table (the fold operand, Vlite.hs:1212-1222):
             // positions at or beyond that length are dropped like any out-of-range Scatter position, also when the indexed
             // table is the longer one
-            d->dn[it.index_col] = std::min(nbits, n);
+            // (sharded: n is this rank's share of the table; the merge clips at the global length: semi_unclamped)
+            d->dn[it.index_col] = p->semi_unclamped ? nbits : std::min(nbits, n);
+            p->prelude_rows[k] = n;
             d->out_ptr[0] = (int64_t *)p->prelude_buf[k]->p;
             descs.push_back(dev_alloc(c, sizeof(MScanDesc)));
             HIP_CHECK(hipMemcpyAsync(descs.back()->p, d, sizeof(MScanDesc), hipMemcpyHostToDevice, c->stream));
@@ -680,6 +684,7 @@ void run_prelude(vdl_ctx *c, vdl_plan *p) {
         for (const ScanColumn &sc : (s < ns ? F.scans[s].cols : F.gscans[s - ns].cols))
             if (sc.prelude >= 0) wanted[(size_t)sc.prelude] = 1;
     run_prelude_items(c, p, wanted);
+    if (p->after_prelude) p->after_prelude(c, p);
     for (size_t s = 0; s < ns + F.gscans.size(); s++) patch_prelude(p, s < ns ? F.scans[s].cols : F.gscans[s - ns].cols, p->mcols[s], p->mdesc[s]);
 }
 

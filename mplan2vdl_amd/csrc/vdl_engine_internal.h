@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <set>
 #include <memory>
@@ -223,6 +224,11 @@ struct vdl_plan {
     std::string jit_note;                    // what was specialised, or why not
     std::vector<BufP> prelude_buf;           // fused join scans: dimension bitmaps / LIKE tables of the current run (FusedPlan::prelude)
     std::vector<int64_t> prelude_n;
+    std::vector<int64_t> prelude_rows;       // SEMI_BITMAP items: rows of the (local) source table the set was built from
+    // sharded runs of a plan with a semi-join set (vdl_comm.cpp): every rank builds the set from its rows of the source table,
+    // `after_prelude` merges the ranks' sets (and clips them at the GLOBAL length of that table) before any scan reads them
+    bool semi_unclamped = false;
+    std::function<void(vdl_ctx *, vdl_plan *)> after_prelude;
     std::vector<int64_t> gword_offset;
     int dominant = -1;
     std::string dominant_kernel;

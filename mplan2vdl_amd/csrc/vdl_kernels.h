@@ -141,6 +141,10 @@ VDL_HD inline int64_t merge_word(const int64_t *g, int world, int64_t n_words, i
 // gathered: `stride` words per rank = n_words raw, n_words resolved, then (stride > 2 * n_words) the rank's status word.
 // status_out (may be null; needs that word): [0] = the first non-zero status over the ranks (0 = every rank's local phase
 // succeeded), [1] = that rank.
+// OR of the ranks' semi-join sets: gathered holds, per rank, `words` set words then ONE word = the rows of the set's source table on
+// that rank; out = the union, with the bits at and beyond the table's GLOBAL length (the sum of those words) cleared -- the Scatter
+// the set stands for is that long, positions beyond it are dropped (Vlite.hs:1212-1222).
+hipError_t launch_or_sets(const uint64_t *gathered, int world, int64_t words, uint64_t *out, hipStream_t s);
 hipError_t launch_merge_words(const int64_t *gathered, int world, int64_t n_words, int64_t stride, const int32_t *ops, int64_t *out,
                               int64_t *status_out, hipStream_t s);
 hipError_t launch_fold_words(const int64_t *rec, int reduce, int64_t row0, int64_t *out, hipStream_t s);

@@ -494,6 +494,24 @@ hipError_t launch_fold_record(const int64_t *words, int64_t *rec, hipStream_t s)
     k_fold_record<<<1, 1, 0, s>>>(words, rec);
     return launch_status();
 }
+__global__ void k_or_sets(const uint64_t *g, int world, int64_t words, uint64_t *out) {
+    int64_t rows = 0;
+    for (int r = 0; r < world; r++) rows += (int64_t)g[(int64_t)r * (words + 1) + words];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += stride) {
+        uint64_t x = 0;
+        for (int r = 0; r < world; r++) x |= g[(int64_t)r * (words + 1) + w];
+        if ((w << 6) >= rows) x = 0;
+        else if (rows - (w << 6) < 64) x &= (1ull << (rows - (w << 6))) - 1;
+        out[w] = x;
+    }
+}
+hipError_t launch_or_sets(const uint64_t *gathered, int world, int64_t words, uint64_t *out, hipStream_t s) {
+    (void)hipGetLastError();
+    if (words <= 0) return hipSuccess;
+    k_or_sets<<<grid_for(words, 256, 1), 256, 0, s>>>(gathered, world, words, out);
+    return launch_status();
+}
 __global__ void k_merge_words(const int64_t *g, int world, int64_t n_words, int64_t stride, const int32_t *ops, int64_t *out, int64_t *status_out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_words) out[i] = merge_word(g, world, n_words, ops[i], i, stride);

@@ -207,8 +207,10 @@ int run_rank(const Options &o, const std::string &text, int rank, int world, con
         if ((rc = vdl_comm_init(ctx, rank, world, id))) return die(ctx, "vdl_comm_init", rc);
         vdl_plan_set_sharded_table(plan, o.shard.c_str());
         vdl_plan_set_row_offset(plan, row0);
-        int64_t nw = 0;
-        reply.replicated = vdl_plan_partial_spec(plan, &nw, nullptr) == VDL_OK;
+        int whole = 0;
+        const char *route = nullptr;
+        if ((rc = vdl_plan_sharded_route(ctx, plan, &route, &whole))) return die(ctx, "vdl_plan_sharded_route", rc);
+        reply.replicated = whole != 0;
         if ((rc = vdl_run_sharded(ctx, plan))) return die(ctx, "vdl_run_sharded", rc);
     }
     collect(plan, reply);

@@ -189,6 +189,13 @@ class Plan:
         self._e._check(self._e._L.vdl_run_sharded(self._e._c, self._h))
         return self._collect(as_numpy)
 
+    def sharded_route(self):
+        """("fold" | "set" | "exchange", every rank ends with the whole answer?) -- vdl_plan_sharded_route; raises when the plan
+        has no sharded route under the placement named with set_sharded_table."""
+        name, whole = ctypes.c_char_p(), ctypes.c_int()
+        self._e._check(self._e._L.vdl_plan_sharded_route(self._e._c, self._h, ctypes.byref(name), ctypes.byref(whole)))
+        return name.value.decode(), bool(whole.value)
+
     def execute_sharded(self):
         """vdl_run_sharded only: the outputs stay in the plan (`collect()` converts them)."""
         self._e._check(self._e._L.vdl_run_sharded(self._e._c, self._h))

@@ -156,6 +156,51 @@ def test_plans_with_a_partition_exchange_rows_and_concatenate(plan_no, fuse, wor
     assert any(len(list(v.values())[0]) for v in want.values())
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_semi_join_sets_are_merged_across_the_ranks(world):
+    """TPC-H Q4 (EXISTS: a semi-join set over orders filled by a scan of lineitem, then a grouped scan of orders): lineitem sharded by
+    rows, orders replicated -- every rank builds the set from its rows, ONE all-gather + OR kernel completes it, every rank ends
+    with the whole answer.  Also random semi-join programs (the generator of test_random_semijoins, fact table t sharded):
+    indices outside the dimension, fact tables shorter than the dimension (the union is clipped at the GLOBAL fact length)."""
+    cfg = frontend.load_metadata(META)
+    text = frontend.compile_plan(open(os.path.join(META, "04.sql.mplan")).read(), cfg)
+    cols = catalog.synth_columns(META, cfg, text, scale=1e-3, seed=7)
+    want = oracle_run(text, cols)
+    assert any(len(list(v.values())[0]) for v in want.values())
+    e = m.Engine(device=None)
+    p = e.parse(text)
+    p.set_sharded_table("lineitem")
+    assert p.is_fused and p.sharded_route() == ("set", True)
+    p.set_sharded_table("orders")
+    with pytest.raises(m.VdlError, match="no sharded route"):
+        p.sharded_route()
+    for got in sharded_run(text, lineitem_shards(cols, world), world, table="lineitem"):
+        assert got == want
+    from test_random_semijoins import Gen
+    ran = 0
+    for seed in range(16):
+        for short in (False, True):
+            text, cols = Gen(seed, short_fact=short).build()
+            p = e.parse(text)
+            p.set_sharded_table("t")
+            try:
+                route = p.sharded_route()
+            except m.VdlError:
+                continue
+            if route != ("set", True):
+                continue
+            nt = len(cols["t.a"])
+            shards = []
+            for r in range(world):
+                r0, r1 = shard_rows(nt, r, world)
+                shards.append((r0, {k: (v[r0:r1] if k.startswith("t.") else v) for k, v in cols.items()}))
+            want = oracle_run(text, cols)
+            for got in sharded_run(text, shards, world, table="t"):
+                assert got == want, (seed, short)
+            ran += 1
+    assert ran >= 20, ran
+
+
 def test_a_failure_on_one_rank_is_reported_on_every_rank():
     """A key outside the Partition pivots on ONE rank (the local phase of that rank fails): the status travels with the
     counts, nobody is left waiting in a collective, every rank returns an error."""
