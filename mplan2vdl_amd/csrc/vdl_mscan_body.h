@@ -176,9 +176,15 @@ __device__ __forceinline__ void derive(const MsArgs &C, const MsArgs &Cr, const 
             }
         }
     }
+    // (a row-id column has no source and may come FIRST -- the select pass of a front whose only deciding columns are the row id and
+    // the set it is looked up in; every other derived column has an earlier one to derive from, so the loop starts at 1)
+    if ((only & 1u) && D.dkind[0] == VC_ROWID) {
 #pragma unroll
-    for (int c = 0; c < NC; c++) {                         // (from 0: a row-id column has no source and may come first -- the select pass of a front
-        if ((only >> c) & 1u) {                            //  whose only deciding columns are the row id and the set it is looked up in; wave-uniform)
+        for (int r = 0; r < RW; r++) v[0][r] = rowid[r] - Cr.row0;
+    }
+#pragma unroll
+    for (int c = 1; c < NC; c++) {
+        if ((only >> c) & 1u) {                            // wave-uniform
             const int kind = D.dkind[c], a = D.dsrc[c], b = D.dsrc2[c];
             if (kind == VC_ROWID) {
 #pragma unroll
