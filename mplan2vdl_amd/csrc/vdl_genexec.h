@@ -74,6 +74,14 @@ struct GenExec {
         HIP_CHECK(launch_fill_words((uint64_t *)o->p, 0, nwords(n), s));
         return o;
     }
+    // k (<= 64) int64 words from the device to the host, waited for: through the context's pinned words (a pageable destination is
+    // staged by the runtime and keeps the GPU idle two to three times as long)
+    void fetch_words(const void *dev, int k, int64_t *out) {
+        int64_t *pin = c->pinned(k);
+        HIP_CHECK(hipMemcpyAsync(pin ? pin : out, dev, sizeof(int64_t) * (size_t)k, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        if (pin) std::memcpy(out, pin, sizeof(int64_t) * (size_t)k);
+    }
     // population of a bitmap over n slots; leaves the per-tile offsets for compact_write in *offsets
     int64_t popcount(const BufP &bits, int64_t n, BufP *offsets) {
         const int64_t nb = (n + compact_tile() - 1) / compact_tile();
@@ -82,8 +90,7 @@ struct GenExec {
         HIP_CHECK(launch_compact_count(bits ? (const uint64_t *)bits->p : nullptr, n, (int64_t *)counts->p, s));
         HIP_CHECK(launch_compact_scan((int64_t *)counts->p, nb, s));
         int64_t total = 0;
-        HIP_CHECK(hipMemcpyAsync(&total, (int64_t *)counts->p + nb, sizeof total, hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipStreamSynchronize(s));
+        fetch_words((int64_t *)counts->p + nb, 1, &total);
         if (offsets) *offsets = counts;
         return total;
     }
@@ -144,8 +151,7 @@ struct GenExec {
     int64_t first_slot_of(const SelP &sel) {
         if (!sel->idx || sel->m <= 0) return 0;
         if (sel->first_slot < 0) {
-            HIP_CHECK(hipMemcpyAsync(&sel->first_slot, sel->idx->p, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-            HIP_CHECK(hipStreamSynchronize(s));
+            fetch_words(sel->idx->p, 1, &sel->first_slot);
         }
         return sel->first_slot;
     }
@@ -350,7 +356,8 @@ struct GenExec {
         const bool ta = a.kind == DVec::EXPR, tb = b.kind == DVec::EXPR;
         if (!(ta || leafable(a)) || !(tb || leafable(b)) || a.n != b.n) return false;
         if (!ta && !tb && a.kind == DVec::RANGE && b.kind == DVec::RANGE && a.step == 0 && b.step == 0) return false;   // constant folding stays
-        const bool lazy = (n_uses[(size_t)n.id] == 1 && read_by_binary_only[(size_t)n.id]) || (pred_on && lazy_pred_ok[(size_t)n.id]);
+        // (RangeV readers take the shape only -- exec(RangeV) reads the validity of a pending tree's leaves -- so they do not end a chain)
+        const bool lazy = (value_uses[(size_t)n.id] == 1 && value_read_by_binary_only[(size_t)n.id]) || (pred_on && lazy_pred_ok[(size_t)n.id]);
         if (!lazy && !ta && !tb) return false;                   // a lone operator: the plain kernel
         DVec x = a, y = b;
         for (;;) {
@@ -611,8 +618,7 @@ struct GenExec {
         if (v.kind == DVec::OHCONST) v = densify(v);
         if (v.kind == DVec::ONEHOT) {
             int64_t h[3];
-            HIP_CHECK(hipMemcpyAsync(h, v.data->p, sizeof h, hipMemcpyDeviceToHost, s));
-            HIP_CHECK(hipStreamSynchronize(s));
+            fetch_words(v.data->p, 3, h);
             if (h[2] > 0) o.vals.push_back(h[0]);
         } else {
             const int64_t nb = (v.n + compact_tile() - 1) / compact_tile();
@@ -621,8 +627,7 @@ struct GenExec {
                 HIP_CHECK(launch_compact_count(vp(v), v.n, (int64_t *)counts->p, s));
                 HIP_CHECK(launch_compact_scan((int64_t *)counts->p, nb, s));
                 int64_t total = 0;
-                HIP_CHECK(hipMemcpyAsync(&total, (int64_t *)counts->p + nb, sizeof total, hipMemcpyDeviceToHost, s));
-                HIP_CHECK(hipStreamSynchronize(s));
+                fetch_words((int64_t *)counts->p + nb, 1, &total);
                 if (total > 0) {
                     BufP outb = dev_alloc(c, sizeof(int64_t) * (size_t)total);
                     HIP_CHECK(launch_compact_write(src_of(v), vp(v), v.n, (const int64_t *)counts->p, (int64_t *)outb->p, s));
