@@ -881,10 +881,21 @@ static void bind_front(vdl_ctx *c, vdl_plan *p, FrontBound &b) {
     scols.n = b.n;
     // the take pass: one packed vector per produced column (statements that are the same column share it), and what those
     // columns are derived from
-    for (int oc : J.node_col) if (oc >= 0 && std::find(b.distinct.begin(), b.distinct.end(), oc) == b.distinct.end()) b.distinct.push_back(oc);
+    // (`distinct` holds output codes: a column, or -2 - e for the row expression e the pass evaluates: ProjPlan::exprs)
+    for (int oc : J.node_col) if (oc != -1 && std::find(b.distinct.begin(), b.distinct.end(), oc) == b.distinct.end()) b.distinct.push_back(oc);
     d.nout = (int)b.distinct.size();
     d.take = 0;
-    for (size_t o = 0; o < b.distinct.size(); o++) { d.out_col[o] = b.distinct[o]; d.take |= 1u << b.distinct[o]; }
+    d.nexpr = (int)J.exprs.size();
+    d.nkey = 0;
+    for (size_t e = 0; e < J.exprs.size(); e++) {
+        d.expr_at[e] = d.nkey; d.expr_len[e] = (int)J.exprs[e].size();
+        for (const KeyStep &st : J.exprs[e]) {
+            if (d.nkey >= kMaxKeySteps) throw Error(VDL_ERR_UNSUPPORTED, "internal: the front's expressions exceed the descriptor's step pool");
+            d.key[d.nkey++] = st;
+            if (st.kind == KeyStep::LOAD) d.take |= 1u << st.col;
+        }
+    }
+    for (size_t o = 0; o < b.distinct.size(); o++) { d.out_col[o] = b.distinct[o]; if (b.distinct[o] >= 0) d.take |= 1u << b.distinct[o]; }
     for (int k = cols.ncol - 1; k >= 0; k--) {
         if (!((d.take >> k) & 1u)) continue;
         for (int src : J.cols[(size_t)k].sources()) d.take |= 1u << src;
@@ -974,7 +985,7 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
     for (size_t k = 0; k < J.nodes.size(); k++) {
         DVec v;
         v.kind = DVec::SPARSE; v.n = n; v.sel = sel;
-        if (J.node_col[k] < 0) { v.data = sel->idx; v.ids = true; }
+        if (J.node_col[k] == -1) { v.data = sel->idx; v.ids = true; }
         else v.data = outs[(size_t)(std::find(distinct.begin(), distinct.end(), J.node_col[k]) - distinct.begin())];
         over[J.nodes[k]] = v;
     }

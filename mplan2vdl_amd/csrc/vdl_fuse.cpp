@@ -989,24 +989,45 @@ static void build_projection(const Program &P, Builder &B, FusedPlan &F) {
     const Sym &pt = B.sym[(size_t)part];
     if (pt.kind != Sym::PART || pt.sel == 0) { J.why = "the Partition key is not a filtered row expression"; return; }
     J.table = pt.table;
-    // candidates: statements whose vector is an atom (or the row ids) on exactly that selection
-    std::vector<char> cand(P.nodes.size(), 0);
+    // candidates: statements whose vector is an atom (or the row ids) on exactly that selection -- or an element-wise expression
+    // over such atoms that has the two-accumulator program form of the group keys (emit_key): the scan then evaluates it for the
+    // survivors and the executor never sees its operands (Q3: the composite key and the revenue term instead of seven columns)
+    struct DryIndex { int operator()(const RowP &) const { return 0; } } dry;
+    std::vector<char> cand(P.nodes.size(), 0), is_expr(P.nodes.size(), 0);
+    std::vector<int> expr_steps(P.nodes.size(), 0);
+    const bool exprs_on = !getenv("VDL_NO_FRONT_EXPR");
     for (int id : P.order) {
         const Sym &s = B.sym[(size_t)id];
         if (s.kind != Sym::ROW || s.table != pt.table || s.sel != pt.sel) continue;
         const Op op = P.at(id).op;
         if (op == Op::Project || op == Op::Shuffle || op == Op::Materialize) continue;      // aliases: their operand is the candidate
         const bool ids = s.e->k == Row::IOTA && s.e->c0 == 0 && s.e->c1 == 1;
-        if (ids || (is_atom(s.e) && s.e->k != Row::BIN)) cand[(size_t)id] = 1;
+        if (ids || (is_atom(s.e) && s.e->k != Row::BIN)) { cand[(size_t)id] = 1; continue; }
+        if (exprs_on && s.e->k == Row::BIN && op == Op::Binary) {
+            std::vector<KeyStep> trial;
+            if (emit_key(s.e, 0, trial, dry) && (int)trial.size() <= kMaxKeySteps) { cand[(size_t)id] = 1; is_expr[(size_t)id] = 1; expr_steps[(size_t)id] = (int)trial.size(); }
+        }
     }
-    // which of them does the rest of the program read?  (walk back from the outputs, stopping at candidates)
-    std::vector<char> needed(P.nodes.size(), 0), used(P.nodes.size(), 0);
-    for (int id : P.outputs) needed[(size_t)id] = 1;
-    for (auto it = P.order.rbegin(); it != P.order.rend(); ++it) {
-        const Node &n = P.at(*it);
-        if (!needed[(size_t)n.id]) continue;
-        if (cand[(size_t)n.id]) { used[(size_t)n.id] = 1; continue; }
-        for (int opnd : {n.a, n.b, n.c}) if (opnd > 0) needed[(size_t)opnd] = 1;
+    // which of them does the rest of the program read?  (walk back from the outputs, stopping at candidates; when the
+    // expressions in use do not fit the descriptor's step pool together, the longest one stops being a candidate)
+    std::vector<char> needed, used;
+    for (;;) {
+        needed.assign(P.nodes.size(), 0); used.assign(P.nodes.size(), 0);
+        for (int id : P.outputs) needed[(size_t)id] = 1;
+        for (auto it = P.order.rbegin(); it != P.order.rend(); ++it) {
+            const Node &n = P.at(*it);
+            if (!needed[(size_t)n.id]) continue;
+            if (cand[(size_t)n.id]) { used[(size_t)n.id] = 1; continue; }
+            for (int opnd : {n.a, n.b, n.c}) if (opnd > 0) needed[(size_t)opnd] = 1;
+        }
+        int total = 0, nex = 0, longest = -1;
+        for (int id : P.order)
+            if (used[(size_t)id] && is_expr[(size_t)id]) {
+                total += expr_steps[(size_t)id]; nex++;
+                if (longest < 0 || expr_steps[(size_t)id] > expr_steps[(size_t)longest]) longest = id;
+            }
+        if (total <= kMaxKeySteps && nex <= kMaxProjOuts) break;
+        cand[(size_t)longest] = 0; is_expr[(size_t)longest] = 0;
     }
     Clause cl;
     if (!to_clause(B.pred_of(pt.sel), cl)) {
@@ -1022,7 +1043,12 @@ static void build_projection(const Program &P, Builder &B, FusedPlan &F) {
         if (!used[(size_t)id]) continue;
         const Sym &s = B.sym[(size_t)id];
         int c = -1;
-        if (s.e->k != Row::IOTA) { c = vc(s.e); if (c < 0) return; }
+        if (is_expr[(size_t)id]) {
+            std::vector<KeyStep> prog;
+            if (!emit_key(s.e, 0, prog, vc)) { if (J.why.empty()) J.why = "an expression of the front has an operand without a column form"; return; }
+            c = -2 - (int)J.exprs.size();
+            J.exprs.push_back(prog);
+        } else if (s.e->k != Row::IOTA) { c = vc(s.e); if (c < 0) return; }
         J.nodes.push_back(id); J.node_col.push_back(c);
     }
     if (J.nodes.empty()) { J.why = "nothing downstream reads a column on the Partition's selection"; return; }
@@ -1030,8 +1056,11 @@ static void build_projection(const Program &P, Builder &B, FusedPlan &F) {
     // a range check that a lookup through the same index column performs anyway needs no column of its own (the first such
     // lookup then decides about the row and is not deferred to the survivors: run_projection)
     {
-        const std::vector<int> map = VCols::tidy_columns(J.cols, J.node_col);
+        std::vector<int> keep = J.node_col;                       // (what the expressions load stays a column too)
+        for (const auto &prog : J.exprs) for (const KeyStep &st : prog) if (st.kind == KeyStep::LOAD) keep.push_back(st.col);
+        const std::vector<int> map = VCols::tidy_columns(J.cols, keep);
         for (int &nc : J.node_col) if (nc >= 0) nc = map[(size_t)nc];
+        for (auto &prog : J.exprs) for (KeyStep &st : prog) if (st.kind == KeyStep::LOAD) st.col = map[(size_t)st.col];
     }
     if ((int)J.cols.size() > kMaxProjCols) {
         std::ostringstream o;
@@ -1236,7 +1265,9 @@ std::string describe_fused(const FusedPlan &F) {
         if (F.proj.ok) {
             show_prelude(F, o);
             o << "fused front: one scan of " << F.proj.table << (F.proj.never ? " [never]" : "") << " hands these statements to the per-operator executor as sparse vectors:";
-            for (size_t k = 0; k < F.proj.nodes.size(); k++) o << " Id " << F.proj.nodes[k] << (F.proj.node_col[k] < 0 ? "=rowid" : "=col" + std::to_string(F.proj.node_col[k]));
+            for (size_t k = 0; k < F.proj.nodes.size(); k++)
+                o << " Id " << F.proj.nodes[k] << (F.proj.node_col[k] == -1 ? "=rowid" : F.proj.node_col[k] < -1 ? "=expr" + std::to_string(-2 - F.proj.node_col[k]) + "(" +
+                     std::to_string(F.proj.exprs[(size_t)(-2 - F.proj.node_col[k])].size()) + " steps)" : "=col" + std::to_string(F.proj.node_col[k]));
             o << "\n";
             for (size_t c = 0; c < F.proj.cols.size(); c++) show_col(F.proj.cols[c], c, o);
         } else if (!F.proj.why.empty()) {

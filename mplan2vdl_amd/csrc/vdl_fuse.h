@@ -125,7 +125,8 @@ struct ProjPlan {
     std::vector<ScanColumn> cols;    // as in ScanPlan (filters, derived columns)
     bool never = false;
     std::vector<int> nodes;          // statements the scan produces ...
-    std::vector<int> node_col;       // ... and the column each one is (-1: the row ids themselves)
+    std::vector<int> node_col;       // ... and the column each one is (-1: the row ids themselves; -2 - e: the row expression exprs[e])
+    std::vector<std::vector<KeyStep>> exprs;     // element-wise expressions over the columns that the scan evaluates for the survivors
 };
 
 struct FusedPlan {

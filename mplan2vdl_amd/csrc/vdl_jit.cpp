@@ -213,6 +213,8 @@ static std::string desc_text(Kind kind, const MsArgs &C, const MScanDesc &D) {
     if (kind != MSCAN) {
         o << "    d.take = " << D.take << "u; d.nout = " << D.nout << "; d.bitmap_only = " << D.bitmap_only << ";\n";
         for (int k = 0; k < D.nout; k++) o << "    d.out_col[" << k << "] = " << D.out_col[k] << ";\n";
+        o << "    d.nexpr = " << D.nexpr << ";\n";
+        for (int k = 0; k < D.nexpr; k++) o << "    d.expr_at[" << k << "] = " << D.expr_at[k] << "; d.expr_len[" << k << "] = " << D.expr_len[k] << ";\n";
     }
     o << "    return d;\n}\n}  // namespace vdl\n";
     return o.str();

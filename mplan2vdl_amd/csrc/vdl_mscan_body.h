@@ -762,8 +762,28 @@ __device__ __forceinline__ void project_take_body(const MsArgs &C, const MsArgs 
             for (int o = 0; o < D.nout; o++) {
                 const int oc = D.out_col[o];
                 int64_t x = 0;
+                if (oc >= 0) {
 #pragma unroll
-                for (int c = 0; c < NC; c++) if (c == oc) x = v[c][0];
+                    for (int c = 0; c < NC; c++) if (c == oc) x = v[c][0];
+                } else {
+                    // a row expression over the columns, in the two-accumulator program form of the group keys (ProjPlan::exprs)
+                    int64_t acc[1] = {0}, tmp[1] = {0};
+                    const int at = D.expr_at[-2 - oc], len = D.expr_len[-2 - oc];
+                    VDL_SPEC_UNROLL
+                    for (int s = at; s < at + len; s++) {
+                        const KeyStep st = D.key[s];               // wave-uniform
+                        if (st.kind == KeyStep::LOAD) {
+#pragma unroll
+                            for (int c = 0; c < NC; c++) if (c == st.col) { if (st.target) tmp[0] = v[c][0]; else acc[0] = v[c][0]; }
+                        } else if (st.kind == KeyStep::OPK) {
+                            if (st.target) key_rows<1>(st.bin, st.const_left, tmp, st.k);
+                            else key_rows<1>(st.bin, st.const_left, acc, st.k);
+                        } else {
+                            key_combine<1>(st.bin, st.const_left, acc, tmp);
+                        }
+                    }
+                    x = acc[0];
+                }
                 if (on) Dr.out_ptr[o][off + k] = x;
             }
         }

@@ -68,7 +68,7 @@ constexpr int kMaxFormPool = 160;                       // all formula columns o
 //   acc / tmp <- column, then (op constant) steps on either, and `acc = acc op tmp` combines.
 // This is exactly the shape makeCompositeKey emits (/root/reference/src/Vlite.hs:1123-1170):
 // ((c0 >> tz0) - min0) << bits | ((c1 >> tz1) - min1) ... & mask.
-constexpr int kMaxKeySteps = 24;
+constexpr int kMaxKeySteps = 32;
 struct KeyStep {
     enum Kind : int { LOAD = 0, OPK = 1, COMBINE = 2 } kind = LOAD;
     int target = 0;          // 0 = acc, 1 = tmp (LOAD / OPK)
@@ -119,7 +119,11 @@ struct MScanDesc {                           // lives in device memory, read wit
     FormStep form[kMaxFormPool];
     int64_t dn[kMaxVCols] = {};              // derived columns: entries of the table looked up
     // projection scan (k_project): what to write for the surviving rows
-    int nout = 0, out_col[kMaxProjOuts] = {};
+    int nout = 0, out_col[kMaxProjOuts] = {};     // out_col[o] >= 0: that column; -2 - e: the row expression e (below)
+    // row expressions the take pass computes for the survivors instead of handing their operands over (Q3's composite group key
+    // and its revenue term: the executor then starts at the Partition): expression e = steps key[expr_at[e] .. + expr_len[e]) of the
+    // two-accumulator program form of the group keys (KeyStep), its value the accumulator at the end
+    int nexpr = 0, expr_at[kMaxProjOuts] = {}, expr_len[kMaxProjOuts] = {};
     int64_t *out_ptr[kMaxProjOuts] = {};     // one packed int64 vector per produced column
     int64_t *out_idx = nullptr;              // the surviving rows' slot ids, ascending
     int64_t *tile_counts = nullptr;          // [tiles + 1]: survivors per tile
