@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <functional>
+#include <set>
 #include <sstream>
 
 namespace vdl {
@@ -1026,8 +1027,14 @@ static void build_projection(const Program &P, Builder &B, FusedPlan &F) {
                 total += expr_steps[(size_t)id]; nex++;
                 if (longest < 0 || expr_steps[(size_t)id] > expr_steps[(size_t)longest]) longest = id;
             }
-        if (total <= kMaxKeySteps && nex <= kMaxProjOuts) break;
-        cand[(size_t)longest] = 0; is_expr[(size_t)longest] = 0;
+        if (total > kMaxKeySteps || nex > kMaxProjOuts) { cand[(size_t)longest] = 0; is_expr[(size_t)longest] = 0; continue; }
+        // distinct vectors to produce (statements that are the same expression share one; row ids cost none): with more than the
+        // take pass writes, the expressions stop being candidates altogether -- the front is then what it was without them
+        std::set<std::string> distinct;
+        for (int id : P.order)
+            if (used[(size_t)id] && B.sym[(size_t)id].e->k != Row::IOTA) distinct.insert(row_key(B.sym[(size_t)id].e));
+        if ((int)distinct.size() <= kMaxProjOuts || nex == 0) break;
+        for (int id : P.order) if (is_expr[(size_t)id]) { cand[(size_t)id] = 0; is_expr[(size_t)id] = 0; }
     }
     Clause cl;
     if (!to_clause(B.pred_of(pt.sel), cl)) {
@@ -1052,7 +1059,11 @@ static void build_projection(const Program &P, Builder &B, FusedPlan &F) {
         J.nodes.push_back(id); J.node_col.push_back(c);
     }
     if (J.nodes.empty()) { J.why = "nothing downstream reads a column on the Partition's selection"; return; }
-    if ((int)J.nodes.size() > kMaxProjOuts) { J.why = "more than " + std::to_string(kMaxProjOuts) + " vectors to produce"; return; }
+    {
+        std::set<int> outs;
+        for (int nc : J.node_col) if (nc != -1) outs.insert(nc);
+        if ((int)outs.size() > kMaxProjOuts) { J.why = "more than " + std::to_string(kMaxProjOuts) + " vectors to produce"; return; }
+    }
     // a range check that a lookup through the same index column performs anyway needs no column of its own (the first such
     // lookup then decides about the row and is not deferred to the survivors: run_projection)
     {
