@@ -548,8 +548,8 @@ def main():
         eng.comm_init_host(rank, world, gloo_all_gather, gloo_all_to_all)
     if world > 1 and comm_mode in ("native", "host"):
         _, n_ranks, name = eng.comm_info()
-        transport = {"rccl": "RCCL inside libvdl: one all-gather of %d int64 words + merge kernel per query, on a communication stream",
-                     "host": "libvdl host transport over gloo (REHEARSAL): one all-gather of %d int64 words + merge kernel per query"}[name] % (2 * nw)
+        transport = {"rccl": "RCCL inside libvdl: one all-gather of %d int64 words (partial words twice + status) + merge kernel per query, on a communication stream",
+                     "host": "libvdl host transport over gloo (REHEARSAL): one all-gather of %d int64 words + merge kernel per query"}[name] % (2 * nw + 1)
         if n_ranks != args.gpus:
             print("bench.py: the communicator has %d rank(s), --gpus asked for %d" % (n_ranks, args.gpus), file=sys.stderr)
             sys.exit(2)
@@ -711,7 +711,7 @@ def main():
             except Exception as exc:              # noqa: BLE001
                 read_everything = {"error": "%s: %s" % (type(exc).__name__, exc)}
         out = {
-            "metric": "rows/s, TPC-H %s %s (fused VDL scan), + achieved HBM GB/s in roofline" % (args.query.upper(), args.sf.upper()),
+            "metric": "rows/s, TPC-H %s %s (fused VDL scan), + achieved HBM GB/s in roofline" % (args.query.upper(), args.sf.upper() if not args.rows else "%d rows" % total_rows),
             "value": rows_per_s, "unit": "rows/s", "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "latency_ms_per_query": latency_ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int64", "data": "synthetic",

@@ -287,14 +287,19 @@ static void sharded_exchange(vdl_ctx *c, vdl_plan *p) {
     int ncols = 0;
     const std::string table = p->sharded_table;
     if (table.empty()) throw Error(VDL_ERR_ARG, "vdl_run_sharded: name the row-sharded table first (vdl_plan_set_sharded_table)");
+    struct AllowFolds { vdl_plan *p; AllowFolds(vdl_plan *q) : p(q) { p->ex_allow_folds = true; } ~AllowFolds() { p->ex_allow_folds = false; } } allow(p);
     if (vdl_exchange_spec(p, table.c_str(), &ncols) != VDL_OK) throw Error(VDL_ERR_UNSUPPORTED, c->err);
-    // local phase; its outcome travels with the counts so that no rank is left waiting in a collective after a failure elsewhere
-    std::vector<int64_t> mine((size_t)m.world + 1, 0);
+    // local phase; its outcome travels with the counts so that no rank is left waiting in a collective after a failure elsewhere.
+    // Global folds over the sharded table that the tail reads beside the Partition (Q11's HAVING threshold) travel in the same
+    // all-gather: three mergeable words each, merged on the host below.
+    const size_t n_fold_words = 3 * exchange_fold_count(p, table);
+    std::vector<int64_t> mine((size_t)m.world + 1 + n_fold_words, 0);
     std::string local_error;
     const int rc = vdl_exchange_begin(c, p, m.world, mine.data() + 1);
-    if (rc != VDL_OK) { local_error = c->err; mine.assign((size_t)m.world + 1, 0); }
+    if (rc != VDL_OK) { local_error = c->err; mine.assign((size_t)m.world + 1 + n_fold_words, 0); }
+    else if (p->ex.fold_words.size() == n_fold_words) std::copy(p->ex.fold_words.begin(), p->ex.fold_words.end(), mine.begin() + m.world + 1);
     mine[0] = rc;
-    const size_t row = (size_t)m.world + 1;
+    const size_t row = (size_t)m.world + 1 + n_fold_words;
     BufP dsend = dev_alloc(c, sizeof(int64_t) * row), drecv = dev_alloc(c, sizeof(int64_t) * row * (size_t)m.world);
     HIP_CHECK(hipMemcpyAsync(dsend->p, mine.data(), sizeof(int64_t) * row, hipMemcpyHostToDevice, c->stream));
     std::vector<int64_t> all(row * (size_t)m.world);
@@ -310,7 +315,21 @@ static void sharded_exchange(vdl_ctx *c, vdl_plan *p) {
             if (rc != VDL_OK) throw Error(rc, local_error);
             throw Error(VDL_ERR_UNSUPPORTED, "sharded Partition exchange failed on rank " + std::to_string(r));
         }
-    std::vector<int64_t> scnt(mine.begin() + 1, mine.end()), rcnt((size_t)m.world);
+    if (n_fold_words) {
+        // merge: value by the fold's reduction, first row by MIN, count by SUM (vdl_exchange.cpp: k_fold_words / k_fold_record)
+        std::vector<int64_t> merged(n_fold_words);
+        for (size_t w = 0; w < n_fold_words; w++) {
+            const int kind = w % 3 == 0 ? exchange_fold_kind(p, w / 3) : (w % 3 == 1 ? 1 : 0);      // 0 sum, 1 min, 2 max
+            int64_t acc = all[(size_t)m.world + 1 + w];
+            for (int r = 1; r < m.world; r++) {
+                const int64_t v = all[(size_t)r * row + (size_t)m.world + 1 + w];
+                acc = kind == 1 ? std::min(acc, v) : kind == 2 ? std::max(acc, v) : (int64_t)((uint64_t)acc + (uint64_t)v);
+            }
+            merged[w] = acc;
+        }
+        p->ex.fold_merged = merged;
+    }
+    std::vector<int64_t> scnt(mine.begin() + 1, mine.begin() + 1 + m.world), rcnt((size_t)m.world);
     int64_t n_send = 0, n_recv = 0;
     for (int r = 0; r < m.world; r++) {
         rcnt[(size_t)r] = all[(size_t)r * row + 1 + (size_t)m.rank];
@@ -458,7 +477,9 @@ int vdl_plan_sharded_route(vdl_ctx *c, vdl_plan *p, const char **route, int *rep
     } else {
         int ncols = 0;
         if (p->sharded_table.empty()) { c->err = "name the row-sharded table first (vdl_plan_set_sharded_table)"; return VDL_ERR_ARG; }
+        p->ex_allow_folds = true;                              // (vdl_run_sharded merges global folds beside the Partition)
         const int rc = vdl_exchange_spec(p, p->sharded_table.c_str(), &ncols);
+        p->ex_allow_folds = false;
         if (rc != VDL_OK) return rc;
         name = "exchange";
     }

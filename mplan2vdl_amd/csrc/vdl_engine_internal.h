@@ -244,7 +244,12 @@ struct vdl_plan {
         BufP vdest, pos;
         std::vector<int> nodes;
         int64_t pmin = 0, pcount = 0;
+        // global folds over the sharded table that the tail reads beside the Partition (Q11: HAVING sum(..) > (select sum(..) * k)):
+        // their local records travel with the counts as three mergeable words each {value, first global row, count}
+        std::vector<int> folds;
+        std::vector<int64_t> fold_n, fold_words, fold_merged;
     } ex;
+    bool ex_allow_folds = false;           // set by vdl_run_sharded around the exchange calls (callers of the bare calls get no fold merge)
     std::shared_ptr<ShardState> shard;     // vdl_run_sharded: send / receive / merged word buffers
     BufP shard_keep;                       // vdl_run_sharded: received rows while the tail of an exchange plan reads them
     std::string sharded_table;             // placement named in the last vdl_exchange_spec ("" = not stated)
@@ -337,6 +342,8 @@ inline const Column &find_col(vdl_ctx *c, const std::string &name) {
 }
 
 std::string describe_plan(const vdl_plan *p);
+size_t exchange_fold_count(const vdl_plan *p, const std::string &table);      // vdl_exchange.cpp: global folds beside the Partition (sharded runs)
+int exchange_fold_kind(const vdl_plan *p, size_t k);                          // ... 0 sum / count, 1 min, 2 max of the k-th one (after vdl_exchange_begin)
 bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over);     // vdl_engine.cpp: the fused front of a plan that does not fuse as a whole
 // general (not fused) plans sharded by rows through their global folds, vdl_exchange.cpp
 bool general_partial_spec(const vdl_plan *p, std::vector<int32_t> &ops, std::string &why);

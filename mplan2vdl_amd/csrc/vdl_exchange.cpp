@@ -13,6 +13,7 @@ struct ExchangeSpec {
     int part = 0, key = 0;             // Partition statement, its (resolved) data operand
     std::vector<int> sources;          // resolved source statements of the Scatters that use the partition; [0] = key
     int64_t pmin = 0, pcount = 0;
+    std::vector<int> folds;            // global folds over rows of the sharded table that the tail reads beside the Partition
 };
 
 int resolve_alias(const Program &P, int id) {
@@ -83,7 +84,9 @@ bool classify_rows(const Program &P, const std::vector<int> &roots, const std::s
 // `table`: name of the row-sharded table ("" = trust the caller).  With a table name the statements
 // below the scatters are checked to be row-local over that table: its columns may pass through
 // element-wise operators, constants and Gathers *from* replicated vectors only.
-ExchangeSpec analyse_exchange(const Program &P, const std::string &table = std::string()) {
+// allow_folds: the caller merges global fold records across the ranks (vdl_run_sharded); then a global Fold over row-local data
+// of the sharded table may stand beside the Partition and what is above it may read its (merged) result.
+ExchangeSpec analyse_exchange(const Program &P, const std::string &table = std::string(), bool allow_folds = false) {
     ExchangeSpec x;
     std::vector<char> needed(P.nodes.size(), 0);
     for (int id : P.outputs) needed[(size_t)id] = 1;
@@ -129,6 +132,13 @@ ExchangeSpec analyse_exchange(const Program &P, const std::string &table = std::
         seen[(size_t)id] = 1;
         const Node &n = P.at(id);
         if (is_cut[(size_t)id]) continue;
+        if (allow_folds && !table.empty() && (n.op == Op::FoldSum || n.op == Op::FoldMin || n.op == Op::FoldMax || n.op == Op::FoldCount)) {
+            const Node &ctl = P.at(resolve_alias(P, n.a));
+            if (ctl.op == Op::RangeV && ctl.imm1 == 0) {          // one run over everything: a candidate (kept if its data is row-local)
+                if (std::find(x.folds.begin(), x.folds.end(), id) == x.folds.end()) x.folds.push_back(id);
+                continue;
+            }
+        }
         if (n.op == Op::Load) {
             // columns of the other (replicated) tables are there on every rank: the tail may gather from them by values
             // that travelled (Q10 prints customer columns through the group's FK value)
@@ -155,11 +165,24 @@ ExchangeSpec analyse_exchange(const Program &P, const std::string &table = std::
     }
     if (!table.empty()) {
         std::vector<char> cls;
-        if (!classify_rows(P, x.sources, table, "the Partition", cls, x.why)) return x;
+        std::vector<int> roots = x.sources;
+        for (int id : x.folds) { roots.push_back(P.at(id).a); roots.push_back(P.at(id).b); }
+        if (!classify_rows(P, roots, table, "the Partition", cls, x.why)) return x;
         for (int id : x.sources) {
             if (cls[(size_t)id] == N) { x.why = "statement " + std::to_string(id) + " feeds the Partition with rank-local row numbers"; return x; }
             if (cls[(size_t)id] != V) { x.why = "statement " + std::to_string(id) + " feeds the Partition but does not depend on table " + table; return x; }
         }
+        // a candidate fold over replicated data is the same on every rank: no cut (nothing below it reads the sharded table)
+        std::vector<int> kept;
+        for (int id : x.folds) {
+            const char cd = cls[(size_t)P.at(id).b], cc = cls[(size_t)P.at(id).a];
+            if (cd == N) { x.why = "statement " + std::to_string(id) + " folds rank-local row numbers"; return x; }
+            if (cd == V || cc == V) kept.push_back(id);
+        }
+        std::sort(kept.begin(), kept.end());
+        x.folds = kept;
+    } else {
+        x.folds.clear();
     }
     x.ok = true;
     return x;
@@ -241,6 +264,12 @@ int fold_reduce_kind(Op op) { return op == Op::FoldMin ? 1 : op == Op::FoldMax ?
 namespace vdl {
 namespace eng {
 
+size_t exchange_fold_count(const vdl_plan *p, const std::string &table) {
+    ExchangeSpec x = analyse_exchange(p->prog, table, true);
+    return x.ok ? x.folds.size() : 0;
+}
+int exchange_fold_kind(const vdl_plan *p, size_t k) { return k < p->ex.folds.size() ? fold_reduce_kind(p->prog.at(p->ex.folds[k]).op) : 0; }
+
 bool general_partial_spec(const vdl_plan *p, std::vector<int32_t> &ops, std::string &why) {
     FoldCut x = analyse_folds(p->prog, p->sharded_table);
     if (!x.ok) { why = x.why; return false; }
@@ -294,7 +323,7 @@ extern "C" {
 
 int vdl_exchange_spec(const vdl_plan *p, const char *sharded_table, int *n_columns) {
     if (!p) return VDL_ERR_ARG;
-    ExchangeSpec x = analyse_exchange(p->prog, sharded_table ? sharded_table : "");
+    ExchangeSpec x = analyse_exchange(p->prog, sharded_table ? sharded_table : "", p->ex_allow_folds);
     if (!x.ok) {
         if (p->ctx) p->ctx->err = "no sharded-Partition structure: " + x.why;
         return VDL_ERR_UNSUPPORTED;
@@ -308,15 +337,33 @@ int vdl_exchange_begin(vdl_ctx *c, vdl_plan *p, int world, int64_t *counts_host)
     if (!c || !p || !counts_host || world < 1 || world > kMaxExWorld) return VDL_ERR_ARG;
     return guard(c, [&] {
         need_device(c);
-        ExchangeSpec x = analyse_exchange(p->prog, p->sharded_table);
+        ExchangeSpec x = analyse_exchange(p->prog, p->sharded_table, p->ex_allow_folds);
         if (!x.ok) throw Error(VDL_ERR_UNSUPPORTED, "no sharded-Partition structure: " + x.why);
         std::map<int, DVec> front;                          // the fused front of the local phase (ProjPlan), when the plan has one
         const bool has_front = run_projection(c, p, front);
         GenExec g(c, p);
-        g.run_nodes(x.sources, has_front ? &front : nullptr);
+        std::vector<int> targets = x.sources;
+        targets.insert(targets.end(), x.folds.begin(), x.folds.end());
+        g.run_nodes(targets, has_front ? &front : nullptr);
         vdl_plan::ExState &ex = p->ex;
         ex = vdl_plan::ExState{};
         ex.world = world; ex.nodes = x.sources; ex.pmin = x.pmin; ex.pcount = x.pcount;
+        ex.folds = x.folds;
+        if (!x.folds.empty()) {
+            // this rank's records of the global folds, as mergeable words {value | identity, first global row | none, count}
+            BufP fw = dev_alloc(c, sizeof(int64_t) * 3 * x.folds.size());
+            for (size_t k = 0; k < x.folds.size(); k++) {
+                DVec v = g.vec[(size_t)x.folds[k]];
+                if (v.kind == DVec::OHCONST) v = g.densify(v);
+                if (v.kind != DVec::ONEHOT) throw Error(VDL_ERR_UNSUPPORTED, "global fold " + std::to_string(x.folds[k]) + " did not yield a scalar record");
+                ex.fold_n.push_back(v.n);
+                HIP_CHECK(launch_fold_words((const int64_t *)v.data->p, fold_reduce_kind(p->prog.at(x.folds[k]).op), p->row_offset, (int64_t *)fw->p + 3 * (int64_t)k, c->stream));
+            }
+            ex.fold_words.resize(3 * x.folds.size());
+            HIP_CHECK(hipMemcpyAsync(ex.fold_words.data(), fw->p, sizeof(int64_t) * ex.fold_words.size(), hipMemcpyDeviceToHost, c->stream));
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            ex.fold_merged = ex.fold_words;                 // (a single rank: its own records are the merged ones)
+        }
         // sources that live on one sparse selection travel as their entries (m rows instead of n slots to route and pack)
         bool all_sparse = !x.sources.empty();
         for (int id : x.sources) {
@@ -406,6 +453,16 @@ int vdl_exchange_finish(vdl_ctx *c, vdl_plan *p, const void *dev_recv, int64_t n
                 HIP_CHECK(launch_ex_unmask(in + (int64_t)m * n_recv, n_recv, (int)k - 1, (uint64_t *)v.valid->p, c->stream));
             }
             over[ex.nodes[k]] = v;
+        }
+        for (size_t k = 0; k < ex.folds.size(); k++) {             // the merged records of the global folds beside the Partition
+            DVec v;
+            v.kind = DVec::ONEHOT; v.n = std::max<int64_t>(ex.fold_n[k], 1);
+            BufP w = dev_alloc(c, 3 * sizeof(int64_t));
+            v.data = dev_alloc(c, 3 * sizeof(int64_t));
+            HIP_CHECK(hipMemcpyAsync(w->p, ex.fold_merged.data() + 3 * k, 3 * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+            HIP_CHECK(launch_fold_record((const int64_t *)w->p, (int64_t *)v.data->p, c->stream));
+            HIP_CHECK(hipStreamSynchronize(c->stream));            // (`w` and the host words may go)
+            over[ex.folds[k]] = v;
         }
         ex.src.clear(); ex.vdest.reset(); ex.pos.reset();          // phase-A vectors are no longer needed
         ex.active = false;

@@ -67,13 +67,17 @@ def run_ranks(world, work):
     return out
 
 
-def lineitem_shards(cols, world):
-    n = len(next(v for k, v in cols.items() if k.startswith("lineitem.") and not k.endswith(".heap")))
+def table_shards(cols, world, table):
+    n = len(next(v for k, v in cols.items() if k.startswith(table + ".") and not k.endswith(".heap")))
     shards = []
     for r in range(world):
         r0, r1 = shard_rows(n, r, world)
-        shards.append((r0, {k: (v[r0:r1] if k.startswith("lineitem.") and not k.endswith(".heap") else v) for k, v in cols.items()}))
+        shards.append((r0, {k: (v[r0:r1] if k.startswith(table + ".") and not k.endswith(".heap") else v) for k, v in cols.items()}))
     return shards
+
+
+def lineitem_shards(cols, world):
+    return table_shards(cols, world, "lineitem")
 
 
 def sharded_run(text, shards, world, table=None, pipelined=0, fuse=True):
@@ -199,6 +203,26 @@ def test_semi_join_sets_are_merged_across_the_ranks(world):
                 assert got == want, (seed, short)
             ran += 1
     assert ran >= 20, ran
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_a_global_fold_beside_the_partition_is_merged_with_the_counts(world):
+    """TPC-H Q11: GROUP BY ps_partkey HAVING sum(..) > (select sum(..) * 0.0001 ..) over the same filtered partsupp rows -- a Partition
+    AND a global fold over the sharded table, which the tail compares the group sums with.  partsupp sharded by rows: the fold's
+    record of every rank travels in the all-gather that carries the row counts, is merged on the host, and the tail of every rank
+    reads the merged threshold; the ranks' outputs concatenate to the unsharded result."""
+    cfg = frontend.load_metadata(META)
+    text = frontend.compile_plan(open(os.path.join(META, "11.sql.mplan")).read(), cfg)
+    cols = catalog.synth_columns(META, cfg, text, scale=2e-3, seed=3)
+    want = oracle_run(text, cols)
+    assert any(len(list(v.values())[0]) for v in want.values())
+    e = m.Engine(device=None)
+    p = e.parse(text)
+    p.set_sharded_table("partsupp")
+    assert p.sharded_route() == ("exchange", False)
+    parts = sharded_run(text, table_shards(cols, world, "partsupp"), world, table="partsupp")
+    got = {k: {name: sum((part[k][name] for part in parts), []) for name in v} for k, v in want.items()}
+    assert got == want
 
 
 def test_a_failure_on_one_rank_is_reported_on_every_rank():
