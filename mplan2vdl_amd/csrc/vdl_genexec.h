@@ -87,8 +87,7 @@ struct GenExec {
         const int64_t nb = (n + compact_tile() - 1) / compact_tile();
         if (nb <= 0) return 0;
         BufP counts = dev_alloc(c, sizeof(int64_t) * (size_t)(nb + 1));
-        HIP_CHECK(launch_compact_count(bits ? (const uint64_t *)bits->p : nullptr, n, (int64_t *)counts->p, s));
-        HIP_CHECK(launch_compact_scan((int64_t *)counts->p, nb, s));
+        HIP_CHECK(launch_compact_offsets(bits ? (const uint64_t *)bits->p : nullptr, n, (int64_t *)counts->p, s));
         int64_t total = 0;
         fetch_words((int64_t *)counts->p + nb, 1, &total);
         if (offsets) *offsets = counts;
@@ -624,8 +623,7 @@ struct GenExec {
             const int64_t nb = (v.n + compact_tile() - 1) / compact_tile();
             if (nb > 0) {
                 BufP counts = dev_alloc(c, sizeof(int64_t) * (size_t)(nb + 1));
-                HIP_CHECK(launch_compact_count(vp(v), v.n, (int64_t *)counts->p, s));
-                HIP_CHECK(launch_compact_scan((int64_t *)counts->p, nb, s));
+                HIP_CHECK(launch_compact_offsets(vp(v), v.n, (int64_t *)counts->p, s));
                 int64_t total = 0;
                 fetch_words((int64_t *)counts->p + nb, 1, &total);
                 if (total > 0) {

@@ -604,6 +604,49 @@ __global__ __launch_bounds__(1024) void k_scan_counts(int64_t *c, int64_t nb) {
     }
     if (tid == 0) c[nb] = carry;
 }
+// count + scan in ONE launch for vectors of up to 1024 tiles (4 M slots): thread t counts tile t, the block scans the counts.
+// (Small selections -- the few thousand groups left after a HAVING, the entries behind a selective filter -- paid two launches
+// of 3-4 us each for a few hundred bytes of work, eighteen times per Q18.)
+__global__ __launch_bounds__(1024) void k_compact_count_scan(const uint64_t *valid, int64_t n, int64_t nb, int64_t *counts) {
+    __shared__ int64_t wsum[1024 / kWave];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const int64_t nw = (n + 63) >> 6;
+    int64_t c = 0;
+    if (tid < nb) {
+        const int64_t w0 = (int64_t)tid * kCompactWords;
+        for (int k = 0; k < kCompactWords; k++) {
+            const int64_t w = w0 + k;
+            if (w >= nw) break;
+            uint64_t m = valid ? valid[w] : ~0ull;
+            const int64_t rem = n - (w << 6);
+            if (rem < 64) m &= (1ull << rem) - 1;
+            c += __popcll(m);
+        }
+    }
+    int64_t incl = c;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) { const int64_t y = __shfl_up(incl, off, kWave); if (lane >= off) incl += y; }
+    if (lane == kWave - 1) wsum[wave] = incl;
+    __syncthreads();
+    int64_t pre = 0, total = 0;
+    for (int w = 0; w < 1024 / kWave; w++) { if (w < wave) pre += wsum[w]; total += wsum[w]; }
+    if (tid < nb) counts[tid] = pre + incl - c;
+    if (tid == 0) counts[nb] = total;
+}
+// counts[0 .. nb) = exclusive prefix of the tile populations, counts[nb] = their total (what launch_compact_count followed by
+// launch_compact_scan leave)
+hipError_t launch_compact_offsets(const uint64_t *valid, int64_t n, int64_t *counts, hipStream_t s) {
+    (void)hipGetLastError();
+    const int64_t nb = (n + compact_tile() - 1) / compact_tile();
+    if (nb <= 0) return hipSuccess;
+    if (nb <= 1024 && n <= ((int64_t)1 << 18)) {               // (beyond a few tiles per thread-row the serial count stops paying)
+        k_compact_count_scan<<<1, 1024, 0, s>>>(valid, n, nb, counts);
+        return launch_status();
+    }
+    hipError_t e = launch_compact_count(valid, n, counts, s);
+    if (e != hipSuccess) return e;
+    return launch_compact_scan(counts, nb, s);
+}
 hipError_t launch_compact_scan(int64_t *counts, int64_t nb, hipStream_t s) {
     (void)hipGetLastError();   // see launch_status()
     k_scan_counts<<<1, 1024, 0, s>>>(counts, nb);

@@ -10,8 +10,11 @@ if sys.argv[1] == "run":
     import mplan2vdl_amd as m
     from mplan2vdl_amd import datagen
     e = m.Engine(0)
-    keep = datagen.register_q3_columns(e, 15000000)
-    p = e.parse(open(os.path.join(ROOT, "tests", "golden", "q3.vdl")).read())
+    n_orders = int(os.environ.get("Q3_ORDERS", "15000000"))
+    keep = datagen.register_q3_columns(e, n_orders)
+    sys.path.insert(0, ROOT)
+    import bench
+    p = e.parse(bench.q3_program(n_orders))
     if os.environ.get("Q3_JIT", "1") == "1":
         p.set_jit(True)
     p.set_device_outputs(True)
