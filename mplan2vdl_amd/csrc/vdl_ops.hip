@@ -604,34 +604,39 @@ __global__ __launch_bounds__(1024) void k_scan_counts(int64_t *c, int64_t nb) {
     }
     if (tid == 0) c[nb] = carry;
 }
-// count + scan in ONE launch for vectors of up to 1024 tiles (4 M slots): thread t counts tile t, the block scans the counts.
+// count + scan in ONE launch for vectors of up to 64 tiles (262 144 slots).
 // (Small selections -- the few thousand groups left after a HAVING, the entries behind a selective filter -- paid two launches
 // of 3-4 us each for a few hundred bytes of work, eighteen times per Q18.)
 __global__ __launch_bounds__(1024) void k_compact_count_scan(const uint64_t *valid, int64_t n, int64_t nb, int64_t *counts) {
-    __shared__ int64_t wsum[1024 / kWave];
-    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    // up to 64 tiles = 4096 words: 4 words per thread, a tile = 16 neighbouring threads; the first wave scans the tile counts
+    __shared__ int tilecnt[kWave];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
     const int64_t nw = (n + 63) >> 6;
-    int64_t c = 0;
-    if (tid < nb) {
-        const int64_t w0 = (int64_t)tid * kCompactWords;
-        for (int k = 0; k < kCompactWords; k++) {
-            const int64_t w = w0 + k;
-            if (w >= nw) break;
+    if (tid < kWave) tilecnt[tid] = 0;
+    __syncthreads();
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int64_t w = (int64_t)tid * 4 + k;
+        if (w < nw) {
             uint64_t m = valid ? valid[w] : ~0ull;
             const int64_t rem = n - (w << 6);
             if (rem < 64) m &= (1ull << rem) - 1;
             c += __popcll(m);
         }
     }
-    int64_t incl = c;
 #pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) { const int64_t y = __shfl_up(incl, off, kWave); if (lane >= off) incl += y; }
-    if (lane == kWave - 1) wsum[wave] = incl;
+    for (int off = 1; off < 16; off <<= 1) c += __shfl_xor(c, off, kWave);
+    if ((lane & 15) == 0) tilecnt[tid >> 4] = c;
     __syncthreads();
-    int64_t pre = 0, total = 0;
-    for (int w = 0; w < 1024 / kWave; w++) { if (w < wave) pre += wsum[w]; total += wsum[w]; }
-    if (tid < nb) counts[tid] = pre + incl - c;
-    if (tid == 0) counts[nb] = total;
+    if (tid < kWave) {
+        const int mine = tilecnt[tid];
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) { const int y = __shfl_up(incl, off, kWave); if (lane >= off) incl += y; }
+        if (tid < nb) counts[tid] = incl - mine;
+        if (tid == kWave - 1) counts[nb] = incl;
+    }
 }
 // counts[0 .. nb) = exclusive prefix of the tile populations, counts[nb] = their total (what launch_compact_count followed by
 // launch_compact_scan leave)
@@ -639,7 +644,7 @@ hipError_t launch_compact_offsets(const uint64_t *valid, int64_t n, int64_t *cou
     (void)hipGetLastError();
     const int64_t nb = (n + compact_tile() - 1) / compact_tile();
     if (nb <= 0) return hipSuccess;
-    if (nb <= 1024 && n <= ((int64_t)1 << 18)) {               // (beyond a few tiles per thread-row the serial count stops paying)
+    if (nb <= kWave) {                                         // (64 tiles = 262 144 slots: one block, four words per thread)
         k_compact_count_scan<<<1, 1024, 0, s>>>(valid, n, nb, counts);
         return launch_status();
     }
