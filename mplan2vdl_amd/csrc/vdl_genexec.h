@@ -793,9 +793,10 @@ struct GenExec {
             HIP_CHECK(hipMemcpyAsync(back, (int64_t *)counts->p + nb, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
             HIP_CHECK(hipStreamSynchronize(s));
             const int64_t nheads = back[0], seen[2] = {back[1], back[2]};
-            if (!seen[0] && data.kind == DVec::DENSE && data.data) {
-                SortedHeads &sh = sorted_heads[data.data->p];
-                sh.key = data.data; sh.heads = heads; sh.offsets = counts; sh.count = nheads;
+            if (!seen[0] && ((data.kind == DVec::DENSE && data.data) || (data.kind == DVec::COLUMN && data.ptr))) {
+                // (COLUMN: the key of a sharded Partition's tail lies in the receive buffer, which the plan keeps for the run)
+                SortedHeads &sh = sorted_heads[data.kind == DVec::DENSE ? data.data->p : data.ptr];
+                sh.key = data.kind == DVec::DENSE ? data.data : data.keep; sh.heads = heads; sh.offsets = counts; sh.count = nheads;
             }
             const int64_t descends = seen[0];
             // the largest bucket that occurs (bucket = clamp(data - min, 0, cnt) is monotone in the data)
