@@ -1345,6 +1345,12 @@ __global__ __launch_bounds__(256) void k_seg_fold(int kind, Src d, const uint64_
                 if (w0 + u >= w_end) break;                    // wave-uniform
                 const int64_t w = w0 + u;
                 const uint64_t hw = hw_[u];
+                if (hw == 0 && okw_[u] == ~0ull && carry_h >= 0 && prev_[u] == carry_h) {
+                    // no run begins in this word and all 64 slots take part: the word continues the run the wave carries (long
+                    // runs -- a dense-domain GROUP BY has a handful -- are nearly all such words): one wave reduction, no segments
+                    carry_x = r_combine(rk, carry_x, __shfl(wave_reduce(x_[u], rk), 0, kWave));
+                    continue;
+                }
                 const uint64_t hm = hw & upto;                 // heads at or before this lane
                 const int64_t h = hm ? (w << 6) + 63 - __clzll((long long)hm) : prev_[u];
                 const bool ok = ((okw_[u] >> lane) & 1ull) != 0 && h >= 0;
@@ -1412,6 +1418,19 @@ __global__ void k_seg_fill(int64_t *out, int64_t v, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = v;
 }
+// the reduction's identity at the run heads only: every partial of a run lands on out[head], nothing else of `out` is ever read
+// (its validity bitmap holds heads only) -- filling all n slots wrote 8 B/row for nothing (a fifth of the fold over 60 M rows)
+__global__ void k_seg_init_heads(const uint64_t *heads, int64_t nw, int64_t v, int64_t *out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nw; w += stride) {
+        uint64_t m = heads[w];
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            out[(w << 6) + b] = v;
+            m &= m - 1;
+        }
+    }
+}
 
 // FoldChoose second pass: out[h] currently holds the smallest data slot of the run -> its value
 __global__ void k_seg_choose_fix(Src d, const uint64_t *vout, int64_t n, int64_t *out) {
@@ -1445,7 +1464,7 @@ hipError_t launch_fold_runs(int kind, Src d, const uint64_t *vd, const uint64_t 
     (void)hipGetLastError();
     if (n <= 0) return hipSuccess;
     const int rk = (kind == 1 || kind == 4) ? R_MIN : kind == 2 ? R_MAX : R_SUM;
-    k_seg_fill<<<grid_for(n, 256, 4), 256, 0, s>>>(out, rk == R_SUM ? 0 : rk == R_MIN ? INT64_MAX : INT64_MIN, n);
+    k_seg_init_heads<<<grid_for((n + 63) >> 6, 256, 1), 256, 0, s>>>(heads, (n + 63) >> 6, rk == R_SUM ? 0 : rk == R_MIN ? INT64_MAX : INT64_MIN, out);
     k_seg_fold<<<seg_fold_grid(n), 256, 0, s>>>(kind, d, vd, vc, heads, wordhd, n, out, vout);
     if (kind == 4) k_seg_choose_fix<<<grid_for(n, 256, 4), 256, 0, s>>>(d, vout, n, out);
     return launch_status();
