@@ -115,7 +115,13 @@ class Oracle:
         data = vdl_text.encode() if isinstance(vdl_text, str) else vdl_text
         rc = self._L.orc_run(self._c, data, len(data))
         if rc:
-            raise OracleError(self._L.orc_last_error(self._c).decode())
+            msg = self._L.orc_last_error(self._c).decode()
+            if isinstance(vdl_text, str):               # evidence for DESIGN.md section 8 (9): did the bytes handed over change?
+                fresh = vdl_text.encode()
+                changed = [(i, data[i], fresh[i]) for i in range(min(len(data), len(fresh))) if data[i] != fresh[i]][:16]
+                if changed:
+                    msg += "  [the bytes handed to orc_run differ from their source str at (offset, is, was) %r]" % (changed,)
+            raise OracleError(msg)
         results = {}
         for k in range(self._L.orc_n_outputs(self._c)):
             name, tmp = ctypes.c_char_p(), ctypes.c_char_p()
