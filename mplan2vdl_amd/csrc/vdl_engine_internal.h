@@ -184,7 +184,14 @@ struct vdl_ctx {
         if (!pinned_words && hipHostMalloc((void **)&pinned_words, sizeof(int64_t) * 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); pinned_words = nullptr; }
         return words <= 64 ? pinned_words : nullptr;
     }
-    ~vdl_ctx() { if (pinned_words) (void)hipHostFree(pinned_words); }
+    // pinned staging for small result vectors (GenExec::copy_out): copied in stream order, read after ONE synchronise per run
+    static constexpr size_t kSmallStageWords = (size_t)1 << 17;
+    int64_t *small_stage_words = nullptr;
+    int64_t *small_stage() {
+        if (!small_stage_words && hipHostMalloc((void **)&small_stage_words, sizeof(int64_t) * kSmallStageWords, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); small_stage_words = nullptr; }
+        return small_stage_words;
+    }
+    ~vdl_ctx() { if (pinned_words) (void)hipHostFree(pinned_words); if (small_stage_words) (void)hipHostFree(small_stage_words); }
 };
 
 struct vdl_plan {

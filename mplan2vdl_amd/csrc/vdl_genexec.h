@@ -154,6 +154,8 @@ struct GenExec {
         }
         return sel->first_slot;
     }
+    struct GatherLive { BufP pos, fvalid, sub, offsets; SelP sel, child; int64_t live = 0; };      // (every buffer of the key is kept alive by the entry)
+    std::map<std::tuple<const void *, const void *, int64_t>, GatherLive> gather_live;
     struct RunHeads { BufP ctl, heads, wordhd, offsets; int64_t count = 0; SelP sel, child; };
     // run heads a Partition's sortedness pass left behind (partition_positions): when the key turns out to be in order, the folds of
     // the GROUP BY run over that very buffer and need neither a head pass nor a count of their own
@@ -573,7 +575,18 @@ struct GenExec {
             return;
         }
         int64_t *dst = host_out(o, count);
-        if (!o.big) {                                   // small / pageable: the plain blocking route
+        if (!o.big) {
+            // small: through the context's pinned staging area, in stream order, ONE synchronise for all of them when the run ends
+            // (a copy into pageable memory blocks the host until the GPU has caught up: six result columns of a few rows each were
+            // six idle gaps of 30-40 us)
+            int64_t *stage = c->small_stage();
+            if (stage && count <= vdl_ctx::kSmallStageWords) {
+                if (stage_used + count > vdl_ctx::kSmallStageWords) flush_small();
+                HIP_CHECK(hipMemcpyAsync(stage + stage_used, dev->p, sizeof(int64_t) * count, hipMemcpyDeviceToHost, s));
+                small_copies.push_back({p->outs.size(), stage_used, count});
+                stage_used += count;
+                return;
+            }
             HIP_CHECK(hipMemcpyAsync(dst, dev->p, sizeof(int64_t) * count, hipMemcpyDeviceToHost, s));
             HIP_CHECK(hipStreamSynchronize(s));
             return;
@@ -587,7 +600,19 @@ struct GenExec {
         HIP_CHECK(hipMemcpyAsync(dst, dev->p, sizeof(int64_t) * count, hipMemcpyDeviceToHost, c->copy_stream));
         copies_in_flight.push_back(dev);                // the pool must not hand the buffer out again before the copy ran
     }
+    struct SmallCopy { size_t out, at, count; };
+    std::vector<SmallCopy> small_copies;
+    size_t stage_used = 0;
+    void flush_small() {
+        if (small_copies.empty()) return;
+        HIP_CHECK(hipStreamSynchronize(s));
+        const int64_t *stage = c->small_stage();
+        for (const SmallCopy &k : small_copies) std::memcpy(p->outs[k.out].vals.data(), stage + k.at, sizeof(int64_t) * k.count);
+        small_copies.clear();
+        stage_used = 0;
+    }
     void finish_copies() {
+        flush_small();
         if (copies_in_flight.empty()) return;
         HIP_CHECK(hipStreamSynchronize(c->copy_stream));
         copies_in_flight.clear();
@@ -720,7 +745,25 @@ struct GenExec {
             BufP data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(sel->m, 1));
             BufP sub = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(sel->m), 1));
             HIP_CHECK(launch_gather(src_of(from), vp(from), from.n, i64_src(pos.data), nullptr, sel->m, (int64_t *)data->p, (uint64_t *)sub->p, s));
-            o = sparse_normalised(sel, data, sub);
+            // which entries come back with a value depends on the positions, the source's length and its validity alone: the columns
+            // of one table read through one key (a join printing five columns of the dimension) share the answer -- one count and one
+            // round trip to the host instead of one per column
+            const auto key = std::make_tuple((const void *)pos.data->p, (const void *)(from.valid ? from.valid->p : nullptr), from.n);
+            auto known = gather_live.find(key);
+            if (known != gather_live.end() && known->second.sel == sel && !getenv("VDL_NO_GATHER_LIVE_CACHE")) {
+                const GatherLive &g = known->second;
+                o = g.live == sel->m ? make_sparse(sel, data) : make_sparse(g.child, compact_write(i64_src(data), g.sub, sel->m, g.offsets, g.live));
+                return true;
+            }
+            GatherLive g;
+            g.pos = pos.data; g.fvalid = from.valid; g.sel = sel; g.sub = sub;
+            g.live = popcount(sub, sel->m, &g.offsets);
+            if (g.live == sel->m) o = make_sparse(sel, data);
+            else {
+                g.child = child_selection(sel, sub, g.live, g.offsets);
+                o = make_sparse(g.child, compact_write(i64_src(data), sub, sel->m, g.offsets, g.live));
+            }
+            gather_live[key] = g;
             return true;
         }
         return false;

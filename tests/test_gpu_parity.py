@@ -482,6 +482,45 @@ def test_fold_over_unsorted_control_with_holes_matches_oracle():
     e.close()
 
 
+@pytest.mark.parametrize("holes", ["none", "data", "both"])
+def test_folds_over_a_few_very_long_runs_match_oracle(holes):
+    """20 M slots in a few dozen runs: k_seg_fold's waves carry a run across their whole chunk, and stretches of 16 / 8 words that
+    begin no run and hold a value in every slot are reduced with wide loads (the long-run path).  Rare EPS slots in the data and in
+    the control interrupt those stretches at arbitrary places; run boundaries fall inside words, at word ends and at chunk ends."""
+    rng = np.random.default_rng({"none": 1, "data": 2, "both": 3}[holes])
+    n = 20_000_003
+    cuts = np.unique(np.concatenate([rng.integers(1, n, size=40), [64 * 1000, 64 * 1000 + 1, 1024 * 5000 - 1, 1024 * 5000, n - 1]]))
+    ctl = np.zeros(n, np.int64)
+    ctl[cuts] = 1
+    ctl = np.cumsum(ctl) % 7                                                   # runs of up to millions of slots, values repeat
+    cols = {"t.c": ctl, "t.a": rng.integers(-10**9, 10**9, size=n).astype(np.int64)}
+    nb = np.ones(n, np.int8)
+    nd = np.ones(n, np.int8)
+    if holes != "none":
+        nd[rng.integers(0, n, size=300)] = 0
+        nd[[0, 63, 64, 1023, 1024, n - 1]] = 0
+    if holes == "both":
+        nb[rng.integers(0, n, size=200)] = 0
+        nb[cuts[::3]] = 0                                                       # a run's first member is an EPS control slot
+    cols["t.b"], cols["t.d"] = nb, nd
+    lines = ["1,Load,t.c", "2,Project,val,Id 1,c", "3,Load,t.a", "4,Project,val,Id 3,a", "5,Load,t.b", "6,Project,val,Id 5,b",
+             "7,Load,t.d", "8,Project,val,Id 7,d",
+             "9,RangeV,val,0,Id 6,1", "10,FoldSelect,val,Id 9,val,Id 6,val", "11,Gather,Id 2,Id 10,val",
+             "12,RangeV,val,0,Id 8,1", "13,FoldSelect,val,Id 12,val,Id 8,val", "14,Gather,Id 4,Id 13,val"]
+    k = 15
+    for fold in ("FoldSum", "FoldMin", "FoldMax", "FoldCount", "FoldChoose"):
+        lines += ["%d,%s,val,Id 11,val,Id 14,val" % (k, fold), "%d,MaterializeCompact,Id %d" % (k + 1, k)]
+        k += 2
+    text = prog(*lines)
+    want = oracle_run(text, cols)
+    e = engine_with(cols)
+    assert e.run_vdl(text)["results"] == want
+    p = e.parse(text)
+    p.set_fusion(False)
+    assert p.run()["results"] == want
+    e.close()
+
+
 @pytest.mark.parametrize("n_orders", [1, 100, 15000, 150000])
 def test_q3_matches_oracle(n_orders):
     """TPC-H Q3: FK joins lowered to Gather/Scatter over join-index columns, GROUP BY over a 2^38 key
