@@ -9,6 +9,19 @@
 
 namespace {
 
+// the descriptor `d` on the device under `role` (vdl_plan::desc_slots): uploaded when it differs from the bytes already there
+static const MScanDesc *desc_on_device(vdl_ctx *c, vdl_plan *p, const std::string &role, const MScanDesc &d) {
+    vdl_plan::DescSlot &sl = p->desc_slots[role];
+    if (!sl.dev) sl.dev = dev_alloc(c, sizeof(MScanDesc));
+    static const bool always = getenv("VDL_NO_DESC_CACHE") != nullptr;
+    if (always || sl.shadow.size() != sizeof(MScanDesc) || std::memcmp(sl.shadow.data(), &d, sizeof(MScanDesc)) != 0) {
+        // the shadow is the SOURCE of the copy: it stays put until the next upload, the caller's `d` may be a local
+        sl.shadow.assign((const unsigned char *)&d, (const unsigned char *)&d + sizeof(MScanDesc));
+        HIP_CHECK(hipMemcpyAsync(sl.dev->p, sl.shadow.data(), sizeof(MScanDesc), hipMemcpyHostToDevice, c->stream));
+    }
+    return (const MScanDesc *)sl.dev->p;
+}
+
 // ------------------------------------------------------------------------------------------------
 // fused execution
 // ------------------------------------------------------------------------------------------------
@@ -648,9 +661,7 @@ void run_prelude_items(vdl_ctx *c, vdl_plan *p, const std::vector<char> &asked) 
             d->dn[it.index_col] = p->semi_unclamped ? nbits : std::min(nbits, n);
             p->prelude_rows[k] = n;
             d->out_ptr[0] = (int64_t *)p->prelude_buf[k]->p;
-            descs.push_back(dev_alloc(c, sizeof(MScanDesc)));
-            HIP_CHECK(hipMemcpyAsync(descs.back()->p, d, sizeof(MScanDesc), hipMemcpyHostToDevice, c->stream));
-            HIP_CHECK(launch_project_select(cols, (const MScanDesc *)descs.back()->p, c->num_cus, c->stream,
+            HIP_CHECK(launch_project_select(cols, desc_on_device(c, p, "semi" + std::to_string(k), *d), c->num_cus, c->stream,
                                             front_kernel(c, p, "semi" + std::to_string(k), jit::SELECT, cols, *d)));
             continue;
         }
@@ -660,9 +671,7 @@ void run_prelude_items(vdl_ctx *c, vdl_plan *p, const std::vector<char> &asked) 
         if (it.never || n <= 0) { HIP_CHECK(hipMemsetAsync(p->prelude_buf[k]->p, 0, sizeof(uint64_t) * words, c->stream)); continue; }
         d->out_ptr[0] = (int64_t *)p->prelude_buf[k]->p;           // bitmap only: no positions, no counts
         d->bitmap_only = 1;
-        descs.push_back(dev_alloc(c, sizeof(MScanDesc)));
-        HIP_CHECK(hipMemcpyAsync(descs.back()->p, d, sizeof(MScanDesc), hipMemcpyHostToDevice, c->stream));
-        HIP_CHECK(launch_project_select(cols, (const MScanDesc *)descs.back()->p, c->num_cus, c->stream,
+        HIP_CHECK(launch_project_select(cols, desc_on_device(c, p, "dim" + std::to_string(k), *d), c->num_cus, c->stream,
                                         front_kernel(c, p, "dim" + std::to_string(k), jit::SELECT, cols, *d)));
     }
 }
@@ -729,10 +738,10 @@ void run_fused_local(vdl_ctx *c, vdl_plan *p, int64_t *dev_words, bool single_ra
             }
             HIP_CHECK(launch_scan_finish(a.block_partials, nblocks, a.nagg, nullptr, a, out, c->stream));
         } else {
-            HIP_CHECK(hipMemcpyAsync(p->mdev[s]->p, &p->mdesc[s], sizeof(MScanDesc), hipMemcpyHostToDevice, c->stream));
+            const MScanDesc *on_dev = desc_on_device(c, p, "scan" + std::to_string(s), p->mdesc[s]);
             // events bracket the scan together with its tiny finish kernel(s)
             if (timed) HIP_CHECK(hipEventRecord(p->ev0[ei], c->stream));
-            HIP_CHECK(launch_mscan(p->mcols[s], p->mdesc[s], (const MScanDesc *)p->mdev[s]->p, p->mcfg[s], grouped, never, out,
+            HIP_CHECK(launch_mscan(p->mcols[s], p->mdesc[s], on_dev, p->mcfg[s], grouped, never, out,
                                    grouped && single_rank, c->stream, p->mjit[s] ? p->mjit[s]->fn : nullptr));
             if (timed) { HIP_CHECK(hipEventRecord(p->ev1[ei], c->stream)); p->ev_pending[ei] = true; }
         }
@@ -949,15 +958,13 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
     if (n > 0 && !J.never) {
         BufP counts = dev_alloc(c, sizeof(int64_t) * (size_t)(ntiles + 1)), offsets = dev_alloc(c, sizeof(int64_t) * (size_t)(ntiles + 1));
         BufP scratch = dev_alloc(c, (size_t)project_scratch_bytes(n));
-        BufP ddev = dev_alloc(c, sizeof(MScanDesc)), sdev = dev_alloc(c, sizeof(MScanDesc));
         sel->bitmap = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>((n + 63) >> 6, 1));
         sdesc->tile_counts = (int64_t *)counts->p;
         sdesc->out_idx = (int64_t *)scratch->p;
         sdesc->out_ptr[0] = (int64_t *)sel->bitmap->p;
         sdesc->out_ptr[1] = (int64_t *)offsets->p;
         BufP sums = dev_alloc(c, sizeof(int64_t) * (size_t)(prefix_sum_blocks(ntiles + 1) + 1));
-        HIP_CHECK(hipMemcpyAsync(sdev->p, sdesc.get(), sizeof(MScanDesc), hipMemcpyHostToDevice, c->stream));
-        HIP_CHECK(launch_project_select(scols, (const MScanDesc *)sdev->p, c->num_cus, c->stream, front_kernel(c, p, "select", jit::SELECT, scols, *sdesc)));
+        HIP_CHECK(launch_project_select(scols, desc_on_device(c, p, "select", *sdesc), c->num_cus, c->stream, front_kernel(c, p, "select", jit::SELECT, scols, *sdesc)));
         // (the select pass left the counts in `offsets` too, with a 0 behind them: a device-wide exclusive prefix sum over
         // ntiles + 1 words puts the total there -- Q3 at SF10 has 29 K tiles, a one-block scan took 26 us)
         HIP_CHECK(launch_prefix_sum((int64_t *)offsets->p, ntiles + 1, (int64_t *)sums->p, c->stream));
@@ -972,8 +979,7 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
             d.out_ptr[o] = (int64_t *)outs[o]->p;
         }
         if (m > 0) {
-            HIP_CHECK(hipMemcpyAsync(ddev->p, &d, sizeof d, hipMemcpyHostToDevice, c->stream));
-            HIP_CHECK(launch_project_take(cols, (const MScanDesc *)ddev->p, scratch->p, (const int64_t *)counts->p, (const int64_t *)offsets->p,
+            HIP_CHECK(launch_project_take(cols, desc_on_device(c, p, "take", d), scratch->p, (const int64_t *)counts->p, (const int64_t *)offsets->p,
                                           c->num_cus, c->stream, front_kernel(c, p, "take", jit::TAKE, cols, d)));
         }
     } else {
@@ -1455,7 +1461,7 @@ int vdl_resolve_first(vdl_ctx *c, vdl_plan *p, void *dev_partials) {
             bool any = false;
             for (const ScanAgg &ag : p->fused.gscans[g].aggs) any |= ag.kind == AGG_FIRST;
             if (!any) continue;
-            HIP_CHECK(launch_mscan_resolve_first(p->mcols[ns + g], p->mdesc[ns + g], (const MScanDesc *)p->mdev[ns + g]->p,
+            HIP_CHECK(launch_mscan_resolve_first(p->mcols[ns + g], p->mdesc[ns + g], desc_on_device(c, p, "scan" + std::to_string(ns + g), p->mdesc[ns + g]),
                                                  (int64_t *)dev_partials + p->gword_offset[g], c->stream));
         }
     });

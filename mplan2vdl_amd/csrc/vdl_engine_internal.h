@@ -265,6 +265,11 @@ struct vdl_plan {
     BufP words;
     int64_t words_cap = 0;
     std::string fallback_note, front_note;
+    // scan descriptors on the device, by role ("scan3", "dim0", "select", "take"): a plan-owned buffer and the bytes it holds -- the
+    // descriptor of a run is uploaded only when it differs from what is there (pool buffers come back at the same addresses run
+    // after run, so it rarely does: each upload was a 5 us staged copy on the stream plus the host's part of it)
+    struct DescSlot { BufP dev; std::vector<unsigned char> shadow; };
+    std::map<std::string, DescSlot> desc_slots;
     double front_usec = 0;
     bool bound = false;
     uint64_t bound_version = 0;

@@ -87,9 +87,15 @@ struct GenExec {
         const int64_t nb = (n + compact_tile() - 1) / compact_tile();
         if (nb <= 0) return 0;
         BufP counts = dev_alloc(c, sizeof(int64_t) * (size_t)(nb + 1));
-        HIP_CHECK(launch_compact_offsets(bits ? (const uint64_t *)bits->p : nullptr, n, (int64_t *)counts->p, s));
         int64_t total = 0;
-        fetch_words((int64_t *)counts->p + nb, 1, &total);
+        if (int64_t *pin = c->pinned(1)) {                     // the kernel leaves the total in pinned host memory itself: no copy to launch
+            HIP_CHECK(launch_compact_offsets(bits ? (const uint64_t *)bits->p : nullptr, n, (int64_t *)counts->p, s, pin));
+            HIP_CHECK(hipStreamSynchronize(s));
+            total = *(volatile int64_t *)pin;
+        } else {
+            HIP_CHECK(launch_compact_offsets(bits ? (const uint64_t *)bits->p : nullptr, n, (int64_t *)counts->p, s));
+            fetch_words((int64_t *)counts->p + nb, 1, &total);
+        }
         if (offsets) *offsets = counts;
         return total;
     }

@@ -573,7 +573,7 @@ hipError_t launch_compact_count(const uint64_t *valid, int64_t n, int64_t *count
 }
 
 // single-block exclusive scan (in place); total written at [nblocks]
-__global__ __launch_bounds__(1024) void k_scan_counts(int64_t *c, int64_t nb) {
+__global__ __launch_bounds__(1024) void k_scan_counts(int64_t *c, int64_t nb, int64_t *host_total) {
     constexpr int K = 8;                                        // consecutive entries per thread: 8192 per trip of the block
     __shared__ int64_t wsum[1024 / kWave];
     __shared__ int64_t carry;
@@ -602,12 +602,12 @@ __global__ __launch_bounds__(1024) void k_scan_counts(int64_t *c, int64_t nb) {
         if (tid == 1023) carry = run;
         __syncthreads();
     }
-    if (tid == 0) c[nb] = carry;
+    if (tid == 0) { c[nb] = carry; if (host_total) *host_total = carry; }      // (pinned host memory the caller reads after its synchronise)
 }
 // count + scan in ONE launch for vectors of up to 64 tiles (262 144 slots).
 // (Small selections -- the few thousand groups left after a HAVING, the entries behind a selective filter -- paid two launches
 // of 3-4 us each for a few hundred bytes of work, eighteen times per Q18.)
-__global__ __launch_bounds__(1024) void k_compact_count_scan(const uint64_t *valid, int64_t n, int64_t nb, int64_t *counts) {
+__global__ __launch_bounds__(1024) void k_compact_count_scan(const uint64_t *valid, int64_t n, int64_t nb, int64_t *counts, int64_t *host_total) {
     // up to 64 tiles = 4096 words: 4 words per thread, a tile = 16 neighbouring threads; the first wave scans the tile counts
     __shared__ int tilecnt[kWave];
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -635,26 +635,26 @@ __global__ __launch_bounds__(1024) void k_compact_count_scan(const uint64_t *val
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) { const int y = __shfl_up(incl, off, kWave); if (lane >= off) incl += y; }
         if (tid < nb) counts[tid] = incl - mine;
-        if (tid == kWave - 1) counts[nb] = incl;
+        if (tid == kWave - 1) { counts[nb] = incl; if (host_total) *host_total = incl; }
     }
 }
 // counts[0 .. nb) = exclusive prefix of the tile populations, counts[nb] = their total (what launch_compact_count followed by
 // launch_compact_scan leave)
-hipError_t launch_compact_offsets(const uint64_t *valid, int64_t n, int64_t *counts, hipStream_t s) {
+hipError_t launch_compact_offsets(const uint64_t *valid, int64_t n, int64_t *counts, hipStream_t s, int64_t *host_total) {
     (void)hipGetLastError();
     const int64_t nb = (n + compact_tile() - 1) / compact_tile();
     if (nb <= 0) return hipSuccess;
     if (nb <= kWave) {                                         // (64 tiles = 262 144 slots: one block, four words per thread)
-        k_compact_count_scan<<<1, 1024, 0, s>>>(valid, n, nb, counts);
+        k_compact_count_scan<<<1, 1024, 0, s>>>(valid, n, nb, counts, host_total);
         return launch_status();
     }
     hipError_t e = launch_compact_count(valid, n, counts, s);
     if (e != hipSuccess) return e;
-    return launch_compact_scan(counts, nb, s);
+    return launch_compact_scan(counts, nb, s, host_total);
 }
-hipError_t launch_compact_scan(int64_t *counts, int64_t nb, hipStream_t s) {
+hipError_t launch_compact_scan(int64_t *counts, int64_t nb, hipStream_t s, int64_t *host_total) {
     (void)hipGetLastError();   // see launch_status()
-    k_scan_counts<<<1, 1024, 0, s>>>(counts, nb);
+    k_scan_counts<<<1, 1024, 0, s>>>(counts, nb, host_total);
     return launch_status();
 }
 
