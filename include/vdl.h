@@ -271,8 +271,13 @@ void vdl_comm_free(vdl_ctx *ctx);                       /* also done by vdl_clos
  *   fused plans with a semi-join set (EXISTS / IN, TPC-H Q4) whose source table is the sharded one and whose scans read replicated
  *   tables: every rank builds the set from its rows -> ONE all-gather of the sets -> OR kernel -> the scans run everywhere
  *   against the complete set; every rank ends with the full result.
- * vdl_plan_sharded_route tells which of the three a plan takes ("fold" | "set" | "exchange") and whether every rank ends with
- * the whole answer (replicated = 1) or with its slice (0: concatenate the ranks' outputs in rank order). */
+ * A fourth, for plans the exchange cannot serve (two Partitions, folds over grouped results: TPC-H Q16) whose work on the sharded
+ *   table is a fused front (filter + projection in one scan): every rank runs the front over its rows -> all-gather of the row
+ *   counts -> all-gather of {status, survivors} -> ONE grouped send / receive of the survivors' vectors to every rank (rank after
+ *   rank = row order) -> the statements above the front run everywhere on the complete vectors; every rank ends with the full
+ *   result.  Tried after the exchange; the row-id conditions of the front count from the table's first row.
+ * vdl_plan_sharded_route tells which of the four a plan takes ("fold" | "set" | "exchange" | "front") and whether every rank ends
+ * with the whole answer (replicated = 1) or with its slice (0: concatenate the ranks' outputs in rank order). */
 int  vdl_plan_sharded_route(vdl_ctx *ctx, vdl_plan *plan, const char **route, int *replicated);
 int  vdl_run_sharded(vdl_ctx *ctx, vdl_plan *plan);     /* results through vdl_output as after vdl_run */
 int  vdl_run_sharded_begin(vdl_ctx *ctx, vdl_plan *plan, int slot);

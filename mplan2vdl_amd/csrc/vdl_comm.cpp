@@ -393,6 +393,168 @@ static void sharded_semi(vdl_ctx *c, vdl_plan *p) {
             throw Error(VDL_ERR_UNSUPPORTED, "sharded run: the fused plan does not hold for this data (" + t.label + "), and statement by statement the plan has no sharded route");
 }
 
+// ---- the "front" route: a plan whose work on the sharded table is a fused front (select + take: vdl_fuse.h ProjPlan) ----
+// Every rank runs the front over its rows; the survivors' vectors (a few per cent of the table for the TPC-H plans) are
+// all-gathered, rank after rank = global row order, and every rank runs the statements above the front on the complete vectors:
+// any number of Partitions, folds over folds, lookups in the replicated tables -- whatever the program says, since from there on
+// it is the unsharded program on the unsharded data.  Every rank ends with the whole answer.  It scales the scan of the sharded
+// table (the part that grows with it), not the tail; plans whose tail is heavy and has ONE Partition take the exchange route,
+// which is tried first.  TPC-H Q16 (two Partitions: count(distinct ..) under a GROUP BY) runs this way.
+// "" = the plan and placement qualify, else why not.
+static std::string front_route_refusal(const vdl_plan *p) {
+    const ProjPlan &J = p->fused.proj;
+    const std::string &t = p->sharded_table;
+    if (t.empty()) return "name the row-sharded table first (vdl_plan_set_sharded_table)";
+    if (!p->use_fusion || (p->fused.ok)) return "the plan has no fused front (it fuses as a whole, or fusion is off)";
+    if (!J.ok) return "the plan has no fused front: " + J.why;
+    if (J.table != t) return "the fused front scans table '" + J.table + "', not the sharded one";
+    for (const PreludeItem &it : p->fused.prelude)
+        if (it.table == t) return "a dimension-side scan of the front reads the sharded table";
+    // nothing above the front may read the sharded table by itself (its length included): walk down from the outputs, stopping
+    // at the statements the front produces
+    const Program &P = p->prog;
+    std::vector<char> seen(P.nodes.size(), 0);
+    std::vector<int> stack(P.outputs.begin(), P.outputs.end());
+    for (int id : J.nodes) if (id > 0 && (size_t)id < seen.size()) seen[(size_t)id] = 2;
+    while (!stack.empty()) {
+        const int id = stack.back(); stack.pop_back();
+        if (id <= 0 || (size_t)id >= seen.size() || seen[(size_t)id]) continue;
+        seen[(size_t)id] = 1;
+        const Node &n = P.at(id);
+        if (n.op == Op::Load && n.column.compare(0, t.size() + 1, t + ".") == 0)
+            return "statement " + std::to_string(id) + " above the front reads " + n.column + " of the sharded table";
+        for (int o : {n.a, n.b, n.c}) if (o > 0) stack.push_back(o);
+    }
+    return "";
+}
+
+// the same `ncols` columns from every rank, rank after rank: column k of rank r (cnt[r] int64) lands at recv[k] + sum(cnt[0..r))
+static void all_gather_rows(vdl_ctx *c, const std::vector<const int64_t *> &send, const std::vector<int64_t *> &recv, const std::vector<int64_t> &cnt, hipStream_t s) {
+    CommState &m = comm_of(c);
+    const int ncols = (int)send.size();
+    std::vector<int64_t> off((size_t)m.world + 1, 0);
+    int64_t biggest = 0;
+    for (int r = 0; r < m.world; r++) { off[(size_t)r + 1] = off[(size_t)r] + cnt[(size_t)r]; biggest = std::max(biggest, cnt[(size_t)r]); }
+    const int64_t mine = cnt[(size_t)m.rank];
+    if (m.kind == CommState::RCCL) {
+        RCCL_CHECK(rccl().GroupStart());
+        for (int k = 0; k < ncols; k++)
+            for (int r = 0; r < m.world; r++) {
+                if (mine > 0) RCCL_CHECK(rccl().Send(send[(size_t)k], (size_t)mine, kNcclInt64, r, m.comm, s));
+                if (cnt[(size_t)r] > 0) RCCL_CHECK(rccl().Recv(recv[(size_t)k] + off[(size_t)r], (size_t)cnt[(size_t)r], kNcclInt64, r, m.comm, s));
+            }
+        RCCL_CHECK(rccl().GroupEnd());
+        return;
+    }
+    // HOST transport: one all_gather of blocks padded to the largest rank's rows (a rehearsal transport: simplicity over bytes)
+    if (biggest == 0) return;
+    const size_t block = sizeof(int64_t) * (size_t)ncols * (size_t)biggest;
+    char *h = m.staging(block * (size_t)(m.world + 1));
+    int64_t *hs = (int64_t *)h, *hr = (int64_t *)(h + block);
+    for (int k = 0; k < ncols; k++)
+        if (mine > 0) HIP_CHECK(hipMemcpyAsync(hs + (size_t)k * (size_t)biggest, send[(size_t)k], sizeof(int64_t) * (size_t)mine, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (m.host.all_gather(m.host.user, hs, hr, block)) throw Error(VDL_ERR_DEVICE, "the host transport's all_gather failed");
+    for (int r = 0; r < m.world; r++)
+        for (int k = 0; k < ncols; k++)
+            if (cnt[(size_t)r] > 0)
+                HIP_CHECK(hipMemcpyAsync(recv[(size_t)k] + off[(size_t)r], hr + ((size_t)r * (size_t)ncols + (size_t)k) * (size_t)biggest, sizeof(int64_t) * (size_t)cnt[(size_t)r],
+                                         hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));          // the staging buffer is reused by the next call
+}
+
+static void sharded_front(vdl_ctx *c, vdl_plan *p) {
+    need_device(c);
+    CommState &m = comm_of(c);
+    const ProjPlan &J = p->fused.proj;
+    // this rank's rows of the table and everybody's: the front's row-id columns count from the table's first row
+    int64_t n_local = -1;
+    for (const auto &kv : c->cols)
+        if (kv.first.compare(0, J.table.size() + 1, J.table + ".") == 0 && kv.first.find(".heap") == std::string::npos) { n_local = kv.second.n; break; }
+    // {status, rows}: a rank without the table says so here and everybody stops together
+    std::vector<int64_t> rows((size_t)m.world * 2, 0);
+    {
+        BufP dsend = dev_alloc(c, sizeof(int64_t) * 2), drecv = dev_alloc(c, sizeof(int64_t) * 2 * (size_t)m.world);
+        const int64_t mine[2] = {n_local < 0 ? (int64_t)VDL_ERR_ARG : (int64_t)VDL_OK, std::max<int64_t>(n_local, 0)};
+        HIP_CHECK(hipMemcpyAsync(dsend->p, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        all_gather(c, dsend->p, drecv->p, sizeof mine, c->stream);
+        HIP_CHECK(hipMemcpyAsync(rows.data(), drecv->p, sizeof(int64_t) * rows.size(), hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    int64_t row0 = 0, n_global = 0;
+    for (int r = 0; r < m.world; r++) {
+        if (rows[(size_t)r * 2] != VDL_OK) throw Error(VDL_ERR_ARG, "sharded run: rank " + std::to_string(r) + " holds no column of table '" + J.table + "'");
+        if (r < m.rank) row0 += rows[(size_t)r * 2 + 1];
+        n_global += rows[(size_t)r * 2 + 1];
+    }
+    struct Restore { vdl_plan *p; int64_t row_offset; ~Restore() { p->after_front = nullptr; p->row_offset = row_offset; p->front_rowid_global = false; } } restore{p, p->row_offset};
+    p->row_offset = row0;
+    p->front_rowid_global = true;
+    p->after_front = [&m, row0, n_global](vdl_ctx *cc, vdl_plan *pp, std::map<int, DVec> &over, bool front, const std::string &failure) {
+        const ProjPlan &JJ = pp->fused.proj;
+        hipStream_t s = cc->stream;
+        // what travels: the survivors' row ids (made global) and every distinct packed vector of the front
+        SelP sel;
+        std::vector<BufP> bufs;                                 // [0] = row ids
+        if (front) {
+            for (const auto &kv : over) if (kv.second.kind == DVec::SPARSE && kv.second.sel) { sel = kv.second.sel; break; }
+            if (sel) {
+                bufs.push_back(sel->idx);
+                for (int id : JJ.nodes) {
+                    const DVec &v = over.at(id);
+                    if (v.kind != DVec::SPARSE || v.sel != sel || v.valid) { sel.reset(); break; }
+                    if (std::find(bufs.begin(), bufs.end(), v.data) == bufs.end()) bufs.push_back(v.data);
+                }
+            }
+        }
+        const bool ok = front && sel;
+        std::vector<int64_t> all((size_t)m.world * 2, 0);
+        {
+            BufP dsend = dev_alloc(cc, sizeof(int64_t) * 2), drecv = dev_alloc(cc, sizeof(int64_t) * 2 * (size_t)m.world);
+            const int64_t mine[2] = {ok ? (int64_t)VDL_OK : (int64_t)VDL_ERR_UNSUPPORTED, ok ? sel->m : 0};
+            HIP_CHECK(hipMemcpyAsync(dsend->p, mine, sizeof mine, hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            all_gather(cc, dsend->p, drecv->p, sizeof mine, s);
+            HIP_CHECK(hipMemcpyAsync(all.data(), drecv->p, sizeof(int64_t) * all.size(), hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+        }
+        if (!ok) throw Error(VDL_ERR_UNSUPPORTED, "sharded run: the fused front did not run on this rank (" + (failure.empty() ? (pp->fallback_note.empty() ? std::string("its vectors do not share one selection") : pp->fallback_note) : failure) +
+                                                   "), and statement by statement the plan has no sharded route");
+        std::vector<int64_t> cnt((size_t)m.world);
+        int64_t total = 0;
+        for (int r = 0; r < m.world; r++) {
+            if (all[(size_t)r * 2] != VDL_OK) throw Error(VDL_ERR_DEVICE, "sharded run: the fused front failed on rank " + std::to_string(r) + " (its error is reported there)");
+            cnt[(size_t)r] = all[(size_t)r * 2 + 1];
+            total += cnt[(size_t)r];
+        }
+        // global row ids of this rank's survivors
+        BufP gids = dev_alloc(cc, sizeof(int64_t) * (size_t)std::max<int64_t>(sel->m, 1));
+        if (sel->m > 0) {
+            Src a; a.p = sel->idx->p; a.kind = SRC_I64;
+            Src b; b.kind = SRC_RANGE; b.from = row0; b.step = 0;
+            HIP_CHECK(launch_binary(B_ADD, a, b, (int64_t *)gids->p, sel->m, s));
+        }
+        std::vector<const int64_t *> send;
+        std::vector<int64_t *> recv;
+        std::vector<BufP> got;
+        for (size_t k = 0; k < bufs.size(); k++) {
+            send.push_back(k == 0 ? (const int64_t *)gids->p : (const int64_t *)bufs[k]->p);
+            got.push_back(dev_alloc(cc, sizeof(int64_t) * (size_t)std::max<int64_t>(total, 1)));
+            recv.push_back((int64_t *)got.back()->p);
+        }
+        all_gather_rows(cc, send, recv, cnt, s);
+        auto whole = std::make_shared<Sel>();
+        whole->n = n_global; whole->m = total; whole->idx = got[0]; whole->first_slot = -1;
+        for (int id : JJ.nodes) {
+            DVec &v = over.at(id);
+            const size_t k = (size_t)(std::find(bufs.begin(), bufs.end(), v.data) - bufs.begin());
+            v.n = n_global; v.sel = whole; v.data = got[k];
+        }
+    };
+    if (vdl_run(c, p) != VDL_OK) throw Error(VDL_ERR_DEVICE, c->err);
+}
+
 static bool fold_route(vdl_ctx *c, vdl_plan *p) {
     int64_t nw = 0;
     const int32_t *ops = nullptr;
@@ -462,7 +624,9 @@ void vdl_comm_free(vdl_ctx *c) {
 
 /* which route vdl_run_sharded takes for this plan and placement: "fold" (partial words merged: every rank ends with the whole
  * answer), "set" (a semi-join set merged, scans over replicated tables: every rank ends with the whole answer), "exchange" (rows
- * travel by key range: the ranks' outputs concatenate in rank order); VDL_ERR_UNSUPPORTED with the reason when there is none */
+ * travel by key range: the ranks' outputs concatenate in rank order), "front" (the fused front's survivors are all-gathered and
+ * the statements above it run on every rank: every rank ends with the whole answer); VDL_ERR_UNSUPPORTED with the reason when
+ * there is none */
 int vdl_plan_sharded_route(vdl_ctx *c, vdl_plan *p, const char **route, int *replicated) {
     if (!c || !p) return VDL_ERR_ARG;
     const char *name = nullptr;
@@ -480,8 +644,13 @@ int vdl_plan_sharded_route(vdl_ctx *c, vdl_plan *p, const char **route, int *rep
         p->ex_allow_folds = true;                              // (vdl_run_sharded merges global folds beside the Partition)
         const int rc = vdl_exchange_spec(p, p->sharded_table.c_str(), &ncols);
         p->ex_allow_folds = false;
-        if (rc != VDL_OK) return rc;
-        name = "exchange";
+        if (rc == VDL_OK) name = "exchange";
+        else {
+            const std::string why_not_exchange = c->err;
+            const std::string why = front_route_refusal(p);
+            if (!why.empty()) { c->err = why_not_exchange + "; no front route either: " + why; return rc; }
+            name = "front";
+        }
     }
     if (route) *route = name;
     if (replicated) *replicated = std::strcmp(name, "exchange") != 0;
@@ -517,8 +686,19 @@ int vdl_run_sharded(vdl_ctx *c, vdl_plan *p) {
         }
     }
     int rc = guard(c, [&] {
-        if (fold_route(c, p)) sharded_begin(c, p, 0);
-        else sharded_exchange(c, p);
+        if (fold_route(c, p)) { sharded_begin(c, p, 0); return; }
+        if (c->comm && c->comm->world > 1 && !p->sharded_table.empty()) {
+            // rows travel by key range when the plan allows it; otherwise, if its work on the sharded table is a fused front, the
+            // survivors are gathered and the rest runs on every rank (the "front" route)
+            int ncols = 0;
+            const std::string keep = c->err;
+            p->ex_allow_folds = true;
+            const bool exchange_ok = vdl_exchange_spec(p, p->sharded_table.c_str(), &ncols) == VDL_OK;
+            p->ex_allow_folds = false;
+            if (!exchange_ok && front_route_refusal(p).empty()) { c->err = keep; sharded_front(c, p); return; }
+            c->err = keep;
+        }
+        sharded_exchange(c, p);
     });
     if (rc != VDL_OK) return rc;
     return fold_route(c, p) ? vdl_run_sharded_end(c, p, 0) : VDL_OK;

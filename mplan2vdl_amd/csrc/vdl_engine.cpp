@@ -88,6 +88,19 @@ static void bind_forms(const std::vector<ScanColumn> &sc, MScanDesc &d) {
     }
 }
 
+// A row-id column that only CONDITIONS read (the reference's anti-join shape `k - row id` as a truth value: every row but row k)
+// means the row's number in the table: on a rank of a sharded run it counts from the table's first row.  One that INDEXES a lookup
+// (the bit of the row's own id in a set built over this shard's rows: co-partitioned placements) keeps counting from the shard's.
+static bool rowid_counts_from_the_table(const std::vector<ScanColumn> &sc) {
+    bool any = false, as_index = false;
+    for (const ScanColumn &c : sc) any |= c.kind == VC_ROWID;
+    for (const ScanColumn &c : sc) {
+        if (c.kind == VC_DIRECT || c.kind == VC_FORM || c.kind == VC_ROWID) continue;
+        for (int src : {c.idx, c.idx2}) if (src >= 0 && (size_t)src < sc.size() && sc[(size_t)src].kind == VC_ROWID) as_index = true;
+    }
+    return any && !as_index;
+}
+
 template <typename PlanT>
 int64_t bind_mscan(vdl_ctx *c, const PlanT &sp, MScanCols &cols, MScanDesc &d, int64_t *bytes_per_row, int64_t row0) {
     cols = MScanCols{};
@@ -122,6 +135,7 @@ int64_t bind_mscan(vdl_ctx *c, const PlanT &sp, MScanCols &cols, MScanDesc &d, i
     bind_forms(sp.cols, d);
     cols.n = n;
     cols.row0 = row0;
+    cols.rowid_global = rowid_counts_from_the_table(sp.cols);
     for (int j = 0; j < d.nagg; j++) {
         const ScanAgg &ag = sp.aggs[(size_t)j];
         MAggDesc &m = d.agg[j];
@@ -842,6 +856,8 @@ static void bind_front(vdl_ctx *c, vdl_plan *p, FrontBound &b) {
     MScanDesc &d = *b.d;
     b.wanted.assign(p->fused.prelude.size(), 0);
     b.n = bind_vcols(c, J.table, J.cols, cols, d, b.wanted);
+    cols.row0 = b.scols.row0 = p->row_offset;
+    cols.rowid_global = b.scols.rowid_global = p->front_rowid_global || rowid_counts_from_the_table(J.cols);      // (the sharded front route: every row id is the table's)
     // columns that decide a row's survival: the filtered ones and what they are derived from; a lookup whose range check is
     // done by another deciding column through the same index (the dimension bitmap, an INRANGE) decides nothing itself.
     // Everything else is read for the surviving rows only, in the write pass.
@@ -1345,7 +1361,13 @@ int vdl_run(vdl_ctx *c, vdl_plan *p) {
             }
         }
         std::map<int, DVec> over;
-        const bool front = run_projection(c, p, over);
+        bool front = false;
+        if (p->after_front) {
+            // a sharded run: whatever happens to the front here, this rank takes part in the collective that follows it
+            std::string failure;
+            try { front = run_projection(c, p, over); } catch (const Error &e) { failure = e.what(); }
+            p->after_front(c, p, over, front, failure);
+        } else front = run_projection(c, p, over);
         GenExec g(c, p);
         g.run_nodes(p->prog.outputs, front ? &over : nullptr);
         if (front) p->timings.push_back({p->front_note, p->front_usec});

@@ -235,7 +235,11 @@ struct vdl_plan {
     // sharded runs of a plan with a semi-join set (vdl_comm.cpp): every rank builds the set from its rows of the source table,
     // `after_prelude` merges the ranks' sets (and clips them at the GLOBAL length of that table) before any scan reads them
     bool semi_unclamped = false;
+    bool front_rowid_global = false;         // sharded front route: the front's row-id columns are global row numbers
     std::function<void(vdl_ctx *, vdl_plan *)> after_prelude;
+    // sharded "front" route (vdl_comm.cpp): called once the fused front has run over this rank's rows -- or has failed, or was
+    // abandoned: `failure` says why -- to replace the front's vectors by the ranks' vectors one after the other
+    std::function<void(vdl_ctx *, vdl_plan *, std::map<int, DVec> &, bool, const std::string &)> after_front;
     std::vector<int64_t> gword_offset;
     int dominant = -1;
     std::string dominant_kernel;

@@ -27,7 +27,7 @@ namespace {
 
 static MsArgs ms_args(const MScanCols &cols) {
     MsArgs a;
-    a.ncol = cols.ncol; a.n = cols.n; a.row0 = cols.row0;
+    a.ncol = cols.ncol; a.n = cols.n; a.row0 = cols.row0; a.rowid_base = cols.rowid_global ? 0 : cols.row0;
     for (int c = 0; c < cols.ncol; c++) {
         a.ptr[c] = cols.ptr[c];
         a.widths |= (uint64_t)cols.width[c] << (4 * c);

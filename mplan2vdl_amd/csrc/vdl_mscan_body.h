@@ -180,7 +180,7 @@ __device__ __forceinline__ void derive(const MsArgs &C, const MsArgs &Cr, const 
     // the set it is looked up in; every other derived column has an earlier one to derive from, so the loop starts at 1)
     if ((only & 1u) && D.dkind[0] == VC_ROWID) {
 #pragma unroll
-        for (int r = 0; r < RW; r++) v[0][r] = rowid[r] - Cr.row0;
+        for (int r = 0; r < RW; r++) v[0][r] = rowid[r] - Cr.rowid_base;
     }
 #pragma unroll
     for (int c = 1; c < NC; c++) {
@@ -188,7 +188,7 @@ __device__ __forceinline__ void derive(const MsArgs &C, const MsArgs &Cr, const 
             const int kind = D.dkind[c], a = D.dsrc[c], b = D.dsrc2[c];
             if (kind == VC_ROWID) {
 #pragma unroll
-                for (int r = 0; r < RW; r++) v[c][r] = rowid[r] - Cr.row0;
+                for (int r = 0; r < RW; r++) v[c][r] = rowid[r] - Cr.rowid_base;
                 continue;
             }
             if (kind == VC_FORM) {

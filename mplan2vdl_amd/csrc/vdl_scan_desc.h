@@ -93,6 +93,7 @@ static_assert(kMaxVCols >= kMaxScanCols && kMaxVCols >= kMaxJoinScanCols, "the a
 struct MScanCols {                           // host-side description of a scan's columns
     int ncol = 0;
     int64_t n = 0, row0 = 0;
+    bool rowid_global = false;               // row-id columns count from the TABLE's first row (the sharded front route) instead of the shard's
     const void *ptr[kMaxVCols] = {};         // VC_DIRECT: the column; derived columns: the table looked up (column / bitmap words / LUT)
     int width[kMaxVCols] = {};
     int filtered[kMaxVCols] = {};
@@ -156,6 +157,7 @@ struct MsArgs {
     uint64_t stages = 0;
     VDL_SD constexpr int stage(int c) const { return (int)((stages >> (4 * c)) & 15u); }
     int64_t n = 0, row0 = 0;
+    int64_t rowid_base = 0;                  // what a row-id column subtracts from the global row number: row0 (ids inside this shard) or 0
     const void *ptr[kMaxVCols] = {};
     VDL_SD constexpr int width(int c) const { return (int)((widths >> (4 * c)) & 15u); }
 };

@@ -225,6 +225,88 @@ def test_a_global_fold_beside_the_partition_is_merged_with_the_counts(world):
     assert got == want
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_partitions_run_above_the_gathered_front(world):
+    """TPC-H Q16 (count(distinct ps_suppkey) under a GROUP BY: two Partitions) has no exchange route; its work on partsupp is a
+    fused front, so the survivors' vectors of every rank are all-gathered -- rank after rank = row order -- and every rank runs
+    the two Partitions on the complete vectors: the "front" route, whole answer everywhere."""
+    cfg = frontend.load_metadata(META)
+    text = frontend.compile_plan(open(os.path.join(META, "16.sql.mplan")).read(), cfg)
+    cols = catalog.synth_columns(META, cfg, text, scale=2e-3, seed=3)
+    want = oracle_run(text, cols)
+    assert any(len(list(v.values())[0]) for v in want.values())
+    e = m.Engine(device=None)
+    p = e.parse(text)
+    p.set_sharded_table("partsupp")
+    assert p.sharded_route() == ("front", True)
+    parts = sharded_run(text, table_shards(cols, world, "partsupp"), world, table="partsupp")
+    assert parts == [want] * world
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_the_front_route_serves_any_tail_over_a_filtered_fact_table(world):
+    """A filter over the sharded table whose condition names the ROW ID (the reference's anti-join shape), a lookup in a replicated table, then two GROUP BYs one above
+    the other (the second over the first's result) and a global fold of the group sums: nothing the exchange route can do, all of
+    it above a front.  One rank's share is empty; the row-id condition must count from the table's first row on every rank."""
+    from helpers import prog
+    rng = np.random.default_rng(11 + world)
+    n, nd = 9000, 300
+    cols = {"f.k": rng.integers(0, nd, n).astype(np.int64), "f.a": rng.integers(0, 50, n).astype(np.int64), "f.v": rng.integers(-100, 100, n).astype(np.int64),
+            "d.g": rng.integers(0, 12, nd).astype(np.int64), "d.pk": np.arange(nd, dtype=np.int64)}
+    cols["f.a"][[4000, 8500]] = 0                              # both pass a < 7: row 4000 of the TABLE goes, row 4000 of the second of two shards (8500) stays
+    cols["f.v"][[4000, 8500]] = [77, -99]
+    text = prog("1,Load,f.k", "2,Project,val,Id 1,k", "3,Load,f.a", "4,Project,val,Id 3,a", "5,Load,f.v", "6,Project,val,Id 5,v",
+                "7,Load,d.g", "8,Project,val,Id 7,g",
+                "9,RangeV,val,7,Id 4,0", "10,Greater,val,Id 9,val,Id 4,val",                       # a < 7
+                "11,RangeV,val,0,Id 4,1", "12,RangeV,val,4000,Id 4,0", "13,Subtract,val,Id 12,val,Id 11,val",  # 4000 - row id as a truth value: every row but row 4000
+                "14,LogicalAnd,val,Id 10,val,Id 13,val",
+                "15,RangeV,val,0,Id 14,1", "16,FoldSelect,val,Id 15,val,Id 14,val",
+                "17,Gather,Id 2,Id 16,val", "18,Gather,Id 6,Id 16,val", "19,Gather,Id 8,Id 17,val",        # key, value, dimension group of the survivors
+                "20,RangeC,val,0,%d,1" % nd, "21,Partition,val,Id 17,val,Id 20,val",
+                "22,RangeV,val,0,Id 17,1", "23,Scatter,Id 17,Id 22,val,Id 21,val", "24,Scatter,Id 18,Id 22,val,Id 21,val", "25,Scatter,Id 19,Id 22,val,Id 21,val",
+                "26,FoldSum,val,Id 23,val,Id 24,val", "27,FoldChoose,val,Id 23,val,Id 25,val",                # per key: sum(v), its group
+                "28,RangeV,val,0,Id 27,1", "29,FoldSelect,val,Id 28,val,Id 27,val",                            # the groups' slots (valid where a run starts) ...
+                "30,RangeC,val,0,12,1", "31,Partition,val,Id 27,val,Id 30,val",
+                "32,RangeV,val,0,Id 27,1", "33,Scatter,Id 27,Id 32,val,Id 31,val", "34,Scatter,Id 26,Id 32,val,Id 31,val",
+                "35,FoldSum,val,Id 33,val,Id 34,val", "36,FoldCount,val,Id 33,val,Id 34,val",                 # per dimension group: sum of sums, number of keys
+                "37,Project,total,Id 35,val", "38,MaterializeCompact,Id 37", "39,Project,keys,Id 36,val", "40,MaterializeCompact,Id 39",
+                "41,RangeV,val,0,Id 26,0", "42,FoldMax,val,Id 41,val,Id 26,val", "43,Project,best,Id 42,val", "44,MaterializeCompact,Id 43")
+    want = oracle_run(text, cols)
+    assert len(want["tmp38"][".total"]) > 3
+    e = m.Engine(device=None)
+    p = e.parse(text)
+    p.set_sharded_table("f")
+    assert p.sharded_route() == ("front", True), p.describe()
+    shards = table_shards(cols, world, "f")
+    assert sharded_run(text, shards, world, table="f") == [want] * world
+    # a rank without rows
+    cut = [(0, {k: (v[:0] if k.startswith("f.") else v) for k, v in cols.items()})] + [(0, cols)] + ([(n, {k: (v[:0] if k.startswith("f.") else v) for k, v in cols.items()})] if world == 3 else [])
+    assert sharded_run(text, cut, world, table="f") == [want] * world
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_a_row_id_condition_counts_from_the_tables_first_row_on_every_rank(world):
+    """`k - row id` as a truth value (every row but row k: what the reference's anti-join compiles to) inside a FUSED scan of the
+    sharded table: rank r tests the row's number in the table, not in its shard (one row of the whole table goes, not one per rank)."""
+    from helpers import prog
+    rng = np.random.default_rng(3)
+    n = 9000
+    cols = {"f.a": rng.integers(0, 50, n).astype(np.int64), "f.v": rng.integers(1, 100, n).astype(np.int64)}
+    cols["f.a"][[1000, 4000, 5500, 7000]] = 0
+    text = prog("1,Load,f.a", "2,Project,val,Id 1,a", "3,Load,f.v", "4,Project,val,Id 3,v",
+                "5,RangeV,val,7,Id 2,0", "6,Greater,val,Id 5,val,Id 2,val",
+                "7,RangeV,val,0,Id 2,1", "8,RangeV,val,1000,Id 2,0", "9,Subtract,val,Id 8,val,Id 7,val",
+                "10,LogicalAnd,val,Id 6,val,Id 9,val",
+                "11,RangeV,val,0,Id 10,1", "12,FoldSelect,val,Id 11,val,Id 10,val", "13,Gather,Id 4,Id 12,val",
+                "14,RangeV,val,0,Id 13,0", "15,FoldSum,val,Id 14,val,Id 13,val", "16,MaterializeCompact,Id 15",
+                "17,FoldCount,val,Id 14,val,Id 13,val", "18,MaterializeCompact,Id 17")
+    want = oracle_run(text, cols)
+    e = m.Engine(device=None)
+    p = e.parse(text)
+    assert p.is_fused, p.describe()
+    assert sharded_run(text, table_shards(cols, world, "f"), world, table="f") == [want] * world
+
+
 def test_a_failure_on_one_rank_is_reported_on_every_rank():
     """A key outside the Partition pivots on ONE rank (the local phase of that rank fails): the status travels with the
     counts, nobody is left waiting in a collective, every rank returns an error."""
