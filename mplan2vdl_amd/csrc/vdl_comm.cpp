@@ -687,7 +687,7 @@ int vdl_run_sharded(vdl_ctx *c, vdl_plan *p) {
     }
     int rc = guard(c, [&] {
         if (fold_route(c, p)) { sharded_begin(c, p, 0); return; }
-        if (c->comm && c->comm->world > 1 && !p->sharded_table.empty()) {
+        if (c->comm && !p->sharded_table.empty()) {
             // rows travel by key range when the plan allows it; otherwise, if its work on the sharded table is a fused front, the
             // survivors are gathered and the rest runs on every rank (the "front" route)
             int ncols = 0;
@@ -695,7 +695,12 @@ int vdl_run_sharded(vdl_ctx *c, vdl_plan *p) {
             p->ex_allow_folds = true;
             const bool exchange_ok = vdl_exchange_spec(p, p->sharded_table.c_str(), &ncols) == VDL_OK;
             p->ex_allow_folds = false;
-            if (!exchange_ok && front_route_refusal(p).empty()) { c->err = keep; sharded_front(c, p); return; }
+            if (!exchange_ok && front_route_refusal(p).empty()) {
+                c->err = keep;
+                if (c->comm->world > 1) sharded_front(c, p);
+                else if (vdl_run(c, p) != VDL_OK) throw Error(VDL_ERR_DEVICE, c->err);      // one rank holds the whole table
+                return;
+            }
             c->err = keep;
         }
         sharded_exchange(c, p);

@@ -36,16 +36,17 @@ def test_vdlrun_gpus_merges_the_partial_words_over_rccl(query, world):
 
 
 @pytest.mark.parametrize("world", WORLDS)
-@pytest.mark.parametrize("plan", [3, 14, 10])
-def test_vdlrun_gpus_exchanges_rows_over_rccl(tmp_path, plan, world):
-    """Q3 / Q10: the Partition exchange (rows by key range, outputs of the ranks concatenate in rank order); Q14: fold records."""
+@pytest.mark.parametrize("plan,table", [(3, "lineitem"), (14, "lineitem"), (10, "lineitem"), (4, "lineitem"), (11, "partsupp"), (16, "partsupp")])
+def test_vdlrun_gpus_exchanges_rows_over_rccl(tmp_path, plan, table, world):
+    """Q3 / Q10: the Partition exchange (rows by key range, outputs of the ranks concatenate in rank order); Q14: fold records; Q4: merged
+    semi-join sets; Q11: a global fold beside the Partition; Q16: the front's survivors gathered, the tail on every rank."""
     cfg = frontend.load_metadata(META)
     text = frontend.compile_plan(open(os.path.join(META, "%02d.sql.mplan" % plan)).read(), cfg)
     text = "\n".join(ln.split(";;")[0].rstrip() for ln in text.splitlines()) + "\n"
     cols = catalog.synth_columns(META, cfg, text, scale=2e-3, seed=5)
     coldir = str(tmp_path / "cols")
     catalog.export_columns(cols, coldir)
-    reply = pipe(text, ["--gpus", str(world), "--shard", "lineitem", "--data", coldir])
+    reply = pipe(text, ["--gpus", str(world), "--shard", table, "--data", coldir])
     want = oracle_run(text, cols)
     assert reply["results"] == want
     assert any(len(list(v.values())[0]) for v in want.values())

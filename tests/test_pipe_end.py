@@ -107,16 +107,17 @@ def test_vdlrun_gpus_forks_its_ranks_and_runs_through_rccl(query):
     assert reply["results"] == oracle_run(text, lineitem(names, 60175))
 
 
-@pytest.mark.parametrize("plan", [3, 14])
-def test_vdlrun_gpus_with_a_data_directory(tmp_path, plan):
-    """--gpus with --data / --shard: the exchange route (Q3) and the fold-record route (Q14) from exported column files."""
+@pytest.mark.parametrize("plan,table", [(3, "lineitem"), (14, "lineitem"), (4, "lineitem"), (11, "partsupp"), (16, "partsupp")])
+def test_vdlrun_gpus_with_a_data_directory(tmp_path, plan, table):
+    """--gpus with --data / --shard: the exchange route (Q3), the fold-record route (Q14), the merged sets (Q4), a global fold beside the
+    Partition (Q11) and the front route (Q16) from exported column files, through a one-rank RCCL communicator."""
     cfg = frontend.load_metadata(META)
     text = frontend.compile_plan(open(os.path.join(META, "%02d.sql.mplan" % plan)).read(), cfg)
     text = "\n".join(ln.split(";;")[0].rstrip() for ln in text.splitlines()) + "\n"
     cols = catalog.synth_columns(META, cfg, text, scale=1e-3, seed=5)
     coldir = str(tmp_path / "cols")
     catalog.export_columns(cols, coldir)
-    reply = pipe(text, ["--gpus", "1", "--shard", "lineitem", "--data", coldir])
+    reply = pipe(text, ["--gpus", "1", "--shard", table, "--data", coldir])
     assert reply["results"] == oracle_run(text, cols)
 
 
