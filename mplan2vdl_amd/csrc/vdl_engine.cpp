@@ -13,7 +13,7 @@ namespace {
 static const MScanDesc *desc_on_device(vdl_ctx *c, vdl_plan *p, const std::string &role, const MScanDesc &d) {
     vdl_plan::DescSlot &sl = p->desc_slots[role];
     if (!sl.dev) sl.dev = dev_alloc(c, sizeof(MScanDesc));
-    static const bool always = getenv("VDL_NO_DESC_CACHE") != nullptr;
+    const bool always = getenv("VDL_NO_DESC_CACHE") != nullptr;
     if (always || sl.shadow.size() != sizeof(MScanDesc) || std::memcmp(sl.shadow.data(), &d, sizeof(MScanDesc)) != 0) {
         // the shadow is the SOURCE of the copy: it stays put until the next upload, the caller's `d` may be a local
         sl.shadow.assign((const unsigned char *)&d, (const unsigned char *)&d + sizeof(MScanDesc));
@@ -1212,6 +1212,7 @@ int vdl_parse(vdl_ctx *c, const char *text, size_t len, vdl_plan **out) {
         p->ctx = c;
         p->device = c->device;
         p->prog = parse_program(text, len);
+        rewrite_program(p->prog);
         p->fused = fuse_program(p->prog);
         { const char *j = getenv("VDL_JIT"); p->use_jit = j && *j && *j != '0'; p->jit_tune = p->use_jit && atoi(j) >= 2; }
         p->description = describe_plan(p.get());

@@ -1087,6 +1087,71 @@ static void build_projection(const Program &P, Builder &B, FusedPlan &F) {
     J.ok = true;
 }
 
+// ---- program rewrites ahead of planning -------------------------------------------------------------------------------------
+// "The column of the group's first row", as the reference's compiler writes it (Vlite.hs: an aggregate's representative read
+// through the row id the FoldChoose picked; TPC-H Q15 `lineitem_supplier`, Q18 `lineitem_orders`):
+//     R = Gather(RangeV 0 .. step 1 over table T, S)      row ids of the selected rows            (or R = the RangeV itself: no filter)
+//     D = Scatter(R, .., P)                               ... in group order
+//     I = FoldChoose(C, D)                                the first row id of every group
+//     G = Gather(X, I)                                    column X of T at that row            (X: a loaded column of T, every slot valid)
+// is   G = FoldChoose(C, Scatter(Gather(X, S), .., P)):   the column travels through the same positions and the fold picks the value of
+// the same slot (the two Gathers through S hold a value in exactly the same slots: X is a loaded column as long as the RangeV).
+// What it buys: the statement no longer reads a column of T by row NUMBER above the GROUP BY -- the column becomes one more vector of
+// the filter (a fused front takes it with the survivors), and a sharded run need not have T's rows of other ranks (Q15 then takes the
+// front route, vdl_comm.cpp).  The row-id statements stay for whoever else reads them; unread they never run.
+void rewrite_program(Program &P) {
+    if (getenv("VDL_NO_REWRITE")) return;
+    auto alias = [&](int id) { while (id > 0 && (P.at(id).op == Op::Project || P.at(id).op == Op::Shuffle)) id = P.at(id).a; return id; };
+    auto table_of = [](const std::string &column) { const size_t dot = column.find('.'); return dot == std::string::npos ? column : column.substr(0, dot); };
+    // row ids of a whole table: RangeV 0 step 1 over (an alias of) a Load; "" if not
+    auto rowids_of = [&](int id) -> std::string {
+        const Node &r = P.at(alias(id));
+        if (r.op != Op::RangeV || r.imm0 != 0 || r.imm1 != 1) return "";
+        const Node &l = P.at(alias(r.a));
+        return l.op == Op::Load ? table_of(l.column) : "";
+    };
+    const std::vector<int> order = P.order;
+    int next_id = 0;
+    for (int id : order) next_id = std::max(next_id, id);
+    std::vector<int> out;
+    out.reserve(order.size() + 8);
+    for (int id : order) {
+        Node g = P.at(id);
+        bool done = false;
+        if (g.op == Op::Gather) {
+            const Node &x = P.at(alias(g.a));
+            const Node &fc = P.at(alias(g.b));
+            if (x.op == Op::Load && x.column.find(".heap") == std::string::npos && fc.op == Op::FoldChoose) {
+                const Node &sc = P.at(alias(fc.b));
+                if (sc.op == Op::Scatter) {
+                    const Node &r = P.at(alias(sc.a));
+                    const std::string t = table_of(x.column);
+                    int through = -2;                                  // -1: no filter; >= 0: the selection S
+                    if (r.op == Op::Gather && rowids_of(r.a) == t) through = r.b;
+                    else if (rowids_of(sc.a) == t) through = -1;
+                    if (through != -2 && (size_t)next_id + 2 < ((size_t)1 << 24)) {
+                        int src = g.a;
+                        if (through >= 0) {
+                            Node n1; n1.id = ++next_id; n1.op = Op::Gather; n1.a = g.a; n1.b = through; n1.field = "val"; n1.line = g.line;
+                            if (P.nodes.size() <= (size_t)n1.id) P.nodes.resize((size_t)n1.id + 64);
+                            P.nodes[(size_t)n1.id] = n1; out.push_back(n1.id); src = n1.id;
+                        }
+                        Node n2; n2.id = ++next_id; n2.op = Op::Scatter; n2.a = src; n2.b = sc.b; n2.c = sc.c; n2.field = "val"; n2.line = g.line;
+                        if (P.nodes.size() <= (size_t)n2.id) P.nodes.resize((size_t)n2.id + 64);
+                        P.nodes[(size_t)n2.id] = n2; out.push_back(n2.id);
+                        g.op = Op::FoldChoose; g.a = fc.a; g.b = n2.id; g.c = -1;
+                        P.nodes[(size_t)id] = g;
+                        done = true;
+                    }
+                }
+            }
+        }
+        (void)done;
+        out.push_back(id);
+    }
+    P.order = out;
+}
+
 FusedPlan fuse_program(const Program &P) {
     FusedPlan F;
     Builder B(P);

@@ -140,6 +140,7 @@ struct FusedPlan {
     std::vector<FusedOutput> outputs;
 };
 
+void rewrite_program(Program &P);            // equivalent forms the planner and the sharded routes prefer (vdl_fuse.cpp)
 FusedPlan fuse_program(const Program &P);
 std::string describe_fused(const FusedPlan &F);
 int64_t eval_scalar(const Scalar &s, const int64_t *agg_values);

@@ -226,20 +226,23 @@ def test_a_global_fold_beside_the_partition_is_merged_with_the_counts(world):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_two_partitions_run_above_the_gathered_front(world):
+@pytest.mark.parametrize("plan,table", [(16, "partsupp"), (15, "lineitem")])
+def test_two_partitions_run_above_the_gathered_front(plan, table, world):
     """TPC-H Q16 (count(distinct ps_suppkey) under a GROUP BY: two Partitions) has no exchange route; its work on partsupp is a
     fused front, so the survivors' vectors of every rank are all-gathered -- rank after rank = row order -- and every rank runs
-    the two Partitions on the complete vectors: the "front" route, whole answer everywhere."""
+    the two Partitions on the complete vectors: the "front" route, whole answer everywhere.  Q15 (a global max over the grouped sums,
+    then the suppliers that reach it) goes the same way once the column its FoldChoose'd row ids looked up travels through the
+    fold itself (rewrite_program, vdl_fuse.cpp)."""
     cfg = frontend.load_metadata(META)
-    text = frontend.compile_plan(open(os.path.join(META, "16.sql.mplan")).read(), cfg)
+    text = frontend.compile_plan(open(os.path.join(META, "%02d.sql.mplan" % plan)).read(), cfg)
     cols = catalog.synth_columns(META, cfg, text, scale=2e-3, seed=3)
     want = oracle_run(text, cols)
     assert any(len(list(v.values())[0]) for v in want.values())
     e = m.Engine(device=None)
     p = e.parse(text)
-    p.set_sharded_table("partsupp")
+    p.set_sharded_table(table)
     assert p.sharded_route() == ("front", True)
-    parts = sharded_run(text, table_shards(cols, world, "partsupp"), world, table="partsupp")
+    parts = sharded_run(text, table_shards(cols, world, table), world, table=table)
     assert parts == [want] * world
 
 
