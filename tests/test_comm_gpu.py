@@ -408,3 +408,20 @@ def test_rccl_communicator_of_one_rank_runs_both_routes(q6_text):
     p.set_sharded_table("lineitem")
     assert p.run_sharded()["results"] == oracle_run(golden("q3.vdl"), t)
     e.close()
+
+
+def test_rccl_communicator_of_one_rank_runs_the_set_and_front_routes(monkeypatch):
+    """The other two routes through real RCCL with one rank: Q4's all-gather of the semi-join set, and -- with
+    VDL_FRONT_ROUTE_ALWAYS, which keeps a one-rank run on the collectives -- Q16's and Q15's grouped send / receive of the front's vectors."""
+    cfg = frontend.load_metadata(META)
+    monkeypatch.setenv("VDL_FRONT_ROUTE_ALWAYS", "1")
+    for plan, table, route in ((4, "lineitem", "set"), (16, "partsupp", "front"), (15, "lineitem", "front")):
+        text = frontend.compile_plan(open(os.path.join(META, "%02d.sql.mplan" % plan)).read(), cfg)
+        cols = catalog.synth_columns(META, cfg, text, scale=2e-3, seed=3)
+        e = engine_with(cols)
+        e.comm_init_rccl(0, 1, e.comm_unique_id())
+        p = e.parse(text)
+        p.set_sharded_table(table)
+        assert p.sharded_route()[0] == route
+        assert p.run_sharded()["results"] == oracle_run(text, cols), plan
+        e.close()
