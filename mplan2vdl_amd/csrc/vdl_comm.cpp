@@ -305,7 +305,7 @@ static void sharded_exchange(vdl_ctx *c, vdl_plan *p) {
     std::vector<int64_t> all(row * (size_t)m.world);
     if (m.world > 1) {
         all_gather(c, dsend->p, drecv->p, sizeof(int64_t) * row, c->stream);
-        HIP_CHECK(hipMemcpyAsync(all.data(), drecv->p, sizeof(int64_t) * all.size(), hipMemcpyDeviceToHost, c->stream));
+        c->fetch_to_host(drecv->p, all.size(), all.data(), c->stream);
     } else {
         all = mine;
     }
@@ -479,8 +479,7 @@ static void sharded_front(vdl_ctx *c, vdl_plan *p) {
         HIP_CHECK(hipMemcpyAsync(dsend->p, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
         HIP_CHECK(hipStreamSynchronize(c->stream));
         all_gather(c, dsend->p, drecv->p, sizeof mine, c->stream);
-        HIP_CHECK(hipMemcpyAsync(rows.data(), drecv->p, sizeof(int64_t) * rows.size(), hipMemcpyDeviceToHost, c->stream));
-        HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->fetch_to_host(drecv->p, rows.size(), rows.data(), c->stream);
     }
     int64_t row0 = 0, n_global = 0;
     for (int r = 0; r < m.world; r++) {
@@ -516,8 +515,7 @@ static void sharded_front(vdl_ctx *c, vdl_plan *p) {
             HIP_CHECK(hipMemcpyAsync(dsend->p, mine, sizeof mine, hipMemcpyHostToDevice, s));
             HIP_CHECK(hipStreamSynchronize(s));
             all_gather(cc, dsend->p, drecv->p, sizeof mine, s);
-            HIP_CHECK(hipMemcpyAsync(all.data(), drecv->p, sizeof(int64_t) * all.size(), hipMemcpyDeviceToHost, s));
-            HIP_CHECK(hipStreamSynchronize(s));
+            cc->fetch_to_host(drecv->p, all.size(), all.data(), s);
         }
         if (!ok) throw Error(VDL_ERR_UNSUPPORTED, "sharded run: the fused front did not run on this rank (" + (failure.empty() ? (pp->fallback_note.empty() ? std::string("its vectors do not share one selection") : pp->fallback_note) : failure) +
                                                    "), and statement by statement the plan has no sharded route");

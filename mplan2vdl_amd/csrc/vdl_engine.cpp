@@ -427,8 +427,7 @@ static int64_t scan_bytes_moved(vdl_ctx *c, vdl_plan *p, std::string &detail) {
     int64_t *out = (int64_t *)words->p + (grouped ? p->gword_offset[s - ns] : p->word_offset[s]);
     HIP_CHECK(launch_mscan(cols, d, (const MScanDesc *)ddev->p, cfg, grouped, false, out, false, c->stream, cen.k->fn));
     unsigned long long lines[kMaxVCols] = {};
-    HIP_CHECK(hipMemcpyAsync(lines, counts->p, sizeof lines, hipMemcpyDeviceToHost, c->stream));
-    HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->fetch_to_host(counts->p, kMaxVCols, (int64_t *)lines, c->stream);
     const MsArgs args = [&] { MsArgs a = mscan_args(cols); uint32_t lz = 0; a.stages = staged_columns(c, cols, p->mdesc[s], grouped, &lz, p->mjit_form[s].lazy); a.lazy = lz; return a; }();
     for (int k = 0; k < cols.ncol; k++) {
         if (cols.kind[k] != VC_DIRECT) continue;
@@ -1080,6 +1079,14 @@ int vdl_open(vdl_ctx **out, int device) {
     }
     *out = c;
     return rc;
+}
+
+void vdl_ctx::fetch_to_host(const void *dev, size_t k, int64_t *out, hipStream_t s) {
+    if (k == 0) return;
+    int64_t *pin = pinned((int64_t)k);
+    HIP_CHECK(hipMemcpyAsync(pin ? pin : out, dev, sizeof(int64_t) * k, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (pin) std::memcpy(out, pin, sizeof(int64_t) * k);
 }
 
 void vdl_close(vdl_ctx *c) {

@@ -180,10 +180,14 @@ struct vdl_ctx {
     // a few words of PINNED host memory for the round trips of the executors (survivor counts, sortedness verdicts): a copy
     // into pageable memory is staged by the runtime and cost 20-30 us of idle GPU each (Q3 at SF10: three of them per query)
     int64_t *pinned_words = nullptr;
-    int64_t *pinned(int words) {
-        if (!pinned_words && hipHostMalloc((void **)&pinned_words, sizeof(int64_t) * 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); pinned_words = nullptr; }
-        return words <= 64 ? pinned_words : nullptr;
+    static constexpr int kPinnedWords = 1 << 15;       // 256 KiB: also the per-rank count tables of the sharded routes (128 ranks x 130 words)
+    int64_t *pinned(int64_t words) {
+        if (!pinned_words && hipHostMalloc((void **)&pinned_words, sizeof(int64_t) * kPinnedWords, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); pinned_words = nullptr; }
+        return words <= kPinnedWords ? pinned_words : nullptr;
     }
+    // `k` int64 words from the device to `out`, waited for on `s`: through the pinned words when they fit -- no copy of this library
+    // has pageable host memory for its destination unless it is larger than that (result vectors, traces)
+    void fetch_to_host(const void *dev, size_t k, int64_t *out, hipStream_t s);
     // pinned staging for small result vectors (GenExec::copy_out): copied in stream order, read after ONE synchronise per run
     static constexpr size_t kSmallStageWords = (size_t)1 << 17;
     int64_t *small_stage_words = nullptr;

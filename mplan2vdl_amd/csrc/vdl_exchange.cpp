@@ -360,7 +360,7 @@ int vdl_exchange_begin(vdl_ctx *c, vdl_plan *p, int world, int64_t *counts_host)
                 HIP_CHECK(launch_fold_words((const int64_t *)v.data->p, fold_reduce_kind(p->prog.at(x.folds[k]).op), p->row_offset, (int64_t *)fw->p + 3 * (int64_t)k, c->stream));
             }
             ex.fold_words.resize(3 * x.folds.size());
-            HIP_CHECK(hipMemcpyAsync(ex.fold_words.data(), fw->p, sizeof(int64_t) * ex.fold_words.size(), hipMemcpyDeviceToHost, c->stream));
+            c->fetch_to_host(fw->p, ex.fold_words.size(), ex.fold_words.data(), c->stream);
             HIP_CHECK(hipStreamSynchronize(c->stream));
             ex.fold_merged = ex.fold_words;                 // (a single rank: its own records are the merged ones)
         }
@@ -394,8 +394,7 @@ int vdl_exchange_begin(vdl_ctx *c, vdl_plan *p, int world, int64_t *counts_host)
                                        nullptr, nullptr, (int64_t *)nvalid->p, (int64_t *)ex.pos->p, c->stream));
         }
         std::vector<int64_t> h((size_t)world + 1);
-        HIP_CHECK(hipMemcpyAsync(h.data(), counts->p, sizeof(int64_t) * (size_t)(world + 1), hipMemcpyDeviceToHost, c->stream));
-        HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->fetch_to_host(counts->p, (size_t)(world + 1), h.data(), c->stream);
         if (h[(size_t)world] > 0)
             throw Error(VDL_ERR_UNSUPPORTED, std::to_string(h[(size_t)world]) + " row(s) carry a partition key outside the pivots; run unsharded");
         ex.n_send = 0;
@@ -441,8 +440,7 @@ int vdl_exchange_finish(vdl_ctx *c, vdl_plan *p, const void *dev_recv, int64_t n
             Src mk; mk.p = in + (int64_t)m * n_recv; mk.kind = SRC_I64;
             HIP_CHECK(launch_fold_global(1 /* min */, mk, nullptr, nullptr, n_recv, (int64_t *)scratch->p, (int64_t *)r->p, c->stream));
             int64_t h[3];
-            HIP_CHECK(hipMemcpyAsync(h, r->p, sizeof h, hipMemcpyDeviceToHost, c->stream));
-            HIP_CHECK(hipStreamSynchronize(c->stream));
+            c->fetch_to_host(r->p, 3, h, c->stream);
             all_valid = h[0] == (int64_t)(((uint64_t)1 << (m - 1)) - 1);
         }
         for (size_t k = 0; k < m; k++) {

@@ -77,10 +77,7 @@ struct GenExec {
     // k (<= 64) int64 words from the device to the host, waited for: through the context's pinned words (a pageable destination is
     // staged by the runtime and keeps the GPU idle two to three times as long)
     void fetch_words(const void *dev, int k, int64_t *out) {
-        int64_t *pin = c->pinned(k);
-        HIP_CHECK(hipMemcpyAsync(pin ? pin : out, dev, sizeof(int64_t) * (size_t)k, hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipStreamSynchronize(s));
-        if (pin) std::memcpy(out, pin, sizeof(int64_t) * (size_t)k);
+        c->fetch_to_host(dev, (size_t)k, out, s);
     }
     // population of a bitmap over n slots; leaves the per-tile offsets for compact_write in *offsets
     int64_t popcount(const BufP &bits, int64_t n, BufP *offsets) {
@@ -805,9 +802,14 @@ struct GenExec {
         HIP_CHECK(launch_fsel_keys((const int64_t *)excl->p, (const int64_t *)flags->p, (const int64_t *)de->p, (const uint64_t *)dv->p, m,
                                    (int64_t *)keys->p, (uint64_t *)selected->p, s));
         int64_t last[2];
-        HIP_CHECK(hipMemcpyAsync(&last[0], (const int64_t *)excl->p + (m - 1), sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipMemcpyAsync(&last[1], (const int64_t *)flags->p + (m - 1), sizeof(int64_t), hipMemcpyDeviceToHost, s));
-        HIP_CHECK(hipStreamSynchronize(s));
+        {                                                   // (two words from two buffers: side by side in the pinned words, one wait)
+            int64_t *pin = c->pinned(2);
+            int64_t *to = pin ? pin : last;
+            HIP_CHECK(hipMemcpyAsync(&to[0], (const int64_t *)excl->p + (m - 1), sizeof(int64_t), hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipMemcpyAsync(&to[1], (const int64_t *)flags->p + (m - 1), sizeof(int64_t), hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            if (pin) { last[0] = pin[0]; last[1] = pin[1]; }
+        }
         const int64_t nruns = last[0] + last[1];
         DVec kv; kv.kind = DVec::DENSE; kv.n = m; kv.data = keys;
         DVec rank = partition_positions(kv, 0, 2 * nruns);
@@ -1291,8 +1293,7 @@ struct GenExec {
             HIP_CHECK(launch_fold_global(1, src_of(d), vp(d), nullptr, d.n, (int64_t *)scratch->p, (int64_t *)mm->p, s));
             HIP_CHECK(launch_fold_global(2, src_of(d), vp(d), nullptr, d.n, (int64_t *)scratch->p, (int64_t *)mm->p + 3, s));
             int64_t h[6];
-            HIP_CHECK(hipMemcpyAsync(h, mm->p, sizeof h, hipMemcpyDeviceToHost, s));
-            HIP_CHECK(hipStreamSynchronize(s));
+            fetch_words(mm->p, 6, h);
             if (h[2] == 0) return o;                                      // nothing but EPS
             const uint64_t span = (uint64_t)h[3] - (uint64_t)h[0];
             if (span >= ((uint64_t)1 << 62))
@@ -1348,8 +1349,11 @@ struct GenExec {
     }
     template <typename T> std::vector<T> fetch(const void *dev, size_t count) {
         std::vector<T> h(count);
-        if (count) HIP_CHECK(hipMemcpyAsync(h.data(), dev, sizeof(T) * count, hipMemcpyDeviceToHost, s));
+        const size_t words = (sizeof(T) * count + 7) / 8;
+        int64_t *pin = count ? c->pinned((int64_t)words) : nullptr;          // (traces of small vectors: pinned; long ones: pageable)
+        if (count) HIP_CHECK(hipMemcpyAsync(pin ? (void *)pin : (void *)h.data(), dev, sizeof(T) * count, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
+        if (pin) std::memcpy(h.data(), pin, sizeof(T) * count);
         return h;
     }
     void snapshot(const Node &n, const DVec &v) {
