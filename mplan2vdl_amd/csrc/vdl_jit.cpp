@@ -30,6 +30,10 @@ namespace jit {
 
 namespace {
 
+#ifndef VDL_PROJ_U
+#define VDL_PROJ_U 4
+#endif
+constexpr int VDL_PROJ_U_HOST = VDL_PROJ_U;
 const char kEmbedded[] =
 #include "vdl_jit_src.inc"
     ;
@@ -270,7 +274,7 @@ std::string scan_source(Kind kind, const MsArgs &C, const MScanDesc &D, const Sh
         for (int c = 0; c < C.ncol; c++) if (!((C.derived >> c) & 1u) && C.stage(c) == 15) o << load(c, "pass");
         o << "\n";
     }
-    o << kEmbedded << "\n" << desc_text(kind, C, D);
+    o << "#define VDL_PROJ_U " << VDL_PROJ_U_HOST << "\n" << kEmbedded << "\n" << desc_text(kind, C, D);      // (the tile of the projection scan as this library was built)
     const char *b = sh.vec ? "true" : "false";
     if (kind == MSCAN)
         o << "extern \"C\" __global__ __launch_bounds__(256) void " << entry_name(kind, C, D, sh) << "(const vdl::MsArgs Cr, const vdl::MScanDesc *__restrict__ Dp) {\n"

@@ -632,7 +632,10 @@ __device__ __forceinline__ void mscan_body(const MsArgs &C, const MsArgs &Cr, co
 // lane busy, loads what the rest of the program wants of them -- fact columns at the row, dimension columns through the
 // index -- and writes the packed vectors.  (A second full pass with exec-masked loads for 5 % of the lanes took 4x as long.)
 // Row order inside a tile is (sub-iteration u, wave, lane, row of the lane's pair).
-constexpr int kProjU = 4;
+#ifndef VDL_PROJ_U
+#define VDL_PROJ_U 4                          // row pairs per lane and tile of the projection scan (variant builds: -DVDL_PROJ_U=2|8)
+#endif
+constexpr int kProjU = VDL_PROJ_U;
 constexpr int kProjTile = kMsBlock * 2 * kProjU;
 static_assert(kProjTile <= 65536, "positions inside a tile fit 16 bits");
 
