@@ -21,6 +21,9 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <map>
+#include <mutex>
+
 namespace vdl {
 
 namespace {
@@ -211,8 +214,28 @@ hipError_t launch_project_select(const MScanCols &cols, const MScanDesc *dev_des
     (void)hipGetLastError();
     if (cols.n <= 0) return hipSuccess;
     const bool vec = project_select_vec(cols);
+    // The blocks walk the tiles with the grid as their stride, so the grid is what the chip holds at once -- blocks per CU by the
+    // kernel's registers (88 VGPRs for Q3's select pass: 5, not 8): no block waits for a slot while others hold theirs for the whole
+    // pass.  (Measured: no difference for Q3 at SF10, 150 us either way -- the pass is bound by its dependent lookups, DESIGN.md.)
+    int per_cu = 8;
+    if (jit_fn) {
+        static std::mutex mu;
+        static std::map<hipFunction_t, int> known;
+        std::lock_guard<std::mutex> g(mu);
+        auto it = known.find(jit_fn);
+        if (it == known.end()) {
+            int n = 0;
+            if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&n, jit_fn, kMsBlock, 0) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 8; }
+            if (known.size() > 4096) known.clear();
+            it = known.emplace(jit_fn, n).first;
+        }
+        per_cu = it->second;
+    } else {
+        per_cu = cols.ncol <= 4 ? 8 : cols.ncol <= 8 ? 5 : 3;            // (precompiled: 4 / 8 / 12 columns x 8 rows of 64 bits in registers)
+    }
+    if (const char *e = getenv("VDL_PROJ_BLOCKS_PER_CU")) { if (atoi(e) > 0) per_cu = atoi(e); }
     int64_t grid = project_tiles(cols.n);
-    if (grid > (int64_t)num_cus * 8) grid = (int64_t)num_cus * 8;
+    if (grid > (int64_t)num_cus * per_cu) grid = (int64_t)num_cus * per_cu;
     MsArgs a = ms_args(cols);
     if (jit_fn) {
         void *params[] = {&a, &dev_desc};

@@ -642,7 +642,8 @@ static_assert(kProjTile <= 65536, "positions inside a tile fit 16 bits");
 template <int NC, int U, bool VEC, bool NT>
 __device__ __forceinline__ void project_select_body(const MsArgs &C, const MsArgs &Cr, const MScanDesc &D, const MScanDesc &Dr) {
     constexpr int BS = kMsBlock, ROWS = 2 * U, TILE = BS * ROWS, NW = BS / kWave;
-    __shared__ int wcnt[U][NW];
+    __shared__ int wcnt[2][U][NW];        // by tile parity: one barrier per tile (a wave that runs ahead writes the other half)
+    int par = 0;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     const int64_t full = Cr.n / TILE, ntiles = (Cr.n + TILE - 1) / TILE;
     uint16_t *__restrict__ scratch = (uint16_t *)Dr.out_idx;            // [tiles][TILE] positions
@@ -708,14 +709,14 @@ __device__ __forceinline__ void project_select_body(const MsArgs &C, const MsArg
         if (D.bitmap_only) continue;                       // a dimension scan wants the bitmap only
         if (lane == 0) {
 #pragma unroll
-            for (int u = 0; u < U; u++) wcnt[u][wave] = __popcll(m[2 * u]) + __popcll(m[2 * u + 1]);
+            for (int u = 0; u < U; u++) wcnt[par][u][wave] = __popcll(m[2 * u]) + __popcll(m[2 * u + 1]);
         }
         __syncthreads();
         int total = 0, mybase[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
 #pragma unroll
-            for (int w = 0; w < NW; w++) { if (w == wave) mybase[u] = total; total += wcnt[u][w]; }
+            for (int w = 0; w < NW; w++) { if (w == wave) mybase[u] = total; total += wcnt[par][u][w]; }
         }
         if (tid == 0) {
             Dr.tile_counts[tile] = total;
@@ -731,7 +732,7 @@ __device__ __forceinline__ void project_select_body(const MsArgs &C, const MsArg
             const int rank = mybase[u] + __popcll(m[2 * u] & below) + __popcll(m[2 * u + 1] & below) + ((r & 1) && alive[2 * u] ? 1 : 0);
             if (alive[r]) scratch[tile * TILE + rank] = (uint16_t)(tid * 2 + u * (BS * 2) + (r & 1));
         }
-        __syncthreads();                                   // wcnt is rewritten by the next tile
+        par ^= 1;                                          // (no second barrier: the next tile's counts go to the other half)
     }
 }
 
