@@ -747,48 +747,78 @@ __device__ __forceinline__ void project_take_body(const MsArgs &C, const MsArgs 
     for (int64_t tile = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; tile < ntiles; tile += wstride) {
         const int cnt = (int)counts[tile];
         const int64_t off = offsets[tile];
-        for (int k0 = 0; k0 < cnt; k0 += kWave) {          // wave-uniform
-            const int k = k0 + lane;
-            const bool on = k < cnt;
-            const int64_t row = tile * TILE + (on ? (int64_t)scratch[tile * TILE + k] : 0);      // idle lanes re-read a row of the tile
-            int64_t v[NC][1];
-            // every table column the outputs need (directly or as a lookup's index), at the row; then the lookups
+        // two survivors per lane and trip (k and k + 64): a tile of 2048 rows keeps about a hundred at TPC-H's selectivities, and the trip
+        // is a chain of dependent loads (position -> columns at the row -> lookups through the index) whose latency is what the pass
+        // costs -- both chains in flight together
+        constexpr int RW = 2;
+        for (int k0 = 0; k0 < cnt; k0 += RW * kWave) {     // wave-uniform
+            int k[RW];
+            bool on[RW];
+            int64_t row[RW];
+#pragma unroll
+            for (int r = 0; r < RW; r++) {
+                k[r] = k0 + r * kWave + lane;
+                on[r] = k[r] < cnt;
+            }
+#pragma unroll
+            for (int r = 0; r < RW; r++) row[r] = tile * TILE + (on[r] ? (int64_t)scratch[tile * TILE + k[r]] : 0);      // idle lanes re-read a row of the tile
+            int64_t v[NC][RW];
+            // every table column the outputs need (directly or as a lookup's index), at the rows; then the lookups
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                v[c][0] = 0;
-                if (c < C.ncol && ((D.take >> c) & 1u) && !((C.derived >> c) & 1u)) v[c][0] = load_scalar(Cr.ptr[c], C.width(c), row < Cr.n ? row : Cr.n - 1);
+#pragma unroll
+                for (int r = 0; r < RW; r++) v[c][r] = 0;
+                if (c < C.ncol && ((D.take >> c) & 1u) && !((C.derived >> c) & 1u)) {
+#pragma unroll
+                    for (int r = 0; r < RW; r++) v[c][r] = load_scalar(Cr.ptr[c], C.width(c), row[r] < Cr.n ? row[r] : Cr.n - 1);
+                }
             }
-            bool alive[1] = {on};
-            const int64_t rid[1] = {Cr.row0 + row};
-            derive<NC, 1>(C, Cr, D, Dr, v, alive, C.derived & D.take, rid, false);
-            if (on) Dr.out_idx[off + k] = row;
+            bool alive[RW];
+            int64_t rid[RW];
+#pragma unroll
+            for (int r = 0; r < RW; r++) { alive[r] = on[r]; rid[r] = Cr.row0 + row[r]; }
+            derive<NC, RW>(C, Cr, D, Dr, v, alive, C.derived & D.take, rid, false);
+#pragma unroll
+            for (int r = 0; r < RW; r++) if (on[r]) Dr.out_idx[off + k[r]] = row[r];
             VDL_SPEC_UNROLL
             for (int o = 0; o < D.nout; o++) {
                 const int oc = D.out_col[o];
-                int64_t x = 0;
+                int64_t x[RW];
+#pragma unroll
+                for (int r = 0; r < RW; r++) x[r] = 0;
                 if (oc >= 0) {
 #pragma unroll
-                    for (int c = 0; c < NC; c++) if (c == oc) x = v[c][0];
+                    for (int c = 0; c < NC; c++) if (c == oc) {
+#pragma unroll
+                        for (int r = 0; r < RW; r++) x[r] = v[c][r];
+                    }
                 } else {
                     // a row expression over the columns, in the two-accumulator program form of the group keys (ProjPlan::exprs)
-                    int64_t acc[1] = {0}, tmp[1] = {0};
+                    int64_t acc[RW], tmp[RW];
+#pragma unroll
+                    for (int r = 0; r < RW; r++) acc[r] = tmp[r] = 0;
                     const int at = D.expr_at[-2 - oc], len = D.expr_len[-2 - oc];
                     VDL_SPEC_UNROLL
                     for (int s = at; s < at + len; s++) {
                         const KeyStep st = D.key[s];               // wave-uniform
                         if (st.kind == KeyStep::LOAD) {
 #pragma unroll
-                            for (int c = 0; c < NC; c++) if (c == st.col) { if (st.target) tmp[0] = v[c][0]; else acc[0] = v[c][0]; }
+                            for (int c = 0; c < NC; c++) if (c == st.col) {
+#pragma unroll
+                                for (int r = 0; r < RW; r++) { if (st.target) tmp[r] = v[c][r]; else acc[r] = v[c][r]; }
+                            }
                         } else if (st.kind == KeyStep::OPK) {
-                            if (st.target) key_rows<1>(st.bin, st.const_left, tmp, st.k);
-                            else key_rows<1>(st.bin, st.const_left, acc, st.k);
+                            if (st.target) key_rows<RW>(st.bin, st.const_left, tmp, st.k);
+                            else key_rows<RW>(st.bin, st.const_left, acc, st.k);
                         } else {
-                            key_combine<1>(st.bin, st.const_left, acc, tmp);
+                            key_combine<RW>(st.bin, st.const_left, acc, tmp);
                         }
                     }
-                    x = acc[0];
+#pragma unroll
+                    for (int r = 0; r < RW; r++) x[r] = acc[r];
                 }
-                if (on) Dr.out_ptr[o][off + k] = x;
+#pragma unroll
+                for (int r = 0; r < RW; r++) if (on[r]) Dr.out_ptr[o][off + k[r]] = x[r];
             }
         }
     }
