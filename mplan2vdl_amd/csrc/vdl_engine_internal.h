@@ -125,6 +125,8 @@ struct DVec {
     int64_t from = 0, step = 0; // RANGE; OHCONST: from = the constant
     BufP valid;                 // bitmap, null = every slot holds a value
     BufP keep;                  // COLUMN: keeps an engine-owned column alive
+    BufP order;                 // Partition positions whose only readers are Scatters: the slots in RANK order (order[pos[slot]] = slot); `data` (the
+                                // positions themselves) is filled in only if somebody asks (GenExec::need_positions)
 };
 
 // Element-wise operators whose only reader is another element-wise operator are not run one by one: they pile up

@@ -74,6 +74,7 @@ struct PartIn {
     const int64_t *n_dev;        // later passes: number of elements (device scalar)
     int64_t n;                   // first pass: number of slots; later: upper bound for the grid
     int shift;
+    int order_out;               // this (last) pass writes the slots in rank order to slots_out instead of the sorted pairs / the ranks
     int slot_bits;               // > 0: packed form -- a pair travels as ONE word (bucket << slot_bits) | slot, `slots` is unused:
                                  // every later pass moves 8 instead of 16 bytes per row (taken when bits(pcount) + bits(n) <= 64)
 };
@@ -247,7 +248,8 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(PartIn in, int64_t 
         if (idx < total) {
             const uint64_t key = stage[idx];
             dest[k] = gdelta[(key >> in.shift) & (kRadix - 1)] + idx;
-            keys_out[dest[k]] = key;
+            if (!in.order_out) keys_out[dest[k]] = key;
+            else if (in.slot_bits) slots_out[dest[k]] = (int64_t)(key & ((1ull << in.slot_bits) - 1));     // the last pass of a lazy Partition: slots in rank order
         }
     }
     if (in.slot_bits) return;                                  // packed: the slot travelled inside the key word
@@ -346,7 +348,7 @@ hipError_t launch_sorted_heads(Src d, int64_t n, uint64_t *heads, int64_t *flag,
 hipError_t launch_partition(Src data, const uint64_t *valid, int64_t n, int64_t pmin, int64_t pcount,
                             int64_t *hist /* 256*ntiles + 1 */, int64_t *scan_scratch /* prefix_sum_blocks(256*ntiles)+1 */,
                             uint64_t *keys_a, int64_t *slots_a, uint64_t *keys_b, int64_t *slots_b /* n each, or null if one pass */,
-                            int64_t *n_valid_dev /* 1 word */, int64_t *pos_out, hipStream_t s, int64_t max_bucket) {
+                            int64_t *n_valid_dev /* 1 word */, int64_t *pos_out, hipStream_t s, int64_t max_bucket, int64_t *order_out) {
     (void)hipGetLastError();   // see launch_status()
     if (n <= 0) return hipSuccess;
     int bits = 0;
@@ -372,7 +374,14 @@ hipError_t launch_partition(Src data, const uint64_t *valid, int64_t n, int64_t 
             e = hipMemcpyAsync(n_valid_dev, scan_scratch + prefix_sum_blocks(hn), sizeof(int64_t), hipMemcpyDeviceToDevice, s);
             if (e != hipSuccess) return e;
         }
-        if (first && last) k_part_scatter<true, true><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist, nullptr, nullptr, pos_out);
+        // order_out: the caller wants the slots in rank order (the inverse of the positions) -- the last pass then stores like a middle
+        // pass, consecutive lanes on consecutive words, instead of one 8-byte store per slot at the slot's own address
+        in.order_out = (last && order_out) ? 1 : 0;
+        if (in.order_out) {
+            if (first) k_part_scatter<true, false><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist, nullptr, order_out, nullptr);
+            else k_part_scatter<false, false><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist, nullptr, order_out, nullptr);
+        }
+        else if (first && last) k_part_scatter<true, true><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist, nullptr, nullptr, pos_out);
         else if (first) k_part_scatter<true, false><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist, kout, sout, nullptr);
         else if (last) k_part_scatter<false, true><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist, nullptr, nullptr, pos_out);
         else k_part_scatter<false, false><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist, kout, sout, nullptr);

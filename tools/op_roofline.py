@@ -32,13 +32,17 @@ lines = ["1,Load,lineitem.l_quantity", "2,Project,val,Id 1,l_quantity", "3,Load,
          # keep every measured statement alive through a cheap global fold
          "33,RangeV,val,0,Id 11,0", "34,FoldMax,val,Id 33,val,Id 11,val", "35,MaterializeCompact,Id 34",
          "36,RangeV,val,0,Id 16,0", "37,FoldMax,val,Id 36,val,Id 16,val", "38,MaterializeCompact,Id 37",
-         "39,RangeV,val,0,Id 32,0", "40,FoldMax,val,Id 39,val,Id 32,val", "41,MaterializeCompact,Id 40"]
+         # the sparse-domain Partition's readers are Scatters, as in every compiled GROUP BY (its positions then stay in rank order)
+         "39,RangeV,val,0,Id 31,1", "40,Scatter,Id 31,Id 39,val,Id 32,val", "41,Scatter,Id 2,Id 39,val,Id 32,val",
+         "42,RangeV,val,0,Id 40,0", "43,FoldMax,val,Id 42,val,Id 40,val", "44,MaterializeCompact,Id 43",
+         "45,RangeV,val,0,Id 41,0", "46,FoldMax,val,Id 45,val,Id 41,val", "47,MaterializeCompact,Id 46"]
 p = e.parse("\n".join(lines) + "\n")
 p.set_fusion(False)
 p.execute(); p.set_profiling(True); p.execute()
 t = p.collect()["timings"]
 algo = {"11_Multiply": 24, "13_Greater": 16, "15_FoldSelect": 8.125, "16_Gather": 24, "24_Partition": 16, "26_Scatter": 24.25, "27_Scatter": 24.25,
-        "28_FoldSum": 16.25, "19_FoldSum": 8.25, "34_FoldMax": 8, "32_Partition": 16, "22_BitwiseAnd": 16, "31_Multiply": 24}
+        "28_FoldSum": 16.25, "19_FoldSum": 8.25, "34_FoldMax": 8, "32_Partition": 16, "22_BitwiseAnd": 16, "31_Multiply": 24,
+        "40_Scatter": 24, "41_Scatter": 24}
 print("%d rows" % n, len(t), list(t)[:4])
 for k, v in t.items():
     name = k.replace("timeInMicrosecondsForStatement", "")
