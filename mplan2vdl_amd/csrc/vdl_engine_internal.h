@@ -125,6 +125,8 @@ struct DVec {
     int64_t from = 0, step = 0; // RANGE; OHCONST: from = the constant
     BufP valid;                 // bitmap, null = every slot holds a value
     BufP keep;                  // COLUMN: keeps an engine-owned column alive
+    BufP sorted_keys, sorted_keys_src;   // with `order`: the partitioned values themselves in rank order, and the buffer they are the values of
+                                // (a Scatter of that very vector by these positions -- the key of a GROUP BY -- is then already written)
     BufP order;                 // Partition positions whose only readers are Scatters: the slots in RANK order (order[pos[slot]] = slot); `data` (the
                                 // positions themselves) is filled in only if somebody asks (GenExec::need_positions)
 };

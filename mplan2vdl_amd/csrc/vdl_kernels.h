@@ -215,7 +215,7 @@ hipError_t launch_sorted_check(Src d, int64_t n, int64_t *flag, hipStream_t s);
 // The same pass also leaves the RUN HEADS of the (fully valid) vector: heads bit i = (i == 0 or d[i] != d[i-1]) -- what the folds of
 // the GROUP BY that this Partition serves need when the data turns out to be in order (their control vector is then this
 // vector, unmoved).  flag[0] / flag[1] as above (pre-set to 0 / INT64_MIN).
-hipError_t launch_sorted_heads(Src d, int64_t n, uint64_t *heads /* (n + 63) / 64 words */, int64_t *flag, hipStream_t s);
+hipError_t launch_sorted_heads(Src d, int64_t n, uint64_t *heads /* (n + 63) / 64 words */, int64_t *flag /* 3 words: descends, largest, smallest */, hipStream_t s);
 // Every fold of one GROUP BY in one launch, results PACKED (one per run, in run order): fold j reduces data[j] over the runs whose
 // heads are given (m entries, all holding a value; entry 0 is a head) and writes out[j][g] for the g-th run.  offsets = exclusive
 // prefix of the head counts per compaction tile (launch_compact_count + launch_compact_scan over `heads`).  kind: 0 sum, 1 min,
@@ -231,7 +231,8 @@ hipError_t launch_group_fold(const GroupFoldArgs &a, const uint64_t *heads, int6
 hipError_t launch_partition(Src data, const uint64_t *valid, int64_t n, int64_t pmin, int64_t pcount, int64_t *hist,
                             int64_t *scan_scratch, uint64_t *keys_a, int64_t *slots_a, uint64_t *keys_b, int64_t *slots_b,
                             int64_t *n_valid_dev, int64_t *pos_out, hipStream_t s, int64_t max_bucket = -1 /* largest bucket known to occur */,
-                            int64_t *order_out = nullptr /* instead of pos_out: the slots in rank order (order[pos[slot]] = slot), stored sequentially */);
+                            int64_t *order_out = nullptr /* instead of pos_out: the slots in rank order (order[pos[slot]] = slot), stored sequentially */,
+                            int64_t *sorted_keys_out = nullptr /* with order_out: bucket + pmin in rank order (= the keys, when all lie inside the pivots) */);
 
 // Fold over a general control vector; kind 0 sum, 1 min, 2 max, 3 count, 4 choose
 // heads: nwords uint64; wordhd: nwords + maxscan_blocks(nwords) int64

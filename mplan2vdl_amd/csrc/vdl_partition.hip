@@ -74,6 +74,7 @@ struct PartIn {
     const int64_t *n_dev;        // later passes: number of elements (device scalar)
     int64_t n;                   // first pass: number of slots; later: upper bound for the grid
     int shift;
+    int64_t *sorted_keys;        // with order_out: also the key VALUES in rank order (bucket + pmin: the caller knows every key lies inside the pivots)
     int order_out;               // this (last) pass writes the slots in rank order to slots_out instead of the sorted pairs / the ranks
     int slot_bits;               // > 0: packed form -- a pair travels as ONE word (bucket << slot_bits) | slot, `slots` is unused:
                                  // every later pass moves 8 instead of 16 bytes per row (taken when bits(pcount) + bits(n) <= 64)
@@ -249,7 +250,10 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(PartIn in, int64_t 
             const uint64_t key = stage[idx];
             dest[k] = gdelta[(key >> in.shift) & (kRadix - 1)] + idx;
             if (!in.order_out) keys_out[dest[k]] = key;
-            else if (in.slot_bits) slots_out[dest[k]] = (int64_t)(key & ((1ull << in.slot_bits) - 1));     // the last pass of a lazy Partition: slots in rank order
+            else {
+                if (in.slot_bits) slots_out[dest[k]] = (int64_t)(key & ((1ull << in.slot_bits) - 1));     // the last pass of a lazy Partition: slots in rank order
+                if (in.sorted_keys) in.sorted_keys[dest[k]] = (int64_t)((uint64_t)in.pmin + (in.slot_bits ? key >> in.slot_bits : key));
+            }
         }
     }
     if (in.slot_bits) return;                                  // packed: the slot travelled inside the key word
@@ -300,15 +304,15 @@ hipError_t launch_sorted_check(Src d, int64_t n, int64_t *flag, hipStream_t s) {
 // One wave per 64 entries: neighbour compare through a shuffle (lane 0 reads its predecessor), heads word by ballot.  flag[0] /
 // flag[1] are initialised by a first tiny launch (no host copy).  One atomic per BLOCK for the maximum: data in ascending order
 // -- the case this pass exists for -- gives every wave a new maximum, and 50 K atomics on one word took 80 us (3 M entries).
-__global__ void k_sorted_init(int64_t *flag) { flag[0] = 0; flag[1] = INT64_MIN; }
+__global__ void k_sorted_init(int64_t *flag) { flag[0] = 0; flag[1] = INT64_MIN; flag[2] = INT64_MAX; }      // {descends, largest, smallest}
 __global__ __launch_bounds__(256) void k_sorted_heads(Src d, int64_t n, uint64_t *heads, int64_t *flag) {
-    __shared__ int64_t wmax[256 / kWave];
+    __shared__ int64_t wmax[256 / kWave], wmin[256 / kWave];
     __shared__ int wbad[256 / kWave];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const int64_t nw = (n + 63) >> 6;
     const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave);
     bool bad = false;
-    int64_t mx = INT64_MIN;
+    int64_t mx = INT64_MIN, mn = INT64_MAX;
     by_kind(d.kind, [&](auto kd) {
         for (int64_t w = (int64_t)blockIdx.x * (blockDim.x / kWave) + wave; w < nw; w += wstride) {
             const int64_t i = (w << 6) + lane;
@@ -318,20 +322,23 @@ __global__ __launch_bounds__(256) void k_sorted_heads(Src d, int64_t n, uint64_t
             if (lane == 0) prev = i > 0 ? ldk<decltype(kd)::value>(d, i - 1) : x;
             bad |= in && x < prev;
             mx = in && x > mx ? x : mx;
+            mn = in && x < mn ? x : mn;
             const uint64_t hm = __ballot(in && (i == 0 || x != prev));
             if (lane == 0) heads[w] = hm;
         }
     });
     const bool anybad = __ballot(bad) != 0;
     mx = wave_reduce(mx, R_MAX);
-    if (lane == 0) { wmax[wave] = mx; wbad[wave] = anybad ? 1 : 0; }
+    mn = wave_reduce(mn, R_MIN);
+    if (lane == 0) { wmax[wave] = mx; wmin[wave] = mn; wbad[wave] = anybad ? 1 : 0; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int64_t m = wmax[0];
+        int64_t m = wmax[0], lo = wmin[0];
         int b = wbad[0];
-        for (int w = 1; w < 256 / kWave; w++) { m = wmax[w] > m ? wmax[w] : m; b |= wbad[w]; }
+        for (int w = 1; w < 256 / kWave; w++) { m = wmax[w] > m ? wmax[w] : m; lo = wmin[w] < lo ? wmin[w] : lo; b |= wbad[w]; }
         if (b) flag[0] = 1;
         if (m > *(volatile int64_t *)&flag[1]) atomicMax((long long *)&flag[1], (long long)m);
+        if (lo < *(volatile int64_t *)&flag[2]) atomicMin((long long *)&flag[2], (long long)lo);
     }
 }
 hipError_t launch_sorted_heads(Src d, int64_t n, uint64_t *heads, int64_t *flag, hipStream_t s) {
@@ -348,7 +355,7 @@ hipError_t launch_sorted_heads(Src d, int64_t n, uint64_t *heads, int64_t *flag,
 hipError_t launch_partition(Src data, const uint64_t *valid, int64_t n, int64_t pmin, int64_t pcount,
                             int64_t *hist /* 256*ntiles + 1 */, int64_t *scan_scratch /* prefix_sum_blocks(256*ntiles)+1 */,
                             uint64_t *keys_a, int64_t *slots_a, uint64_t *keys_b, int64_t *slots_b /* n each, or null if one pass */,
-                            int64_t *n_valid_dev /* 1 word */, int64_t *pos_out, hipStream_t s, int64_t max_bucket, int64_t *order_out) {
+                            int64_t *n_valid_dev /* 1 word */, int64_t *pos_out, hipStream_t s, int64_t max_bucket, int64_t *order_out, int64_t *sorted_keys_out) {
     (void)hipGetLastError();   // see launch_status()
     if (n <= 0) return hipSuccess;
     int bits = 0;
@@ -377,6 +384,7 @@ hipError_t launch_partition(Src data, const uint64_t *valid, int64_t n, int64_t 
         // order_out: the caller wants the slots in rank order (the inverse of the positions) -- the last pass then stores like a middle
         // pass, consecutive lanes on consecutive words, instead of one 8-byte store per slot at the slot's own address
         in.order_out = (last && order_out) ? 1 : 0;
+        in.sorted_keys = in.order_out ? sorted_keys_out : nullptr;
         if (in.order_out) {
             if (first) k_part_scatter<true, false><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist, nullptr, order_out, nullptr);
             else k_part_scatter<false, false><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist, nullptr, order_out, nullptr);
