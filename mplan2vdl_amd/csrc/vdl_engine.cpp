@@ -924,6 +924,18 @@ static void bind_front(vdl_ctx *c, vdl_plan *p, FrontBound &b) {
         if (!((d.take >> k) & 1u)) continue;
         for (int src : J.cols[(size_t)k].sources()) d.take |= 1u << src;
     }
+    // table columns both passes read (they decide survival AND the outputs need them: the join index of a fact table whose
+    // dimension is filtered) travel from the select pass to the take pass (MScanDesc::carry)
+    d.carry = 0; sdesc->carry = 0;
+    if (!getenv("VDL_NO_FRONT_CARRY")) {
+        int taken = 0;
+        for (int k = 0; k < cols.ncol && taken < kMaxCarry; k++) {
+            if (cols.lazy[k] || cols.kind[k] != VC_DIRECT || !((d.take >> k) & 1u) || renum[(size_t)k] < 0) continue;
+            d.carry |= 1u << k;
+            sdesc->carry |= 1u << renum[(size_t)k];
+            taken++;
+        }
+    }
 }
 // the prelude's tables of this run, in both passes' arguments
 static void patch_front(const vdl_plan *p, FrontBound &b) {
@@ -973,6 +985,14 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
     if (n > 0 && !J.never) {
         BufP counts = dev_alloc(c, sizeof(int64_t) * (size_t)(ntiles + 1)), offsets = dev_alloc(c, sizeof(int64_t) * (size_t)(ntiles + 1));
         BufP scratch = dev_alloc(c, (size_t)project_scratch_bytes(n));
+        BufP carried[kMaxCarry];
+        for (int i = 0; i < kMaxCarry; i++) {
+            sdesc->carry_ptr[i] = d.carry_ptr[i] = nullptr;
+            if (i < __builtin_popcount(d.carry)) {
+                carried[i] = dev_alloc(c, (size_t)project_carry_bytes(n));
+                sdesc->carry_ptr[i] = d.carry_ptr[i] = (int64_t *)carried[i]->p;
+            }
+        }
         sel->bitmap = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>((n + 63) >> 6, 1));
         sdesc->tile_counts = (int64_t *)counts->p;
         sdesc->out_idx = (int64_t *)scratch->p;

@@ -215,7 +215,7 @@ static std::string desc_text(Kind kind, const MsArgs &C, const MScanDesc &D) {
             if ((a.used >> k) & 1u) o << "    d.agg[" << j << "].fa[" << k << "] = " << lit(a.fa[k]) << "; d.agg[" << j << "].fs[" << k << "] = " << lit(a.fs[k]) << ";\n";
     }
     if (kind != MSCAN) {
-        o << "    d.take = " << D.take << "u; d.nout = " << D.nout << "; d.bitmap_only = " << D.bitmap_only << ";\n";
+        o << "    d.take = " << D.take << "u; d.nout = " << D.nout << "; d.bitmap_only = " << D.bitmap_only << "; d.carry = " << D.carry << "u;\n";
         for (int k = 0; k < D.nout; k++) o << "    d.out_col[" << k << "] = " << D.out_col[k] << ";\n";
         o << "    d.nexpr = " << D.nexpr << ";\n";
         for (int k = 0; k < D.nexpr; k++) o << "    d.expr_at[" << k << "] = " << D.expr_at[k] << "; d.expr_len[" << k << "] = " << D.expr_len[k] << ";\n";

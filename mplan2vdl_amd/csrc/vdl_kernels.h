@@ -65,6 +65,7 @@ size_t mscan_lds_bytes(const MScanDesc &d, bool grouped);
 // exclusive prefix sum over the counts) writes their slot ids and the produced columns, packed, in row order.
 int64_t project_tiles(int64_t n);
 int64_t project_scratch_bytes(int64_t n);
+int64_t project_carry_bytes(int64_t n);
 // d.out_idx = the scratch area (project_scratch_bytes), d.tile_counts = [tiles + 1]
 hipError_t launch_project_select(const MScanCols &cols, const MScanDesc *dev_desc, int num_cus, hipStream_t s, hipFunction_t jit_fn = nullptr);
 bool project_select_vec(const MScanCols &cols);          // the 16-byte-load form applies (alignment of the deciding columns)

@@ -203,6 +203,7 @@ hipError_t launch_mscan(const MScanCols &cols, const MScanDesc &d, const MScanDe
 
 int64_t project_tiles(int64_t n) { return (n + kProjTile - 1) / kProjTile; }
 int64_t project_scratch_bytes(int64_t n) { return project_tiles(n) * kProjTile * (int64_t)sizeof(uint16_t); }
+int64_t project_carry_bytes(int64_t n) { return project_tiles(n) * kProjCarry * (int64_t)sizeof(int64_t); }      // per carried column (MScanDesc::carry)
 
 bool project_select_vec(const MScanCols &cols) {
     bool vec = true;

@@ -638,6 +638,7 @@ __device__ __forceinline__ void mscan_body(const MsArgs &C, const MsArgs &Cr, co
 constexpr int kProjU = VDL_PROJ_U;
 constexpr int kProjTile = kMsBlock * 2 * kProjU;
 static_assert(kProjTile <= 65536, "positions inside a tile fit 16 bits");
+constexpr int kProjCarry = kProjTile / 4;  // carried values per tile (MScanDesc::carry)
 
 template <int NC, int U, bool VEC, bool NT>
 __device__ __forceinline__ void project_select_body(const MsArgs &C, const MsArgs &Cr, const MScanDesc &D, const MScanDesc &Dr) {
@@ -726,11 +727,30 @@ __device__ __forceinline__ void project_select_body(const MsArgs &C, const MsArg
             }
         }
         const uint64_t below = (1ull << lane) - 1;
+        int rank[ROWS];
 #pragma unroll
         for (int r = 0; r < ROWS; r++) {
             const int u = r >> 1;
-            const int rank = mybase[u] + __popcll(m[2 * u] & below) + __popcll(m[2 * u + 1] & below) + ((r & 1) && alive[2 * u] ? 1 : 0);
-            if (alive[r]) scratch[tile * TILE + rank] = (uint16_t)(tid * 2 + u * (BS * 2) + (r & 1));
+            rank[r] = mybase[u] + __popcll(m[2 * u] & below) + __popcll(m[2 * u + 1] & below) + ((r & 1) && alive[2 * u] ? 1 : 0);
+            if (alive[r]) scratch[tile * TILE + rank[r]] = (uint16_t)(tid * 2 + u * (BS * 2) + (r & 1));
+        }
+        if (D.carry) {
+            // the survivors' values of the columns the take pass wants too: put in survivor order in LDS, then stored with consecutive
+            // threads on consecutive words (a store per survivor from wherever its lane sits cost the pass 23 us at Q3 SF10)
+            __shared__ int64_t cstage[kProjCarry];
+            int ci = 0;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                if ((D.carry >> c) & 1u) {
+                    int64_t *__restrict__ area = Dr.carry_ptr[ci++] + tile * kProjCarry;
+                    __syncthreads();                       // (the previous column's / tile's stores have read cstage)
+#pragma unroll
+                    for (int r = 0; r < ROWS; r++) if (alive[r] && rank[r] < kProjCarry) cstage[rank[r]] = v[c][r];
+                    __syncthreads();
+                    const int held = total < kProjCarry ? total : kProjCarry;
+                    for (int i = tid; i < held; i += BS) area[i] = cstage[i];
+                }
+            }
         }
         par ^= 1;                                          // (no second barrier: the next tile's counts go to the other half)
     }
@@ -769,8 +789,14 @@ __device__ __forceinline__ void project_take_body(const MsArgs &C, const MsArgs 
 #pragma unroll
                 for (int r = 0; r < RW; r++) v[c][r] = 0;
                 if (c < C.ncol && ((D.take >> c) & 1u) && !((C.derived >> c) & 1u)) {
+                    if (((D.carry >> c) & 1u) && cnt <= kProjCarry) {      // (wave-uniform) the select pass left them in survivor order
+                        const int64_t *__restrict__ area = Dr.carry_ptr[__builtin_popcount(D.carry & ((1u << c) - 1u))] + tile * kProjCarry;
 #pragma unroll
-                    for (int r = 0; r < RW; r++) v[c][r] = load_scalar(Cr.ptr[c], C.width(c), row[r] < Cr.n ? row[r] : Cr.n - 1);
+                        for (int r = 0; r < RW; r++) v[c][r] = on[r] ? area[k[r]] : 0;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < RW; r++) v[c][r] = load_scalar(Cr.ptr[c], C.width(c), row[r] < Cr.n ? row[r] : Cr.n - 1);
+                    }
                 }
             }
             bool alive[RW];

@@ -139,7 +139,14 @@ struct MScanDesc {                           // lives in device memory, read wit
     // census builds of a staged scan (vdl_jit.cpp, VDL_CENSUS; measurement only, never the timed kernel): [column] = number of
     // distinct 128-byte lines the late loads of that column asked for
     unsigned long long *census = nullptr;
+    // projection scan: columns the select pass has in registers anyway (they decide survival) AND the take pass wants for the
+    // survivors -- Q3's join index -- travel from one pass to the other in a per-tile area (kProjCarry entries per tile, in the tile's
+    // survivor order) instead of being fetched again line by isolated line.  Bit c: column c (of this descriptor's own numbering)
+    // is carried; carry_ptr[i] = the area of the i-th set bit.  A tile with more survivors than the area holds is read the old way.
+    uint32_t carry = 0;
+    int64_t *carry_ptr[2] = {nullptr, nullptr};
 };
+constexpr int kMaxCarry = 2;
 
 // What the scan kernels take by value: column bases (kept in the global address space), the widths and the
 // filtered-column set packed into one word each.  (MScanCols itself held 64 SGPRs live across the tile loop -- widths,
