@@ -1005,18 +1005,43 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
         HIP_CHECK(launch_prefix_sum((int64_t *)offsets->p, ntiles + 1, (int64_t *)sums->p, c->stream));
         int64_t *back = c->pinned(1) ? c->pinned(1) : &m;          // (pinned: a pageable destination is staged and costs a second round trip)
         HIP_CHECK(hipMemcpyAsync(back, (int64_t *)offsets->p + ntiles, sizeof m, hipMemcpyDeviceToHost, c->stream));
-        HIP_CHECK(hipStreamSynchronize(c->stream));             // (also: `d` has been read by the first copy)
-        m = *back;
-        sel->idx = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(m, 1));
-        d.out_idx = (int64_t *)sel->idx->p;
-        for (size_t o = 0; o < distinct.size(); o++) {
-            outs[o] = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(m, 1));
-            d.out_ptr[o] = (int64_t *)outs[o]->p;
-        }
-        if (m > 0) {
+        auto room_for = [&](int64_t cap) {
+            sel->idx = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(cap, 1));
+            d.out_idx = (int64_t *)sel->idx->p;
+            for (size_t o = 0; o < distinct.size(); o++) {
+                outs[o] = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(cap, 1));
+                d.out_ptr[o] = (int64_t *)outs[o]->p;
+            }
+            d.out_cap = cap;
+        };
+        auto take = [&] {
             HIP_CHECK(launch_project_take(cols, desc_on_device(c, p, "take", d), scratch->p, (const int64_t *)counts->p, (const int64_t *)offsets->p,
                                           c->num_cus, c->stream, front_kernel(c, p, "take", jit::TAKE, cols, d)));
+        };
+        if (p->front_m_seen >= 0 && back != &m && !getenv("VDL_NO_FRONT_GUESS")) {
+            // The number of survivors decides how long the output vectors are, and waiting for it left the GPU idle for 20-30 us in
+            // the middle of every query.  From the second run on the take pass is launched at once, with room for an eighth more
+            // than last time (it writes nothing beyond that), and the host reads the number while the pass runs; a guess that
+            // turns out short costs a second run of the pass.
+            if (!p->front_ev) HIP_CHECK(hipEventCreateWithFlags(&p->front_ev, hipEventDisableTiming));
+            HIP_CHECK(hipEventRecord(p->front_ev, c->stream));
+            const int64_t cap = std::min<int64_t>(n, p->front_m_seen + p->front_m_seen / 8 + 4096);
+            room_for(cap);
+            take();
+            HIP_CHECK(hipEventSynchronize(p->front_ev));
+            m = *back;
+            if (m > cap) {
+                HIP_CHECK(hipStreamSynchronize(c->stream));
+                room_for(m);
+                take();
+            }
+        } else {
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            m = *back;
+            room_for(m);
+            if (m > 0) take();
         }
+        p->front_m_seen = m;
     } else {
         sel->idx = dev_alloc(c, sizeof(int64_t));
         for (size_t o = 0; o < distinct.size(); o++) outs[o] = dev_alloc(c, sizeof(int64_t));

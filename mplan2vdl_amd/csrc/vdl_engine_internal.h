@@ -283,6 +283,8 @@ struct vdl_plan {
     struct DescSlot { BufP dev; std::vector<unsigned char> shadow; };
     std::map<std::string, DescSlot> desc_slots;
     double front_usec = 0;
+    int64_t front_m_seen = -1;               // survivors of the front's last run: the next run launches its take pass with room for about as many
+    hipEvent_t front_ev = nullptr;           // ... and learns the real number while the pass runs
     bool bound = false;
     uint64_t bound_version = 0;
     // pipelined finalisation: two pinned host slots, one event each
@@ -316,6 +318,7 @@ struct vdl_plan {
     ~vdl_plan() {
         for (auto &b : out_pinned) if (b.first) (void)hipHostFree(b.first);
         for (hipEvent_t e : stmt_ev) if (e) (void)hipEventDestroy(e);
+        if (front_ev) (void)hipEventDestroy(front_ev);
         for (int k = 0; k < 2; k++) {
             if (ev0[k]) (void)hipEventDestroy(ev0[k]);
             if (ev1[k]) (void)hipEventDestroy(ev1[k]);

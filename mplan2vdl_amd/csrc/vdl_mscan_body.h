@@ -805,6 +805,8 @@ __device__ __forceinline__ void project_take_body(const MsArgs &C, const MsArgs 
             for (int r = 0; r < RW; r++) { alive[r] = on[r]; rid[r] = Cr.row0 + row[r]; }
             derive<NC, RW>(C, Cr, D, Dr, v, alive, C.derived & D.take, rid, false);
 #pragma unroll
+            for (int r = 0; r < RW; r++) on[r] = on[r] && off + k[r] < Dr.out_cap;
+#pragma unroll
             for (int r = 0; r < RW; r++) if (on[r]) Dr.out_idx[off + k[r]] = row[r];
             VDL_SPEC_UNROLL
             for (int o = 0; o < D.nout; o++) {

@@ -145,6 +145,9 @@ struct MScanDesc {                           // lives in device memory, read wit
     // is carried; carry_ptr[i] = the area of the i-th set bit.  A tile with more survivors than the area holds is read the old way.
     uint32_t carry = 0;
     int64_t *carry_ptr[2] = {nullptr, nullptr};
+    // take pass: entries the output vectors hold (the pass may be launched before the host knows the survivors' number, with room for a
+    // guess: what does not fit is not written, and the host runs the pass again when it learns that the guess was short)
+    int64_t out_cap = INT64_MAX;
 };
 constexpr int kMaxCarry = 2;
 

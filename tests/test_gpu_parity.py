@@ -521,6 +521,32 @@ def test_folds_over_a_few_very_long_runs_match_oracle(holes):
     e.close()
 
 
+def test_the_front_guesses_its_survivors_from_the_last_run_and_recovers_when_wrong():
+    """From its second run on a plan's fused front launches its take pass before the host knows how many rows survived, with room for
+    an eighth more than last time.  The same plan over data that changes under it: 14 % of the rows survive, then all of them (the
+    guess is short: the pass runs again with room), then none, then a few again -- every answer equals the oracle's."""
+    rng = np.random.default_rng(8)
+    n, nd = 70001, 300
+    base = {"f.k": rng.integers(0, nd, n).astype(np.int64), "f.a": rng.integers(0, 50, n).astype(np.int64), "f.v": rng.integers(-100, 100, n).astype(np.int64),
+            "d.g": rng.integers(0, 12, nd).astype(np.int64)}
+    text = prog("1,Load,f.k", "2,Project,val,Id 1,k", "3,Load,f.a", "4,Project,val,Id 3,a", "5,Load,f.v", "6,Project,val,Id 5,v", "7,Load,d.g", "8,Project,val,Id 7,g",
+                "9,RangeV,val,7,Id 4,0", "10,Greater,val,Id 9,val,Id 4,val",
+                "15,RangeV,val,0,Id 10,1", "16,FoldSelect,val,Id 15,val,Id 10,val",
+                "17,Gather,Id 2,Id 16,val", "18,Gather,Id 6,Id 16,val", "19,Gather,Id 8,Id 17,val",
+                "20,RangeC,val,0,%d,1" % (1 << 20), "21,Partition,val,Id 17,val,Id 20,val",
+                "22,RangeV,val,0,Id 17,1", "23,Scatter,Id 17,Id 22,val,Id 21,val", "24,Scatter,Id 18,Id 22,val,Id 21,val", "25,Scatter,Id 19,Id 22,val,Id 21,val",
+                "26,FoldSum,val,Id 23,val,Id 24,val", "27,FoldChoose,val,Id 23,val,Id 25,val", "28,FoldCount,val,Id 23,val,Id 24,val",
+                "29,MaterializeCompact,Id 26", "30,MaterializeCompact,Id 27", "31,MaterializeCompact,Id 28")
+    e = engine_with(base)
+    p = e.parse(text)
+    assert "fused front" in p.describe()
+    for a in (base["f.a"], np.zeros(n, np.int64), np.full(n, 40, np.int64), base["f.a"], base["f.a"] // 8, base["f.a"]):
+        cols = dict(base, **{"f.a": a})
+        e.upload("f.a", a)
+        assert p.run()["results"] == oracle_run(text, cols)
+    e.close()
+
+
 @pytest.mark.parametrize("n_orders", [1, 100, 15000, 150000])
 def test_q3_matches_oracle(n_orders):
     """TPC-H Q3: FK joins lowered to Gather/Scatter over join-index columns, GROUP BY over a 2^38 key
