@@ -341,13 +341,85 @@ __global__ __launch_bounds__(256) void k_sorted_heads(Src d, int64_t n, uint64_t
         if (lo < *(volatile int64_t *)&flag[2]) atomicMin((long long *)&flag[2], (long long)lo);
     }
 }
+// The same for an int64 vector at a 16-byte aligned address (the entries of a GROUP BY key): four consecutive entries per lane (two
+// 16-byte loads), the left neighbour's last value by shuffle, the four head bits of every lane gathered into the wave's four bitmap
+// words by an OR across each group of 16 lanes; two groups of 256 entries in flight per wave.  3 M entries: 24 -> ~10 us.
+__global__ __launch_bounds__(256) void k_sorted_heads_dense(const int64_t *__restrict__ d, int64_t n, uint64_t *__restrict__ heads, int64_t *flag) {
+    typedef long long i64x2 __attribute__((ext_vector_type(2)));
+    constexpr int R = 2;
+    __shared__ int64_t wmax[256 / kWave], wmin[256 / kWave];
+    __shared__ int wbad[256 / kWave];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int64_t nq = (n + 255) >> 8;
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / kWave);
+    bool bad = false;
+    int64_t mx = INT64_MIN, mn = INT64_MAX;
+    for (int64_t q0 = ((int64_t)blockIdx.x * (blockDim.x / kWave) + wave) * R; q0 < nq; q0 += nwaves * R) {
+        int64_t v[R][4], left[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int64_t q = q0 + r, i0 = (q << 8) + 4 * lane;
+            if (i0 + 4 <= n) {
+                const i64x2 a = *(const i64x2 *)(d + i0), b = *(const i64x2 *)(d + i0 + 2);
+                v[r][0] = a.x; v[r][1] = a.y; v[r][2] = b.x; v[r][3] = b.y;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[r][k] = i0 + k < n ? d[i0 + k] : 0;
+            }
+            left[r] = (lane == 0 && q > 0 && q < nq) ? d[(q << 8) - 1] : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int64_t q = q0 + r, i0 = (q << 8) + 4 * lane;
+            if (q >= nq) break;                                       // wave-uniform
+            const int64_t up = __shfl_up(v[r][3], 1, kWave);
+            int64_t prev = lane == 0 ? left[r] : up;
+            unsigned nib = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool in = i0 + k < n;
+                const int64_t x = v[r][k];
+                const bool first = i0 + k == 0;
+                if (in) {
+                    bad |= !first && x < prev;
+                    mx = x > mx ? x : mx;
+                    mn = x < mn ? x : mn;
+                    if (first || x != prev) nib |= 1u << k;
+                }
+                prev = x;
+            }
+            uint64_t m = (uint64_t)nib << (4 * (lane & 15));
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) m |= __shfl_xor(m, off, kWave);
+            const int64_t w = (q << 2) + (lane >> 4);
+            if ((lane & 15) == 0 && w < ((n + 63) >> 6)) heads[w] = m;
+        }
+    }
+    const bool anybad = __ballot(bad) != 0;
+    mx = wave_reduce(mx, R_MAX);
+    mn = wave_reduce(mn, R_MIN);
+    if (lane == 0) { wmax[wave] = mx; wmin[wave] = mn; wbad[wave] = anybad ? 1 : 0; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t m = wmax[0], lo = wmin[0];
+        int b = wbad[0];
+        for (int w = 1; w < 256 / kWave; w++) { m = wmax[w] > m ? wmax[w] : m; lo = wmin[w] < lo ? wmin[w] : lo; b |= wbad[w]; }
+        if (b) flag[0] = 1;
+        if (m > *(volatile int64_t *)&flag[1]) atomicMax((long long *)&flag[1], (long long)m);
+        if (lo < *(volatile int64_t *)&flag[2]) atomicMin((long long *)&flag[2], (long long)lo);
+    }
+}
 hipError_t launch_sorted_heads(Src d, int64_t n, uint64_t *heads, int64_t *flag, hipStream_t s) {
     (void)hipGetLastError();
     k_sorted_init<<<1, 1, 0, s>>>(flag);
     if (n <= 0) return launch_status();
     int grid = grid_for(n, 256, 4);
     if (grid > 2048) grid = 2048;
-    k_sorted_heads<<<grid, 256, 0, s>>>(d, n, heads, flag);
+    if (d.kind == SRC_I64 && ((uintptr_t)d.p & 15u) == 0 && !getenv("VDL_NO_DENSE_HEADS")) {
+        int g4 = grid_for((n + 3) / 4, 256, 2);
+        if (g4 > 2048) g4 = 2048;
+        k_sorted_heads_dense<<<g4, 256, 0, s>>>((const int64_t *)d.p, n, heads, flag);
+    } else k_sorted_heads<<<grid, 256, 0, s>>>(d, n, heads, flag);
     return launch_status();
 }
 
