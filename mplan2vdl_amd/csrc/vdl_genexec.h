@@ -821,10 +821,15 @@ struct GenExec {
 
     // positions of a Partition that were left in rank order (DVec::order): written out now, for a reader that is not a Scatter
     void need_positions(DVec &v) {
-        if (!v.order || v.data) return;
+        if (v.data || !(v.order || (v.iota && v.perm))) return;
         const int64_t m = v.kind == DVec::SPARSE ? v.sel->m : v.n;
         v.data = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(m, 1));
-        if (m > 0) HIP_CHECK(launch_scatter(iota_src(), nullptr, i64_src(v.order), nullptr, m, m, (int64_t *)v.data->p, nullptr, s));
+        if (m <= 0) return;
+        if (v.order) HIP_CHECK(launch_scatter(iota_src(), nullptr, i64_src(v.order), nullptr, m, m, (int64_t *)v.data->p, nullptr, s));
+        else {                                              // the identity (the partitioned data was in order)
+            Src zero; zero.kind = SRC_RANGE; zero.from = 0; zero.step = 0;
+            HIP_CHECK(launch_binary(B_ADD, iota_src(), zero, (int64_t *)v.data->p, m, s));
+        }
     }
     std::vector<char> order_only;          // Partition statements whose every reader is a Scatter taking them as positions
 
@@ -865,9 +870,10 @@ struct GenExec {
             // the largest bucket that occurs (bucket = clamp(data - min, 0, cnt) is monotone in the data)
             max_bucket = seen[1] <= pmin ? 0 : ((int64_t)((uint64_t)seen[1] - (uint64_t)pmin) < 0 ? pcount : std::min<int64_t>((int64_t)((uint64_t)seen[1] - (uint64_t)pmin), pcount));
             if (!descends) {
+                o.iota = true;
+                if (order_only && !getenv("VDL_NO_LAZY_POSITIONS")) { o.data = nullptr; return o; }      // only Scatters read them, and a Scatter by the identity moves nothing (need_positions writes them out for anything else)
                 Src zero; zero.kind = SRC_RANGE; zero.from = 0; zero.step = 0;
                 HIP_CHECK(launch_binary(B_ADD, iota_src(), zero, (int64_t *)o.data->p, o.n, s));
-                o.iota = true;
                 return o;
             }
         }
@@ -1178,7 +1184,10 @@ struct GenExec {
                         if (sp.order && !sp.data) {                    // positions left in rank order: out[r] = src[order[r]], stored in sequence
                             BufP junk = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(m), 1));
                             HIP_CHECK(launch_gather(ssrc, nullptr, m, i64_src(sp.order), nullptr, m, (int64_t *)data->p, (uint64_t *)junk->p, s));
-                        } else HIP_CHECK(launch_scatter(ssrc, nullptr, i64_src(sp.data), nullptr, m, m, (int64_t *)data->p, nullptr, s));
+                        } else {
+                            need_positions(vec[(size_t)n.c]);
+                            HIP_CHECK(launch_scatter(ssrc, nullptr, i64_src(sp.data), nullptr, m, m, (int64_t *)data->p, nullptr, s));
+                        }
                         return make_sparse(pre, data);
                     }
                     need_positions(vec[(size_t)n.c]);
@@ -1188,6 +1197,15 @@ struct GenExec {
                     HIP_CHECK(launch_scatter(ssrc, nullptr, i64_src(sp.data), nullptr, m, nout, (int64_t *)o.data->p, (uint64_t *)o.valid->p, s));
                     return o;
                 }
+            }
+            if (!V(n.c).data && V(n.c).iota && V(n.c).perm && !V(n.c).order) {
+                // identity positions that were never written: a Scatter of a whole vector by them is that vector; anything else asks for them
+                const DVec &lp = V(n.c);
+                if (lp.kind == DVec::DENSE && !lp.valid && lp.n == V(n.b).n) {
+                    DVec sv = densify(V(n.a));
+                    if (sv.n == lp.n) return sv;
+                }
+                need_positions(vec[(size_t)n.c]);
             }
             if (V(n.c).order && !V(n.c).data) {
                 const DVec &lp = V(n.c);
