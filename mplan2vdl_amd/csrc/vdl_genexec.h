@@ -183,8 +183,11 @@ struct GenExec {
     SelP child_selection(const SelP &ps, const BufP &flags, int64_t count, const BufP &offsets) {
         SelP ch = std::make_shared<Sel>();
         ch->n = ps->n; ch->parent = ps; ch->m = count;
-        ch->idx = compact_write(idx_src(*ps), flags, ps->m, offsets, count);
-        ch->ppos = compact_write(iota_src(), flags, ps->m, offsets, count);
+        // the selected entries' slot ids and their entry numbers inside the parent: one launch writes both
+        ch->idx = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(count, 1));
+        ch->ppos = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(count, 1));
+        if (count > 0)
+            HIP_CHECK(launch_compact_write(idx_src(*ps), flags ? (const uint64_t *)flags->p : nullptr, ps->m, (const int64_t *)offsets->p, (int64_t *)ch->idx->p, s, (int64_t *)ch->ppos->p));
         if (!ps->idx && ps->m == ps->n && flags && !sel_of_bitmap.count(flags->p)) {
             // the parent is ALL n slots: the flags over its entries are the child's bitmap over the slots as they stand
             ch->bitmap = flags;

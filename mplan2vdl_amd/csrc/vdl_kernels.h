@@ -184,7 +184,7 @@ int64_t compact_tile();
 hipError_t launch_compact_count(const uint64_t *valid, int64_t n, int64_t *block_counts, hipStream_t s);
 hipError_t launch_compact_scan(int64_t *block_counts, int64_t nblocks, hipStream_t s, int64_t *host_total = nullptr);   // exclusive scan in place, total at [nblocks]
 hipError_t launch_compact_offsets(const uint64_t *valid, int64_t n, int64_t *block_counts, hipStream_t s, int64_t *host_total = nullptr);   // host_total: pinned host word that also receives the total   // count + scan (one launch for small n)
-hipError_t launch_compact_write(Src v, const uint64_t *valid, int64_t n, const int64_t *block_offsets, int64_t *out, hipStream_t s);
+hipError_t launch_compact_write(Src v, const uint64_t *valid, int64_t n, const int64_t *block_offsets, int64_t *out, hipStream_t s, int64_t *out_pos = nullptr /* also: the slot number of every packed entry */);
 
 // Gather / Scatter / Partition / segmented folds
 hipError_t launch_gather(Src src, const uint64_t *vsrc, int64_t nsrc, Src pos, const uint64_t *vpos, int64_t n,

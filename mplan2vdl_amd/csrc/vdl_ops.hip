@@ -658,7 +658,7 @@ hipError_t launch_compact_scan(int64_t *counts, int64_t nb, hipStream_t s, int64
     return launch_status();
 }
 
-__global__ __launch_bounds__(256) void k_compact_write(Src v, const uint64_t *valid, int64_t n, const int64_t *offsets, int64_t *out) {
+__global__ __launch_bounds__(256) void k_compact_write(Src v, const uint64_t *valid, int64_t n, const int64_t *offsets, int64_t *out, int64_t *out_pos) {
     __shared__ int wprefix[kCompactWords];
     __shared__ uint64_t wmask[kCompactWords];
     const int64_t nw = (n + 63) >> 6;
@@ -700,16 +700,17 @@ __global__ __launch_bounds__(256) void k_compact_write(Src v, const uint64_t *va
                 if ((m >> lane) & 1ull) {
                     const int rank = __popcll(m & ((1ull << lane) - 1));
                     out[base + wprefix[k0 + u] + rank] = x[u];
+                    if (out_pos) out_pos[base + wprefix[k0 + u] + rank] = ((w0 + k0 + u) << 6) + lane;      // ... and the slot it came from (a child selection wants both)
                 }
             }
         }
     });
 }
-hipError_t launch_compact_write(Src v, const uint64_t *valid, int64_t n, const int64_t *offsets, int64_t *out, hipStream_t s) {
+hipError_t launch_compact_write(Src v, const uint64_t *valid, int64_t n, const int64_t *offsets, int64_t *out, hipStream_t s, int64_t *out_pos) {
     (void)hipGetLastError();   // see launch_status()
     const int64_t nb = (n + compact_tile() - 1) / compact_tile();
     if (nb <= 0) return hipSuccess;
-    k_compact_write<<<(int)nb, 256, 0, s>>>(v, valid, n, offsets, out);
+    k_compact_write<<<(int)nb, 256, 0, s>>>(v, valid, n, offsets, out, out_pos);
     return launch_status();
 }
 
