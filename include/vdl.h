@@ -276,8 +276,12 @@ void vdl_comm_free(vdl_ctx *ctx);                       /* also done by vdl_clos
  *   counts -> all-gather of {status, survivors} -> ONE grouped send / receive of the survivors' vectors to every rank (rank after
  *   rank = row order) -> the statements above the front run everywhere on the complete vectors; every rank ends with the full
  *   result.  Tried after the exchange; the row-id conditions of the front count from the table's first row.
- * vdl_plan_sharded_route tells which of the four a plan takes ("fold" | "set" | "exchange" | "front") and whether every rank ends
- * with the whole answer (replicated = 1) or with its slice (0: concatenate the ranks' outputs in rank order). */
+ * The last resort, for a plan none of the four serves (TPC-H Q18): the sharded table's columns the plan loads are all-gathered ONCE per
+ *   catalog state into plan-owned buffers, and every rank runs the whole query over them -- the query itself does not scale, later
+ *   runs move nothing, every rank ends with the full result ("replicate"; VDL_NO_REPLICATE_ROUTE=1 turns it into the refusal with the
+ *   reasons).
+ * vdl_plan_sharded_route tells which route a plan takes ("fold" | "set" | "exchange" | "front" | "replicate") and whether every rank
+ * ends with the whole answer (replicated = 1) or with its slice (0: concatenate the ranks' outputs in rank order). */
 int  vdl_plan_sharded_route(vdl_ctx *ctx, vdl_plan *plan, const char **route, int *replicated);
 int  vdl_run_sharded(vdl_ctx *ctx, vdl_plan *plan);     /* results through vdl_output as after vdl_run */
 int  vdl_run_sharded_begin(vdl_ctx *ctx, vdl_plan *plan, int slot);

@@ -26,7 +26,7 @@ namespace eng {
 typedef struct ncclComm *ncclComm_t;
 typedef struct { char internal[128]; } ncclUniqueId;
 static_assert(sizeof(ncclUniqueId) == VDL_COMM_ID_BYTES, "vdl.h promises the size of ncclUniqueId");
-enum { kNcclSuccess = 0, kNcclInt64 = 4 };          // ncclResult_t / ncclDataType_t values (nccl.h: ncclInt64 = 4)
+enum { kNcclSuccess = 0, kNcclInt8 = 0, kNcclInt64 = 4 };          // ncclResult_t / ncclDataType_t values (nccl.h: ncclInt8 = 0, ncclInt64 = 4)
 struct Rccl {
     void *lib = nullptr;
     int (*GetUniqueId)(ncclUniqueId *) = nullptr;
@@ -553,6 +553,92 @@ static void sharded_front(vdl_ctx *c, vdl_plan *p) {
     if (vdl_run(c, p) != VDL_OK) throw Error(VDL_ERR_DEVICE, c->err);
 }
 
+// ---- the "replicate" route: the last resort, for a plan no other route serves (TPC-H Q18: it groups ALL lineitems by order before it
+// filters anything, feeds a semi-join set from that and scans lineitem a second time) ----
+// The columns of the sharded table that the program loads are all-gathered ONCE per catalog state into plan-owned buffers (rank after
+// rank = row order), and every rank runs the whole program over them: no scaling of the query itself, but a correct answer on every
+// rank from the placement the other plans of the session use, and no communication at all from the second run on.
+// every rank's block of `bytes[r]` bytes, rank after rank, into recv
+static void all_gather_bytes(vdl_ctx *c, const void *send, void *recv, const std::vector<int64_t> &bytes, hipStream_t s) {
+    CommState &m = comm_of(c);
+    std::vector<int64_t> off((size_t)m.world + 1, 0);
+    int64_t biggest = 0;
+    for (int r = 0; r < m.world; r++) { off[(size_t)r + 1] = off[(size_t)r] + bytes[(size_t)r]; biggest = std::max(biggest, bytes[(size_t)r]); }
+    const int64_t mine = bytes[(size_t)m.rank];
+    if (m.kind == CommState::RCCL) {
+        RCCL_CHECK(rccl().GroupStart());
+        for (int r = 0; r < m.world; r++) {
+            if (mine > 0) RCCL_CHECK(rccl().Send(send, (size_t)mine, kNcclInt8, r, m.comm, s));
+            if (bytes[(size_t)r] > 0) RCCL_CHECK(rccl().Recv((char *)recv + off[(size_t)r], (size_t)bytes[(size_t)r], kNcclInt8, r, m.comm, s));
+        }
+        RCCL_CHECK(rccl().GroupEnd());
+        return;
+    }
+    if (biggest == 0) return;
+    const size_t block = ((size_t)biggest + 7) & ~(size_t)7;
+    char *h = m.staging(block * (size_t)(m.world + 1));
+    if (mine > 0) HIP_CHECK(hipMemcpyAsync(h, send, (size_t)mine, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (m.host.all_gather(m.host.user, h, h + block, block)) throw Error(VDL_ERR_DEVICE, "the host transport's all_gather failed");
+    for (int r = 0; r < m.world; r++)
+        if (bytes[(size_t)r] > 0) HIP_CHECK(hipMemcpyAsync((char *)recv + off[(size_t)r], h + block * (size_t)(r + 1), (size_t)bytes[(size_t)r], hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+}
+
+static void sharded_replicate(vdl_ctx *c, vdl_plan *p) {
+    need_device(c);
+    CommState &m = comm_of(c);
+    const std::string &t = p->sharded_table;
+    if (p->replica.empty() || p->replica_version != c->catalog_version) {
+        p->replica.clear();
+        std::vector<std::string> names;
+        for (int id : p->prog.order) {
+            const Node &n = p->prog.at(id);
+            if (n.op != Op::Load || n.column.compare(0, t.size() + 1, t + ".") != 0 || n.column.find(".heap") != std::string::npos) continue;
+            if (std::find(names.begin(), names.end(), n.column) == names.end()) names.push_back(n.column);
+        }
+        // {status, rows}: every rank holds the same columns, all as long as each other
+        int64_t n_local = -1, status = VDL_OK;
+        for (const std::string &name : names) {
+            auto it = c->cols.find(name);
+            if (it == c->cols.end()) { status = VDL_ERR_COLUMN; break; }
+            if (n_local >= 0 && it->second.n != n_local) { status = VDL_ERR_SHAPE; break; }
+            n_local = it->second.n;
+        }
+        std::vector<int64_t> rows((size_t)m.world * 2, 0);
+        {
+            BufP dsend = dev_alloc(c, sizeof(int64_t) * 2), drecv = dev_alloc(c, sizeof(int64_t) * 2 * (size_t)m.world);
+            const int64_t mine[2] = {status, std::max<int64_t>(n_local, 0)};
+            HIP_CHECK(hipMemcpyAsync(dsend->p, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            all_gather(c, dsend->p, drecv->p, sizeof mine, c->stream);
+            c->fetch_to_host(drecv->p, rows.size(), rows.data(), c->stream);
+        }
+        int64_t n_global = 0;
+        for (int r = 0; r < m.world; r++) {
+            if (rows[(size_t)r * 2] != VDL_OK) throw Error(VDL_ERR_COLUMN, "sharded run: rank " + std::to_string(r) + " does not hold the columns of table '" + t + "' this plan loads (or they differ in length)");
+            n_global += rows[(size_t)r * 2 + 1];
+        }
+        for (const std::string &name : names) {
+            const Column &mine = c->cols.at(name);
+            std::vector<int64_t> bytes((size_t)m.world);
+            for (int r = 0; r < m.world; r++) bytes[(size_t)r] = rows[(size_t)r * 2 + 1] * (int64_t)mine.width;
+            Column whole;
+            whole.width = mine.width; whole.n = n_global;
+            whole.owned = dev_alloc(c, (size_t)std::max<int64_t>(n_global * (int64_t)mine.width, 8));
+            whole.dev = whole.owned->p;
+            all_gather_bytes(c, mine.dev, whole.owned->p, bytes, c->stream);
+            p->replica[name] = whole;
+        }
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        p->replica_version = c->catalog_version;
+    }
+    struct Restore { vdl_ctx *c; vdl_plan *p; int64_t row_offset; ~Restore() { c->overlay = nullptr; p->row_offset = row_offset; } } restore{c, p, p->row_offset};
+    c->overlay = &p->replica;
+    p->row_offset = 0;                                          // every rank runs the whole table
+    if (vdl_run(c, p) != VDL_OK) throw Error(VDL_ERR_DEVICE, c->err);
+}
+
 static bool fold_route(vdl_ctx *c, vdl_plan *p) {
     int64_t nw = 0;
     const int32_t *ops = nullptr;
@@ -623,8 +709,9 @@ void vdl_comm_free(vdl_ctx *c) {
 /* which route vdl_run_sharded takes for this plan and placement: "fold" (partial words merged: every rank ends with the whole
  * answer), "set" (a semi-join set merged, scans over replicated tables: every rank ends with the whole answer), "exchange" (rows
  * travel by key range: the ranks' outputs concatenate in rank order), "front" (the fused front's survivors are all-gathered and
- * the statements above it run on every rank: every rank ends with the whole answer); VDL_ERR_UNSUPPORTED with the reason when
- * there is none */
+ * the statements above it run on every rank: every rank ends with the whole answer), "replicate" (no other route: the sharded
+ * table's columns the plan loads are all-gathered once and the whole query runs on every rank); VDL_ERR_UNSUPPORTED with the reason
+ * when there is none (VDL_NO_REPLICATE_ROUTE) */
 int vdl_plan_sharded_route(vdl_ctx *c, vdl_plan *p, const char **route, int *replicated) {
     if (!c || !p) return VDL_ERR_ARG;
     const char *name = nullptr;
@@ -646,8 +733,13 @@ int vdl_plan_sharded_route(vdl_ctx *c, vdl_plan *p, const char **route, int *rep
         else {
             const std::string why_not_exchange = c->err;
             const std::string why = front_route_refusal(p);
-            if (!why.empty()) { c->err = why_not_exchange + "; no front route either: " + why; return rc; }
-            name = "front";
+            if (why.empty()) name = "front";
+            else if (getenv("VDL_NO_REPLICATE_ROUTE")) { c->err = why_not_exchange + "; no front route either: " + why; return rc; }
+            else {
+                // the last resort: the table's columns gathered once, the whole query on every rank -- the reasons stay readable
+                c->err.clear();
+                name = "replicate";
+            }
         }
     }
     if (route) *route = name;
@@ -693,11 +785,14 @@ int vdl_run_sharded(vdl_ctx *c, vdl_plan *p) {
             p->ex_allow_folds = true;
             const bool exchange_ok = vdl_exchange_spec(p, p->sharded_table.c_str(), &ncols) == VDL_OK;
             p->ex_allow_folds = false;
-            if (!exchange_ok && front_route_refusal(p).empty()) {
-                c->err = keep;
-                if (c->comm->world > 1 || getenv("VDL_FRONT_ROUTE_ALWAYS")) sharded_front(c, p);      // (the switch: tests send a one-rank communicator through the collectives)
-                else if (vdl_run(c, p) != VDL_OK) throw Error(VDL_ERR_DEVICE, c->err);      // one rank holds the whole table
-                return;
+            if (!exchange_ok) {
+                const bool front = front_route_refusal(p).empty();
+                if (front || !getenv("VDL_NO_REPLICATE_ROUTE")) {
+                    c->err = keep;
+                    if (c->comm->world > 1 || getenv("VDL_FRONT_ROUTE_ALWAYS")) { if (front) sharded_front(c, p); else sharded_replicate(c, p); }      // (the switch: tests send a one-rank communicator through the collectives)
+                    else if (vdl_run(c, p) != VDL_OK) throw Error(VDL_ERR_DEVICE, c->err);      // one rank holds the whole table
+                    return;
+                }
             }
             c->err = keep;
         }

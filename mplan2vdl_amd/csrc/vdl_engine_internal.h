@@ -178,6 +178,7 @@ struct vdl_ctx {
     std::string arch = "gfx950";           // --offload-arch of run-time specialisation (the device's, when there is one)
     std::map<std::string, Column> cols;
     uint64_t catalog_version = 1;      // bumped on every catalog change: plans re-bind only when it moved
+    const std::map<std::string, Column> *overlay = nullptr;     // columns that stand in for catalog entries during one run (vdl_comm.cpp: sharded_replicate)
     std::shared_ptr<Pool> pool = std::make_shared<Pool>();
     std::shared_ptr<CommState> comm;       // vdl_comm_init / vdl_comm_init_host
     std::string err;
@@ -243,6 +244,8 @@ struct vdl_plan {
     // sharded runs of a plan with a semi-join set (vdl_comm.cpp): every rank builds the set from its rows of the source table,
     // `after_prelude` merges the ranks' sets (and clips them at the GLOBAL length of that table) before any scan reads them
     bool semi_unclamped = false;
+    std::map<std::string, Column> replica;   // "replicate" route: the sharded table's columns this plan loads, all ranks' rows (gathered when the catalog changed)
+    uint64_t replica_version = 0;
     bool front_rowid_global = false;         // sharded front route: the front's row-id columns are global row numbers
     std::function<void(vdl_ctx *, vdl_plan *)> after_prelude;
     // sharded "front" route (vdl_comm.cpp): called once the fused front has run over this rank's rows -- or has failed, or was
@@ -363,6 +366,10 @@ inline uint64_t fnv1a(const std::string &s) {
 }
 
 inline const Column &find_col(vdl_ctx *c, const std::string &name) {
+    if (c->overlay) {                                   // a sharded run on the "replicate" route: the whole table instead of this rank's rows
+        auto o = c->overlay->find(name);
+        if (o != c->overlay->end()) return o->second;
+    }
     auto it = c->cols.find(name);
     if (it == c->cols.end()) throw Error(VDL_ERR_COLUMN, "Load: column '" + name + "' is not in the catalog");
     return it->second;

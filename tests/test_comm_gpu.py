@@ -226,6 +226,34 @@ def test_a_global_fold_beside_the_partition_is_merged_with_the_counts(world):
 
 
 @pytest.mark.parametrize("world", [2, 3])
+def test_a_plan_no_route_serves_runs_on_the_replicated_table(world):
+    """TPC-H Q18 groups ALL lineitems by order before it filters anything, feeds a semi-join set from the groups and scans lineitem a
+    second time: no fold, no exchange, no front.  The last resort gathers the lineitem columns it loads once (rank after rank = row
+    order) and runs the whole query on every rank; the second run of the same plan moves nothing."""
+    cfg = frontend.load_metadata(META)
+    text = frontend.compile_plan(open(os.path.join(META, "18.sql.mplan")).read(), cfg)
+    cols = catalog.synth_columns(META, cfg, text, scale=2e-3, seed=3, clustered=("lineitem.lineitem_orders",))
+    want = oracle_run(text, cols)
+    assert any(len(list(v.values())[0]) for v in want.values())
+    shards = table_shards(cols, world, "lineitem")
+
+    def work(rank, rv):
+        r0, c = shards[rank]
+        e = engine_with(c)
+        e.comm_init_host(rank, world, *rv.transport(rank))
+        p = e.parse(text)
+        p.set_sharded_table("lineitem")
+        p.set_row_offset(r0)
+        assert p.sharded_route() == ("replicate", True)
+        first = p.run_sharded()["results"]
+        second = p.run_sharded()["results"]
+        e.close()
+        return first, second
+
+    assert run_ranks(world, work) == [(want, want)] * world
+
+
+@pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("plan,table", [(16, "partsupp"), (15, "lineitem")])
 def test_two_partitions_run_above_the_gathered_front(plan, table, world):
     """TPC-H Q16 (count(distinct ps_suppkey) under a GROUP BY: two Partitions) has no exchange route; its work on partsupp is a
@@ -415,7 +443,7 @@ def test_rccl_communicator_of_one_rank_runs_the_set_and_front_routes(monkeypatch
     VDL_FRONT_ROUTE_ALWAYS, which keeps a one-rank run on the collectives -- Q16's and Q15's grouped send / receive of the front's vectors."""
     cfg = frontend.load_metadata(META)
     monkeypatch.setenv("VDL_FRONT_ROUTE_ALWAYS", "1")
-    for plan, table, route in ((4, "lineitem", "set"), (16, "partsupp", "front"), (15, "lineitem", "front")):
+    for plan, table, route in ((4, "lineitem", "set"), (16, "partsupp", "front"), (15, "lineitem", "front"), (18, "lineitem", "replicate")):
         text = frontend.compile_plan(open(os.path.join(META, "%02d.sql.mplan" % plan)).read(), cfg)
         cols = catalog.synth_columns(META, cfg, text, scale=2e-3, seed=3)
         e = engine_with(cols)

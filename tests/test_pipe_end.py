@@ -107,7 +107,7 @@ def test_vdlrun_gpus_forks_its_ranks_and_runs_through_rccl(query):
     assert reply["results"] == oracle_run(text, lineitem(names, 60175))
 
 
-@pytest.mark.parametrize("plan,table", [(3, "lineitem"), (14, "lineitem"), (4, "lineitem"), (11, "partsupp"), (16, "partsupp"), (15, "lineitem")])
+@pytest.mark.parametrize("plan,table", [(3, "lineitem"), (14, "lineitem"), (4, "lineitem"), (11, "partsupp"), (16, "partsupp"), (15, "lineitem"), (18, "lineitem")])
 def test_vdlrun_gpus_with_a_data_directory(tmp_path, plan, table):
     """--gpus with --data / --shard: the exchange route (Q3), the fold-record route (Q14), the merged sets (Q4), a global fold beside the
     Partition (Q11) and the front route (Q16) from exported column files, through a one-rank RCCL communicator."""
