@@ -1,4 +1,6 @@
 """Shared helpers for the parity tests."""
+import threading
+
 import numpy as np
 
 from mplan2vdl_amd import datagen
@@ -48,6 +50,54 @@ def engine_with(cols, device=0):
     for k, v in cols.items():
         e.upload(k, v)
     return e
+
+
+# ---- W ranks = W threads of this process, one context each on device 0 (tests/test_comm_gpu.py, tests/test_full_size.py) ----
+class Rendezvous:
+    """In-process stand-in for a host collective library (TEST ONLY)."""
+
+    def __init__(self, world):
+        self.world, self.barrier = world, threading.Barrier(world)
+        self.slots = [None] * world
+
+    def transport(self, rank):
+        def all_gather(send):
+            self.slots[rank] = send
+            self.barrier.wait()
+            out = list(self.slots)
+            self.barrier.wait()
+            return out
+
+        def all_to_all(pieces):
+            self.slots[rank] = pieces
+            self.barrier.wait()
+            out = [self.slots[src][rank] for src in range(self.world)]
+            self.barrier.wait()
+            return out
+
+        return all_gather, all_to_all
+
+
+def run_ranks(world, work, timeout=300):
+    """work(rank, rendezvous) in `world` threads; returns the per-rank results, re-raising the first failure."""
+    rv = Rendezvous(world)
+    out, errs = [None] * world, []
+
+    def body(rank):
+        try:
+            out[rank] = work(rank, rv)
+        except BaseException as exc:          # noqa: BLE001
+            errs.append(exc)
+            rv.barrier.abort()
+
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout)
+    if errs:
+        raise errs[0]
+    return out
 
 
 def prog(*lines):

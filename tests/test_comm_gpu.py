@@ -6,7 +6,6 @@ through a barrier.  Everything else is the production path: vdl_run_sharded pick
 device kernel, exchanges rows, runs the tail.  RCCL itself is exercised at world = 1 (real ncclCommInitRank,
 all-gather-free merge, grouped send/receive to self is skipped by construction)."""
 import os
-import threading
 
 import numpy as np
 import pytest
@@ -14,57 +13,10 @@ import pytest
 import mplan2vdl_amd as m
 from mplan2vdl_amd import catalog, datagen, frontend, shard_rows
 from conftest import ROOT, golden
-from helpers import engine_with, lineitem, oracle_run
+from helpers import Rendezvous, engine_with, lineitem, oracle_run, run_ranks
 
 pytestmark = pytest.mark.gpu
 META = os.path.join(ROOT, "tests", "golden", "tpch10noorder")
-
-
-class Rendezvous:
-    """In-process stand-in for a host collective library (TEST ONLY)."""
-
-    def __init__(self, world):
-        self.world, self.barrier = world, threading.Barrier(world)
-        self.slots = [None] * world
-
-    def transport(self, rank):
-        def all_gather(send):
-            self.slots[rank] = send
-            self.barrier.wait()
-            out = list(self.slots)
-            self.barrier.wait()
-            return out
-
-        def all_to_all(pieces):
-            self.slots[rank] = pieces
-            self.barrier.wait()
-            out = [self.slots[src][rank] for src in range(self.world)]
-            self.barrier.wait()
-            return out
-
-        return all_gather, all_to_all
-
-
-def run_ranks(world, work):
-    """work(rank, rendezvous) in `world` threads; returns the per-rank results, re-raising the first failure."""
-    rv = Rendezvous(world)
-    out, errs = [None] * world, []
-
-    def body(rank):
-        try:
-            out[rank] = work(rank, rv)
-        except BaseException as exc:          # noqa: BLE001
-            errs.append(exc)
-            rv.barrier.abort()
-
-    threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join(300)
-    if errs:
-        raise errs[0]
-    return out
 
 
 def table_shards(cols, world, table):
