@@ -385,12 +385,10 @@ int vdl_exchange_begin(vdl_ctx *c, vdl_plan *p, int world, int64_t *counts_host)
                                  (int64_t *)counts->p, (int64_t *)counts->p + world, c->stream));
         if (ex.n > 0) {
             // stable order inside each destination = one 8-bit Partition pass over the destination ranks
-            const int64_t hn = 256 * partition_tiles(ex.n);
-            BufP hist = dev_alloc(c, sizeof(int64_t) * (size_t)(hn + 1));
-            BufP scr = dev_alloc(c, sizeof(int64_t) * (size_t)(prefix_sum_blocks(hn) + 2));
+            BufP scr = dev_alloc(c, partition_scratch_bytes(ex.n, world));
             BufP nvalid = dev_alloc(c, sizeof(int64_t));
             Src d; d.p = dest->p; d.kind = SRC_I64;
-            HIP_CHECK(launch_partition(d, (const uint64_t *)ex.vdest->p, ex.n, 0, world, (int64_t *)hist->p, (int64_t *)scr->p, nullptr, nullptr,
+            HIP_CHECK(launch_partition(d, (const uint64_t *)ex.vdest->p, ex.n, 0, world, scr->p, nullptr, nullptr,
                                        nullptr, nullptr, (int64_t *)nvalid->p, (int64_t *)ex.pos->p, c->stream));
         }
         std::vector<int64_t> h((size_t)world + 1);

@@ -882,9 +882,7 @@ struct GenExec {
         }
         if (o.n > 0) {
             const int passes = partition_passes(pcount);
-            const int64_t hn = 256 * partition_tiles(o.n);
-            BufP hist = dev_alloc(c, sizeof(int64_t) * (size_t)(hn + 1));
-            BufP scr = dev_alloc(c, sizeof(int64_t) * (size_t)(prefix_sum_blocks(hn) + 2));
+            BufP scr = dev_alloc(c, partition_scratch_bytes(o.n, pcount));
             BufP nvalid = dev_alloc(c, sizeof(int64_t));
             BufP ka, sa, kb, sb;
             if (passes > 1) {
@@ -902,7 +900,7 @@ struct GenExec {
                 o.sorted_keys = dev_alloc(c, sizeof(int64_t) * (size_t)o.n);
                 o.sorted_keys_src = data.data;
             }
-            HIP_CHECK(launch_partition(src_of(data), vp(data), o.n, pmin, pcount, (int64_t *)hist->p, (int64_t *)scr->p,
+            HIP_CHECK(launch_partition(src_of(data), vp(data), o.n, pmin, pcount, scr->p,
                                        ka ? (uint64_t *)ka->p : nullptr, sa ? (int64_t *)sa->p : nullptr,
                                        kb ? (uint64_t *)kb->p : nullptr, sb ? (int64_t *)sb->p : nullptr,
                                        (int64_t *)nvalid->p, (int64_t *)o.data->p, s, max_bucket, lazy ? (int64_t *)o.order->p : nullptr,

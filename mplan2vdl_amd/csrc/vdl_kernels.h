@@ -229,8 +229,9 @@ struct GroupFoldArgs {
     int64_t *out[kMaxGroupFolds] = {};
 };
 hipError_t launch_group_fold(const GroupFoldArgs &a, const uint64_t *heads, int64_t m, const int64_t *offsets, hipStream_t s);
-hipError_t launch_partition(Src data, const uint64_t *valid, int64_t n, int64_t pmin, int64_t pcount, int64_t *hist,
-                            int64_t *scan_scratch, uint64_t *keys_a, int64_t *slots_a, uint64_t *keys_b, int64_t *slots_b,
+size_t partition_scratch_bytes(int64_t n, int64_t pcount);
+hipError_t launch_partition(Src data, const uint64_t *valid, int64_t n, int64_t pmin, int64_t pcount, void *scratch /* partition_scratch_bytes(n, pcount) */,
+                            uint64_t *keys_a, int64_t *slots_a, uint64_t *keys_b, int64_t *slots_b,
                             int64_t *n_valid_dev, int64_t *pos_out, hipStream_t s, int64_t max_bucket = -1 /* largest bucket known to occur */,
                             int64_t *order_out = nullptr /* instead of pos_out: the slots in rank order (order[pos[slot]] = slot), stored sequentially */,
                             int64_t *sorted_keys_out = nullptr /* with order_out: bucket + pmin in rank order (= the keys, when all lie inside the pivots) */);

@@ -2,6 +2,7 @@
 // Partition.
 #include "vdl_device.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace vdl {
@@ -58,11 +59,44 @@ hipError_t launch_prefix_sum(int64_t *x, int64_t n, int64_t *sums, hipStream_t s
 // Partition (/root/reference/src/Vdl.hs:130,266-269; Vlite.hs:358-366,508,1082-1098): positions
 // that stably group `data` by pivot bucket.  Pivots are the emitted RangeC min cnt 1, so
 // bucket = clamp(data - min, 0, cnt).  Implemented as an LSD radix sort of (bucket, slot) over the
-// non-EPS slots, 8 bits per pass; each pass = tile histogram (LDS atomics) -> device-wide prefix
-// sum in digit-major order -> stable scatter (see k_part_scatter).  The last pass writes out[slot] = rank instead of the sorted pair.
+// non-EPS slots, 8 bits per pass, as a ONE-SWEEP sort (round 4): ONE pass over the input up front counts every
+// digit of every pass (k_part_digits), and each pass is then a single kernel that reads its tile once, ranks it, learns where
+// its digits start from the tiles before it *while they run* (decoupled look-back, below) and stores the tile in digit order.
+// Per pass the keys are read once and written once; the separate histogram pass and the device-wide prefix sum of the previous
+// design (one more read of the keys + three launches per pass) are gone.
+// The last pass writes out[slot] = rank, or -- lazy positions -- the slots in rank order.
 // Dense group-by domains (Q1: 32 buckets) need one pass, Q3's 2^38 domain five.
+//
+// Look-back.  A tile's slots of digit d go to  goff[d] + (slots of digit d in all EARLIER tiles) + rank inside the tile.  The
+// middle term is a prefix over tiles that are in flight at the same time.  The textbook chained scan walks back tile by tile
+// until it meets a tile that knows its own prefix; on this chip a polled word costs 1-3 us under streaming load
+// (MI355X_MICROARCH.md, handoff-1to1), ~500 tiles are in flight and a new one starts every few tens of ns, so such a walk is
+// hundreds of tiles deep.  Here the tiles keep a FENWICK TREE of fan-out 16 instead: a node is one ROW of 256 status words
+// {ready bit, count} -- row (u, 0) = the digit counts of tile u, row (u, j) = those of the 16^j tiles ending at u, made by tile u
+// when 16^j divides u + 1 out of its own row (u, j-1) and its 15 siblings'.  The prefix of tile t is the sum of at most 15 rows
+// per level (one per unit of each hex digit of t); which rows follows from t alone, so every load goes out at once and nothing is
+// walked.  Rows are read by whole waves (a lane takes 4 digits), a block's waves share the rows out and add their partial sums in
+// LDS.  A tile publishes its counts BEFORE it ranks its slots (a plain LDS histogram costs 16 atomics per lane) and asks for its
+// prefix only after it has ranked and staged them, so what it asks for has usually been published for microseconds.  Measured at
+// 60 M keys (tools/ubench/part_bench.hip): a binary tree polled right after ranking cost 392 us per pass against 250 us with the
+// waits compiled out (VDL_PART_NOWAIT); this form waits 1.5-2 of a tile's 16 us and a pass takes 280 us.
+// A status word is written once by one agent-scope relaxed store and polled with agent-scope relaxed loads (value and flag
+// travel together: no fence).  Tiles take their number from a counter, so a tile only waits for tiles that already run.
 // ------------------------------------------------------------------------------------------
-constexpr int kPartBlock = 256, kPartSteps = 16, kPartTile = kPartBlock * kPartSteps, kRadix = 256;
+// (tile shape: -DVDL_PART_BLOCK / -DVDL_PART_STEPS / -DVDL_PART_EU for tools/ubench/part_bench.hip's sweeps)
+#ifndef VDL_PART_BLOCK
+#define VDL_PART_BLOCK 512
+#endif
+#ifndef VDL_PART_STEPS
+#define VDL_PART_STEPS 16
+#endif
+#ifndef VDL_PART_EU
+#define VDL_PART_EU 4
+#endif
+constexpr int kPartBlock = VDL_PART_BLOCK, kPartSteps = VDL_PART_STEPS, kPartTile = kPartBlock * kPartSteps, kRadix = 256, kPartWaves = kPartBlock / kWave;
+static_assert(kPartBlock >= kRadix, "threads 0..255 own a digit each");
+constexpr int kPartMaxPasses = 8;
+constexpr int kFanBits = 4, kFan = 1 << kFanBits, kFenLevels = 6;            // tiles < 16^6 (launch_partition checks)
 int64_t partition_tiles(int64_t n) { return (n + kPartTile - 1) / kPartTile; }
 
 struct PartIn {
@@ -78,7 +112,117 @@ struct PartIn {
     int order_out;               // this (last) pass writes the slots in rank order to slots_out instead of the sorted pairs / the ranks
     int slot_bits;               // > 0: packed form -- a pair travels as ONE word (bucket << slot_bits) | slot, `slots` is unused:
                                  // every later pass moves 8 instead of 16 bytes per row (taken when bits(pcount) + bits(n) <= 64)
+    // one-sweep state of this pass
+    const int64_t *goff;         // [256] where each digit starts in the output (exclusive scan of the up-front histogram)
+    void *nodes;                 // Fenwick rows of this pass (partition_rows(ntiles) rows of 256 status words, zeroed)
+    unsigned int *ticket;        // tile numbers are handed out in starting order (zeroed)
+    int64_t ntiles;
+#ifdef VDL_PART_TIMING
+    unsigned long long *timing;  // [ntiles][8] phase timestamps (tools/ubench/part_bench.hip)
+#endif
 };
+#ifdef VDL_PART_TIMING
+#define PART_STAMP(k) do { if (tid == 0 && in.timing) in.timing[tile * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define PART_STAMP(k) do { } while (0)
+#endif
+
+// ---- status rows -------------------------------------------------------------------------------------------------------------
+// row of node (u, level) in a pass's rows: level j holds the tiles u with 16^j | u + 1, in order
+__host__ __device__ static inline int64_t partition_rows(int64_t ntiles) { int64_t r = 0; for (int j = 0; j < kFenLevels; j++) r += ntiles >> (kFanBits * j); return r; }
+__device__ __forceinline__ int64_t fen_row(int64_t ntiles, int64_t u, int level) {
+    int64_t base = 0;
+    for (int j = 0; j < level; j++) base += ntiles >> (kFanBits * j);
+    return base + ((u + 1) >> (kFanBits * level)) - 1;
+}
+// the i-th row of the prefix of tile t: one row per unit of each hex digit of t
+__device__ __forceinline__ int fen_prefix_rows(int64_t t) { int r = 0; for (int j = 0; j < kFenLevels; j++) r += (int)((t >> (kFanBits * j)) & (kFan - 1)); return r; }
+__device__ __forceinline__ int64_t fen_prefix_row(int64_t ntiles, int64_t t, int i) {
+    for (int j = 0; j < kFenLevels; j++) {
+        const int v = (int)((t >> (kFanBits * j)) & (kFan - 1));
+        if (i < v) {
+            const int64_t hi = t & ~(((int64_t)kFan << (kFanBits * j)) - 1);
+            return fen_row(ntiles, hi + ((int64_t)(i + 1) << (kFanBits * j)) - 1, j);
+        }
+        i -= v;
+    }
+    return 0;   // not reached
+}
+// A wave reads a row with every lane taking 4 of its 256 words.  32-bit words: two 8-byte loads, the lane's digits are
+// 2l, 2l+1, 128+2l, 129+2l; 64-bit words (counts beyond 2^31): four loads, digits l, 64+l, 128+l, 192+l.
+template <class ST> struct StRow;
+template <> struct StRow<uint32_t> {
+    static constexpr uint32_t kReady = 0x80000000u;
+    uint64_t a, b;
+    __device__ __forceinline__ void fetch(const uint32_t *row, int lane) {
+        const uint64_t *p = (const uint64_t *)row;
+        a = __hip_atomic_load(p + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b = __hip_atomic_load(p + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ __forceinline__ bool ready() const { return ((a & b) & 0x8000000080000000ull) == 0x8000000080000000ull; }
+    __device__ __forceinline__ void add(int64_t (&acc)[4]) const {
+        acc[0] += (int64_t)(a & 0x7fffffffull); acc[1] += (int64_t)((a >> 32) & 0x7fffffffull);
+        acc[2] += (int64_t)(b & 0x7fffffffull); acc[3] += (int64_t)((b >> 32) & 0x7fffffffull);
+    }
+    __device__ static __forceinline__ int digit(int lane, int q) { return (q >> 1) * 128 + 2 * lane + (q & 1); }
+};
+template <> struct StRow<uint64_t> {
+    static constexpr uint64_t kReady = 0x8000000000000000ull;
+    uint64_t w[4];
+    __device__ __forceinline__ void fetch(const uint64_t *row, int lane) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) w[q] = __hip_atomic_load(row + 64 * q + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ __forceinline__ bool ready() const { return ((w[0] & w[1] & w[2] & w[3]) & kReady) != 0; }
+    __device__ __forceinline__ void add(int64_t (&acc)[4]) const {
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] += (int64_t)(w[q] & ~kReady);
+    }
+    __device__ static __forceinline__ int digit(int lane, int q) { return 64 * q + lane; }
+};
+// sum[d] += the counts of digit d in the `nrows` rows rowf(0) .. rowf(nrows - 1), for every d: the block's waves take four rows
+// each per sweep, all of a wave's loads go out before the first is looked at, a row that is not there yet is polled.
+template <class ST, class RowF, class AT>
+__device__ __forceinline__ void add_rows(const ST *nodes, int nrows, RowF rowf, int wave, int lane, AT *sum /* LDS [256] */) {
+    int64_t acc[4] = {0, 0, 0, 0};
+    for (int base = wave * 4; base < nrows; base += kPartWaves * 4) {
+        StRow<ST> r[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (base + q < nrows) r[q].fetch(nodes + rowf(base + q) * kRadix, lane);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (base + q < nrows) {
+#ifndef VDL_PART_NOWAIT                                           // (ablation, tools/ubench/part_bench.hip: wrong results, the data path's own time)
+                while (!r[q].ready()) { __builtin_amdgcn_s_sleep(2); r[q].fetch(nodes + rowf(base + q) * kRadix, lane); }
+#endif
+                r[q].add(acc);
+            }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (acc[q]) atomicAdd(&sum[StRow<ST>::digit(lane, q)], (AT)acc[q]);
+}
+
+__device__ __forceinline__ int64_t part_bucket(const PartIn &in, int64_t x) {     // bucket = clamp(data - min, 0, cnt)
+    int64_t b = 0;
+    if (x > in.pmin) { b = (int64_t)((uint64_t)x - (uint64_t)in.pmin); if (b < 0 || b > in.pcount) b = in.pcount; }
+    return b;
+}
+// histogram update of one step of a wave: when every lane holds the same digit (the high digits of neighbouring keys mostly do; 64
+// lanes adding to one LDS word would serialise) lane 0 adds the wave's population once
+template <bool FULL>
+__device__ __forceinline__ void part_count(unsigned int *h, unsigned d, bool ok, int lane) {
+    const unsigned d0 = (unsigned)__builtin_amdgcn_readfirstlane((int)d);
+    if (__ballot(FULL ? d != d0 : (!ok || d != d0)) == 0) { if (lane == 0) atomicAdd(&h[d0], (unsigned)kWave); }      // (wave-uniform branch)
+    else if (FULL || ok) atomicAdd(&h[d], 1u);
+}
+// the 8-bit digit at `shift` of a 64-bit word, from whichever half holds it (one or two 32-bit operations instead of a 64-bit shift)
+__device__ __forceinline__ unsigned part_digit(uint64_t key, int shift) {
+    const unsigned lo = (unsigned)key, hi = (unsigned)(key >> 32);
+    const unsigned x = shift >= 32 ? hi >> (shift - 32) : __builtin_amdgcn_alignbit(hi, lo, (unsigned)shift);     // (shift is uniform: a scalar select)
+    return x & (kRadix - 1);
+}
 
 // A wave's share of a tile: kPartSteps x 64 consecutive slots starting at a multiple of 64, fetched with every load
 // issued before the first use (the validity word of a step is the same for all lanes).
@@ -104,10 +248,8 @@ __device__ __forceinline__ void part_fetch_share(const PartIn &in, int64_t n, in
             for (int st = 0; st < kPartSteps; st++) oks[st] = oks[st] & (((t[st] >> lane) & 1ull) != 0);
         }
 #pragma unroll
-        for (int st = 0; st < kPartSteps; st++) {                // bucket = clamp(data - min, 0, cnt)
-            const int64_t x = (int64_t)keys[st];
-            int64_t b = 0;
-            if (x > in.pmin) { b = (int64_t)((uint64_t)x - (uint64_t)in.pmin); if (b < 0 || b > in.pcount) b = in.pcount; }
+        for (int st = 0; st < kPartSteps; st++) {
+            const int64_t b = part_bucket(in, (int64_t)keys[st]);
             keys[st] = in.slot_bits ? (((uint64_t)b << in.slot_bits) | (uint64_t)slots[st]) : (uint64_t)b;
         }
     } else if (in.slot_bits) {
@@ -129,142 +271,254 @@ __device__ __forceinline__ void part_fetch_share(const PartIn &in, int64_t n, in
     }
 }
 
-template <bool FIRST>
-__global__ __launch_bounds__(kPartBlock) void k_part_hist(PartIn in, int64_t ntiles, int64_t *hist /*[256][ntiles]*/) {
-    __shared__ unsigned int h[kRadix];
-    const int64_t n = FIRST ? in.n : *in.n_dev;
+// The up-front histogram: every 8-bit digit of every bucket, counted in ONE pass over the data (ghist[pass][digit], pre-zeroed).
+// A wave takes four 64-slot words per trip.
+__global__ __launch_bounds__(256) void k_part_digits(PartIn in, int passes, unsigned long long *ghist) {
+    constexpr int U = 4;
+    __shared__ unsigned int h[kPartMaxPasses][kRadix];
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-    h[tid] = 0;
+    for (int i = tid; i < kPartMaxPasses * kRadix; i += 256) (&h[0][0])[i] = 0;
     __syncthreads();
-    if ((int64_t)blockIdx.x * kPartTile < n) {                   // (n = 0 leaves the key buffers unwritten)
-        uint64_t keys[kPartSteps];
-        int64_t slots[kPartSteps];
-        bool oks[kPartSteps];
-        part_fetch_share<FIRST>(in, n, (int64_t)blockIdx.x * kPartTile + (int64_t)wave * (kPartSteps * kWave), lane, keys, slots, oks);
+    const int64_t n = in.n, nw = (n + 63) >> 6;
+    by_kind(in.data.kind, [&](auto kd) {
+        for (int64_t w0 = ((int64_t)blockIdx.x * 4 + wave) * U; w0 < nw; w0 += (int64_t)gridDim.x * 4 * U) {
+            int64_t x[U];
+            bool ok[U];
 #pragma unroll
-        for (int st = 0; st < kPartSteps; st++)
-            if (oks[st]) atomicAdd(&h[(keys[st] >> in.shift) & (kRadix - 1)], 1u);
-    }
+            for (int u = 0; u < U; u++) {
+                const int64_t i = ((w0 + u) << 6) + lane;
+                ok[u] = i < n;
+                x[u] = ldk_stream<decltype(kd)::value>(in.data, ok[u] ? i : 0);
+            }
+            if (in.valid) {
+                uint64_t t[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) t[u] = in.valid[w0 + u < nw ? w0 + u : nw - 1];
+#pragma unroll
+                for (int u = 0; u < U; u++) ok[u] = ok[u] & (((t[u] >> lane) & 1ull) != 0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint64_t b = (uint64_t)part_bucket(in, x[u]);
+                for (int p = 0; p < passes; p++) part_count<false>(h[p], (unsigned)((b >> (8 * p)) & (kRadix - 1)), ok[u], lane);
+            }
+        }
+    });
     __syncthreads();
-    hist[(int64_t)tid * ntiles + blockIdx.x] = h[tid];
+    for (int i = tid; i < passes * kRadix; i += 256) {
+        const unsigned c = (&h[0][0])[i];
+        if (c) atomicAdd(&ghist[i], (unsigned long long)c);
+    }
+}
+// one block per pass: exclusive scan of its 256 counts; block 0 also leaves the number of non-EPS slots
+__global__ __launch_bounds__(kRadix) void k_part_digit_offsets(const unsigned long long *ghist, int64_t *goff, int64_t *n_valid) {
+    __shared__ int64_t wsum[kRadix / kWave];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const int64_t c = (int64_t)ghist[blockIdx.x * kRadix + tid];
+    int64_t incl = c;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) { const int64_t y = __shfl_up(incl, off, kWave); if (lane >= off) incl += y; }
+    if (lane == kWave - 1) wsum[wave] = incl;
+    __syncthreads();
+    int64_t pre = 0;
+    for (int w = 0; w < wave; w++) pre += wsum[w];
+    goff[blockIdx.x * kRadix + tid] = pre + incl - c;
+    if (blockIdx.x == 0 && tid == kRadix - 1) *n_valid = pre + incl;
 }
 
-// Each wave owns a contiguous quarter of the tile (16 steps of 64 slots), so the stable order inside a tile is wave,
-// step, lane.  A wave ranks its slots on its own (peer masks from 8 ballots, its running digit counts in its row of
-// whist: LDS operations of one wave execute in order); one barrier later the rows are turned into per-wave offsets
-// and every slot knows its destination.  (A version that kept the block in step order needed three barriers per
-// step, 48 per tile, and was twice as slow.)
-template <bool FIRST, bool LAST>
-__global__ __launch_bounds__(kPartBlock) void k_part_scatter(PartIn in, int64_t ntiles, const int64_t *offsets,
-                                                              uint64_t *keys_out, int64_t *slots_out, int64_t *pos_out) {
-    constexpr int NW = kPartBlock / kWave;
-    __shared__ int64_t woff[NW][kRadix];
-    __shared__ unsigned int whist[NW][kRadix];
-    const int64_t n = FIRST ? in.n : *in.n_dev;
+// One radix pass over one tile per block.  Order of events: fetch the tile; count its digits (LDS histogram) and PUBLISH the row --
+// a tile that completes a group of 16 / 256 / ... also publishes the wider rows; rank the slots (each wave owns a contiguous share
+// of the tile -- 16 steps of 64 slots --, so the stable order inside a tile is wave, step, lane: a wave ranks its slots on its own,
+// match masks in LDS, its running digit counts in its row of whist: LDS operations of one wave execute in order); turn
+// the rows of whist into offsets inside the sorted tile; stage the tile in LDS in digit order; only then collect the prefix over
+// the earlier tiles (add_rows) and store.
+// The pass is bound by instruction issue, not by memory (a timeline of phase stamps per tile, tools/ubench/part_bench.hip
+// -DVDL_PART_TIMING: 18 us per tile of which 6 waiting for loads and stores, two tiles per CU): hence a body without validity
+// tests for full tiles (FULL), digits extracted once, 32-bit destinations while the Partition has fewer than 2^31 slots.
+// MODE 0: middle pass (sorted pairs out); 1: last pass of a lazy Partition (slots in rank order, optionally the key values);
+// 2: last pass writing pos_out[slot] = rank.
+template <int MODE, class ST> struct PartLds {
+    using IT = typename std::conditional<sizeof(ST) == 4, unsigned int, unsigned long long>::type;     // destinations: modulo 2^32 while they fit
+    unsigned int whist[kPartWaves][kRadix];                     // per wave and digit: count, later offset inside the sorted tile
+    unsigned int chist[kRadix];                                 // the tile's digit counts
+    IT gdelta[kRadix];                                          // destination of sorted index idx with digit d = gdelta[d] + idx
+    IT before[kRadix];                                          // slots of digit d in the earlier tiles
+    unsigned int wtot[kRadix / kWave];
+    unsigned int tile;
+    // The tile is put into digit order in LDS before it is stored (keys, then slots through the same buffer): a digit's slots of
+    // one tile are neighbours at the destination, so consecutive lanes then store consecutive words instead of 64 scattered ones.
+    // Until then the area holds the waves' match masks (NW x 256 words).
+    uint64_t stage[MODE == 2 ? kPartWaves * kRadix : kPartTile];
+};
+static_assert(kPartTile >= kPartWaves * kRadix, "the match masks live in the staging area");
+
+template <bool FIRST, bool PACKED, int MODE, class ST, bool FULL>
+__device__ __forceinline__ void part_pass_tile(const PartIn &in, PartLds<MODE, ST> &L, const int64_t tile, const int64_t n,
+                                               uint64_t *keys_out, int64_t *slots_out, int64_t *pos_out) {
+    constexpr int NW = kPartWaves;
+    using IT = typename PartLds<MODE, ST>::IT;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-#pragma unroll
-    for (int w = 0; w < NW; w++) whist[w][tid] = 0;
-    __syncthreads();
+    PART_STAMP(0);
     uint64_t keys[kPartSteps];
     int64_t slots[kPartSteps];
     bool oks[kPartSteps];
-#pragma unroll
-    for (int st = 0; st < kPartSteps; st++) { keys[st] = 0; slots[st] = 0; oks[st] = false; }
-    if ((int64_t)blockIdx.x * kPartTile < n)                    // the whole share is fetched up front
-        part_fetch_share<FIRST>(in, n, (int64_t)blockIdx.x * kPartTile + (int64_t)wave * (kPartSteps * kWave), lane, keys, slots, oks);
-    unsigned int local[kPartSteps];                             // rank among this wave's slots with the same digit
-    volatile unsigned int *mine = whist[wave];
-#pragma unroll
-    for (int st = 0; st < kPartSteps; st++) {
-        const unsigned d = (unsigned)((keys[st] >> in.shift) & (kRadix - 1));
-        uint64_t peers = __ballot(oks[st]);                     // lanes of this wave holding the same digit (and a value)
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            const uint64_t m = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? m : ~m;
-        }
-        const unsigned rank = (unsigned)__popcll(peers & ((1ull << lane) - 1));
-        const unsigned pre = oks[st] ? mine[d] : 0u;
-        if (oks[st] && rank == 0) mine[d] = pre + (unsigned)__popcll(peers);     // one leader per digit
-        local[st] = pre + rank;
-    }
+    part_fetch_share<FIRST>(in, n, tile * kPartTile + (int64_t)wave * (kPartSteps * kWave), lane, keys, slots, oks);
+#define OK(st) (FULL || oks[st])
+#ifdef VDL_PART_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (LAST) {                                                 // ranks go to out[slot]: scattered whatever the order
-        {
-            int64_t run = offsets[(int64_t)tid * ntiles + blockIdx.x];          // where this tile's slots of digit `tid` start
+#endif
+    PART_STAMP(1);
+    unsigned int dg[kPartSteps];
 #pragma unroll
-            for (int w = 0; w < NW; w++) { woff[w][tid] = run; run += whist[w][tid]; }
+    for (int st = 0; st < kPartSteps; st++) dg[st] = part_digit(keys[st], in.shift);
+    ST *const nodes = (ST *)in.nodes;
+#pragma unroll
+    for (int st = 0; st < kPartSteps; st++) part_count<FULL>(L.chist, dg[st], OK(st), lane);
+    __syncthreads();
+    const unsigned cnt = tid < kRadix ? L.chist[tid] : 0u;
+    PART_STAMP(2);
+    // the tile's row, and the wider rows of a tile that ends a group of 16 / 256 / ...
+    if (tid < kRadix)
+        __hip_atomic_store(nodes + fen_row(in.ntiles, tile, 0) * kRadix + tid, (ST)((ST)cnt | StRow<ST>::kReady), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (((tile + 1) & (kFan - 1)) == 0) {                       // (one tile in 16; block-uniform)
+        ST acc = (ST)cnt;
+        for (int j = 1; j < kFenLevels && ((tile + 1) & (((int64_t)1 << (kFanBits * j)) - 1)) == 0; j++) {
+            const int64_t step = (int64_t)1 << (kFanBits * (j - 1));
+            add_rows<ST>(nodes, kFan - 1, [&](int i) { return fen_row(in.ntiles, tile - (int64_t)(i + 1) * step, j - 1); }, wave, lane, L.before);
+            __syncthreads();
+            if (tid < kRadix) {
+                acc += (ST)L.before[tid];
+                L.before[tid] = 0;
+                __hip_atomic_store(nodes + fen_row(in.ntiles, tile, j) * kRadix + tid, (ST)(acc | StRow<ST>::kReady), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
         }
-        __syncthreads();
+    }
+    PART_STAMP(3);
+    // Which lanes of the wave hold the same digit?  Every lane ORs its bit into the wave's mask of its digit (LDS, one 64-bit word per
+    // digit; the table lies in the staging area, which is not in use yet) and reads the word back: LDS operations of one wave execute
+    // in order, so the read sees all 64 contributions.  (Eight ballots per step with per-lane 64-bit mask arithmetic -- 70 vector
+    // instructions for every 64 keys -- were the first version.)  Three sweeps over the 16 steps, each a train of LDS operations that
+    // never waits for the one before (a dependent round trip per step made ranking 5.3 of a tile's 18 us):
+    //   1. OR the lane's bit in, read the word back, write 0 over it -- issued back to back, the LDS runs them in that order;
+    //   2. the lowest lane of each digit adds the digit's population to the wave's running count (atomic with return: the
+    //      returned values are the counts before each step, in step order);
+    //   3. its peers fetch that value from it (a cross-lane read; through the digit's LDS word it took half as long again).
+    unsigned int local[kPartSteps];                             // rank among this wave's slots with the same digit
+    {
+        unsigned int *mine = L.whist[wave];
+        volatile unsigned long long *mm = (volatile unsigned long long *)L.stage + wave * kRadix;
+        unsigned int info[kPartSteps];                          // rank | population << 8 | lowest peer lane << 16
 #pragma unroll
         for (int st = 0; st < kPartSteps; st++) {
-            if (oks[st]) {
-                const unsigned d = (unsigned)((keys[st] >> in.shift) & (kRadix - 1));
-                pos_out[slots[st]] = woff[wave][d] + local[st];
-            }
+            if (OK(st)) __hip_atomic_fetch_or((unsigned long long *)mm + dg[st], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __builtin_amdgcn_wave_barrier();
+            const unsigned long long peers = OK(st) ? mm[dg[st]] : (1ull << lane);
+            __builtin_amdgcn_wave_barrier();
+            if (OK(st)) mm[dg[st]] = 0ull;
+            __builtin_amdgcn_wave_barrier();
+            const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(peers >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)peers, 0u));
+            info[st] = rank | ((unsigned)__popcll(peers) << 8) | ((unsigned)(__ffsll((long long)peers) - 1) << 16);
         }
-        return;
-    }
-    // The tile is put into digit order in LDS first (keys, then slots through the same buffer): a digit's slots of
-    // one tile are neighbours at the destination, so consecutive lanes then store consecutive words instead of 64
-    // scattered ones.
-    __shared__ uint64_t stage[kPartTile];
-    __shared__ unsigned int wtot[NW];
-    __shared__ int64_t gdelta[kRadix];                          // destination of sorted index idx with digit d = gdelta[d] + idx
-    unsigned total;
-    {
-        unsigned cnt = 0;
 #pragma unroll
-        for (int w = 0; w < NW; w++) cnt += whist[w][tid];
-        unsigned incl = cnt;                                    // exclusive scan of the tile's digit counts over the block
+        for (int st = 0; st < kPartSteps; st++) {
+            unsigned pre = 0;
+            if (OK(st) && (info[st] & 0xffu) == 0) pre = __hip_atomic_fetch_add(mine + dg[st], (info[st] >> 8) & 0xffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __builtin_amdgcn_wave_barrier();
+            local[st] = pre;
+        }
+#pragma unroll
+        for (int st = 0; st < kPartSteps; st++) local[st] = (unsigned)__shfl((int)local[st], (int)(info[st] >> 16), kWave) + (info[st] & 0xffu);
+    }
+    PART_STAMP(4);
+    unsigned incl = cnt;                                        // exclusive scan of the tile's digit counts over threads 0 .. 255
+    if (tid < kRadix) {
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) { const unsigned y = __shfl_up(incl, off, kWave); if (lane >= off) incl += y; }
-        if (lane == kWave - 1) wtot[wave] = incl;
-        __syncthreads();
-        unsigned pre = 0;
-        for (int w = 0; w < wave; w++) pre += wtot[w];
-        total = 0;
+        if (lane == kWave - 1) L.wtot[wave] = incl;
+    }
+    __syncthreads();
+    unsigned total = 0;
 #pragma unroll
-        for (int w = 0; w < NW; w++) total += wtot[w];
+    for (int w = 0; w < kRadix / kWave; w++) total += L.wtot[w];
+    if (tid < kRadix) {
+        unsigned pre = 0;
+        for (int w = 0; w < wave; w++) pre += L.wtot[w];
         const unsigned tstart = pre + incl - cnt;               // where digit `tid` starts inside the sorted tile
         unsigned run = tstart;
 #pragma unroll
-        for (int w = 0; w < NW; w++) { woff[w][tid] = run; run += whist[w][tid]; }                            // tile-local
-        gdelta[tid] = offsets[(int64_t)tid * ntiles + blockIdx.x] - (int64_t)tstart;
-        __syncthreads();
-    }
-    unsigned lpos[kPartSteps];
-#pragma unroll
-    for (int st = 0; st < kPartSteps; st++) {
-        const unsigned d = (unsigned)((keys[st] >> in.shift) & (kRadix - 1));
-        lpos[st] = (unsigned)woff[wave][d] + local[st];
-        if (oks[st]) stage[lpos[st]] = keys[st];
+        for (int w = 0; w < NW; w++) { const unsigned c = L.whist[w][tid]; L.whist[w][tid] = run; run += c; }
+        L.gdelta[tid] = (IT)in.goff[tid] - (IT)tstart;
     }
     __syncthreads();
-    int64_t dest[kPartSteps];
+    unsigned lpos[kPartSteps];
+#pragma unroll
+    for (int st = 0; st < kPartSteps; st++) lpos[st] = L.whist[wave][dg[st]] + local[st];
+    const int nrows = fen_prefix_rows(tile);
+    auto prefix_row = [&](int i) { return fen_prefix_row(in.ntiles, tile, i); };
+    if (MODE != 2) {
+#pragma unroll
+        for (int st = 0; st < kPartSteps; st++)
+            if (OK(st)) L.stage[lpos[st]] = keys[st];
+    }
+    PART_STAMP(5);
+    add_rows<ST>(nodes, nrows, prefix_row, wave, lane, L.before);
+    __syncthreads();
+    if (tid < kRadix) L.gdelta[tid] += L.before[tid];
+    __syncthreads();
+    PART_STAMP(6);
+    if (MODE == 2) {                                            // ranks go to out[slot]: scattered whatever the order
+#pragma unroll
+        for (int st = 0; st < kPartSteps; st++)
+            if (OK(st)) pos_out[slots[st]] = (int64_t)(IT)(L.gdelta[dg[st]] + (IT)lpos[st]);
+        return;
+    }
+    IT dest[kPartSteps];
 #pragma unroll
     for (int k = 0; k < kPartSteps; k++) {
         const unsigned idx = (unsigned)k * kPartBlock + tid;
-        dest[k] = -1;
-        if (idx < total) {
-            const uint64_t key = stage[idx];
-            dest[k] = gdelta[(key >> in.shift) & (kRadix - 1)] + idx;
-            if (!in.order_out) keys_out[dest[k]] = key;
+        dest[k] = 0;
+        if (FULL || idx < total) {
+            const uint64_t key = L.stage[idx];
+            dest[k] = L.gdelta[part_digit(key, in.shift)] + (IT)idx;
+            if (MODE == 0) keys_out[dest[k]] = key;
             else {
-                if (in.slot_bits) slots_out[dest[k]] = (int64_t)(key & ((1ull << in.slot_bits) - 1));     // the last pass of a lazy Partition: slots in rank order
-                if (in.sorted_keys) in.sorted_keys[dest[k]] = (int64_t)((uint64_t)in.pmin + (in.slot_bits ? key >> in.slot_bits : key));
+                if (PACKED) slots_out[dest[k]] = (int64_t)(key & ((1ull << in.slot_bits) - 1));     // the last pass of a lazy Partition: slots in rank order
+                if (in.sorted_keys) in.sorted_keys[dest[k]] = (int64_t)((uint64_t)in.pmin + (PACKED ? key >> in.slot_bits : key));
             }
         }
     }
-    if (in.slot_bits) return;                                  // packed: the slot travelled inside the key word
+#ifdef VDL_PART_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    PART_STAMP(7);
+    if (PACKED) return;                                         // packed: the slot travelled inside the key word
     __syncthreads();
 #pragma unroll
     for (int st = 0; st < kPartSteps; st++)
-        if (oks[st]) stage[lpos[st]] = (uint64_t)slots[st];
+        if (OK(st)) L.stage[lpos[st]] = (uint64_t)slots[st];
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kPartSteps; k++)
-        if (dest[k] >= 0) slots_out[dest[k]] = (int64_t)stage[(unsigned)k * kPartBlock + tid];
+        if (FULL || (unsigned)k * kPartBlock + tid < total) slots_out[dest[k]] = (int64_t)L.stage[(unsigned)k * kPartBlock + tid];
+#undef OK
+}
+
+template <bool FIRST, bool PACKED, int MODE, class ST>
+__global__ __launch_bounds__(kPartBlock, VDL_PART_EU) void k_part_pass(PartIn in, uint64_t *keys_out, int64_t *slots_out, int64_t *pos_out) {
+    __shared__ PartLds<MODE, ST> L;
+    const int tid = threadIdx.x;
+    if (tid == 0) L.tile = atomicAdd(in.ticket, 1u);
+#pragma unroll
+    for (int k = 0; k < kPartWaves * kRadix / kPartBlock; k++) { (&L.whist[0][0])[k * kPartBlock + tid] = 0; L.stage[k * kPartBlock + tid] = 0; }
+    if (tid < kRadix) { L.chist[tid] = 0; L.before[tid] = 0; }
+    __syncthreads();
+    const int64_t tile = L.tile;
+    const int64_t n = FIRST ? in.n : *in.n_dev;
+    if (tile * kPartTile >= n) return;                          // (whole block; the tiles before it are all full: nobody waits for this one)
+    if ((tile + 1) * kPartTile <= n && !(FIRST && in.valid)) part_pass_tile<FIRST, PACKED, MODE, ST, true>(in, L, tile, n, keys_out, slots_out, pos_out);
+    else part_pass_tile<FIRST, PACKED, MODE, ST, false>(in, L, tile, n, keys_out, slots_out, pos_out);
 }
 
 // Is the (fully valid) data already in non-decreasing order?  Then its stable partition ranks are 0, 1, 2, ... and none of
@@ -423,48 +677,76 @@ hipError_t launch_sorted_heads(Src d, int64_t n, uint64_t *heads, int64_t *flag,
     return launch_status();
 }
 
-// scratch layout is owned by the caller (vdl_engine.cpp); see launch_partition's arguments.
-hipError_t launch_partition(Src data, const uint64_t *valid, int64_t n, int64_t pmin, int64_t pcount,
-                            int64_t *hist /* 256*ntiles + 1 */, int64_t *scan_scratch /* prefix_sum_blocks(256*ntiles)+1 */,
+// Scratch of one Partition: tickets, the up-front histogram and its scan, and per pass the Fenwick nodes of its tiles
+// (partition_rows(tiles) rows of 256 status words: 32-bit words while a count fits 31 bits).
+static int partition_bits(int64_t top) { int bits = 0; while (bits < 63 && ((uint64_t)top >> bits) != 0) bits++; return bits; }
+static bool partition_narrow_status(int64_t n) { return n < ((int64_t)1 << 31); }
+static size_t partition_head_bytes() { return 64 + 2 * sizeof(int64_t) * (size_t)kPartMaxPasses * kRadix; }
+static size_t partition_node_bytes(int64_t n) { return (size_t)partition_rows(partition_tiles(n)) * kRadix * (partition_narrow_status(n) ? 4 : 8); }
+size_t partition_scratch_bytes(int64_t n, int64_t pcount) {
+    return partition_head_bytes() + (size_t)partition_passes(pcount) * partition_node_bytes(n);
+}
+
+#ifdef VDL_PART_TIMING
+unsigned long long *g_part_timing = nullptr;
+#endif
+template <bool FIRST, bool PACKED, int MODE>
+static void launch_part_pass(const PartIn &in, bool narrow, uint64_t *keys_out, int64_t *slots_out, int64_t *pos_out, hipStream_t s) {
+    if (narrow) k_part_pass<FIRST, PACKED, MODE, uint32_t><<<(int)in.ntiles, kPartBlock, 0, s>>>(in, keys_out, slots_out, pos_out);
+    else k_part_pass<FIRST, PACKED, MODE, uint64_t><<<(int)in.ntiles, kPartBlock, 0, s>>>(in, keys_out, slots_out, pos_out);
+}
+template <bool FIRST, bool PACKED>
+static void launch_part_pass_mode(const PartIn &in, int mode, bool narrow, uint64_t *keys_out, int64_t *slots_out, int64_t *pos_out, hipStream_t s) {
+    if (mode == 0) launch_part_pass<FIRST, PACKED, 0>(in, narrow, keys_out, slots_out, pos_out, s);
+    else if (mode == 1) launch_part_pass<FIRST, PACKED, 1>(in, narrow, keys_out, slots_out, pos_out, s);
+    else launch_part_pass<FIRST, PACKED, 2>(in, narrow, keys_out, slots_out, pos_out, s);
+}
+
+hipError_t launch_partition(Src data, const uint64_t *valid, int64_t n, int64_t pmin, int64_t pcount, void *scratch /* partition_scratch_bytes(n, pcount) */,
                             uint64_t *keys_a, int64_t *slots_a, uint64_t *keys_b, int64_t *slots_b /* n each, or null if one pass */,
                             int64_t *n_valid_dev /* 1 word */, int64_t *pos_out, hipStream_t s, int64_t max_bucket, int64_t *order_out, int64_t *sorted_keys_out) {
     (void)hipGetLastError();   // see launch_status()
     if (n <= 0) return hipSuccess;
-    int bits = 0;
+    if (partition_tiles(n) >= ((int64_t)1 << (kFanBits * kFenLevels))) return hipErrorInvalidValue;      // (2^37 slots: the look-back's level count)
     const int64_t top = (max_bucket >= 0 && max_bucket < pcount) ? max_bucket : pcount;      // buckets 0..pcount, or those known to occur
-    while (bits < 63 && ((uint64_t)top >> bits) != 0) bits++;
+    const int bits = partition_bits(top);
     const int passes = bits <= 8 ? 1 : (bits + 7) / 8;
     const int64_t ntiles = partition_tiles(n);
-    const int64_t hn = (int64_t)kRadix * ntiles;
+    const bool narrow = partition_narrow_status(n);
     PartIn in{};
-    in.data = data; in.valid = valid; in.pmin = pmin; in.pcount = pcount; in.n = n; in.n_dev = n_valid_dev;
+    in.data = data; in.valid = valid; in.pmin = pmin; in.pcount = pcount; in.n = n; in.n_dev = n_valid_dev; in.ntiles = ntiles;
     int nbits = 1;
     while (nbits < 63 && ((uint64_t)(n - 1) >> nbits) != 0) nbits++;    // slots 0..n-1
     in.slot_bits = (passes > 1 && bits + nbits <= 64 && !getenv("VDL_NO_PACKED_PARTITION")) ? nbits : 0;
+    // scratch: tickets | ghist | goff | nodes of pass 0, 1, ...   (tickets, ghist and the nodes start at zero)
+    unsigned int *tickets = (unsigned int *)scratch;
+    unsigned long long *ghist = (unsigned long long *)((char *)scratch + 64);
+    int64_t *goff = (int64_t *)(ghist + (size_t)kPartMaxPasses * kRadix);
+    char *nodes = (char *)scratch + partition_head_bytes();
+    hipError_t e = hipMemsetAsync(scratch, 0, partition_head_bytes() + (size_t)passes * partition_node_bytes(n), s);
+    if (e != hipSuccess) return e;
+    {
+        const int grid = (int)std::min<int64_t>((n + 1023) / 1024, 2048);
+        k_part_digits<<<grid, 256, 0, s>>>(in, passes, ghist);
+        k_part_digit_offsets<<<passes, kRadix, 0, s>>>(ghist, goff, n_valid_dev);
+    }
     uint64_t *kin = nullptr, *kout = keys_a; int64_t *sin = nullptr, *sout = slots_a;
     for (int p = 0; p < passes; p++) {
         in.shift = 8 * p + in.slot_bits; in.keys = kin; in.slots = sin;
+        in.goff = goff + (size_t)p * kRadix; in.nodes = nodes + (size_t)p * partition_node_bytes(n); in.ticket = tickets + p;
+#ifdef VDL_PART_TIMING
+        in.timing = p == VDL_PART_TIMING ? g_part_timing : nullptr;
+#endif
         const bool first = p == 0, last = p == passes - 1;
-        if (first) k_part_hist<true><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist);
-        else k_part_hist<false><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist);
-        hipError_t e = launch_prefix_sum(hist, hn, scan_scratch, s);
-        if (e != hipSuccess) return e;
-        if (first) {   // number of non-EPS slots = grand total of the first histogram
-            e = hipMemcpyAsync(n_valid_dev, scan_scratch + prefix_sum_blocks(hn), sizeof(int64_t), hipMemcpyDeviceToDevice, s);
-            if (e != hipSuccess) return e;
-        }
         // order_out: the caller wants the slots in rank order (the inverse of the positions) -- the last pass then stores like a middle
         // pass, consecutive lanes on consecutive words, instead of one 8-byte store per slot at the slot's own address
         in.order_out = (last && order_out) ? 1 : 0;
         in.sorted_keys = in.order_out ? sorted_keys_out : nullptr;
-        if (in.order_out) {
-            if (first) k_part_scatter<true, false><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist, nullptr, order_out, nullptr);
-            else k_part_scatter<false, false><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist, nullptr, order_out, nullptr);
-        }
-        else if (first && last) k_part_scatter<true, true><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist, nullptr, nullptr, pos_out);
-        else if (first) k_part_scatter<true, false><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist, kout, sout, nullptr);
-        else if (last) k_part_scatter<false, true><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist, nullptr, nullptr, pos_out);
-        else k_part_scatter<false, false><<<(int)ntiles, kPartBlock, 0, s>>>(in, ntiles, hist, kout, sout, nullptr);
+        const int mode = in.order_out ? 1 : last ? 2 : 0;
+        uint64_t *ko = mode == 0 ? kout : nullptr;
+        int64_t *so = mode == 1 ? order_out : mode == 0 ? sout : nullptr;
+        if (first) { if (in.slot_bits) launch_part_pass_mode<true, true>(in, mode, narrow, ko, so, pos_out, s); else launch_part_pass_mode<true, false>(in, mode, narrow, ko, so, pos_out, s); }
+        else { if (in.slot_bits) launch_part_pass_mode<false, true>(in, mode, narrow, ko, so, pos_out, s); else launch_part_pass_mode<false, false>(in, mode, narrow, ko, so, pos_out, s); }
         kin = kout; sin = sout;
         kout = (kout == keys_a) ? keys_b : keys_a;
         sout = (sout == slots_a) ? slots_b : slots_a;
@@ -472,8 +754,7 @@ hipError_t launch_partition(Src data, const uint64_t *valid, int64_t n, int64_t 
     return launch_status();
 }
 int partition_passes(int64_t pcount) {
-    int bits = 0;
-    while (bits < 63 && ((uint64_t)pcount >> bits) != 0) bits++;
+    const int bits = partition_bits(pcount);
     return bits <= 8 ? 1 : (bits + 7) / 8;
 }
 

@@ -99,3 +99,60 @@ def test_folds_over_keys_out_of_order_take_the_radix_route(domain, mode, monkeyp
             got = e.run_vdl(text)["results"]
             e.close()
             check_against_oracle("group_tail_unsorted", n, text, cols, got, want)
+
+
+@pytest.mark.parametrize("shape", ["packed", "pairs", "holes", "clamped", "narrow"])
+def test_partition_over_many_tiles_matches_a_stable_numpy_sort(shape):
+    """The one-sweep radix Partition at a size where its look-back matters (vdl_partition.hip: k_part_pass): ~6 M slots = 730 tiles,
+    i.e. Fenwick nodes up to level 9 and thousands of status words polled while their producers run.  Checked against numpy's stable
+    argsort of the buckets -- positions written out (the last pass scatters ranks), and the GROUP BY idiom whose Scatters read the
+    rank-order list instead (lazy positions, the sorted keys handed over by the last pass).
+    packed: 2^40 domain, five passes of (bucket << 23 | slot) words; pairs: a domain too wide for one word (keys and slots travel
+    side by side); holes: EPS rows in the key (no sortedness pass, the declared domain's pass count); clamped: values outside the
+    pivots on both sides; narrow: a 200-bucket domain (one pass)."""
+    n = 5_982_721
+    r = np.random.default_rng(len(shape))
+    pmin = 0
+    if shape == "pairs":
+        k, domain = r.integers(0, 1 << 52, n), 1 << 52
+    elif shape == "clamped":
+        k, domain, pmin = r.integers(-50_000, 400_000, n), 300_000, 1000
+    elif shape == "narrow":
+        k, domain = r.integers(0, 200, n), 200
+    else:
+        k, domain = (r.integers(1, 1 << 20, n) * r.integers(1, 1 << 19, n)), 1 << 40
+    cols = {"t.k": k.astype(np.int64), "t.v": r.integers(-1000, 1000, n).astype(np.int64), "t.f": (r.integers(0, 10, n) < 7).astype(np.int64)}
+    L = ["1,Load,t.k", "2,Project,val,Id 1,k", "3,Load,t.v", "4,Project,val,Id 3,v", "5,Load,t.f", "6,Project,val,Id 5,f"]
+    kk, vv = 2, 4
+    keep = np.ones(n, bool)
+    if shape == "holes":
+        L += ["7,RangeV,val,0,Id 6,0", "8,Greater,val,Id 6,val,Id 7,val", "9,RangeV,val,0,Id 8,1", "10,FoldSelect,val,Id 9,val,Id 8,val",
+              "11,Gather,Id 2,Id 10,val", "12,Gather,Id 4,Id 10,val"]
+        kk, vv = 11, 12
+        keep = cols["t.f"] > 0
+    L += ["20,RangeC,val,%d,%d,1" % (pmin, domain), "21,Partition,val,Id %d,val,Id 20,val" % kk,
+          "22,RangeV,val,0,Id %d,1" % kk, "23,Scatter,Id %d,Id 22,val,Id 21,val" % kk, "24,Scatter,Id %d,Id 22,val,Id 21,val" % vv,
+          "25,FoldSum,val,Id 23,val,Id 24,val", "26,Project,s,Id 25,val", "27,MaterializeCompact,Id 26",
+          "28,FoldChoose,val,Id 23,val,Id 23,val", "29,Project,key,Id 28,val", "30,MaterializeCompact,Id 29"]
+    lazy = prog(*L)
+    eager = prog(*(L + ["31,Project,pos,Id 21,val", "32,MaterializeCompact,Id 31"]))
+    kept = cols["t.k"][keep]
+    bucket = np.where(kept > pmin, np.minimum(kept - pmin, domain), 0)
+    order = np.argsort(bucket, kind="stable")
+    sk = kept[order]                                        # the folds' control vector: the key VALUES in bucket order (runs = equal neighbours)
+    heads = np.flatnonzero(np.r_[True, sk[1:] != sk[:-1]])
+    want_s = np.add.reduceat(cols["t.v"][keep][order], heads)
+    want_key = sk[heads]
+    pos = np.empty(len(order), np.int64)
+    pos[order] = np.arange(len(order))
+    e = engine_with(cols)
+    for text in (lazy, eager):
+        p = e.parse(text)
+        p.set_fusion(False)
+        got = p.run(as_numpy=True)["results"]
+        assert np.array_equal(got["tmp27"][".s"], want_s), shape
+        assert np.array_equal(got["tmp30"][".key"], want_key), shape
+        if text is eager:
+            assert np.array_equal(got["tmp32"][".pos"], pos), shape
+        p.close()
+    e.close()
