@@ -468,9 +468,8 @@ def main():
     # torch.distributed is the launcher's control channel only (communicator id hand-over, barriers, MAX of the timings):
     # gloo over CPU tensors.  The data-path collectives run inside libvdl on its own RCCL communicator (vdl_comm_init).
     # Rehearsal on one-GPU boxes: VDL_BENCH_SHARE_DEVICE=1 puts every rank on device 0; RCCL refuses two ranks on one
-    # device, so VDL_BENCH_COMM=host then routes the collectives through libvdl's host transport over gloo.  VDL_BENCH_COMM=torch
-    # is the previous formulation (torch.distributed nccl all-reduce from Python), kept as the fallback when RCCL cannot be
-    # bound from libvdl.  Neither rehearsal mode is for reported numbers; the JSON line says which one ran.
+    # device, so VDL_BENCH_COMM=host then routes the collectives through libvdl's host transport over gloo: a rehearsal, not for
+    # reported numbers; the JSON line says which one ran.  When libvdl cannot bind RCCL the run fails (exit code 3).
     comm_mode = os.environ.get("VDL_BENCH_COMM", "native")
     if os.environ.get("VDL_BENCH_BACKEND") == "gloo" and comm_mode == "native":
         comm_mode = "host"                                        # (round-1 spelling of the rehearsal switch)
@@ -510,7 +509,7 @@ def main():
         plan.set_jit(True, tune=args.jit == "tune")
     nw, ops = plan.partial_spec()
 
-    n_ranks, transport, torch_group = 1, "none (single GPU)", None
+    n_ranks, transport = 1, "none (single GPU)"
     if world > 1 and comm_mode == "native":
         # every rank binds RCCL first (so that nobody blocks in ncclCommInitRank while a peer could not even load the
         # library), rank 0's id travels over the control channel, then the communicator is built
@@ -527,12 +526,11 @@ def main():
                 why = ""
             except m.VdlError as exc:
                 why = str(exc)
-            if not everybody(why == ""):
-                comm_mode = "torch"
-        else:
-            comm_mode = "torch"
-        if comm_mode == "torch" and why:
-            print("bench.py[%d]: libvdl could not set up RCCL (%s); falling back to torch.distributed collectives" % (rank, why), file=sys.stderr)
+        if not everybody(uid is not None and why == ""):
+            # no quiet fallback: the collectives of a reported number run inside libvdl over RCCL, or the run fails (round 4: the
+            # torch.distributed all-reduce formulation from Python is gone from this script)
+            print("bench.py[%d]: libvdl could not set up RCCL%s" % (rank, (": " + why) if why else " (another rank failed)"), file=sys.stderr)
+            sys.exit(3)
     if world > 1 and comm_mode == "host":
         def gloo_all_gather(send):
             t = torch.frombuffer(bytearray(send), dtype=torch.uint8)
@@ -554,17 +552,13 @@ def main():
             print("bench.py: the communicator has %d rank(s), --gpus asked for %d" % (n_ranks, args.gpus), file=sys.stderr)
             sys.exit(2)
     query, bufs = None, None
-    if world == 1 or comm_mode == "torch":
-        # one dedicated stream for everything: engine kernels, torch tensor ops and the collective
+    if world == 1:
+        # one rank: local phase -> finalisation, pipelined over two partial buffers (no communicator, nothing to merge)
         side = torch.cuda.Stream()
         torch.cuda.set_stream(side)
         eng.use_torch_stream()
-        if world > 1:
-            torch_group = dist.new_group(backend="nccl")
-            n_ranks = dist.get_world_size(torch_group)
-            transport = "torch.distributed nccl all-reduce of %d int64 words from Python (fallback)" % nw
         bufs = [torch.zeros(max(nw, 1), dtype=torch.int64, device="cuda") for _ in range(2)]
-        query = m.ShardedQuery(plan, bufs[0], dist if world > 1 else None, torch_group)
+        query = m.ShardedQuery(plan, bufs[0])
 
     scan_us = []
 
@@ -720,7 +714,18 @@ def main():
                        "sharding": "row-range, one process per GPU" if world > 1 else "single GPU",
                        "finalise": transport if world > 1 else "local"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "frac": achieved / HBM_PEAK_GBPS,
+                         # SURVEY.md 8(d)'s own figure -- algorithmic bytes (every column of every row, once) / time / peak -- of the kernel
+                         # that really reads them all, timed in this run after the timed region (null with --jit off --no-secondary etc.)
+                         "frac_algorithmic_read_everything": (read_everything or {}).get("frac"),
+                         "definition": {"frac": "bytes the TIMED kernel moved (counted per launch: bytes_moved_per_launch; = FETCH_SIZE x 2 of its committed "
+                                                "profile, traffic) / its mean launch time / peak: <= 1 by construction; a staged scan skips cache lines "
+                                                "that hold no live row, so this is below the algorithmic 28 B/row rate",
+                                        "frac_algorithmic_read_everything": "SURVEY.md 8(d): rows x bytes_per_row / launch time / peak for the kernel "
+                                                                            "that reads every column of every row (read_everything_kernel), same run",
+                                        "algorithmic_equivalent_GBps": "rows x bytes_per_row / the TIMED kernel's launch time: may exceed the peak, it "
+                                                                       "prices bytes the kernel did not move"},
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel_label, "kernel_us": kern_us,
                          "bytes_moved_per_launch": moved,
                          "bytes_moved_source": "vdl_plan_scan_traffic: " + moved_detail,

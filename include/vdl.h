@@ -286,10 +286,13 @@ int  vdl_plan_sharded_route(vdl_ctx *ctx, vdl_plan *plan, const char **route, in
 int  vdl_run_sharded(vdl_ctx *ctx, vdl_plan *plan);     /* results through vdl_output as after vdl_run */
 int  vdl_run_sharded_begin(vdl_ctx *ctx, vdl_plan *plan, int slot);
 int  vdl_run_sharded_end(vdl_ctx *ctx, vdl_plan *plan, int slot);
-/* The merge rule of the gathered partial words on the host (what the device kernel computes): `gathered` holds, per rank,
- * n_words words followed by the same words with VDL_REDUCE_FIRST entries resolved to values.  For hosts / tests that want to
- * check a transport without a GPU. */
-int  vdl_comm_merge_host(int world, int64_t n_words, const int32_t *ops, const int64_t *gathered, int64_t *out);
+/* The merge rule of the gathered partial words on the host (what the device kernel computes): `gathered` holds, per rank, a block
+ * of `stride_words` int64 -- n_words words, the same words with VDL_REDUCE_FIRST entries resolved to values and, in the blocks
+ * vdl_run_sharded itself gathers, ONE status word of the rank's local phase (stride_words = 2 * n_words + 1; pass 0 for bare blocks
+ * of 2 * n_words).  status_out (may be NULL; needs the status word): [0] = the first non-zero status over the ranks, [1] = that
+ * rank (-1: every local phase succeeded).  For hosts / tests that want to check a transport without a GPU. */
+int  vdl_comm_merge_host(int world, int64_t n_words, const int32_t *ops, const int64_t *gathered, int64_t stride_words, int64_t *out,
+                         int64_t *status_out);
 
 #ifdef __cplusplus
 }

@@ -94,7 +94,7 @@ def load():
         "vdl_run_sharded": (i32, [vp, vp]),
         "vdl_run_sharded_begin": (i32, [vp, vp, i32]),
         "vdl_run_sharded_end": (i32, [vp, vp, i32]),
-        "vdl_comm_merge_host": (i32, [i32, i64, P(ctypes.c_int32), P(i64), P(i64)]),
+        "vdl_comm_merge_host": (i32, [i32, i64, P(ctypes.c_int32), P(i64), i64, P(i64), P(i64)]),
     })
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError here = the library does not export the ABI

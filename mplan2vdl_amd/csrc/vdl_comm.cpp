@@ -140,6 +140,21 @@ static void all_gather(vdl_ctx *c, const void *dev_send, void *dev_recv, size_t 
     HIP_CHECK(hipStreamSynchronize(s));          // the staging buffer is reused by the next call
 }
 
+// `mine.size()` int64 words from every rank, rank after rank, on the host: the status / count exchanges of the routes below.  Every rank
+// of a route must reach each of these exactly once per run, whatever happened to its local phase -- that is what they are for.
+static std::vector<int64_t> gather_words(vdl_ctx *c, const std::vector<int64_t> &mine) {
+    CommState &m = comm_of(c);
+    if (m.world == 1) return mine;
+    const size_t k = mine.size();
+    std::vector<int64_t> all(k * (size_t)m.world);
+    BufP dsend = dev_alloc(c, sizeof(int64_t) * k), drecv = dev_alloc(c, sizeof(int64_t) * k * (size_t)m.world);
+    HIP_CHECK(hipMemcpyAsync(dsend->p, mine.data(), sizeof(int64_t) * k, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));                        // (`mine` is the caller's)
+    all_gather(c, dsend->p, drecv->p, sizeof(int64_t) * k, c->stream);
+    c->fetch_to_host(drecv->p, all.size(), all.data(), c->stream);
+    return all;
+}
+
 // every column c of `ncols`: rows [soff[d], soff[d] + scnt[d]) of send + c * n_send go to rank d, which receives them at
 // rows [roff[me-th source]..) of recv + c * n_recv, pieces in source-rank order
 static void all_to_all_columns(vdl_ctx *c, const int64_t *dev_send, int64_t n_send, const std::vector<int64_t> &scnt, int64_t *dev_recv,
@@ -368,13 +383,36 @@ static std::string semi_route_refusal(const vdl_plan *p) {
     for (const GroupScanPlan &gp : p->fused.gscans) if (gp.table == t) return "a scan reads the sharded table itself";
     return "";
 }
+// Every rank exchanges {status, which sets it holds, their sizes} BEFORE the sets travel, and does so exactly once per run: from the
+// hook behind the prelude when that ran, otherwise -- the prelude threw (a missing column, a HIP error), or the fused plan was
+// abandoned for this data and the hook never came -- from here, with its failure, so that no peer is left waiting in ncclAllGather.
 static void sharded_semi(vdl_ctx *c, vdl_plan *p) {
     need_device(c);
     CommState &m = comm_of(c);
     struct Restore { vdl_plan *p; ~Restore() { p->after_prelude = nullptr; p->semi_unclamped = false; } } restore{p};
     p->semi_unclamped = true;
-    p->after_prelude = [&m](vdl_ctx *cc, vdl_plan *pp) {
+    bool met = false;                                          // this rank has taken part in the status exchange of this run
+    auto meet = [&m, &met](vdl_ctx *cc, int64_t status, int64_t mask, int64_t words) {
+        met = true;
+        const std::vector<int64_t> all = gather_words(cc, {status, mask, words});
+        for (int r = 0; r < m.world; r++)
+            if (all[(size_t)r * 3] != VDL_OK) {
+                if (status != VDL_OK) return;                  // (this rank reports its own error)
+                throw Error(VDL_ERR_UNSUPPORTED, "sharded run: the semi-join sets could not be built on rank " + std::to_string(r) + " (its error is reported there)");
+            }
+        for (int r = 0; r < m.world; r++)
+            if (all[(size_t)r * 3 + 1] != mask || all[(size_t)r * 3 + 2] != words)
+                throw Error(VDL_ERR_SHAPE, "sharded run: rank " + std::to_string(r) + " builds other semi-join sets than rank " + std::to_string(m.rank) + " (the replicated tables differ)");
+    };
+    p->after_prelude = [&m, &meet](vdl_ctx *cc, vdl_plan *pp) {
         const FusedPlan &F = pp->fused;
+        int64_t mask = 0, total_words = 0;
+        for (size_t k = 0; k < F.prelude.size(); k++)
+            if (F.prelude[k].kind == PreludeItem::SEMI_BITMAP && pp->prelude_buf[k]) {
+                mask |= (int64_t)1 << (k & 62);
+                total_words += std::max<int64_t>((pp->prelude_n[k] + 63) >> 6, 1);
+            }
+        meet(cc, VDL_OK, mask, total_words);
         for (size_t k = 0; k < F.prelude.size(); k++) {
             if (F.prelude[k].kind != PreludeItem::SEMI_BITMAP || !pp->prelude_buf[k]) continue;
             const int64_t words = std::max<int64_t>((pp->prelude_n[k] + 63) >> 6, 1);
@@ -387,10 +425,16 @@ static void sharded_semi(vdl_ctx *c, vdl_plan *p) {
             HIP_CHECK(launch_or_sets((const uint64_t *)recv->p, m.world, words, (uint64_t *)pp->prelude_buf[k]->p, cc->stream));
         }
     };
-    if (vdl_run(c, p) != VDL_OK) throw Error(VDL_ERR_DEVICE, c->err);
+    const int rc = vdl_run(c, p);
+    const std::string own = c->err;
+    bool abandoned = false;
+    std::string label;
     for (const Timing &t : p->timings)
-        if (t.label.find("fusedPlanAbandoned") != std::string::npos)
-            throw Error(VDL_ERR_UNSUPPORTED, "sharded run: the fused plan does not hold for this data (" + t.label + "), and statement by statement the plan has no sharded route");
+        if (t.label.find("fusedPlanAbandoned") != std::string::npos) { abandoned = true; label = t.label; }
+    if (!met) meet(c, rc != VDL_OK ? rc : (int64_t)VDL_ERR_UNSUPPORTED, 0, 0);      // the hook never ran: say so to the peers, who stop with this rank
+    if (rc != VDL_OK) throw Error(rc, own);
+    if (abandoned)
+        throw Error(VDL_ERR_UNSUPPORTED, "sharded run: the fused plan does not hold for this data (" + label + "), and statement by statement the plan has no sharded route");
 }
 
 // ---- the "front" route: a plan whose work on the sharded table is a fused front (select + take: vdl_fuse.h ProjPlan) ----
@@ -472,15 +516,7 @@ static void sharded_front(vdl_ctx *c, vdl_plan *p) {
     for (const auto &kv : c->cols)
         if (kv.first.compare(0, J.table.size() + 1, J.table + ".") == 0 && kv.first.find(".heap") == std::string::npos) { n_local = kv.second.n; break; }
     // {status, rows}: a rank without the table says so here and everybody stops together
-    std::vector<int64_t> rows((size_t)m.world * 2, 0);
-    {
-        BufP dsend = dev_alloc(c, sizeof(int64_t) * 2), drecv = dev_alloc(c, sizeof(int64_t) * 2 * (size_t)m.world);
-        const int64_t mine[2] = {n_local < 0 ? (int64_t)VDL_ERR_ARG : (int64_t)VDL_OK, std::max<int64_t>(n_local, 0)};
-        HIP_CHECK(hipMemcpyAsync(dsend->p, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
-        HIP_CHECK(hipStreamSynchronize(c->stream));
-        all_gather(c, dsend->p, drecv->p, sizeof mine, c->stream);
-        c->fetch_to_host(drecv->p, rows.size(), rows.data(), c->stream);
-    }
+    const std::vector<int64_t> rows = gather_words(c, {n_local < 0 ? (int64_t)VDL_ERR_ARG : (int64_t)VDL_OK, std::max<int64_t>(n_local, 0)});
     int64_t row0 = 0, n_global = 0;
     for (int r = 0; r < m.world; r++) {
         if (rows[(size_t)r * 2] != VDL_OK) throw Error(VDL_ERR_ARG, "sharded run: rank " + std::to_string(r) + " holds no column of table '" + J.table + "'");
@@ -501,22 +537,16 @@ static void sharded_front(vdl_ctx *c, vdl_plan *p) {
             if (sel) {
                 bufs.push_back(sel->idx);
                 for (int id : JJ.nodes) {
-                    const DVec &v = over.at(id);
+                    const auto at = over.find(id);             // (a missing vector is a failure to REPORT below, not to throw ahead of the collective)
+                    if (at == over.end()) { sel.reset(); break; }
+                    const DVec &v = at->second;
                     if (v.kind != DVec::SPARSE || v.sel != sel || v.valid) { sel.reset(); break; }
                     if (std::find(bufs.begin(), bufs.end(), v.data) == bufs.end()) bufs.push_back(v.data);
                 }
             }
         }
         const bool ok = front && sel;
-        std::vector<int64_t> all((size_t)m.world * 2, 0);
-        {
-            BufP dsend = dev_alloc(cc, sizeof(int64_t) * 2), drecv = dev_alloc(cc, sizeof(int64_t) * 2 * (size_t)m.world);
-            const int64_t mine[2] = {ok ? (int64_t)VDL_OK : (int64_t)VDL_ERR_UNSUPPORTED, ok ? sel->m : 0};
-            HIP_CHECK(hipMemcpyAsync(dsend->p, mine, sizeof mine, hipMemcpyHostToDevice, s));
-            HIP_CHECK(hipStreamSynchronize(s));
-            all_gather(cc, dsend->p, drecv->p, sizeof mine, s);
-            cc->fetch_to_host(drecv->p, all.size(), all.data(), s);
-        }
+        const std::vector<int64_t> all = gather_words(cc, {ok ? (int64_t)VDL_OK : (int64_t)VDL_ERR_UNSUPPORTED, ok ? sel->m : 0});
         if (!ok) throw Error(VDL_ERR_UNSUPPORTED, "sharded run: the fused front did not run on this rank (" + (failure.empty() ? (pp->fallback_note.empty() ? std::string("its vectors do not share one selection") : pp->fallback_note) : failure) +
                                                    "), and statement by statement the plan has no sharded route");
         std::vector<int64_t> cnt((size_t)m.world);
@@ -589,40 +619,49 @@ static void sharded_replicate(vdl_ctx *c, vdl_plan *p) {
     need_device(c);
     CommState &m = comm_of(c);
     const std::string &t = p->sharded_table;
-    if (p->replica.empty() || p->replica_version != c->catalog_version) {
+    // Whether the table has to be gathered (again) is decided by ALL ranks on EVERY run -- one exchange of {needs it, status, rows, row
+    // bytes, bytes this device can spare}: a rank whose catalog alone moved (a column uploaded again, a retry after an error) would
+    // otherwise enter the collectives below by itself and wait there for ever.  The same words carry what the replica will cost, so
+    // that a table that does not fit is refused by every rank together, with the reason, instead of an out-of-memory on some.
+    std::vector<std::string> names;
+    for (int id : p->prog.order) {
+        const Node &n = p->prog.at(id);
+        if (n.op != Op::Load || n.column.compare(0, t.size() + 1, t + ".") != 0 || n.column.find(".heap") != std::string::npos) continue;
+        if (std::find(names.begin(), names.end(), n.column) == names.end()) names.push_back(n.column);
+    }
+    int64_t n_local = -1, status = VDL_OK, row_bytes = 0;
+    for (const std::string &name : names) {                     // every rank holds the same columns, all as long as each other
+        auto it = c->cols.find(name);
+        if (it == c->cols.end()) { status = VDL_ERR_COLUMN; break; }
+        if (n_local >= 0 && it->second.n != n_local) { status = VDL_ERR_SHAPE; break; }
+        n_local = it->second.n;
+        row_bytes += (int64_t)it->second.width;
+    }
+    const bool stale = p->replica.empty() || p->replica_version != c->catalog_version;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+    int64_t held = 0;                                           // what a stale replica of this plan gives back before the new one is made
+    for (const auto &kv : p->replica) held += kv.second.n * (int64_t)kv.second.width;
+    const std::vector<int64_t> all = gather_words(c, {stale ? 1 : 0, status, std::max<int64_t>(n_local, 0), row_bytes, (int64_t)free_b + (int64_t)c->pool->idle_bytes() + held});
+    bool gather = false;
+    int64_t n_global = 0;
+    for (int r = 0; r < m.world; r++) {
+        gather |= all[(size_t)r * 5] != 0;
+        if (all[(size_t)r * 5 + 1] != VDL_OK || all[(size_t)r * 5 + 3] != row_bytes)
+            throw Error(VDL_ERR_COLUMN, "sharded run: rank " + std::to_string(r) + " does not hold the columns of table '" + t + "' this plan loads (or they differ in length or width)");
+        n_global += all[(size_t)r * 5 + 2];
+    }
+    if (gather) {
+        const int64_t need = n_global * row_bytes;
+        for (int r = 0; r < m.world; r++)
+            if (need + (need >> 3) > all[(size_t)r * 5 + 4])    // (an eighth of headroom for the run itself)
+                throw Error(VDL_ERR_DEVICE, "sharded run: the replicate route needs " + std::to_string(need) + " bytes per rank for table '" + t + "' (" + std::to_string(n_global) +
+                                            " rows x " + std::to_string(row_bytes) + " B of loaded columns); rank " + std::to_string(r) + " can spare " + std::to_string(all[(size_t)r * 5 + 4]));
         p->replica.clear();
-        std::vector<std::string> names;
-        for (int id : p->prog.order) {
-            const Node &n = p->prog.at(id);
-            if (n.op != Op::Load || n.column.compare(0, t.size() + 1, t + ".") != 0 || n.column.find(".heap") != std::string::npos) continue;
-            if (std::find(names.begin(), names.end(), n.column) == names.end()) names.push_back(n.column);
-        }
-        // {status, rows}: every rank holds the same columns, all as long as each other
-        int64_t n_local = -1, status = VDL_OK;
-        for (const std::string &name : names) {
-            auto it = c->cols.find(name);
-            if (it == c->cols.end()) { status = VDL_ERR_COLUMN; break; }
-            if (n_local >= 0 && it->second.n != n_local) { status = VDL_ERR_SHAPE; break; }
-            n_local = it->second.n;
-        }
-        std::vector<int64_t> rows((size_t)m.world * 2, 0);
-        {
-            BufP dsend = dev_alloc(c, sizeof(int64_t) * 2), drecv = dev_alloc(c, sizeof(int64_t) * 2 * (size_t)m.world);
-            const int64_t mine[2] = {status, std::max<int64_t>(n_local, 0)};
-            HIP_CHECK(hipMemcpyAsync(dsend->p, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
-            HIP_CHECK(hipStreamSynchronize(c->stream));
-            all_gather(c, dsend->p, drecv->p, sizeof mine, c->stream);
-            c->fetch_to_host(drecv->p, rows.size(), rows.data(), c->stream);
-        }
-        int64_t n_global = 0;
-        for (int r = 0; r < m.world; r++) {
-            if (rows[(size_t)r * 2] != VDL_OK) throw Error(VDL_ERR_COLUMN, "sharded run: rank " + std::to_string(r) + " does not hold the columns of table '" + t + "' this plan loads (or they differ in length)");
-            n_global += rows[(size_t)r * 2 + 1];
-        }
         for (const std::string &name : names) {
             const Column &mine = c->cols.at(name);
             std::vector<int64_t> bytes((size_t)m.world);
-            for (int r = 0; r < m.world; r++) bytes[(size_t)r] = rows[(size_t)r * 2 + 1] * (int64_t)mine.width;
+            for (int r = 0; r < m.world; r++) bytes[(size_t)r] = all[(size_t)r * 5 + 2] * (int64_t)mine.width;
             Column whole;
             whole.width = mine.width; whole.n = n_global;
             whole.owned = dev_alloc(c, (size_t)std::max<int64_t>(n_global * (int64_t)mine.width, 8));
@@ -633,8 +672,11 @@ static void sharded_replicate(vdl_ctx *c, vdl_plan *p) {
         HIP_CHECK(hipStreamSynchronize(c->stream));
         p->replica_version = c->catalog_version;
     }
-    struct Restore { vdl_ctx *c; vdl_plan *p; int64_t row_offset; ~Restore() { c->overlay = nullptr; p->row_offset = row_offset; } } restore{c, p, p->row_offset};
+    // (the overlay changes what find_col hands out under an unchanged catalog: bindings and kernels specialised for column addresses are
+    // keyed by binding_version(), which moves with it)
+    struct Restore { vdl_ctx *c; vdl_plan *p; int64_t row_offset; ~Restore() { c->overlay = nullptr; c->overlay_epoch++; p->row_offset = row_offset; } } restore{c, p, p->row_offset};
     c->overlay = &p->replica;
+    c->overlay_epoch++;
     p->row_offset = 0;                                          // every rank runs the whole table
     if (vdl_run(c, p) != VDL_OK) throw Error(VDL_ERR_DEVICE, c->err);
 }
@@ -804,9 +846,18 @@ int vdl_run_sharded(vdl_ctx *c, vdl_plan *p) {
 
 /* The merge of the gathered partial words on the HOST: the same per-word rule the device kernel applies (merge_word,
  * vdl_kernels.h), exported so that hosts and CPU tests can check a transport without a GPU. */
-int vdl_comm_merge_host(int world, int64_t n_words, const int32_t *ops, const int64_t *gathered, int64_t *out) {
-    if (world < 1 || n_words < 0 || (n_words && (!ops || !gathered || !out))) return VDL_ERR_ARG;
-    for (int64_t i = 0; i < n_words; i++) out[i] = merge_word(gathered, world, n_words, ops[i], i, 2 * n_words);
+int vdl_comm_merge_host(int world, int64_t n_words, const int32_t *ops, const int64_t *gathered, int64_t stride_words, int64_t *out, int64_t *status_out) {
+    if (stride_words == 0) stride_words = 2 * n_words;
+    if (world < 1 || n_words < 0 || stride_words < 2 * n_words || (n_words && (!ops || !gathered || !out))) return VDL_ERR_ARG;
+    if (status_out && (stride_words < 2 * n_words + 1 || !gathered)) return VDL_ERR_ARG;
+    for (int64_t i = 0; i < n_words; i++) out[i] = merge_word(gathered, world, n_words, ops[i], i, stride_words);
+    if (status_out) {                                           // as k_merge_words: the first rank whose local phase failed
+        status_out[0] = 0; status_out[1] = -1;
+        for (int r = world - 1; r >= 0; r--) {
+            const int64_t x = gathered[(int64_t)r * stride_words + 2 * n_words];
+            if (x != 0) { status_out[0] = x; status_out[1] = r; }
+        }
+    }
     return VDL_OK;
 }
 

@@ -579,12 +579,12 @@ static int64_t bind_vcols(vdl_ctx *c, const std::string &table, const std::vecto
 static hipFunction_t front_kernel(vdl_ctx *c, vdl_plan *p, const std::string &role, jit::Kind kind, const MScanCols &cols, const MScanDesc &d) {
     if (!p->use_jit) return nullptr;
     vdl_plan::FrontKernel &fk = p->front_jit[role];
-    if (fk.version == c->catalog_version) return fk.k ? fk.k->fn : nullptr;
+    if (fk.version == c->binding_version()) return fk.k ? fk.k->fn : nullptr;
     {   // a rebuild after a catalog change: this role's old line leaves the note
         const size_t at = p->jit_note.find(role + ": ");
         if (at != std::string::npos) { const size_t end = p->jit_note.find("; ", at); p->jit_note.erase(at, end == std::string::npos ? std::string::npos : end + 2 - at); }
     }
-    fk.version = c->catalog_version;
+    fk.version = c->binding_version();
     fk.k = nullptr;
     jit::Shape sh;
     sh.nc = cols.ncol; sh.u = 4; sh.vec = kind == jit::SELECT ? project_select_vec(cols) : false; sh.der = true;
@@ -712,9 +712,9 @@ void run_prelude(vdl_ctx *c, vdl_plan *p) {
 
 void run_fused_local(vdl_ctx *c, vdl_plan *p, int64_t *dev_words, bool single_rank) {
     const char *tune_a = getenv("VDL_SCAN_TUNE"), *tune_b = getenv("VDL_GROUP_TUNE");
-    if (!p->bound || p->bound_version != c->catalog_version || tune_a || tune_b) {   // tuning sweeps re-bind every run
+    if (!p->bound || p->bound_version != c->binding_version() || tune_a || tune_b) {   // tuning sweeps re-bind every run
         bind_fused(c, p);
-        p->bound_version = c->catalog_version;
+        p->bound_version = c->binding_version();
     }
     run_prelude(c, p);
     if (p->use_jit && p->jit_tune && !p->jit_tuned) {

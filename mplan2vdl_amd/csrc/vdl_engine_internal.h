@@ -69,6 +69,7 @@ struct Pool {
         live_bytes -= cls;
     }
     void trim() { for (auto &kv : free_list) (void)hipFree(kv.second); free_list.clear(); }
+    size_t idle_bytes() const { size_t b = 0; for (const auto &kv : free_list) b += kv.first; return b; }     // parked buffers: handed back to the device when an allocation fails
     bool closed = false;
     ~Pool() { trim(); }
 };
@@ -179,6 +180,9 @@ struct vdl_ctx {
     std::map<std::string, Column> cols;
     uint64_t catalog_version = 1;      // bumped on every catalog change: plans re-bind only when it moved
     const std::map<std::string, Column> *overlay = nullptr;     // columns that stand in for catalog entries during one run (vdl_comm.cpp: sharded_replicate)
+    uint64_t overlay_epoch = 0;                                  // moves whenever the overlay is set or cleared
+    // what bindings and kernels specialised for column addresses / widths / lengths are keyed by: the catalog's state AND the overlay's
+    uint64_t binding_version() const { return catalog_version + (overlay_epoch << 40); }
     std::shared_ptr<Pool> pool = std::make_shared<Pool>();
     std::shared_ptr<CommState> comm;       // vdl_comm_init / vdl_comm_init_host
     std::string err;

@@ -157,6 +157,44 @@ def test_semi_join_sets_are_merged_across_the_ranks(world):
     assert ran >= 20, ran
 
 
+def test_a_failed_prelude_on_the_set_route_reaches_every_rank():
+    """The set route (Q4): the sets travel in an all-gather issued from a hook behind the prelude.  A rank whose prelude fails -- here
+    its replicated orders table lacks the date column the dimension selection reads -- never reaches that hook; it must still meet
+    its peers in the status exchange that precedes the sets, or they wait in the collective for ever.  Every rank returns an error,
+    the failing one its own; the next query on the same communicator, with the catalog repaired, runs normally."""
+    cfg = frontend.load_metadata(META)
+    text = frontend.compile_plan(open(os.path.join(META, "04.sql.mplan")).read(), cfg)
+    cols = catalog.synth_columns(META, cfg, text, scale=1e-3, seed=7)
+    want = oracle_run(text, cols)
+    shards = lineitem_shards(cols, 2)
+    errors, after = [], [None, None]
+
+    def work(rank, rv):
+        r0, c = shards[rank]
+        e = engine_with(c)
+        e.comm_init_host(rank, 2, *rv.transport(rank))
+        p = e.parse(text)
+        p.set_sharded_table("lineitem")
+        p.set_row_offset(r0)
+        assert p.sharded_route() == ("set", True)
+        if rank == 1:
+            e.drop("orders.o_orderdate")
+        try:
+            p.run_sharded()
+        except m.VdlError as exc:
+            errors.append((rank, str(exc)))
+        if rank == 1:
+            e.upload("orders.o_orderdate", c["orders.o_orderdate"])
+        after[rank] = p.run_sharded()["results"]
+        e.close()
+
+    run_ranks(2, work, timeout=120)
+    assert sorted(r for r, _ in errors) == [0, 1], errors
+    assert any(r == 0 and "on rank 1" in msg for r, msg in errors), errors
+    assert any(r == 1 and "o_orderdate" in msg for r, msg in errors), errors
+    assert after == [want, want]
+
+
 @pytest.mark.parametrize("world", [1, 2, 3])
 def test_a_global_fold_beside_the_partition_is_merged_with_the_counts(world):
     """TPC-H Q11: GROUP BY ps_partkey HAVING sum(..) > (select sum(..) * 0.0001 ..) over the same filtered partsupp rows -- a Partition
@@ -199,10 +237,15 @@ def test_a_plan_no_route_serves_runs_on_the_replicated_table(world):
         assert p.sharded_route() == ("replicate", True)
         first = p.run_sharded()["results"]
         second = p.run_sharded()["results"]
+        # the catalog of ONE rank moves (the same column uploaded again): whether the table is gathered again is agreed by all ranks
+        # on every run, so the others join the collectives instead of leaving this rank waiting in them
+        if rank == world - 1:
+            e.upload("lineitem.l_quantity", c["lineitem.l_quantity"])
+        third = p.run_sharded()["results"]
         e.close()
-        return first, second
+        return first, second, third
 
-    assert run_ranks(world, work) == [(want, want)] * world
+    assert run_ranks(world, work, timeout=120) == [(want, want, want)] * world
 
 
 @pytest.mark.parametrize("world", [2, 3])

@@ -328,17 +328,21 @@ def _grouped_partials(lo, hi, groups=6):
 GROUP_OPS = [_lib.REDUCE_SUM, _lib.REDUCE_SUM, _lib.REDUCE_MAX, _lib.REDUCE_MIN, _lib.REDUCE_FIRST]
 
 
-def _merge_host(world, ops, gathered):
+def _merge_host(world, ops, gathered, with_status=False):
+    """gathered: per rank the words raw, the words resolved and -- with_status: the block layout vdl_run_sharded gathers -- ONE status word"""
     import ctypes
 
     L = _lib.load()
     nw = len(ops)
     out = np.zeros(nw, np.int64)
+    status = np.zeros(2, np.int64)
     c_ops = (ctypes.c_int32 * nw)(*ops)
     g = np.ascontiguousarray(gathered, np.int64)
+    assert len(g) == world * (2 * nw + (1 if with_status else 0))
     i64p = ctypes.POINTER(ctypes.c_int64)
-    assert L.vdl_comm_merge_host(world, nw, c_ops, g.ctypes.data_as(i64p), out.ctypes.data_as(i64p)) == 0
-    return out
+    assert L.vdl_comm_merge_host(world, nw, c_ops, g.ctypes.data_as(i64p), 2 * nw + 1 if with_status else 0, out.ctypes.data_as(i64p),
+                                 status.ctypes.data_as(i64p) if with_status else None) == 0
+    return (out, status.tolist()) if with_status else out
 
 
 def _gather_worker(rank, world, port, q):
@@ -347,10 +351,11 @@ def _gather_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = m.shard_rows(5000, rank, world)
     words, resolved = _grouped_partials(lo, hi)
-    send = torch.from_numpy(np.concatenate([words, resolved]))
+    send = torch.from_numpy(np.concatenate([words, resolved, [0]]))       # the block vdl_run_sharded sends: raw, resolved, status of the local phase
     recv = [torch.zeros_like(send) for _ in range(world)]
     dist.all_gather(recv, send)                           # the one collective of the fold route
-    merged = _merge_host(world, GROUP_OPS * 6, torch.cat(recv).numpy())
+    merged, status = _merge_host(world, GROUP_OPS * 6, torch.cat(recv).numpy(), with_status=True)
+    assert status == [0, -1]
     q.put((rank, merged.tolist()))
     dist.barrier()
     dist.destroy_process_group()
@@ -385,3 +390,7 @@ def test_merge_rule_edge_cases():
     assert _merge_host(3, ops, g).tolist() == [np.int64(3 * np.uint64(big)).item() if False else int((3 * big + 2 ** 63) % 2 ** 64 - 2 ** 63), big, small, 0]
     # one rank: the resolved half is the answer
     assert _merge_host(1, ops, np.array([1, 2, 3, 40, 1, 2, 3, 77], np.int64)).tolist() == [1, 2, 3, 77]
+    # the blocks vdl_run_sharded gathers end with the status of the rank's local phase: the first failing rank is handed back
+    blocks = np.array([1, 2, 3, 40, 1, 2, 3, 77, 0,   5, 1, 9, 41, 5, 1, 9, 88, -7,   2, 0, 4, 39, 2, 0, 4, 99, -3], np.int64)
+    merged, status = _merge_host(3, ops, blocks, with_status=True)
+    assert merged.tolist() == [8, 0, 9, 99] and status == [-7, 1]
