@@ -596,6 +596,29 @@ static hipFunction_t front_kernel(vdl_ctx *c, vdl_plan *p, const std::string &ro
     return fk.k ? fk.k->fn : nullptr;
 }
 
+// the one-pass front specialised for this plan: two descriptors in one kernel (jit::front_source)
+static int front_take_cols(const MScanCols &tcols) { return tcols.ncol <= 12 ? 12 : kMaxVCols; }
+static hipFunction_t front_kernel_one_pass(vdl_ctx *c, vdl_plan *p, const MScanCols &scols, const MScanDesc &sd, const MScanCols &tcols, const MScanDesc &td) {
+    if (!p->use_jit) return nullptr;
+    const std::string role = "front";
+    vdl_plan::FrontKernel &fk = p->front_jit[role];
+    if (fk.version == c->binding_version()) return fk.k ? fk.k->fn : nullptr;
+    {
+        const size_t at = p->jit_note.find(role + ": ");
+        if (at != std::string::npos) { const size_t end = p->jit_note.find("; ", at); p->jit_note.erase(at, end == std::string::npos ? std::string::npos : end + 2 - at); }
+    }
+    fk.version = c->binding_version();
+    fk.k = nullptr;
+    jit::Shape sh;
+    sh.nc = scols.ncol; sh.u = 4; sh.vec = project_select_vec(scols); sh.der = true;
+    std::vector<char> code;
+    std::string why;
+    if (jit::compile(jit::front_source(mscan_args(scols), sd, mscan_args(tcols), td, sh, tcols.ncol), c->arch, code, why)) fk.k = jit::load(code, why, jit::entry_name(jit::FRONT));
+    if (fk.k) p->jit_note += role + ": " + jit::entry_name(jit::FRONT) + "<" + std::to_string(sh.nc) + "," + std::to_string(tcols.ncol) + ">, " + std::to_string(code.size()) + " B of code; ";
+    else p->jit_note += role + ": not specialised (" + why.substr(0, 400) + "); ";
+    return fk.k ? fk.k->fn : nullptr;
+}
+
 // Dimension-side work of scans with derived columns (FusedPlan::prelude): the per-operator executor runs the statements
 // that hold the dimension selections (filters on the dimension table, joins of dimensions with further dimensions) and
 // their validity bitmaps become the lookup tables of the fact scan; LIKE patterns are evaluated once per heap offset.
@@ -983,28 +1006,16 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
     int64_t m = 0;
     std::vector<BufP> outs(distinct.size());
     if (n > 0 && !J.never) {
-        BufP counts = dev_alloc(c, sizeof(int64_t) * (size_t)(ntiles + 1)), offsets = dev_alloc(c, sizeof(int64_t) * (size_t)(ntiles + 1));
-        BufP scratch = dev_alloc(c, (size_t)project_scratch_bytes(n));
-        BufP carried[kMaxCarry];
-        for (int i = 0; i < kMaxCarry; i++) {
-            sdesc->carry_ptr[i] = d.carry_ptr[i] = nullptr;
-            if (i < __builtin_popcount(d.carry)) {
-                carried[i] = dev_alloc(c, (size_t)project_carry_bytes(n));
-                sdesc->carry_ptr[i] = d.carry_ptr[i] = (int64_t *)carried[i]->p;
-            }
-        }
+        // ONE kernel (vdl_mscan_body.h: project_front_body): deciding columns, survivors' ranks, where they go (look-back over the tiles'
+        // counts) and the output vectors.  How long those are is only known afterwards: the kernel writes nothing beyond the capacity it
+        // is given and leaves the survivors' number in pinned memory.  From a plan's second run on the capacity is an eighth more than
+        // last time; a first run takes the whole table's length when that is cheap and otherwise counts first (capacity 0: no
+        // survivor is fetched or written); a run that came up short is repeated with the exact number.
         sel->bitmap = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>((n + 63) >> 6, 1));
-        sdesc->tile_counts = (int64_t *)counts->p;
-        sdesc->out_idx = (int64_t *)scratch->p;
         sdesc->out_ptr[0] = (int64_t *)sel->bitmap->p;
-        sdesc->out_ptr[1] = (int64_t *)offsets->p;
-        BufP sums = dev_alloc(c, sizeof(int64_t) * (size_t)(prefix_sum_blocks(ntiles + 1) + 1));
-        HIP_CHECK(launch_project_select(scols, desc_on_device(c, p, "select", *sdesc), c->num_cus, c->stream, front_kernel(c, p, "select", jit::SELECT, scols, *sdesc)));
-        // (the select pass left the counts in `offsets` too, with a 0 behind them: a device-wide exclusive prefix sum over
-        // ntiles + 1 words puts the total there -- Q3 at SF10 has 29 K tiles, a one-block scan took 26 us)
-        HIP_CHECK(launch_prefix_sum((int64_t *)offsets->p, ntiles + 1, (int64_t *)sums->p, c->stream));
-        int64_t *back = c->pinned(1) ? c->pinned(1) : &m;          // (pinned: a pageable destination is staged and costs a second round trip)
-        HIP_CHECK(hipMemcpyAsync(back, (int64_t *)offsets->p + ntiles, sizeof m, hipMemcpyDeviceToHost, c->stream));
+        sdesc->carry_ptr[0] = sdesc->carry_ptr[1] = d.carry_ptr[0] = d.carry_ptr[1] = nullptr;      // (carried values stay in LDS)
+        BufP look = dev_alloc(c, (size_t)project_look_bytes(n)), total = dev_alloc(c, sizeof(int64_t));
+        int64_t *back = c->pinned(1);
         auto room_for = [&](int64_t cap) {
             sel->idx = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(cap, 1));
             d.out_idx = (int64_t *)sel->idx->p;
@@ -1014,33 +1025,26 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
             }
             d.out_cap = cap;
         };
-        auto take = [&] {
-            HIP_CHECK(launch_project_take(cols, desc_on_device(c, p, "take", d), scratch->p, (const int64_t *)counts->p, (const int64_t *)offsets->p,
-                                          c->num_cus, c->stream, front_kernel(c, p, "take", jit::TAKE, cols, d)));
-        };
-        if (p->front_m_seen >= 0 && back != &m && !getenv("VDL_NO_FRONT_GUESS")) {
-            // The number of survivors decides how long the output vectors are, and waiting for it left the GPU idle for 20-30 us in
-            // the middle of every query.  From the second run on the take pass is launched at once, with room for an eighth more
-            // than last time (it writes nothing beyond that), and the host reads the number while the pass runs; a guess that
-            // turns out short costs a second run of the pass.
-            if (!p->front_ev) HIP_CHECK(hipEventCreateWithFlags(&p->front_ev, hipEventDisableTiming));
-            HIP_CHECK(hipEventRecord(p->front_ev, c->stream));
-            const int64_t cap = std::min<int64_t>(n, p->front_m_seen + p->front_m_seen / 8 + 4096);
-            room_for(cap);
-            take();
-            HIP_CHECK(hipEventSynchronize(p->front_ev));
-            m = *back;
-            if (m > cap) {
-                HIP_CHECK(hipStreamSynchronize(c->stream));
-                room_for(m);
-                take();
+        auto pass = [&]() -> int64_t {
+            HIP_CHECK(launch_project_front(scols, desc_on_device(c, p, "select", *sdesc), cols, desc_on_device(c, p, "take", d), look->p, (int64_t *)total->p, back,
+                                           c->num_cus, c->stream, front_kernel_one_pass(c, p, scols, *sdesc, cols, d)));
+            int64_t got = 0;
+            if (back) {
+                if (!p->front_ev) HIP_CHECK(hipEventCreateWithFlags(&p->front_ev, hipEventDisableTiming));
+                HIP_CHECK(hipEventRecord(p->front_ev, c->stream));
+                HIP_CHECK(hipEventSynchronize(p->front_ev));
+                got = *back;
+            } else {
+                c->fetch_to_host(total->p, 1, &got, c->stream);
             }
-        } else {
-            HIP_CHECK(hipStreamSynchronize(c->stream));
-            m = *back;
-            room_for(m);
-            if (m > 0) take();
-        }
+            return got;
+        };
+        const int64_t per_row = (int64_t)sizeof(int64_t) * (int64_t)(distinct.size() + 1);
+        int64_t cap = p->front_m_seen >= 0 ? std::min<int64_t>(n, p->front_m_seen + p->front_m_seen / 8 + 4096)
+                                           : (n * per_row <= ((int64_t)1 << 28) ? n : 0);
+        room_for(cap);
+        m = pass();
+        if (m > cap) { room_for(m); m = pass(); }
         p->front_m_seen = m;
     } else {
         sel->idx = dev_alloc(c, sizeof(int64_t));
@@ -1327,8 +1331,15 @@ int vdl_plan_jit_check(vdl_ctx *c, vdl_plan *p) {
             }
             FrontBound fb;
             bind_front(c, p, fb);
-            build("select", jit::SELECT, fb.scols, *fb.sdesc);
-            build("take", jit::TAKE, fb.cols, *fb.d);
+            {
+                jit::Shape sh;
+                sh.nc = fb.scols.ncol; sh.u = 4; sh.vec = project_select_vec(fb.scols); sh.der = true;
+                std::vector<char> code;
+                std::string log;
+                if (!jit::compile(jit::front_source(mscan_args(fb.scols), *fb.sdesc, mscan_args(fb.cols), *fb.d, sh, fb.cols.ncol), c->arch, code, log))
+                    throw Error(VDL_ERR_UNSUPPORTED, "front does not build: " + log.substr(0, 2000));
+                p->jit_note += std::string("front: ") + jit::entry_name(jit::FRONT) + "<" + std::to_string(sh.nc) + "," + std::to_string(fb.cols.ncol) + ">, " + std::to_string(code.size()) + " B of code; ";
+            }
             return;
         }
         if (!p->fused.ok) throw Error(VDL_ERR_UNSUPPORTED, "the plan has no fused scans: " + p->fused.why_not);

@@ -179,13 +179,13 @@ void cache_write(const std::string &path, const std::string &src, const std::vec
 }  // namespace
 
 // the descriptor as constexpr functions: only what differs from the defaults is written
-static std::string desc_text(Kind kind, const MsArgs &C, const MScanDesc &D) {
+static std::string desc_text(Kind kind, const MsArgs &C, const MScanDesc &D, const char *suffix = "") {
     std::ostringstream o;
     o << "namespace vdl {\n";
-    o << "constexpr MsArgs jit_args() {\n    MsArgs a{};\n";
+    o << "constexpr MsArgs jit_args" << suffix << "() {\n    MsArgs a{};\n";
     o << "    a.ncol = " << C.ncol << "; a.widths = " << C.widths << "ull; a.filtered = " << C.filtered << "u; a.derived = " << C.derived
       << "u; a.lazy = " << C.lazy << "u; a.stages = " << C.stages << "ull;\n    return a;\n}\n";
-    o << "constexpr MScanDesc jit_desc() {\n    MScanDesc d{};\n";
+    o << "constexpr MScanDesc jit_desc" << suffix << "() {\n    MScanDesc d{};\n";
     o << "    d.nagg = " << D.nagg << "; d.nkey = " << D.nkey << "; d.replicas = " << D.replicas << "; d.pmin = " << lit(D.pmin) << "; d.pcount = " << lit(D.pcount) << ";\n";
     int pool = 0;
     for (int k = 0; k < C.ncol; k++) {
@@ -296,7 +296,22 @@ std::string scan_source(Kind kind, const MsArgs &C, const MScanDesc &D, const Sh
     return o.str();
 }
 std::string mscan_source(const MsArgs &C, const MScanDesc &D, const Shape &sh) { return scan_source(MSCAN, C, D, sh); }
-const char *entry_name(Kind kind) { return kind == MSCAN ? "vdl_jit_mscan" : kind == SELECT ? "vdl_jit_project_select" : "vdl_jit_project_take"; }
+// the fused front in one pass: two descriptors -- the deciding columns as the select side numbers them, every column with the outputs
+std::string front_source(const MsArgs &Cs, const MScanDesc &Ds, const MsArgs &Ct, const MScanDesc &Dt, const Shape &sh, int nct) {
+    std::ostringstream o;
+    o << "#define VDL_SPEC_UNROLL _Pragma(\"unroll\")\n";
+    o << "#define VDL_PROJ_U " << VDL_PROJ_U_HOST << "\n" << kEmbedded << "\n" << desc_text(SELECT, Cs, Ds, "_s") << desc_text(TAKE, Ct, Dt, "_t");
+    const char *b = sh.vec ? "true" : "false";
+    o << "extern \"C\" __global__ __launch_bounds__(256) void " << entry_name(FRONT) << "(const vdl::MsArgs Csr, const vdl::MScanDesc *__restrict__ Dsp, const vdl::MsArgs Ctr,\n"
+         "        const vdl::MScanDesc *__restrict__ Dtp, const vdl::FrontLook lk) {\n"
+         "    constexpr vdl::MsArgs Cs = vdl::jit_args_s();\n"
+         "    constexpr vdl::MScanDesc Ds = vdl::jit_desc_s();\n"
+         "    constexpr vdl::MsArgs Ct = vdl::jit_args_t();\n"
+         "    constexpr vdl::MScanDesc Dt = vdl::jit_desc_t();\n"
+         "    vdl::project_front_body<" << sh.nc << ", " << nct << ", vdl::kProjU, " << b << ", " << b << ">(Cs, Csr, Ds, *Dsp, Ct, Ctr, Dt, *Dtp, lk);\n}\n";
+    return o.str();
+}
+const char *entry_name(Kind kind) { return kind == MSCAN ? "vdl_jit_mscan" : kind == SELECT ? "vdl_jit_project_select" : kind == FRONT ? "vdl_jit_project_front" : "vdl_jit_project_take"; }
 // aggregate scans carry their shape in the kernel's name, so that a profile of a tuned run lists the tuner's candidates apart
 std::string entry_name(Kind kind, const MsArgs &C, const MScanDesc &D, const Shape &sh) {
     if (kind != MSCAN) return entry_name(kind);

@@ -70,6 +70,12 @@ int64_t project_carry_bytes(int64_t n);
 hipError_t launch_project_select(const MScanCols &cols, const MScanDesc *dev_desc, int num_cus, hipStream_t s, hipFunction_t jit_fn = nullptr);
 bool project_select_vec(const MScanCols &cols);          // the 16-byte-load form applies (alignment of the deciding columns)
 // d.take = the columns the outputs need, d.out_* = the packed result vectors; counts = survivors per tile, offsets = their prefix
+// the fused front in ONE pass (vdl_mscan_body.h: project_front_body): scols / dev_sdesc = the deciding columns as the select pass saw
+// them (out_ptr[0] = the selection's bitmap or null), tcols / dev_tdesc = every column with the output vectors (out_idx, out_ptr, out_cap);
+// look = project_look_bytes(n) bytes of scratch; the survivors' number is left at total_dev and (if not null) in pinned total_host
+int64_t project_look_bytes(int64_t n);
+hipError_t launch_project_front(const MScanCols &scols, const MScanDesc *dev_sdesc, const MScanCols &tcols, const MScanDesc *dev_tdesc, void *look,
+                                int64_t *total_dev, int64_t *total_host, int num_cus, hipStream_t s, hipFunction_t jit_fn = nullptr);
 hipError_t launch_project_take(const MScanCols &cols, const MScanDesc *dev_desc, const void *scratch, const int64_t *counts, const int64_t *offsets,
                                int num_cus, hipStream_t s, hipFunction_t jit_fn = nullptr);
 // sharded FoldChoose: after the MIN all-reduce of the row-id words, the owning rank substitutes the value, others 0

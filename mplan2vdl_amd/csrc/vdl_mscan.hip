@@ -96,6 +96,12 @@ __global__ __launch_bounds__(kMsBlock) void k_project_take(const MsArgs C, const
     project_take_body<NC>(C, C, *Dp, *Dp, scratch, counts, offsets);
 }
 
+// the fused front in one pass: select-side columns / descriptor (Cs, Dsp) and take-side ones (Ct, Dtp)
+template <int NCS, int NCT, int U, bool VEC, bool NT>
+__global__ __launch_bounds__(kMsBlock) void k_project_front(const MsArgs Cs, const MScanDesc *__restrict__ Dsp, const MsArgs Ct, const MScanDesc *__restrict__ Dtp, const FrontLook lk) {
+    project_front_body<NCS, NCT, U, VEC, NT>(Cs, Cs, *Dsp, *Dsp, Ct, Ct, *Dtp, *Dtp, lk);
+}
+
 typedef void (*mscan_fn)(const MsArgs, const MScanDesc *);
 struct MsVariant { int nc, u; bool vec, grouped, der; mscan_fn fn; const char *name; };
 #define VDL_MS(NC, U, VEC, NT, GR) {NC, U, VEC, GR, false, k_mscan<NC, U, VEC, NT, GR, false>, "k_mscan<" #NC "," #U "," #VEC "," #NT "," #GR ">"}
@@ -247,6 +253,56 @@ hipError_t launch_project_select(const MScanCols &cols, const MScanDesc *dev_des
     if (cols.ncol > kMaxSelectCols) return hipErrorInvalidValue;
     if (cols.ncol <= 4) VDL_PJ(4); else if (cols.ncol <= 8) VDL_PJ(8); else VDL_PJ(kMaxSelectCols);      // (registers: NC x 8 rows x 64 bits)
 #undef VDL_PJ
+    return hipGetLastError();
+}
+// blocks per CU of a projection kernel: by the kernel's registers when it was specialised, else by its column count
+static int project_blocks_per_cu(hipFunction_t jit_fn, int ncol) {
+    int per_cu = 8;
+    if (jit_fn) {
+        static std::mutex mu;
+        static std::map<hipFunction_t, int> known;
+        std::lock_guard<std::mutex> g(mu);
+        auto it = known.find(jit_fn);
+        if (it == known.end()) {
+            int n = 0;
+            if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&n, jit_fn, kMsBlock, 0) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 8; }
+            if (known.size() > 4096) known.clear();
+            it = known.emplace(jit_fn, n).first;
+        }
+        per_cu = it->second;
+    } else {
+        per_cu = ncol <= 4 ? 8 : ncol <= 8 ? 5 : 3;            // (precompiled: 4 / 8 / 12 columns x 8 rows of 64 bits in registers)
+    }
+    if (const char *e = getenv("VDL_PROJ_BLOCKS_PER_CU")) { if (atoi(e) > 0) per_cu = atoi(e); }
+    return per_cu;
+}
+int64_t project_look_bytes(int64_t n) { return 64 + (int64_t)sizeof(unsigned long long) * front_look_words(project_tiles(n)); }
+// look: project_look_bytes(n) bytes, zeroed here; total_dev / total_host: where the survivors' number is left
+hipError_t launch_project_front(const MScanCols &scols, const MScanDesc *dev_sdesc, const MScanCols &tcols, const MScanDesc *dev_tdesc, void *look,
+                                int64_t *total_dev, int64_t *total_host, int num_cus, hipStream_t s, hipFunction_t jit_fn) {
+    (void)hipGetLastError();
+    if (scols.n <= 0) return hipSuccess;
+    if (project_tiles(scols.n) >= ((int64_t)1 << (kFrontFanBits * kFrontLevels))) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(look, 0, (size_t)project_look_bytes(scols.n), s);
+    if (e != hipSuccess) return e;
+    FrontLook lk;
+    lk.ticket = (unsigned int *)look; lk.nodes = (unsigned long long *)((char *)look + 64); lk.total = total_dev; lk.total_host = total_host;
+    const bool vec = project_select_vec(scols);
+    int64_t grid = project_tiles(scols.n);
+    const int per_cu = project_blocks_per_cu(jit_fn, scols.ncol);
+    if (grid > (int64_t)num_cus * per_cu) grid = (int64_t)num_cus * per_cu;        // (tiles are handed out by ticket: any grid is safe, this one fills the chip)
+    MsArgs a = ms_args(scols), b = ms_args(tcols);
+    if (jit_fn) {
+        void *params[] = {&a, &dev_sdesc, &b, &dev_tdesc, &lk};
+        return hipModuleLaunchKernel(jit_fn, (unsigned)grid, 1, 1, kMsBlock, 1, 1, 0, s, params, nullptr);
+    }
+    if (scols.ncol > kMaxSelectCols) return hipErrorInvalidValue;
+#define VDL_PF2(NCS, NCT) do { if (vec) k_project_front<NCS, NCT, kProjU, true, true><<<(int)grid, kMsBlock, 0, s>>>(a, dev_sdesc, b, dev_tdesc, lk); \
+                               else k_project_front<NCS, NCT, kProjU, false, false><<<(int)grid, kMsBlock, 0, s>>>(a, dev_sdesc, b, dev_tdesc, lk); } while (0)
+#define VDL_PF(NCS) do { if (tcols.ncol <= 12) VDL_PF2(NCS, 12); else VDL_PF2(NCS, kMaxVCols); } while (0)
+    if (scols.ncol <= 4) VDL_PF(4); else if (scols.ncol <= 8) VDL_PF(8); else VDL_PF(kMaxSelectCols);
+#undef VDL_PF
+#undef VDL_PF2
     return hipGetLastError();
 }
 hipError_t launch_project_take(const MScanCols &cols, const MScanDesc *dev_desc, const void *scratch, const int64_t *counts, const int64_t *offsets,

@@ -852,5 +852,214 @@ __device__ __forceinline__ void project_take_body(const MsArgs &C, const MsArgs 
     }
 }
 
+
+// ---- the fused front in ONE pass (round 4) ---------------------------------------------------------------------------------
+// k_project_select + prefix sum + host count + k_project_take as one kernel: a block takes a tile (tiles are handed out in
+// starting order), runs the select pass's work on it -- deciding columns, lookups, ballots, the survivors' ranks --, PUBLISHES the
+// tile's survivor count, puts the survivors' positions (and the carried columns' values) in survivor order in LDS, learns where its
+// survivors go from the counts of the tiles before it, and writes the output vectors itself: every lane takes survivors
+// k, k + 256, ... as the take pass's waves did.  No tile counts, no 16-bit position scratch and no carry area in memory, no
+// prefix-sum launches, no second kernel; the isolated-line fetches of the survivors' columns run beside the other blocks' streams.
+// Where a tile's survivors go is a prefix over tiles that run at the same time; as in the radix Partition (vdl_partition.hip, where
+// the reasoning and the measurements are) the tiles keep a Fenwick tree of fan-out 16 over their counts -- here one word per
+// node {ready bit, count} --: a tile's prefix is the sum of at most 15 nodes per level, fetched by the lanes of one wave at once;
+// the node of 16 / 256 / ... tiles is made by the tile that completes them.  A tile only waits for tiles that already run.
+struct FrontLook {
+    unsigned int *ticket;              // zeroed before the launch
+    unsigned long long *nodes;         // front_look_words(tiles) words, zeroed
+    int64_t *total;                    // the survivors' number, left by the last tile (device)
+    int64_t *total_host;               // ... and in pinned host memory (may be null)
+};
+constexpr int kFrontFanBits = 4, kFrontFan = 1 << kFrontFanBits, kFrontLevels = 7;         // tiles < 16^7
+constexpr unsigned long long kFrontReady = 1ull << 63;
+__host__ __device__ inline int64_t front_look_words(int64_t ntiles) { int64_t w = 0; for (int j = 0; j < kFrontLevels; j++) w += ntiles >> (kFrontFanBits * j); return w; }
+__device__ __forceinline__ int64_t front_node(int64_t ntiles, int64_t u, int level) {
+    int64_t base = 0;
+    for (int j = 0; j < level; j++) base += ntiles >> (kFrontFanBits * j);
+    return base + ((u + 1) >> (kFrontFanBits * level)) - 1;
+}
+__device__ __forceinline__ int64_t front_wait(const unsigned long long *p) {
+    unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (!(v & kFrontReady)) { __builtin_amdgcn_s_sleep(2); v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    return (int64_t)(v & ~kFrontReady);
+}
+__device__ __forceinline__ void front_publish(unsigned long long *p, int64_t v) {
+    __hip_atomic_store(p, (unsigned long long)v | kFrontReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int NCS, int NCT, int U, bool VEC, bool NT>
+__device__ __forceinline__ void project_front_body(const MsArgs &Cs, const MsArgs &Csr, const MScanDesc &Ds, const MScanDesc &Dsr,
+                                                   const MsArgs &Ct, const MsArgs &Ctr, const MScanDesc &Dt, const MScanDesc &Dtr, const FrontLook &lk) {
+    constexpr int BS = kMsBlock, ROWS = 2 * U, TILE = BS * ROWS, NW = BS / kWave;
+    static_assert(TILE == kProjTile, "one tile shape for the projection scans");
+    __shared__ int wcnt[U][NW];
+    __shared__ unsigned int s_tile;
+    __shared__ long long s_off;
+    __shared__ uint16_t spos[TILE];                        // the survivors' positions inside the tile, in row order
+    __shared__ int64_t cst[kMaxCarry][kProjCarry];         // the carried columns' values, in survivor order
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const int64_t full = Csr.n / TILE, ntiles = (Csr.n + TILE - 1) / TILE;
+    for (;;) {
+        if (tid == 0) s_tile = atomicAdd(lk.ticket, 1u);
+        __syncthreads();
+        const int64_t tile = s_tile;
+        if (tile >= ntiles) break;                         // (block-uniform)
+        int64_t v[NCS][ROWS];
+        const int64_t base = tile * TILE + (int64_t)tid * 2;
+        if (tile < full) {
+            load_tile<NCS, U, VEC, NT>(Cs, Csr, base, v, Cs.lazy);
+        } else {                                           // the partial last tile: clamped scalar loads
+#pragma unroll
+            for (int c = 0; c < NCS; c++) {
+                if (c < Cs.ncol && !(((Cs.derived | Cs.lazy) >> c) & 1u)) {
+#pragma unroll
+                    for (int r = 0; r < ROWS; r++) {
+                        const int64_t i = base + (int64_t)(r >> 1) * (BS * 2) + (r & 1);
+                        v[c][r] = load_scalar(Csr.ptr[c], Cs.width(c), i < Csr.n ? i : Csr.n - 1);
+                    }
+                }
+            }
+        }
+        bool alive[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) alive[r] = base + (int64_t)(r >> 1) * (BS * 2) + (r & 1) < Csr.n;
+        int64_t rid[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) rid[r] = Csr.row0 + base + (int64_t)(r >> 1) * (BS * 2) + (r & 1);
+        derive<NCS, ROWS>(Cs, Csr, Ds, Dsr, v, alive, Cs.derived & ~Cs.lazy, rid);      // filters fold into `alive` as they are derived
+        uint64_t m[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) m[r] = __ballot(alive[r]);
+        // the selection's bitmap over the table's rows, for whoever asks the sparse vectors for their validity: lanes 2l, 2l+1
+        // of the two ballots of a sub-iteration are rows 2l, 2l+1 of the wave's 128 -- interleave them into two words
+        if (Dsr.out_ptr[0] && lane < 2 * U) {
+            const int u = lane >> 1, half = lane & 1;
+            uint64_t a = 0, b = 0;
+#pragma unroll
+            for (int uu = 0; uu < U; uu++) if (uu == u) { a = m[2 * uu]; b = m[2 * uu + 1]; }
+            uint64_t x = half ? (a >> 32) : (a & 0xffffffffull), y = half ? (b >> 32) : (b & 0xffffffffull);
+            x = (x | (x << 16)) & 0x0000ffff0000ffffull; x = (x | (x << 8)) & 0x00ff00ff00ff00ffull; x = (x | (x << 4)) & 0x0f0f0f0f0f0f0f0full;
+            x = (x | (x << 2)) & 0x3333333333333333ull; x = (x | (x << 1)) & 0x5555555555555555ull;
+            y = (y | (y << 16)) & 0x0000ffff0000ffffull; y = (y | (y << 8)) & 0x00ff00ff00ff00ffull; y = (y | (y << 4)) & 0x0f0f0f0f0f0f0f0full;
+            y = (y | (y << 2)) & 0x3333333333333333ull; y = (y | (y << 1)) & 0x5555555555555555ull;
+            const int64_t word = (tile * TILE + (int64_t)u * (BS * 2) + (int64_t)wave * 128) / 64 + half;
+            if (word < ((Csr.n + 63) >> 6)) ((uint64_t *)Dsr.out_ptr[0])[word] = x | (y << 1);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < U; u++) wcnt[u][wave] = __popcll(m[2 * u]) + __popcll(m[2 * u + 1]);
+        }
+        __syncthreads();
+        int total = 0, mybase[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+#pragma unroll
+            for (int w = 0; w < NW; w++) { if (w == wave) mybase[u] = total; total += wcnt[u][w]; }
+        }
+        // the tile's count goes out first (every later tile needs it); a tile that completes 16 / 256 / ... also sums their nodes
+        if (wave == 0) {
+            if (lane == 0) front_publish(lk.nodes + front_node(ntiles, tile, 0), total);
+            int64_t acc = total;
+            for (int j = 1; j < kFrontLevels && ((tile + 1) & (((int64_t)1 << (kFrontFanBits * j)) - 1)) == 0; j++) {
+                const int64_t step = (int64_t)1 << (kFrontFanBits * (j - 1));
+                int64_t x = 0;
+                if (lane < kFrontFan - 1) x = front_wait(lk.nodes + front_node(ntiles, tile - (int64_t)(lane + 1) * step, j - 1));
+                acc += wave_reduce(x, R_SUM);              // (lane 0 holds the sums)
+                if (lane == 0) front_publish(lk.nodes + front_node(ntiles, tile, j), acc);
+            }
+        }
+        const uint64_t below = (1ull << lane) - 1;
+        int rank[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            const int u = r >> 1;
+            rank[r] = mybase[u] + __popcll(m[2 * u] & below) + __popcll(m[2 * u + 1] & below) + ((r & 1) && alive[2 * u] ? 1 : 0);
+            if (alive[r]) spos[rank[r]] = (uint16_t)(tid * 2 + u * (BS * 2) + (r & 1));
+        }
+        if (Ds.carry) {
+            // the survivors' values of the deciding columns that the outputs want too (the join index of a fact table whose dimension is
+            // filtered): they are in registers here -- kept in survivor order instead of being fetched again line by isolated line
+            int ci = 0;
+#pragma unroll
+            for (int c = 0; c < NCS; c++) {
+                if ((Ds.carry >> c) & 1u) {
+#pragma unroll
+                    for (int r = 0; r < ROWS; r++) if (alive[r] && rank[r] < kProjCarry) cst[ci][rank[r]] = v[c][r];
+                    ci++;
+                }
+            }
+        }
+        // where the survivors go: one node per unit of each hex digit of the tile number, a lane each
+        if (wave == NW - 1) {
+            int64_t x = 0;
+            int i = lane;
+            for (int j = 0; j < kFrontLevels; j++) {
+                const int dgt = (int)((tile >> (kFrontFanBits * j)) & (kFrontFan - 1));
+                const int64_t hi = tile & ~(((int64_t)kFrontFan << (kFrontFanBits * j)) - 1);
+                for (; i < dgt; i += kWave) x += front_wait(lk.nodes + front_node(ntiles, hi + ((int64_t)(i + 1) << (kFrontFanBits * j)) - 1, j));
+                i -= dgt;                                  // (lanes beyond this level's nodes move on to the next level's)
+            }
+            x = wave_reduce(x, R_SUM);
+            if (lane == 0) s_off = x;
+        }
+        __syncthreads();
+        const int64_t off = s_off;
+        if (tile == ntiles - 1 && tid == 0) {
+            *lk.total = off + total;
+            if (lk.total_host) *lk.total_host = off + total;
+        }
+        // the survivors' rows: what the outputs need of them -- fact columns at the row (carried values from LDS), dimension columns
+        // through the index -- and the packed vectors.  (Nothing is written beyond the vectors' capacity: the host may have guessed it.)
+        if (off < Dtr.out_cap) {
+            for (int k = tid; k < total; k += BS) {
+                const int64_t row = tile * TILE + (int64_t)spos[k];
+                int64_t vt[NCT][1];
+#pragma unroll
+                for (int c = 0; c < NCT; c++) {
+                    vt[c][0] = 0;
+                    if (c < Ct.ncol && ((Dt.take >> c) & 1u) && !((Ct.derived >> c) & 1u)) {
+                        if (((Dt.carry >> c) & 1u) && k < kProjCarry) vt[c][0] = cst[__builtin_popcount(Dt.carry & ((1u << c) - 1u))][k];
+                        else vt[c][0] = load_scalar(Ctr.ptr[c], Ct.width(c), row);
+                    }
+                }
+                bool on[1] = {true};
+                int64_t rid1[1] = {Ctr.row0 + row};
+                derive<NCT, 1>(Ct, Ctr, Dt, Dtr, vt, on, Ct.derived & Dt.take, rid1, false);
+                if (off + k >= Dtr.out_cap) continue;
+                Dtr.out_idx[off + k] = row;
+                VDL_SPEC_UNROLL
+                for (int o = 0; o < Dt.nout; o++) {
+                    const int oc = Dt.out_col[o];
+                    int64_t x = 0;
+                    if (oc >= 0) {
+#pragma unroll
+                        for (int c = 0; c < NCT; c++) if (c == oc) x = vt[c][0];
+                    } else {
+                        // a row expression over the columns, in the two-accumulator program form of the group keys (ProjPlan::exprs)
+                        int64_t acc[1] = {0}, tmp[1] = {0};
+                        const int at = Dt.expr_at[-2 - oc], len = Dt.expr_len[-2 - oc];
+                        VDL_SPEC_UNROLL
+                        for (int s = at; s < at + len; s++) {
+                            const KeyStep st = Dt.key[s];               // wave-uniform
+                            if (st.kind == KeyStep::LOAD) {
+#pragma unroll
+                                for (int c = 0; c < NCT; c++) if (c == st.col) { if (st.target) tmp[0] = vt[c][0]; else acc[0] = vt[c][0]; }
+                            } else if (st.kind == KeyStep::OPK) {
+                                if (st.target) key_rows<1>(st.bin, st.const_left, tmp, st.k);
+                                else key_rows<1>(st.bin, st.const_left, acc, st.k);
+                            } else {
+                                key_combine<1>(st.bin, st.const_left, acc, tmp);
+                            }
+                        }
+                        x = acc[0];
+                    }
+                    Dtr.out_ptr[o][off + k] = x;
+                }
+            }
+        }
+        __syncthreads();                                   // (the next tile reuses the LDS areas)
+    }
+}
+
 }  // namespace
 }  // namespace vdl

@@ -386,22 +386,6 @@ class Engine:
         data = vdl_text.encode() if isinstance(vdl_text, str) else vdl_text
         h = ctypes.c_void_p()
         rc = self._L.vdl_parse(self._c, data, len(data), ctypes.byref(h))
-        if rc == _lib.VDL_ERR_PARSE:
-            # Evidence trap ("the intermittent mismatch"): once in this build's history a text that parses -- the
-            # oracle had just run it, and it parsed on the next suite run -- was refused with "line 7: Load expects 3 fields, got 4".
-            # A refusal is re-examined on the spot: the same bytes parsed again; if that succeeds, say so loudly with the bytes seen.
-            first = self._L.vdl_last_error(self._c).decode()
-            fresh = vdl_text.encode() if isinstance(vdl_text, str) else bytes(vdl_text)
-            changed = [(i, data[i], fresh[i]) for i in range(min(len(data), len(fresh))) if data[i] != fresh[i]][:16]
-            if changed:                                   # the bytes handed over no longer equal the str they were made from
-                raise VdlError(rc, "INTERMITTENT PARSE FAILURE: '%s'; the bytes object handed to vdl_parse differs from its source str at "
-                                   "(offset, is, was) %r -- host memory changed under the call" % (first, changed))
-            h2 = ctypes.c_void_p()
-            if self._L.vdl_parse(self._c, data, len(data), ctypes.byref(h2)) == 0:
-                self._L.vdl_plan_free(h2)
-                raise VdlError(rc, "INTERMITTENT PARSE FAILURE: '%s' on the first attempt, accepted on the second (the bytes equal their source str "
-                                   "now); the %d bytes handed over: %r" % (first, len(data), data[:400]))
-            raise VdlError(rc, first)
         self._check(rc)
         plan = Plan(self, h, vdl_text)
         self._plans.add(plan)
