@@ -13,8 +13,7 @@ namespace {
 static const MScanDesc *desc_on_device(vdl_ctx *c, vdl_plan *p, const std::string &role, const MScanDesc &d) {
     vdl_plan::DescSlot &sl = p->desc_slots[role];
     if (!sl.dev) sl.dev = dev_alloc(c, sizeof(MScanDesc));
-    const bool always = getenv("VDL_NO_DESC_CACHE") != nullptr;
-    if (always || sl.shadow.size() != sizeof(MScanDesc) || std::memcmp(sl.shadow.data(), &d, sizeof(MScanDesc)) != 0) {
+    if (sl.shadow.size() != sizeof(MScanDesc) || std::memcmp(sl.shadow.data(), &d, sizeof(MScanDesc)) != 0) {
         // the shadow is the SOURCE of the copy: it stays put until the next upload, the caller's `d` may be a local
         sl.shadow.assign((const unsigned char *)&d, (const unsigned char *)&d + sizeof(MScanDesc));
         HIP_CHECK(hipMemcpyAsync(sl.dev->p, sl.shadow.data(), sizeof(MScanDesc), hipMemcpyHostToDevice, c->stream));
@@ -597,7 +596,6 @@ static hipFunction_t front_kernel(vdl_ctx *c, vdl_plan *p, const std::string &ro
 }
 
 // the one-pass front specialised for this plan: two descriptors in one kernel (jit::front_source)
-static int front_take_cols(const MScanCols &tcols) { return tcols.ncol <= 12 ? 12 : kMaxVCols; }
 static hipFunction_t front_kernel_one_pass(vdl_ctx *c, vdl_plan *p, const MScanCols &scols, const MScanDesc &sd, const MScanCols &tcols, const MScanDesc &td) {
     if (!p->use_jit) return nullptr;
     const std::string role = "front";
@@ -947,17 +945,15 @@ static void bind_front(vdl_ctx *c, vdl_plan *p, FrontBound &b) {
         if (!((d.take >> k) & 1u)) continue;
         for (int src : J.cols[(size_t)k].sources()) d.take |= 1u << src;
     }
-    // table columns both passes read (they decide survival AND the outputs need them: the join index of a fact table whose
-    // dimension is filtered) travel from the select pass to the take pass (MScanDesc::carry)
+    // table columns both sides of the front read (they decide survival AND the outputs need them: the join index of a fact table whose
+    // dimension is filtered) stay in LDS for the survivors (MScanDesc::carry)
     d.carry = 0; sdesc->carry = 0;
-    if (!getenv("VDL_NO_FRONT_CARRY")) {
-        int taken = 0;
-        for (int k = 0; k < cols.ncol && taken < kMaxCarry; k++) {
-            if (cols.lazy[k] || cols.kind[k] != VC_DIRECT || !((d.take >> k) & 1u) || renum[(size_t)k] < 0) continue;
-            d.carry |= 1u << k;
-            sdesc->carry |= 1u << renum[(size_t)k];
-            taken++;
-        }
+    int taken = 0;
+    for (int k = 0; k < cols.ncol && taken < kMaxCarry; k++) {
+        if (cols.lazy[k] || cols.kind[k] != VC_DIRECT || !((d.take >> k) & 1u) || renum[(size_t)k] < 0) continue;
+        d.carry |= 1u << k;
+        sdesc->carry |= 1u << renum[(size_t)k];
+        taken++;
     }
 }
 // the prelude's tables of this run, in both passes' arguments
@@ -1002,7 +998,6 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
     patch_front(p, fb);
     SelP sel = std::make_shared<Sel>();
     sel->n = n;
-    const int64_t ntiles = project_tiles(n);
     int64_t m = 0;
     std::vector<BufP> outs(distinct.size());
     if (n > 0 && !J.never) {
@@ -1013,7 +1008,6 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
         // survivor is fetched or written); a run that came up short is repeated with the exact number.
         sel->bitmap = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>((n + 63) >> 6, 1));
         sdesc->out_ptr[0] = (int64_t *)sel->bitmap->p;
-        sdesc->carry_ptr[0] = sdesc->carry_ptr[1] = d.carry_ptr[0] = d.carry_ptr[1] = nullptr;      // (carried values stay in LDS)
         BufP look = dev_alloc(c, (size_t)project_look_bytes(n)), total = dev_alloc(c, sizeof(int64_t));
         int64_t *back = c->pinned(1);
         auto room_for = [&](int64_t cap) {

@@ -874,7 +874,7 @@ struct GenExec {
             max_bucket = seen[1] <= pmin ? 0 : ((int64_t)((uint64_t)seen[1] - (uint64_t)pmin) < 0 ? pcount : std::min<int64_t>((int64_t)((uint64_t)seen[1] - (uint64_t)pmin), pcount));
             if (!descends) {
                 o.iota = true;
-                if (order_only && !getenv("VDL_NO_LAZY_POSITIONS")) { o.data = nullptr; return o; }      // only Scatters read them, and a Scatter by the identity moves nothing (need_positions writes them out for anything else)
+                if (order_only) { o.data = nullptr; return o; }      // only Scatters read them, and a Scatter by the identity moves nothing (need_positions writes them out for anything else)
                 Src zero; zero.kind = SRC_RANGE; zero.from = 0; zero.step = 0;
                 HIP_CHECK(launch_binary(B_ADD, iota_src(), zero, (int64_t *)o.data->p, o.n, s));
                 return o;
@@ -892,11 +892,11 @@ struct GenExec {
             // Positions that only Scatters read (the GROUP BY idiom: key and values scattered into key order) are never written: the
             // last radix pass leaves the slots in RANK order, stored like any other pass, and the Scatters become gathers through
             // that list.  `pos[slot] = rank` is 60 M isolated 8-byte stores at 60 M rows -- 1.6 of the Partition's 3.9 ms.
-            const bool lazy = order_only && !data.valid && passes > 1 && !getenv("VDL_NO_LAZY_POSITIONS");
+            const bool lazy = order_only && !data.valid && passes > 1;
             if (lazy) o.order = dev_alloc(c, sizeof(int64_t) * (size_t)o.n);
             // ... and the values come out of the sort in rank order for 8 more bytes per row of sequential stores: the Scatter of the key
             // itself by these positions -- every GROUP BY has one -- then costs nothing (it was a 1.2 ms gather at 60 M rows)
-            if (lazy && values_inside && data.kind == DVec::DENSE && data.data && !getenv("VDL_NO_SORTED_KEYS")) {
+            if (lazy && values_inside && data.kind == DVec::DENSE && data.data) {
                 o.sorted_keys = dev_alloc(c, sizeof(int64_t) * (size_t)o.n);
                 o.sorted_keys_src = data.data;
             }

@@ -34,6 +34,10 @@ namespace {
 #define VDL_PROJ_U 4
 #endif
 constexpr int VDL_PROJ_U_HOST = VDL_PROJ_U;
+#ifndef VDL_FRONT_BATCH
+#define VDL_FRONT_BATCH 4
+#endif
+constexpr int VDL_FRONT_BATCH_HOST = VDL_FRONT_BATCH;      // (tiles per batch of the one-pass front as this library was built: the launcher's grid and look-back area follow it)
 const char kEmbedded[] =
 #include "vdl_jit_src.inc"
     ;
@@ -300,7 +304,7 @@ std::string mscan_source(const MsArgs &C, const MScanDesc &D, const Shape &sh) {
 std::string front_source(const MsArgs &Cs, const MScanDesc &Ds, const MsArgs &Ct, const MScanDesc &Dt, const Shape &sh, int nct) {
     std::ostringstream o;
     o << "#define VDL_SPEC_UNROLL _Pragma(\"unroll\")\n";
-    o << "#define VDL_PROJ_U " << VDL_PROJ_U_HOST << "\n" << kEmbedded << "\n" << desc_text(SELECT, Cs, Ds, "_s") << desc_text(TAKE, Ct, Dt, "_t");
+    o << "#define VDL_PROJ_U " << VDL_PROJ_U_HOST << "\n#define VDL_FRONT_BATCH " << VDL_FRONT_BATCH_HOST << "\n" << kEmbedded << "\n" << desc_text(SELECT, Cs, Ds, "_s") << desc_text(TAKE, Ct, Dt, "_t");
     const char *b = sh.vec ? "true" : "false";
     o << "extern \"C\" __global__ __launch_bounds__(256) void " << entry_name(FRONT) << "(const vdl::MsArgs Csr, const vdl::MScanDesc *__restrict__ Dsp, const vdl::MsArgs Ctr,\n"
          "        const vdl::MScanDesc *__restrict__ Dtp, const vdl::FrontLook lk) {\n"

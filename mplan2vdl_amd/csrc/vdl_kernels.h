@@ -61,23 +61,17 @@ hipError_t launch_mscan(const MScanCols &cols, const MScanDesc &d, const MScanDe
 MsArgs mscan_args(const MScanCols &cols);
 void mscan_variant_shape(const ScanLaunch &cfg, int *nc, int *u, bool *vec, bool *grouped, bool *der);
 size_t mscan_lds_bytes(const MScanDesc &d, bool grouped);
-// Projection scan (ProjPlan, vdl_fuse.h): pass 1 counts the surviving rows of every tile into d.tile_counts, pass 2 (after an
-// exclusive prefix sum over the counts) writes their slot ids and the produced columns, packed, in row order.
+// Projection scans (ProjPlan, vdl_fuse.h).  launch_project_select: a selection over a table's rows as a bitmap (d.bitmap_only = 1:
+// a dimension scan, out_ptr[0] = the bitmap) or as bits set in a semi-join set (d.bitmap_only = 2).
 int64_t project_tiles(int64_t n);
-int64_t project_scratch_bytes(int64_t n);
-int64_t project_carry_bytes(int64_t n);
-// d.out_idx = the scratch area (project_scratch_bytes), d.tile_counts = [tiles + 1]
 hipError_t launch_project_select(const MScanCols &cols, const MScanDesc *dev_desc, int num_cus, hipStream_t s, hipFunction_t jit_fn = nullptr);
 bool project_select_vec(const MScanCols &cols);          // the 16-byte-load form applies (alignment of the deciding columns)
-// d.take = the columns the outputs need, d.out_* = the packed result vectors; counts = survivors per tile, offsets = their prefix
 // the fused front in ONE pass (vdl_mscan_body.h: project_front_body): scols / dev_sdesc = the deciding columns as the select pass saw
 // them (out_ptr[0] = the selection's bitmap or null), tcols / dev_tdesc = every column with the output vectors (out_idx, out_ptr, out_cap);
 // look = project_look_bytes(n) bytes of scratch; the survivors' number is left at total_dev and (if not null) in pinned total_host
 int64_t project_look_bytes(int64_t n);
 hipError_t launch_project_front(const MScanCols &scols, const MScanDesc *dev_sdesc, const MScanCols &tcols, const MScanDesc *dev_tdesc, void *look,
                                 int64_t *total_dev, int64_t *total_host, int num_cus, hipStream_t s, hipFunction_t jit_fn = nullptr);
-hipError_t launch_project_take(const MScanCols &cols, const MScanDesc *dev_desc, const void *scratch, const int64_t *counts, const int64_t *offsets,
-                               int num_cus, hipStream_t s, hipFunction_t jit_fn = nullptr);
 // sharded FoldChoose: after the MIN all-reduce of the row-id words, the owning rank substitutes the value, others 0
 hipError_t launch_mscan_resolve_first(const MScanCols &cols, const MScanDesc &d, const MScanDesc *dev_desc, int64_t *table, hipStream_t s);
 

@@ -90,12 +90,6 @@ template <int NC, int U, bool VEC, bool NT>
 __global__ __launch_bounds__(kMsBlock) void k_project_select(const MsArgs C, const MScanDesc *__restrict__ Dp) {
     project_select_body<NC, U, VEC, NT>(C, C, *Dp, *Dp);
 }
-template <int NC>
-__global__ __launch_bounds__(kMsBlock) void k_project_take(const MsArgs C, const MScanDesc *__restrict__ Dp, const uint16_t *__restrict__ scratch,
-                                                           const int64_t *__restrict__ counts, const int64_t *__restrict__ offsets) {
-    project_take_body<NC>(C, C, *Dp, *Dp, scratch, counts, offsets);
-}
-
 // the fused front in one pass: select-side columns / descriptor (Cs, Dsp) and take-side ones (Ct, Dtp)
 template <int NCS, int NCT, int U, bool VEC, bool NT>
 __global__ __launch_bounds__(kMsBlock) void k_project_front(const MsArgs Cs, const MScanDesc *__restrict__ Dsp, const MsArgs Ct, const MScanDesc *__restrict__ Dtp, const FrontLook lk) {
@@ -208,52 +202,12 @@ hipError_t launch_mscan(const MScanCols &cols, const MScanDesc &d, const MScanDe
 }
 
 int64_t project_tiles(int64_t n) { return (n + kProjTile - 1) / kProjTile; }
-int64_t project_scratch_bytes(int64_t n) { return project_tiles(n) * kProjTile * (int64_t)sizeof(uint16_t); }
-int64_t project_carry_bytes(int64_t n) { return project_tiles(n) * kProjCarry * (int64_t)sizeof(int64_t); }      // per carried column (MScanDesc::carry)
 
 bool project_select_vec(const MScanCols &cols) {
     bool vec = true;
     for (int c = 0; c < cols.ncol; c++)
         if (cols.kind[c] == VC_DIRECT && !cols.lazy[c] && ((uintptr_t)cols.ptr[c]) % (uintptr_t)(2 * cols.width[c]) != 0) vec = false;
     return vec;
-}
-hipError_t launch_project_select(const MScanCols &cols, const MScanDesc *dev_desc, int num_cus, hipStream_t s, hipFunction_t jit_fn) {
-    (void)hipGetLastError();
-    if (cols.n <= 0) return hipSuccess;
-    const bool vec = project_select_vec(cols);
-    // The blocks walk the tiles with the grid as their stride, so the grid is what the chip holds at once -- blocks per CU by the
-    // kernel's registers (88 VGPRs for Q3's select pass: 5, not 8): no block waits for a slot while others hold theirs for the whole
-    // pass.  (Measured: no difference for Q3 at SF10, 150 us either way -- the pass is bound by its dependent lookups, DESIGN.md.)
-    int per_cu = 8;
-    if (jit_fn) {
-        static std::mutex mu;
-        static std::map<hipFunction_t, int> known;
-        std::lock_guard<std::mutex> g(mu);
-        auto it = known.find(jit_fn);
-        if (it == known.end()) {
-            int n = 0;
-            if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&n, jit_fn, kMsBlock, 0) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 8; }
-            if (known.size() > 4096) known.clear();
-            it = known.emplace(jit_fn, n).first;
-        }
-        per_cu = it->second;
-    } else {
-        per_cu = cols.ncol <= 4 ? 8 : cols.ncol <= 8 ? 5 : 3;            // (precompiled: 4 / 8 / 12 columns x 8 rows of 64 bits in registers)
-    }
-    if (const char *e = getenv("VDL_PROJ_BLOCKS_PER_CU")) { if (atoi(e) > 0) per_cu = atoi(e); }
-    int64_t grid = project_tiles(cols.n);
-    if (grid > (int64_t)num_cus * per_cu) grid = (int64_t)num_cus * per_cu;
-    MsArgs a = ms_args(cols);
-    if (jit_fn) {
-        void *params[] = {&a, &dev_desc};
-        return hipModuleLaunchKernel(jit_fn, (unsigned)grid, 1, 1, kMsBlock, 1, 1, 0, s, params, nullptr);
-    }
-#define VDL_PJ(NC) do { if (vec) k_project_select<NC, kProjU, true, true><<<(int)grid, kMsBlock, 0, s>>>(a, dev_desc); \
-                        else k_project_select<NC, kProjU, false, false><<<(int)grid, kMsBlock, 0, s>>>(a, dev_desc); } while (0)
-    if (cols.ncol > kMaxSelectCols) return hipErrorInvalidValue;
-    if (cols.ncol <= 4) VDL_PJ(4); else if (cols.ncol <= 8) VDL_PJ(8); else VDL_PJ(kMaxSelectCols);      // (registers: NC x 8 rows x 64 bits)
-#undef VDL_PJ
-    return hipGetLastError();
 }
 // blocks per CU of a projection kernel: by the kernel's registers when it was specialised, else by its column count
 static int project_blocks_per_cu(hipFunction_t jit_fn, int ncol) {
@@ -276,7 +230,28 @@ static int project_blocks_per_cu(hipFunction_t jit_fn, int ncol) {
     if (const char *e = getenv("VDL_PROJ_BLOCKS_PER_CU")) { if (atoi(e) > 0) per_cu = atoi(e); }
     return per_cu;
 }
-int64_t project_look_bytes(int64_t n) { return 64 + (int64_t)sizeof(unsigned long long) * front_look_words(project_tiles(n)); }
+hipError_t launch_project_select(const MScanCols &cols, const MScanDesc *dev_desc, int num_cus, hipStream_t s, hipFunction_t jit_fn) {
+    (void)hipGetLastError();
+    if (cols.n <= 0) return hipSuccess;
+    const bool vec = project_select_vec(cols);
+    // The blocks walk the tiles with the grid as their stride, so the grid is what the chip holds at once -- blocks per CU by the
+    // kernel's registers: no block waits for a slot while others hold theirs for the whole pass.
+    const int per_cu = project_blocks_per_cu(jit_fn, cols.ncol);
+    int64_t grid = project_tiles(cols.n);
+    if (grid > (int64_t)num_cus * per_cu) grid = (int64_t)num_cus * per_cu;
+    MsArgs a = ms_args(cols);
+    if (jit_fn) {
+        void *params[] = {&a, &dev_desc};
+        return hipModuleLaunchKernel(jit_fn, (unsigned)grid, 1, 1, kMsBlock, 1, 1, 0, s, params, nullptr);
+    }
+#define VDL_PJ(NC) do { if (vec) k_project_select<NC, kProjU, true, true><<<(int)grid, kMsBlock, 0, s>>>(a, dev_desc); \
+                        else k_project_select<NC, kProjU, false, false><<<(int)grid, kMsBlock, 0, s>>>(a, dev_desc); } while (0)
+    if (cols.ncol > kMaxSelectCols) return hipErrorInvalidValue;
+    if (cols.ncol <= 4) VDL_PJ(4); else if (cols.ncol <= 8) VDL_PJ(8); else VDL_PJ(kMaxSelectCols);      // (registers: NC x 8 rows x 64 bits)
+#undef VDL_PJ
+    return hipGetLastError();
+}
+int64_t project_look_bytes(int64_t n) { return 64 + (int64_t)sizeof(unsigned long long) * front_look_words((project_tiles(n) + kFrontBatch - 1) / kFrontBatch); }
 // look: project_look_bytes(n) bytes, zeroed here; total_dev / total_host: where the survivors' number is left
 hipError_t launch_project_front(const MScanCols &scols, const MScanDesc *dev_sdesc, const MScanCols &tcols, const MScanDesc *dev_tdesc, void *look,
                                 int64_t *total_dev, int64_t *total_host, int num_cus, hipStream_t s, hipFunction_t jit_fn) {
@@ -288,7 +263,7 @@ hipError_t launch_project_front(const MScanCols &scols, const MScanDesc *dev_sde
     FrontLook lk;
     lk.ticket = (unsigned int *)look; lk.nodes = (unsigned long long *)((char *)look + 64); lk.total = total_dev; lk.total_host = total_host;
     const bool vec = project_select_vec(scols);
-    int64_t grid = project_tiles(scols.n);
+    int64_t grid = (project_tiles(scols.n) + kFrontBatch - 1) / kFrontBatch;
     const int per_cu = project_blocks_per_cu(jit_fn, scols.ncol);
     if (grid > (int64_t)num_cus * per_cu) grid = (int64_t)num_cus * per_cu;        // (tiles are handed out by ticket: any grid is safe, this one fills the chip)
     MsArgs a = ms_args(scols), b = ms_args(tcols);
@@ -305,22 +280,6 @@ hipError_t launch_project_front(const MScanCols &scols, const MScanDesc *dev_sde
 #undef VDL_PF2
     return hipGetLastError();
 }
-hipError_t launch_project_take(const MScanCols &cols, const MScanDesc *dev_desc, const void *scratch, const int64_t *counts, const int64_t *offsets,
-                               int num_cus, hipStream_t s, hipFunction_t jit_fn) {
-    (void)hipGetLastError();
-    if (cols.n <= 0) return hipSuccess;
-    int64_t grid = (project_tiles(cols.n) + 3) / 4;
-    if (grid > (int64_t)num_cus * 16) grid = (int64_t)num_cus * 16;
-    if (jit_fn) {
-        MsArgs a = ms_args(cols);
-        void *params[] = {&a, &dev_desc, &scratch, &counts, &offsets};
-        return hipModuleLaunchKernel(jit_fn, (unsigned)grid, 1, 1, kMsBlock, 1, 1, 0, s, params, nullptr);
-    }
-    if (cols.ncol <= 12) k_project_take<12><<<(int)grid, kMsBlock, 0, s>>>(ms_args(cols), dev_desc, (const uint16_t *)scratch, counts, offsets);
-    else k_project_take<kMaxVCols><<<(int)grid, kMsBlock, 0, s>>>(ms_args(cols), dev_desc, (const uint16_t *)scratch, counts, offsets);
-    return hipGetLastError();
-}
-
 hipError_t launch_mscan_resolve_first(const MScanCols &cols, const MScanDesc &d, const MScanDesc *dev_desc, int64_t *table, hipStream_t s) {
     (void)hipGetLastError();
     k_mscan_first<<<(int)((d.pcount + 255) / 256), 256, 0, s>>>(ms_args(cols), dev_desc, 1, table);

@@ -625,12 +625,11 @@ __device__ __forceinline__ void mscan_body(const MsArgs &C, const MsArgs &Cr, co
 }
 
 // ---- projection scan (ProjPlan, vdl_fuse.h) -----------------------------------------------------------------------------
-// k_project_select: ONE pass over the columns that decide a row's survival (filtered columns and what they are derived from:
-// for Q3 the ship date and the join index, 12 B/row, plus the dimension bitmap looked up through the index).  Per tile it
-// leaves the number of survivors and their positions inside the tile (16 bits each, in row order) in a scratch area.
-// k_project_take: after a prefix sum over the tile counts, one WAVE per tile reads the survivors' positions and, with every
-// lane busy, loads what the rest of the program wants of them -- fact columns at the row, dimension columns through the
-// index -- and writes the packed vectors.  (A second full pass with exec-masked loads for 5 % of the lanes took 4x as long.)
+// k_project_select: ONE pass over the columns that decide a row's survival (filtered columns and what they are derived from),
+// leaving the selection as a BITMAP over the table's rows (a dimension scan: Q3's orders by date and by the customer's segment,
+// through the customer bitmap) or setting the bits of a semi-join set.  The fused FRONT of a fact table -- the same selection,
+// then the survivors' columns as packed vectors -- is project_front_body below.  (Until round 4 the front was this pass leaving
+// counts and 16-bit positions per tile, a prefix sum, and a take pass with one wave per tile.)
 // Row order inside a tile is (sub-iteration u, wave, lane, row of the lane's pair).
 #ifndef VDL_PROJ_U
 #define VDL_PROJ_U 4                          // row pairs per lane and tile of the projection scan (variant builds: -DVDL_PROJ_U=2|8)
@@ -638,16 +637,12 @@ __device__ __forceinline__ void mscan_body(const MsArgs &C, const MsArgs &Cr, co
 constexpr int kProjU = VDL_PROJ_U;
 constexpr int kProjTile = kMsBlock * 2 * kProjU;
 static_assert(kProjTile <= 65536, "positions inside a tile fit 16 bits");
-constexpr int kProjCarry = kProjTile / 4;  // carried values per tile (MScanDesc::carry)
 
 template <int NC, int U, bool VEC, bool NT>
 __device__ __forceinline__ void project_select_body(const MsArgs &C, const MsArgs &Cr, const MScanDesc &D, const MScanDesc &Dr) {
     constexpr int BS = kMsBlock, ROWS = 2 * U, TILE = BS * ROWS, NW = BS / kWave;
-    __shared__ int wcnt[2][U][NW];        // by tile parity: one barrier per tile (a wave that runs ahead writes the other half)
-    int par = 0;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     const int64_t full = Cr.n / TILE, ntiles = (Cr.n + TILE - 1) / TILE;
-    uint16_t *__restrict__ scratch = (uint16_t *)Dr.out_idx;            // [tiles][TILE] positions
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int64_t v[NC][ROWS];
         const int64_t base = tile * TILE + (int64_t)tid * 2;
@@ -707,151 +702,8 @@ __device__ __forceinline__ void project_select_body(const MsArgs &C, const MsArg
             const int64_t word = (tile * TILE + (int64_t)u * (BS * 2) + (int64_t)wave * 128) / 64 + half;
             if (word < ((Cr.n + 63) >> 6)) ((uint64_t *)Dr.out_ptr[0])[word] = x | (y << 1);
         }
-        if (D.bitmap_only) continue;                       // a dimension scan wants the bitmap only
-        if (lane == 0) {
-#pragma unroll
-            for (int u = 0; u < U; u++) wcnt[par][u][wave] = __popcll(m[2 * u]) + __popcll(m[2 * u + 1]);
-        }
-        __syncthreads();
-        int total = 0, mybase[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-#pragma unroll
-            for (int w = 0; w < NW; w++) { if (w == wave) mybase[u] = total; total += wcnt[par][u][w]; }
-        }
-        if (tid == 0) {
-            Dr.tile_counts[tile] = total;
-            if (Dr.out_ptr[1]) {                           // a second copy that the prefix sum overwrites, one longer: the grand total ends up there
-                Dr.out_ptr[1][tile] = total;
-                if (tile == 0) Dr.out_ptr[1][ntiles] = 0;
-            }
-        }
-        const uint64_t below = (1ull << lane) - 1;
-        int rank[ROWS];
-#pragma unroll
-        for (int r = 0; r < ROWS; r++) {
-            const int u = r >> 1;
-            rank[r] = mybase[u] + __popcll(m[2 * u] & below) + __popcll(m[2 * u + 1] & below) + ((r & 1) && alive[2 * u] ? 1 : 0);
-            if (alive[r]) scratch[tile * TILE + rank[r]] = (uint16_t)(tid * 2 + u * (BS * 2) + (r & 1));
-        }
-        if (D.carry) {
-            // the survivors' values of the columns the take pass wants too: put in survivor order in LDS, then stored with consecutive
-            // threads on consecutive words (a store per survivor from wherever its lane sits cost the pass 23 us at Q3 SF10)
-            __shared__ int64_t cstage[kProjCarry];
-            int ci = 0;
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-                if ((D.carry >> c) & 1u) {
-                    int64_t *__restrict__ area = Dr.carry_ptr[ci++] + tile * kProjCarry;
-                    __syncthreads();                       // (the previous column's / tile's stores have read cstage)
-#pragma unroll
-                    for (int r = 0; r < ROWS; r++) if (alive[r] && rank[r] < kProjCarry) cstage[rank[r]] = v[c][r];
-                    __syncthreads();
-                    const int held = total < kProjCarry ? total : kProjCarry;
-                    for (int i = tid; i < held; i += BS) area[i] = cstage[i];
-                }
-            }
-        }
-        par ^= 1;                                          // (no second barrier: the next tile's counts go to the other half)
     }
 }
-
-// one wave per tile; lane k takes the tile's survivors k, k + 64, ...
-template <int NC>
-__device__ __forceinline__ void project_take_body(const MsArgs &C, const MsArgs &Cr, const MScanDesc &D, const MScanDesc &Dr, const uint16_t *__restrict__ scratch,
-                                                  const int64_t *__restrict__ counts /* raw */, const int64_t *__restrict__ offsets /* exclusive prefix */) {
-    constexpr int TILE = kProjTile;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int64_t ntiles = (Cr.n + TILE - 1) / TILE;
-    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave);
-    for (int64_t tile = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; tile < ntiles; tile += wstride) {
-        const int cnt = (int)counts[tile];
-        const int64_t off = offsets[tile];
-        // two survivors per lane and trip (k and k + 64): a tile of 2048 rows keeps about a hundred at TPC-H's selectivities, and the trip
-        // is a chain of dependent loads (position -> columns at the row -> lookups through the index) whose latency is what the pass
-        // costs -- both chains in flight together
-        constexpr int RW = 2;
-        for (int k0 = 0; k0 < cnt; k0 += RW * kWave) {     // wave-uniform
-            int k[RW];
-            bool on[RW];
-            int64_t row[RW];
-#pragma unroll
-            for (int r = 0; r < RW; r++) {
-                k[r] = k0 + r * kWave + lane;
-                on[r] = k[r] < cnt;
-            }
-#pragma unroll
-            for (int r = 0; r < RW; r++) row[r] = tile * TILE + (on[r] ? (int64_t)scratch[tile * TILE + k[r]] : 0);      // idle lanes re-read a row of the tile
-            int64_t v[NC][RW];
-            // every table column the outputs need (directly or as a lookup's index), at the rows; then the lookups
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-#pragma unroll
-                for (int r = 0; r < RW; r++) v[c][r] = 0;
-                if (c < C.ncol && ((D.take >> c) & 1u) && !((C.derived >> c) & 1u)) {
-                    if (((D.carry >> c) & 1u) && cnt <= kProjCarry) {      // (wave-uniform) the select pass left them in survivor order
-                        const int64_t *__restrict__ area = Dr.carry_ptr[__builtin_popcount(D.carry & ((1u << c) - 1u))] + tile * kProjCarry;
-#pragma unroll
-                        for (int r = 0; r < RW; r++) v[c][r] = on[r] ? area[k[r]] : 0;
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < RW; r++) v[c][r] = load_scalar(Cr.ptr[c], C.width(c), row[r] < Cr.n ? row[r] : Cr.n - 1);
-                    }
-                }
-            }
-            bool alive[RW];
-            int64_t rid[RW];
-#pragma unroll
-            for (int r = 0; r < RW; r++) { alive[r] = on[r]; rid[r] = Cr.row0 + row[r]; }
-            derive<NC, RW>(C, Cr, D, Dr, v, alive, C.derived & D.take, rid, false);
-#pragma unroll
-            for (int r = 0; r < RW; r++) on[r] = on[r] && off + k[r] < Dr.out_cap;
-#pragma unroll
-            for (int r = 0; r < RW; r++) if (on[r]) Dr.out_idx[off + k[r]] = row[r];
-            VDL_SPEC_UNROLL
-            for (int o = 0; o < D.nout; o++) {
-                const int oc = D.out_col[o];
-                int64_t x[RW];
-#pragma unroll
-                for (int r = 0; r < RW; r++) x[r] = 0;
-                if (oc >= 0) {
-#pragma unroll
-                    for (int c = 0; c < NC; c++) if (c == oc) {
-#pragma unroll
-                        for (int r = 0; r < RW; r++) x[r] = v[c][r];
-                    }
-                } else {
-                    // a row expression over the columns, in the two-accumulator program form of the group keys (ProjPlan::exprs)
-                    int64_t acc[RW], tmp[RW];
-#pragma unroll
-                    for (int r = 0; r < RW; r++) acc[r] = tmp[r] = 0;
-                    const int at = D.expr_at[-2 - oc], len = D.expr_len[-2 - oc];
-                    VDL_SPEC_UNROLL
-                    for (int s = at; s < at + len; s++) {
-                        const KeyStep st = D.key[s];               // wave-uniform
-                        if (st.kind == KeyStep::LOAD) {
-#pragma unroll
-                            for (int c = 0; c < NC; c++) if (c == st.col) {
-#pragma unroll
-                                for (int r = 0; r < RW; r++) { if (st.target) tmp[r] = v[c][r]; else acc[r] = v[c][r]; }
-                            }
-                        } else if (st.kind == KeyStep::OPK) {
-                            if (st.target) key_rows<RW>(st.bin, st.const_left, tmp, st.k);
-                            else key_rows<RW>(st.bin, st.const_left, acc, st.k);
-                        } else {
-                            key_combine<RW>(st.bin, st.const_left, acc, tmp);
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < RW; r++) x[r] = acc[r];
-                }
-#pragma unroll
-                for (int r = 0; r < RW; r++) if (on[r]) Dr.out_ptr[o][off + k[r]] = x[r];
-            }
-        }
-    }
-}
-
 
 // ---- the fused front in ONE pass (round 4) ---------------------------------------------------------------------------------
 // k_project_select + prefix sum + host count + k_project_take as one kernel: a block takes a tile (tiles are handed out in
@@ -887,124 +739,143 @@ __device__ __forceinline__ void front_publish(unsigned long long *p, int64_t v) 
     __hip_atomic_store(p, (unsigned long long)v | kFrontReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// A block takes kFrontBatch consecutive tiles at a time (a "batch"): selects them one after the other, collecting the survivors of all of
+// them in LDS, and only then asks where they go and fetches their columns -- with one tile per take (the first form) a block
+// waited 12 us per tile for the look-back and for the take's two rounds of dependent loads with a hundred of its 256 lanes busy, and the
+// pass took 435 us for Q3 at SF10 against the two-pass front's 335 (profiles/r04/q3_front_one_tile_per_take.txt).
+#ifndef VDL_FRONT_BATCH
+#define VDL_FRONT_BATCH 4
+#endif
+constexpr int kFrontBatch = VDL_FRONT_BATCH;
+static_assert(kFrontBatch * kProjTile <= 65536, "positions inside a batch fit 16 bits");
+constexpr int kFrontCarry = 512;                           // carried values per batch and column; survivors beyond fetch the column again
+
 template <int NCS, int NCT, int U, bool VEC, bool NT>
 __device__ __forceinline__ void project_front_body(const MsArgs &Cs, const MsArgs &Csr, const MScanDesc &Ds, const MScanDesc &Dsr,
                                                    const MsArgs &Ct, const MsArgs &Ctr, const MScanDesc &Dt, const MScanDesc &Dtr, const FrontLook &lk) {
     constexpr int BS = kMsBlock, ROWS = 2 * U, TILE = BS * ROWS, NW = BS / kWave;
     static_assert(TILE == kProjTile, "one tile shape for the projection scans");
-    __shared__ int wcnt[U][NW];
-    __shared__ unsigned int s_tile;
+    __shared__ int wcnt[2][U][NW];                         // by tile parity: one barrier per tile
+    __shared__ unsigned int s_batch;
     __shared__ long long s_off;
-    __shared__ uint16_t spos[TILE];                        // the survivors' positions inside the tile, in row order
-    __shared__ int64_t cst[kMaxCarry][kProjCarry];         // the carried columns' values, in survivor order
+    __shared__ uint16_t spos[kFrontBatch * TILE];          // the survivors' positions inside the batch, in row order
+    __shared__ int64_t cst[kMaxCarry][kFrontCarry];        // the carried columns' values, in survivor order
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-    const int64_t full = Csr.n / TILE, ntiles = (Csr.n + TILE - 1) / TILE;
+    const int64_t full = Csr.n / TILE, ntiles = (Csr.n + TILE - 1) / TILE, nbatches = (ntiles + kFrontBatch - 1) / kFrontBatch;
+    int par = 0;
     for (;;) {
-        if (tid == 0) s_tile = atomicAdd(lk.ticket, 1u);
+        if (tid == 0) s_batch = atomicAdd(lk.ticket, 1u);
         __syncthreads();
-        const int64_t tile = s_tile;
-        if (tile >= ntiles) break;                         // (block-uniform)
-        int64_t v[NCS][ROWS];
-        const int64_t base = tile * TILE + (int64_t)tid * 2;
-        if (tile < full) {
-            load_tile<NCS, U, VEC, NT>(Cs, Csr, base, v, Cs.lazy);
-        } else {                                           // the partial last tile: clamped scalar loads
+        const int64_t batch = s_batch;
+        if (batch >= nbatches) break;                      // (block-uniform)
+        int total = 0;                                     // survivors of the batch so far
+        for (int sub = 0; sub < kFrontBatch; sub++) {
+            const int64_t tile = batch * kFrontBatch + sub;
+            if (tile >= ntiles) break;                     // (block-uniform)
+            int64_t v[NCS][ROWS];
+            const int64_t base = tile * TILE + (int64_t)tid * 2;
+            if (tile < full) {
+                load_tile<NCS, U, VEC, NT>(Cs, Csr, base, v, Cs.lazy);
+            } else {                                       // the partial last tile: clamped scalar loads
 #pragma unroll
-            for (int c = 0; c < NCS; c++) {
-                if (c < Cs.ncol && !(((Cs.derived | Cs.lazy) >> c) & 1u)) {
+                for (int c = 0; c < NCS; c++) {
+                    if (c < Cs.ncol && !(((Cs.derived | Cs.lazy) >> c) & 1u)) {
 #pragma unroll
-                    for (int r = 0; r < ROWS; r++) {
-                        const int64_t i = base + (int64_t)(r >> 1) * (BS * 2) + (r & 1);
-                        v[c][r] = load_scalar(Csr.ptr[c], Cs.width(c), i < Csr.n ? i : Csr.n - 1);
+                        for (int r = 0; r < ROWS; r++) {
+                            const int64_t i = base + (int64_t)(r >> 1) * (BS * 2) + (r & 1);
+                            v[c][r] = load_scalar(Csr.ptr[c], Cs.width(c), i < Csr.n ? i : Csr.n - 1);
+                        }
                     }
                 }
             }
-        }
-        bool alive[ROWS];
+            bool alive[ROWS];
 #pragma unroll
-        for (int r = 0; r < ROWS; r++) alive[r] = base + (int64_t)(r >> 1) * (BS * 2) + (r & 1) < Csr.n;
-        int64_t rid[ROWS];
+            for (int r = 0; r < ROWS; r++) alive[r] = base + (int64_t)(r >> 1) * (BS * 2) + (r & 1) < Csr.n;
+            int64_t rid[ROWS];
 #pragma unroll
-        for (int r = 0; r < ROWS; r++) rid[r] = Csr.row0 + base + (int64_t)(r >> 1) * (BS * 2) + (r & 1);
-        derive<NCS, ROWS>(Cs, Csr, Ds, Dsr, v, alive, Cs.derived & ~Cs.lazy, rid);      // filters fold into `alive` as they are derived
-        uint64_t m[ROWS];
+            for (int r = 0; r < ROWS; r++) rid[r] = Csr.row0 + base + (int64_t)(r >> 1) * (BS * 2) + (r & 1);
+            derive<NCS, ROWS>(Cs, Csr, Ds, Dsr, v, alive, Cs.derived & ~Cs.lazy, rid);      // filters fold into `alive` as they are derived
+            uint64_t m[ROWS];
 #pragma unroll
-        for (int r = 0; r < ROWS; r++) m[r] = __ballot(alive[r]);
-        // the selection's bitmap over the table's rows, for whoever asks the sparse vectors for their validity: lanes 2l, 2l+1
-        // of the two ballots of a sub-iteration are rows 2l, 2l+1 of the wave's 128 -- interleave them into two words
-        if (Dsr.out_ptr[0] && lane < 2 * U) {
-            const int u = lane >> 1, half = lane & 1;
-            uint64_t a = 0, b = 0;
+            for (int r = 0; r < ROWS; r++) m[r] = __ballot(alive[r]);
+            // the selection's bitmap over the table's rows, for whoever asks the sparse vectors for their validity: lanes 2l, 2l+1
+            // of the two ballots of a sub-iteration are rows 2l, 2l+1 of the wave's 128 -- interleave them into two words
+            if (Dsr.out_ptr[0] && lane < 2 * U) {
+                const int u = lane >> 1, half = lane & 1;
+                uint64_t a = 0, b = 0;
 #pragma unroll
-            for (int uu = 0; uu < U; uu++) if (uu == u) { a = m[2 * uu]; b = m[2 * uu + 1]; }
-            uint64_t x = half ? (a >> 32) : (a & 0xffffffffull), y = half ? (b >> 32) : (b & 0xffffffffull);
-            x = (x | (x << 16)) & 0x0000ffff0000ffffull; x = (x | (x << 8)) & 0x00ff00ff00ff00ffull; x = (x | (x << 4)) & 0x0f0f0f0f0f0f0f0full;
-            x = (x | (x << 2)) & 0x3333333333333333ull; x = (x | (x << 1)) & 0x5555555555555555ull;
-            y = (y | (y << 16)) & 0x0000ffff0000ffffull; y = (y | (y << 8)) & 0x00ff00ff00ff00ffull; y = (y | (y << 4)) & 0x0f0f0f0f0f0f0f0full;
-            y = (y | (y << 2)) & 0x3333333333333333ull; y = (y | (y << 1)) & 0x5555555555555555ull;
-            const int64_t word = (tile * TILE + (int64_t)u * (BS * 2) + (int64_t)wave * 128) / 64 + half;
-            if (word < ((Csr.n + 63) >> 6)) ((uint64_t *)Dsr.out_ptr[0])[word] = x | (y << 1);
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int u = 0; u < U; u++) wcnt[u][wave] = __popcll(m[2 * u]) + __popcll(m[2 * u + 1]);
-        }
-        __syncthreads();
-        int total = 0, mybase[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-#pragma unroll
-            for (int w = 0; w < NW; w++) { if (w == wave) mybase[u] = total; total += wcnt[u][w]; }
-        }
-        // the tile's count goes out first (every later tile needs it); a tile that completes 16 / 256 / ... also sums their nodes
-        if (wave == 0) {
-            if (lane == 0) front_publish(lk.nodes + front_node(ntiles, tile, 0), total);
-            int64_t acc = total;
-            for (int j = 1; j < kFrontLevels && ((tile + 1) & (((int64_t)1 << (kFrontFanBits * j)) - 1)) == 0; j++) {
-                const int64_t step = (int64_t)1 << (kFrontFanBits * (j - 1));
-                int64_t x = 0;
-                if (lane < kFrontFan - 1) x = front_wait(lk.nodes + front_node(ntiles, tile - (int64_t)(lane + 1) * step, j - 1));
-                acc += wave_reduce(x, R_SUM);              // (lane 0 holds the sums)
-                if (lane == 0) front_publish(lk.nodes + front_node(ntiles, tile, j), acc);
+                for (int uu = 0; uu < U; uu++) if (uu == u) { a = m[2 * uu]; b = m[2 * uu + 1]; }
+                uint64_t x = half ? (a >> 32) : (a & 0xffffffffull), y = half ? (b >> 32) : (b & 0xffffffffull);
+                x = (x | (x << 16)) & 0x0000ffff0000ffffull; x = (x | (x << 8)) & 0x00ff00ff00ff00ffull; x = (x | (x << 4)) & 0x0f0f0f0f0f0f0f0full;
+                x = (x | (x << 2)) & 0x3333333333333333ull; x = (x | (x << 1)) & 0x5555555555555555ull;
+                y = (y | (y << 16)) & 0x0000ffff0000ffffull; y = (y | (y << 8)) & 0x00ff00ff00ff00ffull; y = (y | (y << 4)) & 0x0f0f0f0f0f0f0f0full;
+                y = (y | (y << 2)) & 0x3333333333333333ull; y = (y | (y << 1)) & 0x5555555555555555ull;
+                const int64_t word = (tile * TILE + (int64_t)u * (BS * 2) + (int64_t)wave * 128) / 64 + half;
+                if (word < ((Csr.n + 63) >> 6)) ((uint64_t *)Dsr.out_ptr[0])[word] = x | (y << 1);
             }
-        }
-        const uint64_t below = (1ull << lane) - 1;
-        int rank[ROWS];
+            if (lane == 0) {
 #pragma unroll
-        for (int r = 0; r < ROWS; r++) {
-            const int u = r >> 1;
-            rank[r] = mybase[u] + __popcll(m[2 * u] & below) + __popcll(m[2 * u + 1] & below) + ((r & 1) && alive[2 * u] ? 1 : 0);
-            if (alive[r]) spos[rank[r]] = (uint16_t)(tid * 2 + u * (BS * 2) + (r & 1));
-        }
-        if (Ds.carry) {
-            // the survivors' values of the deciding columns that the outputs want too (the join index of a fact table whose dimension is
-            // filtered): they are in registers here -- kept in survivor order instead of being fetched again line by isolated line
-            int ci = 0;
+                for (int u = 0; u < U; u++) wcnt[par][u][wave] = __popcll(m[2 * u]) + __popcll(m[2 * u + 1]);
+            }
+            __syncthreads();
+            int here = 0, mybase[U];
 #pragma unroll
-            for (int c = 0; c < NCS; c++) {
-                if ((Ds.carry >> c) & 1u) {
+            for (int u = 0; u < U; u++) {
 #pragma unroll
-                    for (int r = 0; r < ROWS; r++) if (alive[r] && rank[r] < kProjCarry) cst[ci][rank[r]] = v[c][r];
-                    ci++;
+                for (int w = 0; w < NW; w++) { if (w == wave) mybase[u] = total + here; here += wcnt[par][u][w]; }
+            }
+            par ^= 1;                                      // (no second barrier: the next tile's counts go to the other half)
+            const uint64_t below = (1ull << lane) - 1;
+            int rank[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                const int u = r >> 1;
+                rank[r] = mybase[u] + __popcll(m[2 * u] & below) + __popcll(m[2 * u + 1] & below) + ((r & 1) && alive[2 * u] ? 1 : 0);
+                if (alive[r]) spos[rank[r]] = (uint16_t)(sub * TILE + tid * 2 + u * (BS * 2) + (r & 1));
+            }
+            if (Ds.carry) {
+                // the survivors' values of the deciding columns that the outputs want too (the join index of a fact table whose dimension
+                // is filtered): they are in registers here -- kept in survivor order instead of being fetched again line by isolated line
+                int ci = 0;
+#pragma unroll
+                for (int c = 0; c < NCS; c++) {
+                    if ((Ds.carry >> c) & 1u) {
+#pragma unroll
+                        for (int r = 0; r < ROWS; r++) if (alive[r] && rank[r] < kFrontCarry) cst[ci][rank[r]] = v[c][r];
+                        ci++;
+                    }
                 }
             }
+            total += here;
         }
-        // where the survivors go: one node per unit of each hex digit of the tile number, a lane each
+        // the batch's count goes out (every later batch needs it); a batch that completes 16 / 256 / ... also sums their nodes
+        if (wave == 0) {
+            if (lane == 0) front_publish(lk.nodes + front_node(nbatches, batch, 0), total);
+            int64_t acc = total;
+            for (int j = 1; j < kFrontLevels && ((batch + 1) & (((int64_t)1 << (kFrontFanBits * j)) - 1)) == 0; j++) {
+                const int64_t step = (int64_t)1 << (kFrontFanBits * (j - 1));
+                int64_t x = 0;
+                if (lane < kFrontFan - 1) x = front_wait(lk.nodes + front_node(nbatches, batch - (int64_t)(lane + 1) * step, j - 1));
+                acc += wave_reduce(x, R_SUM);              // (lane 0 holds the sums)
+                if (lane == 0) front_publish(lk.nodes + front_node(nbatches, batch, j), acc);
+            }
+        }
+        // where the survivors go: one node per unit of each hex digit of the batch number, a lane each
         if (wave == NW - 1) {
             int64_t x = 0;
             int i = lane;
             for (int j = 0; j < kFrontLevels; j++) {
-                const int dgt = (int)((tile >> (kFrontFanBits * j)) & (kFrontFan - 1));
-                const int64_t hi = tile & ~(((int64_t)kFrontFan << (kFrontFanBits * j)) - 1);
-                for (; i < dgt; i += kWave) x += front_wait(lk.nodes + front_node(ntiles, hi + ((int64_t)(i + 1) << (kFrontFanBits * j)) - 1, j));
+                const int dgt = (int)((batch >> (kFrontFanBits * j)) & (kFrontFan - 1));
+                const int64_t hi = batch & ~(((int64_t)kFrontFan << (kFrontFanBits * j)) - 1);
+                for (; i < dgt; i += kWave) x += front_wait(lk.nodes + front_node(nbatches, hi + ((int64_t)(i + 1) << (kFrontFanBits * j)) - 1, j));
                 i -= dgt;                                  // (lanes beyond this level's nodes move on to the next level's)
             }
             x = wave_reduce(x, R_SUM);
             if (lane == 0) s_off = x;
         }
-        __syncthreads();
+        __syncthreads();                                   // (also: every tile's positions and carried values are in LDS)
         const int64_t off = s_off;
-        if (tile == ntiles - 1 && tid == 0) {
+        if (batch == nbatches - 1 && tid == 0) {
             *lk.total = off + total;
             if (lk.total_host) *lk.total_host = off + total;
         }
@@ -1012,13 +883,13 @@ __device__ __forceinline__ void project_front_body(const MsArgs &Cs, const MsArg
         // through the index -- and the packed vectors.  (Nothing is written beyond the vectors' capacity: the host may have guessed it.)
         if (off < Dtr.out_cap) {
             for (int k = tid; k < total; k += BS) {
-                const int64_t row = tile * TILE + (int64_t)spos[k];
+                const int64_t row = batch * (kFrontBatch * TILE) + (int64_t)spos[k];
                 int64_t vt[NCT][1];
 #pragma unroll
                 for (int c = 0; c < NCT; c++) {
                     vt[c][0] = 0;
                     if (c < Ct.ncol && ((Dt.take >> c) & 1u) && !((Ct.derived >> c) & 1u)) {
-                        if (((Dt.carry >> c) & 1u) && k < kProjCarry) vt[c][0] = cst[__builtin_popcount(Dt.carry & ((1u << c) - 1u))][k];
+                        if (((Dt.carry >> c) & 1u) && k < kFrontCarry) vt[c][0] = cst[__builtin_popcount(Dt.carry & ((1u << c) - 1u))][k];
                         else vt[c][0] = load_scalar(Ctr.ptr[c], Ct.width(c), row);
                     }
                 }
@@ -1057,7 +928,7 @@ __device__ __forceinline__ void project_front_body(const MsArgs &Cs, const MsArg
                 }
             }
         }
-        __syncthreads();                                   // (the next tile reuses the LDS areas)
+        __syncthreads();                                   // (the next batch reuses the LDS areas)
     }
 }
 

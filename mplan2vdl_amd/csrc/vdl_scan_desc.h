@@ -127,7 +127,6 @@ struct MScanDesc {                           // lives in device memory, read wit
     int nexpr = 0, expr_at[kMaxProjOuts] = {}, expr_len[kMaxProjOuts] = {};
     int64_t *out_ptr[kMaxProjOuts] = {};     // one packed int64 vector per produced column
     int64_t *out_idx = nullptr;              // the surviving rows' slot ids, ascending
-    int64_t *tile_counts = nullptr;          // [tiles + 1]: survivors per tile
     uint32_t take = 0;                       // k_project_take: the columns the outputs need (with the columns they are derived from)
     int bitmap_only = 0;                     // k_project_select: 1 = a dimension scan -- the selection's bitmap, no counts, no positions;
                                              // 2 = a semi-join scan: for every selected row, bit v[out_col[0]] of the set out_ptr[0] (dn[out_col[0]] bits) is set
@@ -139,13 +138,12 @@ struct MScanDesc {                           // lives in device memory, read wit
     // census builds of a staged scan (vdl_jit.cpp, VDL_CENSUS; measurement only, never the timed kernel): [column] = number of
     // distinct 128-byte lines the late loads of that column asked for
     unsigned long long *census = nullptr;
-    // projection scan: columns the select pass has in registers anyway (they decide survival) AND the take pass wants for the
-    // survivors -- Q3's join index -- travel from one pass to the other in a per-tile area (kProjCarry entries per tile, in the tile's
-    // survivor order) instead of being fetched again line by isolated line.  Bit c: column c (of this descriptor's own numbering)
-    // is carried; carry_ptr[i] = the area of the i-th set bit.  A tile with more survivors than the area holds is read the old way.
+    // the fused front: columns its select side has in registers anyway (they decide survival) AND the outputs want for the survivors --
+    // Q3's join index -- stay in LDS in survivor order (kFrontCarry entries per batch of tiles) instead of being fetched again line by
+    // isolated line.  Bit c: column c (of this descriptor's own numbering) is carried; the i-th set bit of the select side's word and
+    // of the take side's name the same column.  Survivors beyond the area's capacity fetch the column again.
     uint32_t carry = 0;
-    int64_t *carry_ptr[2] = {nullptr, nullptr};
-    // take pass: entries the output vectors hold (the pass may be launched before the host knows the survivors' number, with room for a
+    // the fused front: entries the output vectors hold (the pass runs before the host knows the survivors' number, with room for a
     // guess: what does not fit is not written, and the host runs the pass again when it learns that the guess was short)
     int64_t out_cap = INT64_MAX;
 };

@@ -522,9 +522,10 @@ def test_folds_over_a_few_very_long_runs_match_oracle(holes):
 
 
 def test_the_front_guesses_its_survivors_from_the_last_run_and_recovers_when_wrong():
-    """From its second run on a plan's fused front launches its take pass before the host knows how many rows survived, with room for
-    an eighth more than last time.  The same plan over data that changes under it: 14 % of the rows survive, then all of them (the
-    guess is short: the pass runs again with room), then none, then a few again -- every answer equals the oracle's."""
+    """The one-pass front writes its output vectors before the host knows how many rows survive: from a plan's second run on they have
+    room for an eighth more than last time, and nothing is written beyond that.  The same plan over data that changes under it: 14 %
+    of the rows survive, then all of them (the guess is short: the pass runs again with the exact number), then none, then a few
+    again -- every answer equals the oracle's."""
     rng = np.random.default_rng(8)
     n, nd = 70001, 300
     base = {"f.k": rng.integers(0, nd, n).astype(np.int64), "f.a": rng.integers(0, 50, n).astype(np.int64), "f.v": rng.integers(-100, 100, n).astype(np.int64),

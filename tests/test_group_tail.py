@@ -78,15 +78,12 @@ def test_folds_over_keys_in_order_match_the_oracle(filtered, batch, monkeypatch)
             check_against_oracle("group_tail_%s_%s_%s" % ("filtered" if filtered else "all", shape, "batch" if batch else "nobatch"), n, text, cols, got, want)
 
 
-@pytest.mark.parametrize("mode", [None, "VDL_NO_LAZY_POSITIONS", "VDL_NO_SORTED_KEYS"])
 @pytest.mark.parametrize("domain", [1 << 40, 1 << 12])
-def test_folds_over_keys_out_of_order_take_the_radix_route(domain, mode, monkeypatch):
+def test_folds_over_keys_out_of_order_take_the_radix_route(domain):
     """the same programs over keys in random order: the sortedness pass says no, the Partition sorts (its positions stay in rank order:
     only Scatters read them; the key's own Scatter is what the sort wrote), the folds run over the scattered vectors.  With the small
     domain some keys lie beyond the last pivot and some below the first: buckets are clamped, so the sorted buckets are NOT the
     sorted keys and the key is gathered like every other vector."""
-    if mode:
-        monkeypatch.setenv(mode, "1")
     for filtered in (True, False):
         text = program(filtered, domain)
         for n in (9, 513, 4097, 50021):

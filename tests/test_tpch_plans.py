@@ -160,7 +160,7 @@ def test_engine_matches_oracle_on_the_vlite_dialect(cfg, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["VDL_SPARSE_ALWAYS", "VDL_NO_SPARSE", "VDL_NO_EXPR_FUSION", "VDL_NO_FILTER_FUSION", "VDL_NO_PROJECTION", "VDL_NO_DIM_SCAN", "VDL_NO_GROUP_BATCH", "VDL_NO_FRONT_EXPR", "VDL_NO_REWRITE", "VDL_NO_GATHER_LIVE_CACHE", "VDL_NO_DESC_CACHE", "VDL_NO_LAZY_POSITIONS", "VDL_NO_FRONT_CARRY", "VDL_NO_FRONT_GUESS"])
+@pytest.mark.parametrize("mode", ["VDL_SPARSE_ALWAYS", "VDL_NO_SPARSE", "VDL_NO_EXPR_FUSION", "VDL_NO_FILTER_FUSION", "VDL_NO_PROJECTION", "VDL_NO_DIM_SCAN", "VDL_NO_GROUP_BATCH", "VDL_NO_FRONT_EXPR", "VDL_NO_REWRITE", "VDL_NO_GATHER_LIVE_CACHE"])
 def test_sparse_vector_routes_agree(cfg, monkeypatch, mode):
     """The general executor keeps vectors that only hold values on a selection in compact form after selective
     filters, and runs chains of single-reader element-wise operators as one fused kernel.  Sparse forced on for

@@ -26,7 +26,7 @@ else:
     rows = sorted(csv.DictReader(open(sys.argv[2])), key=lambda r: int(r["Start_Timestamp"]))
     # the last query = the kernels after the last gap of more than 200 us ... simpler: find the last launch of the first kernel name of a query
     names = [r["Kernel_Name"] for r in rows]
-    first = next(i for i in range(len(rows) - 1, -1, -1) if "project_select" in names[i] and (i == 0 or int(rows[i]["Start_Timestamp"]) - int(rows[i - 1]["End_Timestamp"]) > 100000))
+    first = next(i for i in range(len(rows) - 1, -1, -1) if ("project_select" in names[i] or "project_front" in names[i]) and (i == 0 or int(rows[i]["Start_Timestamp"]) - int(rows[i - 1]["End_Timestamp"]) > 100000))
     q = rows[first:]
     t0 = int(q[0]["Start_Timestamp"])
     prev_end = t0
