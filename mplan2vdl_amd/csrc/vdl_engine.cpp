@@ -1009,7 +1009,7 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
         sel->bitmap = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>((n + 63) >> 6, 1));
         sdesc->out_ptr[0] = (int64_t *)sel->bitmap->p;
         BufP look = dev_alloc(c, (size_t)project_look_bytes(n)), total = dev_alloc(c, sizeof(int64_t));
-        int64_t *back = c->pinned(1);
+        int64_t *back = c->flag_words() ? c->flag_words() + 1 : nullptr;       // the last batch posts the survivors' number there (system-scope store)
         auto room_for = [&](int64_t cap) {
             sel->idx = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(cap, 1));
             d.out_idx = (int64_t *)sel->idx->p;
@@ -1020,17 +1020,14 @@ bool run_projection(vdl_ctx *c, vdl_plan *p, std::map<int, DVec> &over) {
             d.out_cap = cap;
         };
         auto pass = [&]() -> int64_t {
+            if (back) *(volatile int64_t *)back = -1;
             HIP_CHECK(launch_project_front(scols, desc_on_device(c, p, "select", *sdesc), cols, desc_on_device(c, p, "take", d), look->p, (int64_t *)total->p, back,
                                            c->num_cus, c->stream, front_kernel_one_pass(c, p, scols, *sdesc, cols, d)));
+            // the host goes on as soon as it knows the number -- while the kernel's other batches still fetch their survivors --: what it
+            // queues next runs behind the kernel anyway
             int64_t got = 0;
-            if (back) {
-                if (!p->front_ev) HIP_CHECK(hipEventCreateWithFlags(&p->front_ev, hipEventDisableTiming));
-                HIP_CHECK(hipEventRecord(p->front_ev, c->stream));
-                HIP_CHECK(hipEventSynchronize(p->front_ev));
-                got = *back;
-            } else {
-                c->fetch_to_host(total->p, 1, &got, c->stream);
-            }
+            if (back) { c->wait_flag(back, -1, c->stream); got = *(volatile int64_t *)back; }
+            else c->fetch_to_host(total->p, 1, &got, c->stream);
             return got;
         };
         const int64_t per_row = (int64_t)sizeof(int64_t) * (int64_t)(distinct.size() + 1);
@@ -1124,12 +1121,40 @@ int vdl_open(vdl_ctx **out, int device) {
     return rc;
 }
 
+void vdl_ctx::wait_flag(int64_t *word, int64_t until_not, hipStream_t s) {
+    volatile int64_t *w = word;
+    for (unsigned spins = 0; *w == until_not; spins++) {
+        __builtin_ia32_pause();
+        if ((spins & 0x3fff) == 0x3fff) {                       // every ~16 K polls: is the stream still going?
+            const hipError_t e = hipStreamQuery(s);
+            if (e == hipSuccess) {                              // idle: the word was written (or never will be: a launch failed)
+                if (*w == until_not) throw Error(VDL_ERR_DEVICE, "a kernel that should have reported to the host did not (the stream is idle)");
+                break;
+            }
+            if (e != hipErrorNotReady) throw Error(VDL_ERR_DEVICE, std::string("hipStreamQuery failed: ") + hipGetErrorString(e));
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+}
+void vdl_ctx::wait_here(hipStream_t s) {
+    int64_t *flag = flag_words();
+    if (!flag) { HIP_CHECK(hipStreamSynchronize(s)); return; }
+    const int64_t seq = ++post_seq;
+    HIP_CHECK(launch_post_words(nullptr, 0, nullptr, flag, seq, s));
+    while (*(volatile int64_t *)flag != seq) wait_flag(flag, *(volatile int64_t *)flag, s);
+}
 void vdl_ctx::fetch_to_host(const void *dev, size_t k, int64_t *out, hipStream_t s) {
     if (k == 0) return;
-    int64_t *pin = pinned((int64_t)k);
-    HIP_CHECK(hipMemcpyAsync(pin ? pin : out, dev, sizeof(int64_t) * k, hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));
-    if (pin) std::memcpy(out, pin, sizeof(int64_t) * k);
+    int64_t *pin = pinned((int64_t)k), *flag = flag_words();
+    if (!pin || !flag) {
+        HIP_CHECK(hipMemcpyAsync(out, dev, sizeof(int64_t) * k, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        return;
+    }
+    const int64_t seq = ++post_seq;
+    HIP_CHECK(launch_post_words((const int64_t *)dev, (int64_t)k, pin, flag, seq, s));
+    while (*(volatile int64_t *)flag != seq) wait_flag(flag, *(volatile int64_t *)flag, s);
+    std::memcpy(out, pin, sizeof(int64_t) * k);
 }
 
 void vdl_close(vdl_ctx *c) {

@@ -190,10 +190,18 @@ struct vdl_ctx {
     // into pageable memory is staged by the runtime and cost 20-30 us of idle GPU each (Q3 at SF10: three of them per query)
     int64_t *pinned_words = nullptr;
     static constexpr int kPinnedWords = 1 << 15;       // 256 KiB: also the per-rank count tables of the sharded routes (128 ranks x 130 words)
+    static constexpr int kFlagWords = 8;                // the last words: [0] the flag a posting kernel raises, [1] the fused front's survivor count
     int64_t *pinned(int64_t words) {
         if (!pinned_words && hipHostMalloc((void **)&pinned_words, sizeof(int64_t) * kPinnedWords, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); pinned_words = nullptr; }
-        return words <= kPinnedWords ? pinned_words : nullptr;
+        return words <= kPinnedWords - kFlagWords ? pinned_words : nullptr;
     }
+    int64_t *flag_words() { return pinned(1) ? pinned_words + (kPinnedWords - kFlagWords) : nullptr; }
+    int64_t post_seq = 0;
+    // Round trips without hipStreamSynchronize: a one-block kernel behind whatever is queued posts words and a sequence number into
+    // pinned memory with system-scope stores, the host polls the number (and the stream's state now and then, so that a failed
+    // launch ends the wait).  wait_here: "everything queued on s so far is done".
+    void wait_flag(int64_t *word, int64_t until_not, hipStream_t s);          // until *word != until_not
+    void wait_here(hipStream_t s);
     // `k` int64 words from the device to `out`, waited for on `s`: through the pinned words when they fit -- no copy of this library
     // has pageable host memory for its destination unless it is larger than that (result vectors, traces)
     void fetch_to_host(const void *dev, size_t k, int64_t *out, hipStream_t s);
@@ -291,7 +299,6 @@ struct vdl_plan {
     std::map<std::string, DescSlot> desc_slots;
     double front_usec = 0;
     int64_t front_m_seen = -1;               // survivors of the front's last run: the next run launches its take pass with room for about as many
-    hipEvent_t front_ev = nullptr;           // ... and learns the real number while the pass runs
     bool bound = false;
     uint64_t bound_version = 0;
     // pipelined finalisation: two pinned host slots, one event each
@@ -325,7 +332,6 @@ struct vdl_plan {
     ~vdl_plan() {
         for (auto &b : out_pinned) if (b.first) (void)hipHostFree(b.first);
         for (hipEvent_t e : stmt_ev) if (e) (void)hipEventDestroy(e);
-        if (front_ev) (void)hipEventDestroy(front_ev);
         for (int k = 0; k < 2; k++) {
             if (ev0[k]) (void)hipEventDestroy(ev0[k]);
             if (ev1[k]) (void)hipEventDestroy(ev1[k]);

@@ -87,7 +87,7 @@ struct GenExec {
         int64_t total = 0;
         if (int64_t *pin = c->pinned(1)) {                     // the kernel leaves the total in pinned host memory itself: no copy to launch
             HIP_CHECK(launch_compact_offsets(bits ? (const uint64_t *)bits->p : nullptr, n, (int64_t *)counts->p, s, pin));
-            HIP_CHECK(hipStreamSynchronize(s));
+            c->wait_here(s);
             total = *(volatile int64_t *)pin;
         } else {
             HIP_CHECK(launch_compact_offsets(bits ? (const uint64_t *)bits->p : nullptr, n, (int64_t *)counts->p, s));
@@ -857,10 +857,8 @@ struct GenExec {
             HIP_CHECK(launch_sorted_heads(src_of(data), o.n, (uint64_t *)heads->p, flag, s));     // (sets the two flag words itself)
             HIP_CHECK(launch_compact_count((const uint64_t *)heads->p, o.n, (int64_t *)counts->p, s));
             HIP_CHECK(launch_compact_scan((int64_t *)counts->p, nb, s));
-            int64_t stack[4] = {0, 0, 0, 0};
-            int64_t *back = c->pinned(4) ? c->pinned(4) : stack;
-            HIP_CHECK(hipMemcpyAsync(back, (int64_t *)counts->p + nb, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-            HIP_CHECK(hipStreamSynchronize(s));
+            int64_t back[4] = {0, 0, 0, 0};
+            c->fetch_to_host((int64_t *)counts->p + nb, 4, back, s);      // (posted into pinned memory and polled: no stream synchronise)
             const int64_t nheads = back[0], seen[2] = {back[1], back[2]};
             // every value inside the pivots: bucket = value - pmin exactly, so the sorted buckets ARE the sorted values
             values_inside = back[3] >= pmin && (uint64_t)back[2] - (uint64_t)pmin <= (uint64_t)pcount && back[2] >= back[3];

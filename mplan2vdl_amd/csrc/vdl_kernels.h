@@ -182,7 +182,9 @@ hipError_t launch_onehot_dense(const int64_t *oh, int64_t *out, uint64_t *valid,
 // block_counts: ceil(n / compact_tile()) int64; returns total in block_counts[nblocks] (device).
 int64_t compact_tile();
 hipError_t launch_compact_count(const uint64_t *valid, int64_t n, int64_t *block_counts, hipStream_t s);
-hipError_t launch_compact_scan(int64_t *block_counts, int64_t nblocks, hipStream_t s, int64_t *host_total = nullptr);   // exclusive scan in place, total at [nblocks]
+hipError_t launch_compact_scan(int64_t *block_counts, int64_t nblocks, hipStream_t s, int64_t *host_total = nullptr);
+// k words of device memory into pinned host memory and then `seq` into the pinned flag word, with system-scope stores (the host polls)
+hipError_t launch_post_words(const int64_t *src, int64_t k, int64_t *pinned_dst, int64_t *pinned_flag, int64_t seq, hipStream_t s);   // exclusive scan in place, total at [nblocks]
 hipError_t launch_compact_offsets(const uint64_t *valid, int64_t n, int64_t *block_counts, hipStream_t s, int64_t *host_total = nullptr);   // host_total: pinned host word that also receives the total   // count + scan (one launch for small n)
 hipError_t launch_compact_write(Src v, const uint64_t *valid, int64_t n, const int64_t *block_offsets, int64_t *out, hipStream_t s, int64_t *out_pos = nullptr /* also: the slot number of every packed entry */);
 

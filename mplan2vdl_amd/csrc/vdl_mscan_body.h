@@ -877,7 +877,7 @@ __device__ __forceinline__ void project_front_body(const MsArgs &Cs, const MsArg
         const int64_t off = s_off;
         if (batch == nbatches - 1 && tid == 0) {
             *lk.total = off + total;
-            if (lk.total_host) *lk.total_host = off + total;
+            if (lk.total_host) __hip_atomic_store(lk.total_host, (int64_t)(off + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);    // (the host polls it)
         }
         // the survivors' rows: what the outputs need of them -- fact columns at the row (carried values from LDS), dimension columns
         // through the index -- and the packed vectors.  (Nothing is written beyond the vectors' capacity: the host may have guessed it.)

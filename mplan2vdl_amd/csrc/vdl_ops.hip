@@ -652,6 +652,22 @@ hipError_t launch_compact_offsets(const uint64_t *valid, int64_t n, int64_t *cou
     if (e != hipSuccess) return e;
     return launch_compact_scan(counts, nb, s, host_total);
 }
+// `k` words of device memory into PINNED host memory, then a flag word, all with system-scope stores: the host polls the flag instead
+// of sleeping in hipStreamSynchronize (whose wake-up left the GPU idle for 20-30 us per round trip of a query: verdicts, counts).
+// k = 0: just the flag ("the stream has come this far").
+__global__ __launch_bounds__(256) void k_post_words(const int64_t *__restrict__ src, int64_t k, int64_t *dst, int64_t *flag, int64_t seq) {
+    for (int64_t i = threadIdx.x; i < k; i += blockDim.x) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+hipError_t launch_post_words(const int64_t *src, int64_t k, int64_t *pinned_dst, int64_t *pinned_flag, int64_t seq, hipStream_t s) {
+    (void)hipGetLastError();
+    k_post_words<<<1, 256, 0, s>>>(src, k, pinned_dst, pinned_flag, seq);
+    return launch_status();
+}
 hipError_t launch_compact_scan(int64_t *counts, int64_t nb, hipStream_t s, int64_t *host_total) {
     (void)hipGetLastError();   // see launch_status()
     k_scan_counts<<<1, 1024, 0, s>>>(counts, nb, host_total);
