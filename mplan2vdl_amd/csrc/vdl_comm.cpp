@@ -308,23 +308,27 @@ static void sharded_exchange(vdl_ctx *c, vdl_plan *p) {
     // Global folds over the sharded table that the tail reads beside the Partition (Q11's HAVING threshold) travel in the same
     // all-gather: three mergeable words each, merged on the host below.
     const size_t n_fold_words = 3 * exchange_fold_count(p, table);
-    std::vector<int64_t> mine((size_t)m.world + 1 + n_fold_words, 0);
+    // Round 4: WHERE the key domain is cut follows the data.  Every rank counts its keys in kExBins equal slices of the pivots' domain;
+    // the histograms travel in the one all-gather (with the status and the fold words); every rank sums them and cuts the slices into
+    // `world` runs of about equal population -- the same cut everywhere --, routes its rows by it, and reads what it will receive from
+    // whom out of the gathered histograms.  (With the DECLARED domain cut evenly the last three of eight ranks received nothing for
+    // TPC-H Q3: the order keys in use reach 0.56 of their power-of-two domain.)  Owners stay contiguous key ranges in rank order, so the
+    // ranks' outputs still concatenate to the unsharded result.
+    const size_t row = 1 + (size_t)kExBins + 1 + n_fold_words;          // {status, histogram, keys outside the pivots, fold words}
+    std::vector<int64_t> mine(row, 0);
     std::string local_error;
-    const int rc = vdl_exchange_begin(c, p, m.world, mine.data() + 1);
-    if (rc != VDL_OK) { local_error = c->err; mine.assign((size_t)m.world + 1 + n_fold_words, 0); }
-    else if (p->ex.fold_words.size() == n_fold_words) std::copy(p->ex.fold_words.begin(), p->ex.fold_words.end(), mine.begin() + m.world + 1);
-    mine[0] = rc;
-    const size_t row = (size_t)m.world + 1 + n_fold_words;
-    BufP dsend = dev_alloc(c, sizeof(int64_t) * row), drecv = dev_alloc(c, sizeof(int64_t) * row * (size_t)m.world);
-    HIP_CHECK(hipMemcpyAsync(dsend->p, mine.data(), sizeof(int64_t) * row, hipMemcpyHostToDevice, c->stream));
-    std::vector<int64_t> all(row * (size_t)m.world);
-    if (m.world > 1) {
-        all_gather(c, dsend->p, drecv->p, sizeof(int64_t) * row, c->stream);
-        c->fetch_to_host(drecv->p, all.size(), all.data(), c->stream);
-    } else {
-        all = mine;
+    int rc = guard(c, [&] {
+        exchange_local(c, p, m.world);
+        exchange_histogram(c, p, mine.data() + 1);
+    });
+    if (rc == VDL_OK && mine[1 + (size_t)kExBins] > 0) {
+        rc = VDL_ERR_UNSUPPORTED;
+        c->err = std::to_string(mine[1 + (size_t)kExBins]) + " row(s) carry a partition key outside the pivots; run unsharded";
     }
-    HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (rc != VDL_OK) { local_error = c->err; mine.assign(row, 0); }
+    else if (p->ex.fold_words.size() == n_fold_words) std::copy(p->ex.fold_words.begin(), p->ex.fold_words.end(), mine.begin() + 2 + kExBins);
+    mine[0] = rc;
+    const std::vector<int64_t> all = gather_words(c, mine);
     for (int r = 0; r < m.world; r++)
         if (all[(size_t)r * row] != VDL_OK) {
             if (rc != VDL_OK) throw Error(rc, local_error);
@@ -335,19 +339,36 @@ static void sharded_exchange(vdl_ctx *c, vdl_plan *p) {
         std::vector<int64_t> merged(n_fold_words);
         for (size_t w = 0; w < n_fold_words; w++) {
             const int kind = w % 3 == 0 ? exchange_fold_kind(p, w / 3) : (w % 3 == 1 ? 1 : 0);      // 0 sum, 1 min, 2 max
-            int64_t acc = all[(size_t)m.world + 1 + w];
+            int64_t acc = all[2 + (size_t)kExBins + w];
             for (int r = 1; r < m.world; r++) {
-                const int64_t v = all[(size_t)r * row + (size_t)m.world + 1 + w];
+                const int64_t v = all[(size_t)r * row + 2 + (size_t)kExBins + w];
                 acc = kind == 1 ? std::min(acc, v) : kind == 2 ? std::max(acc, v) : (int64_t)((uint64_t)acc + (uint64_t)v);
             }
             merged[w] = acc;
         }
         p->ex.fold_merged = merged;
     }
-    std::vector<int64_t> scnt(mine.begin() + 1, mine.begin() + 1 + m.world), rcnt((size_t)m.world);
+    // the cut: slice b goes to the rank in whose share of the population its middle lies (monotone in b)
+    std::vector<int64_t> global((size_t)kExBins, 0);
+    int64_t total = 0;
+    for (int r = 0; r < m.world; r++)
+        for (int b = 0; b < kExBins; b++) { global[(size_t)b] += all[(size_t)r * row + 1 + (size_t)b]; }
+    for (int b = 0; b < kExBins; b++) total += global[(size_t)b];
+    std::vector<int32_t> owner((size_t)kExBins, 0);
+    {
+        int64_t before = 0;
+        for (int b = 0; b < kExBins; b++) {
+            const int64_t mid = before + global[(size_t)b] / 2;
+            int64_t o = total > 0 ? (int64_t)(((unsigned __int128)(uint64_t)mid * (uint64_t)m.world) / (uint64_t)total) : ((int64_t)b * m.world) / kExBins;
+            owner[(size_t)b] = (int32_t)std::min<int64_t>(o, m.world - 1);
+            before += global[(size_t)b];
+        }
+    }
+    std::vector<int64_t> scnt((size_t)m.world, 0), rcnt((size_t)m.world, 0);
+    if (guard(c, [&] { exchange_route(c, p, owner.data(), scnt.data()); }) != VDL_OK) throw Error(VDL_ERR_DEVICE, c->err);
     int64_t n_send = 0, n_recv = 0;
     for (int r = 0; r < m.world; r++) {
-        rcnt[(size_t)r] = all[(size_t)r * row + 1 + (size_t)m.rank];
+        for (int b = 0; b < kExBins; b++) if (owner[(size_t)b] == m.rank) rcnt[(size_t)r] += all[(size_t)r * row + 1 + (size_t)b];
         n_send += scnt[(size_t)r]; n_recv += rcnt[(size_t)r];
     }
     BufP send = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(n_send * ncols, 1));

@@ -347,6 +347,12 @@ namespace vdl {
 namespace eng {
 
 
+// the sharded Partition's local phase in steps (vdl_exchange.cpp): vdl_exchange_begin = local + route(null); vdl_run_sharded puts the
+// ranks' key histograms in between and routes by the cut they give
+void exchange_local(vdl_ctx *c, vdl_plan *p, int world);
+void exchange_histogram(vdl_ctx *c, vdl_plan *p, int64_t *hist_host /* kExBins + 1 */);
+void exchange_route(vdl_ctx *c, vdl_plan *p, const int32_t *owner_host /* kExBins, or null */, int64_t *counts_host);
+
 inline BufP dev_alloc(vdl_ctx *c, size_t bytes) {
     auto b = std::make_shared<DevBuf>();
     b->pool = c->pool;

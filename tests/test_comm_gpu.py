@@ -98,7 +98,7 @@ def test_join_then_aggregate_merges_its_words(plan_no, fuse, world):
 
 
 @pytest.mark.parametrize("world", [1, 2, 3])
-@pytest.mark.parametrize("plan_no,fuse", [(3, True), (5, True), (9, True), (10, True), (20, True), (12, False)])
+@pytest.mark.parametrize("plan_no,fuse", [(3, True), (5, True), (9, True), (10, True), (12, False)])
 def test_plans_with_a_partition_exchange_rows_and_concatenate(plan_no, fuse, world):
     """ONE all-gather of {status, counts} + ONE all-to-all of every column: the ranks' outputs, in rank order, are the
     unsharded result."""
@@ -249,13 +249,15 @@ def test_a_plan_no_route_serves_runs_on_the_replicated_table(world):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("plan,table", [(16, "partsupp"), (15, "lineitem")])
+@pytest.mark.parametrize("plan,table", [(16, "partsupp"), (15, "lineitem"), (20, "lineitem")])
 def test_two_partitions_run_above_the_gathered_front(plan, table, world):
     """TPC-H Q16 (count(distinct ps_suppkey) under a GROUP BY: two Partitions) has no exchange route; its work on partsupp is a
     fused front, so the survivors' vectors of every rank are all-gathered -- rank after rank = row order -- and every rank runs
     the two Partitions on the complete vectors: the "front" route, whole answer everywhere.  Q15 (a global max over the grouped sums,
     then the suppliers that reach it) goes the same way once the column its FoldChoose'd row ids looked up travels through the
-    fold itself (rewrite_program, vdl_fuse.cpp)."""
+    fold itself (rewrite_program, vdl_fuse.cpp).  So does Q20 (round 4): one Partition, but its tail feeds a semi-join set over suppliers
+    from the groups, which the exchange route's concatenation cannot serve (the balanced key cut made that visible: a supplier with
+    qualifying groups on two ranks came out twice)."""
     cfg = frontend.load_metadata(META)
     text = frontend.compile_plan(open(os.path.join(META, "%02d.sql.mplan" % plan)).read(), cfg)
     cols = catalog.synth_columns(META, cfg, text, scale=2e-3, seed=3)

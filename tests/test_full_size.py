@@ -147,8 +147,10 @@ def test_q3_sf100_whole_and_as_eight_co_partitioned_shards_through_the_exchange_
         return cols
 
     parts = run_ranks(WORLD, work, timeout=900)
-    # (owners are key ranges of the DECLARED domain, 2^42; the order keys in use reach 0.56 of it, as in dbgen's data: the last ranks' ranges are empty)
-    assert sum(len(part[0]) > 0 for part in parts) >= 4
+    # the key domain is cut where the data is (the ranks' key histograms travel with the counts): every rank ends with about an eighth of
+    # the groups, although the order keys in use reach only 0.56 of the declared 2^42 domain
+    sizes = [len(part[0]) for part in parts]
+    assert min(sizes) > 0.8 * sum(sizes) / WORLD and max(sizes) < 1.2 * sum(sizes) / WORLD, sizes
     for j, name in enumerate(("l_orderkey", "revenue", "o_orderdate", "o_shippriority")):
         whole = np.concatenate([part[j] for part in parts])
         assert whole.shape == want[j].shape and np.array_equal(whole, want[j]), name
