@@ -113,6 +113,10 @@ for query in ("q6", "q1"):
                         "correction": "x2: one TCC_EA0_RDREQ per 128-byte line, tallied at 64 B (MI355X_MICROARCH.md HBM; holds for masked loads: fetch_calib.txt)",
                         "bytes_moved_per_launch_counted": b["roofline"]["bytes_moved_per_launch"], "algorithmic_bytes_per_launch": b["roofline"]["algorithmic_bytes_per_launch"],
                         "bench_kernel_us": b["roofline"]["kernel_us"],
+                        # both fractions of the 8 TB/s peak for this kernel (rocprof's average duration): on the bytes it MOVED (FETCH x 2) and
+                        # on SURVEY.md 8(d)'s algorithmic bytes -- equal for a kernel that reads everything, the latter above 1 for a staged one
+                        "frac_of_peak_on_bytes_moved": fetch * 1024 * 2 / (float(names[kname]["AverageNs"]) * 1e-9) / 8e12,
+                        "frac_of_peak_on_algorithmic_bytes": b["roofline"]["algorithmic_bytes_per_launch"] / (float(names[kname]["AverageNs"]) * 1e-9) / 8e12,
                         "source": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 bench.py %s%s --steps 3 --warmup 1%s (tools/profile_bench.py)" %
                                   (" ".join(q + jit), "", " [VDL_JIT_PIN=%s]" % env["VDL_JIT_PIN"] if env else "")}
         # keep the scan kernels' PMC rows
