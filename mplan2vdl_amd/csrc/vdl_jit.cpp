@@ -306,6 +306,8 @@ std::string front_source(const MsArgs &Cs, const MScanDesc &Ds, const MsArgs &Ct
     o << "#define VDL_SPEC_UNROLL _Pragma(\"unroll\")\n";
     o << "#define VDL_PROJ_U " << VDL_PROJ_U_HOST << "\n#define VDL_FRONT_BATCH " << VDL_FRONT_BATCH_HOST << "\n" << kEmbedded << "\n" << desc_text(SELECT, Cs, Ds, "_s") << desc_text(TAKE, Ct, Dt, "_t");
     const char *b = sh.vec ? "true" : "false";
+    // (Q3's front: 107 VGPRs = 4 blocks per CU; asked to fit 5 or 6 waves per SIMD -- 96 / 80 registers, 12 / 76 bytes of scratch -- the pass
+    // took the same 2.64-2.66 ms at SF100: it moves 14.7 GB, i.e. 5.5 TB/s, and is bound by that, not by occupancy)
     o << "extern \"C\" __global__ __launch_bounds__(256) void " << entry_name(FRONT) << "(const vdl::MsArgs Csr, const vdl::MScanDesc *__restrict__ Dsp, const vdl::MsArgs Ctr,\n"
          "        const vdl::MScanDesc *__restrict__ Dtp, const vdl::FrontLook lk) {\n"
          "    constexpr vdl::MsArgs Cs = vdl::jit_args_s();\n"

@@ -335,6 +335,41 @@ def test_a_row_id_condition_counts_from_the_tables_first_row_on_every_rank(world
     assert sharded_run(text, table_shards(cols, world, "f"), world, table="f") == [want] * world
 
 
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_the_key_domain_is_cut_where_the_data_is(world):
+    """Keys that fill the lowest eighth of their declared domain (and unevenly: three quarters of the rows in the lowest tenth of the keys
+    in use): the ranks' key histograms (4096 slices of the declared domain) travel with the counts, every rank cuts the domain at the
+    same data-driven points, and each ends with about 1 / world of the ROWS -- with the declared domain cut evenly every row would go to
+    rank 0.  The ranks' outputs concatenate to the oracle's answer (key order), and a tail that treats every group by itself is what the
+    analysis insists on."""
+    from helpers import prog
+    rng = np.random.default_rng(17 + world)
+    n = 60000
+    k = np.where(rng.random(n) < 0.75, rng.integers(0, 3000, n), rng.integers(3000, 30000, n)).astype(np.int64) + 77
+    cols = {"t.k": k, "t.x": rng.integers(-50, 50, n).astype(np.int64), "t.f": (rng.integers(0, 10, n) < 8).astype(np.int64)}
+    text = prog("1,Load,t.k", "2,Project,val,Id 1,k", "3,Load,t.x", "4,Project,val,Id 3,x", "5,Load,t.f", "6,Project,val,Id 5,f",
+                "7,RangeV,val,0,Id 6,1", "8,FoldSelect,val,Id 7,val,Id 6,val", "9,Gather,Id 2,Id 8,val", "10,Gather,Id 4,Id 8,val",
+                "11,RangeC,val,0,%d,1" % (1 << 18), "12,Partition,val,Id 9,val,Id 11,val",
+                "13,RangeV,val,0,Id 9,1", "14,Scatter,Id 9,Id 13,val,Id 12,val", "15,Scatter,Id 10,Id 13,val,Id 12,val",
+                "16,FoldSum,val,Id 14,val,Id 15,val", "17,FoldChoose,val,Id 14,val,Id 14,val", "18,FoldCount,val,Id 14,val,Id 15,val",
+                "19,Project,s,Id 16,val", "20,MaterializeCompact,Id 19", "21,Project,key,Id 17,val", "22,MaterializeCompact,Id 21",
+                "23,Project,c,Id 18,val", "24,MaterializeCompact,Id 23")
+    want = oracle_run(text, cols)
+    shards = [(lo, {kk: v[lo:hi] for kk, v in cols.items()}) for lo, hi in (shard_rows(n, r, world) for r in range(world))]
+    parts = sharded_run(text, shards, world, table="t", fuse=False)
+    got = {kk: {name: sum((part[kk][name] for part in parts), []) for name in v} for kk, v in want.items()}
+    assert got == want
+    rows = [sum(part["tmp24"][".c"]) for part in parts]                   # rows each rank received = the sum of its groups' counts
+    assert sum(rows) == int((cols["t.f"] > 0).sum())
+    assert min(rows) > 0.7 * sum(rows) / world and max(rows) < 1.3 * sum(rows) / world, rows
+    # ... and a tail that folds ACROSS groups (a global maximum over the group sums) is refused by the exchange analysis
+    e = m.Engine(device=None)
+    p = e.parse(text + prog("25,RangeV,val,0,Id 16,0", "26,FoldMax,val,Id 25,val,Id 16,val", "27,MaterializeCompact,Id 26"))
+    p.set_fusion(False)
+    with pytest.raises(m.VdlError, match="does not treat every group by itself"):
+        p.exchange_columns("t")
+
+
 def test_a_failure_on_one_rank_is_reported_on_every_rank():
     """A key outside the Partition pivots on ONE rank (the local phase of that rank fails): the status travels with the
     counts, nobody is left waiting in a collective, every rank returns an error."""
