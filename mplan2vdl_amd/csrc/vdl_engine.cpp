@@ -245,8 +245,19 @@ static bool build_specialised(vdl_ctx *c, vdl_plan *p, size_t s, bool grouped, i
     std::vector<char> code;
     MsArgs args = mscan_args(p->mcols[s]);
     if (lazy) {
-        args.stages = staged_columns(c, p->mcols[s], p->mdesc[s], grouped, &args.lazy, lazy);
+        args.stages = staged_columns(c, p->mcols[s], p->mdesc[s], grouped, &args.lazy, lazy == 3 ? 1 : lazy);
         if (!args.lazy) { why = "no column to read late"; return false; }
+        if (lazy == 3) {
+            // the queue form: the most selective filter column with the tile, EVERY other table column for the queued rows
+            int eager = 0;
+            for (int k = 0; k < p->mcols[s].ncol; k++) {
+                if (p->mcols[s].kind[k] != VC_DIRECT) continue;
+                if (!((args.lazy >> k) & 1u)) { eager++; if (!p->mcols[s].filtered[k]) { why = "a column that is no filter would come with the tile"; return false; } }
+            }
+            if (eager != 1) { why = "the queue form wants exactly one filter column with the tile"; return false; }
+            args.queued = 1;
+            args.stages = 0;
+        }
     }
     if (!jit::compile(jit::mscan_source(args, p->mdesc[s], sh), c->arch, code, why)) { why = why.substr(0, 400); return false; }
     // a specialised scan is 10-25 KB of code; ten times that means the compiler did not fold the descriptor (it then sits in
@@ -265,7 +276,7 @@ static bool build_specialised(vdl_ctx *c, vdl_plan *p, size_t s, bool grouped, i
     if (grid > p->mcols[s].n / tile) grid = p->mcols[s].n / tile;
     if (grid < 1) grid = 1;
     out.grid = (int)grid; out.per_cu = per_cu; out.code_bytes = code.size(); out.name = jit_name(sh); out.u = sh.u; out.lazy = lazy;
-    if (lazy) out.name.insert(out.name.size() - 1, lazy > 1 ? ",late2" : ",late");
+    if (lazy) out.name.insert(out.name.size() - 1, lazy == 3 ? ",queue" : lazy > 1 ? ",late2" : ",late");
     if (lazy) out.stages = stages_text(p, s, args);
     return true;
 }
@@ -310,7 +321,8 @@ static void tune_specialised(vdl_ctx *c, vdl_plan *p, int64_t *dev_words) {
         std::string tried;
         // rows per lane first; then, at the winner, at 2 and at 1, the staged form that reads late (fewer rows per lane suit it:
         // its loads depend on each other, and what hides them is more waves, not more loads per wave)
-        std::vector<std::pair<int, int>> cands = {{2, 0}, {3, 0}, {4, 0}, {6, 0}, {0, 1}, {3, 1}, {2, 1}, {1, 1}, {3, 2}, {2, 2}, {4, 2}};
+        // (3 = the queue form: one filter column with the tile, the rows still in queued per wave and finished 64 at a time)
+        std::vector<std::pair<int, int>> cands = {{2, 0}, {3, 0}, {4, 0}, {6, 0}, {0, 1}, {3, 1}, {2, 1}, {1, 1}, {3, 2}, {2, 2}, {4, 2}, {4, 3}, {3, 3}, {6, 3}};
         // VDL_JIT_PIN="u=3,late=2" (profiles: tools/profile_bench.sh runs the form a plain run chose, and nothing else): one candidate
         int pin_u = 0, pin_late = -1;
         if (const char *pin = getenv("VDL_JIT_PIN")) {
@@ -344,7 +356,7 @@ static void tune_specialised(vdl_ctx *c, vdl_plan *p, int64_t *dev_words) {
                 if (rep > 0) times.push_back(t);                // the first launch of a module pays for its load
             }
             const float ms = median_of(times);
-            tried += " u=" + std::to_string(u) + (lazy > 1 ? ",late2:" : lazy ? ",late:" : ":") + std::to_string((int)(ms * 1000)) + "us";
+            tried += " u=" + std::to_string(u) + (lazy == 3 ? ",queue:" : lazy > 1 ? ",late2:" : lazy ? ",late:" : ":") + std::to_string((int)(ms * 1000)) + "us";
             if (!best.k || ms < best_ms * 0.98f) { best = cand; best_ms = ms; }
             if (!lazy && (best_u == 0 || cand.k == best.k)) best_u = u;       // the staged forms start from the quickest eager shape
         }
@@ -427,7 +439,7 @@ static int64_t scan_bytes_moved(vdl_ctx *c, vdl_plan *p, std::string &detail) {
     HIP_CHECK(launch_mscan(cols, d, (const MScanDesc *)ddev->p, cfg, grouped, false, out, false, c->stream, cen.k->fn));
     unsigned long long lines[kMaxVCols] = {};
     c->fetch_to_host(counts->p, kMaxVCols, (int64_t *)lines, c->stream);
-    const MsArgs args = [&] { MsArgs a = mscan_args(cols); uint32_t lz = 0; a.stages = staged_columns(c, cols, p->mdesc[s], grouped, &lz, p->mjit_form[s].lazy); a.lazy = lz; return a; }();
+    const MsArgs args = [&] { MsArgs a = mscan_args(cols); uint32_t lz = 0; a.stages = staged_columns(c, cols, p->mdesc[s], grouped, &lz, p->mjit_form[s].lazy == 3 ? 1 : p->mjit_form[s].lazy); a.lazy = lz; return a; }();
     for (int k = 0; k < cols.ncol; k++) {
         if (cols.kind[k] != VC_DIRECT) continue;
         const bool late = (args.lazy >> k) & 1u;
@@ -1386,9 +1398,10 @@ int vdl_plan_jit_check(vdl_ctx *c, vdl_plan *p) {
             std::string log;
             MsArgs args = mscan_args(cols);
             if (getenv("VDL_JIT_LATE")) args.stages = staged_columns(c, cols, *d, grouped, &args.lazy);      // the staged form of the same scan
+            if (getenv("VDL_JIT_LATE") && atoi(getenv("VDL_JIT_LATE")) == 3 && args.lazy) { args.queued = 1; args.stages = 0; }   // ... or its queue form
             if (!jit::compile(jit::mscan_source(args, *d, sh), c->arch, code, log))
                 throw Error(VDL_ERR_UNSUPPORTED, "scan " + std::to_string(s) + " does not build: " + log.substr(0, 2000));
-            p->jit_note += "scan " + std::to_string(s) + ": " + jit_name(sh) + (args.lazy ? " (late)" : "") + ", " + std::to_string(code.size()) + " B of code; ";
+            p->jit_note += "scan " + std::to_string(s) + ": " + jit_name(sh) + (args.queued ? " (queue)" : args.lazy ? " (late)" : "") + ", " + std::to_string(code.size()) + " B of code; ";
         }
     });
 }

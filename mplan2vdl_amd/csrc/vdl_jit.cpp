@@ -188,7 +188,7 @@ static std::string desc_text(Kind kind, const MsArgs &C, const MScanDesc &D, con
     o << "namespace vdl {\n";
     o << "constexpr MsArgs jit_args" << suffix << "() {\n    MsArgs a{};\n";
     o << "    a.ncol = " << C.ncol << "; a.widths = " << C.widths << "ull; a.filtered = " << C.filtered << "u; a.derived = " << C.derived
-      << "u; a.lazy = " << C.lazy << "u; a.stages = " << C.stages << "ull;\n    return a;\n}\n";
+      << "u; a.lazy = " << C.lazy << "u; a.stages = " << C.stages << "ull; a.queued = " << C.queued << ";\n    return a;\n}\n";
     o << "constexpr MScanDesc jit_desc" << suffix << "() {\n    MScanDesc d{};\n";
     o << "    d.nagg = " << D.nagg << "; d.nkey = " << D.nkey << "; d.replicas = " << D.replicas << "; d.pmin = " << lit(D.pmin) << "; d.pcount = " << lit(D.pcount) << ";\n";
     int pool = 0;
@@ -232,7 +232,14 @@ std::string scan_source(Kind kind, const MsArgs &C, const MScanDesc &D, const Sh
     std::ostringstream o;
     o << "#define VDL_SPEC_UNROLL _Pragma(\"unroll\")\n";
     if (kind == MSCAN && sh.census) o << "#define VDL_CENSUS 1\n";
-    if (kind == MSCAN && C.lazy) {
+    if (kind == MSCAN && C.lazy && C.queued) {
+        // the queue form: only the filters of the columns that come with the tile, as straight-line code over the tile's rows
+        o << "#define VDL_QUEUE_FILTER";
+        for (int c = 0; c < C.ncol; c++)
+            if (!((C.derived >> c) & 1u) && !((C.lazy >> c) & 1u) && ((C.filtered >> c) & 1u))
+                o << " _Pragma(\"unroll\") for (int r = 0; r < RW; r++) alive[r] = alive[r] & (v[" << c << "][r] >= " << lit(D.flo[c]) << ") & (v[" << c << "][r] <= " << lit(D.fhi[c]) << ");";
+        o << "\n";
+    } else if (kind == MSCAN && C.lazy) {
         // the stages of a scan that reads late (MsArgs::stages), as straight-line code inside the body's row loop context
         // a lane's rows come in adjacent pairs (2u, 2u + 1): with aligned columns a pair of which a row is still in is ONE
         // 16-byte (int64) / 8-byte (int32) load instead of two masked scalar ones; the one-row tail and unaligned columns

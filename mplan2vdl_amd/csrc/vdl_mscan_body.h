@@ -406,7 +406,7 @@ __device__ __forceinline__ void mscan_body(const MsArgs &C, const MsArgs &Cr, co
     }
     __syncthreads();
 
-    auto process = [&](auto rows_tag, int64_t (&v)[NC][decltype(rows_tag)::value], const int64_t (&rowid)[decltype(rows_tag)::value], int64_t rows_left) {
+    auto process = [&](auto rows_tag, int64_t (&v)[NC][decltype(rows_tag)::value], const int64_t (&rowid)[decltype(rows_tag)::value], int64_t rows_left, auto staged_tag) {
         constexpr int RW = decltype(rows_tag)::value;
         bool pass[RW];
         // Staged reads (STAGED: specialised builds, when the tuner found them quicker): only the most selective filter column comes
@@ -414,7 +414,7 @@ __device__ __forceinline__ void mscan_body(const MsArgs &C, const MsArgs &Cr, co
         // without a live row is never touched), then what derived columns and the group key need, and last the columns that
         // are only aggregate inputs, for the rows that passed everything.  Q6 keeps 1.9 % of its rows and moves ~13 of its
         // 28 B/row this way; Q14 (1 row in 84 passes the date filter) ~6 of 28.  Worthless when most rows pass (Q1).
-        constexpr bool staged = STAGED;
+        constexpr bool staged = STAGED && decltype(staged_tag)::value != 0;
         bool alive[RW];
 #pragma unroll
         for (int r = 0; r < RW; r++) alive[r] = !DER || (int64_t)((r >> 1) * (BS * 2) + (r & 1)) < rows_left;
@@ -547,13 +547,102 @@ __device__ __forceinline__ void mscan_body(const MsArgs &C, const MsArgs &Cr, co
     };
 
     const int64_t ntiles = Cr.n / TILE;
+#ifdef VDL_QUEUE_FILTER
+    // The QUEUE form (C.queued; specialised builds whose first filter keeps a few rows in a hundred -- Q14: one month of seven years):
+    // the filter column comes with the tile and is tested there; the rows still in are queued per wave (LDS ring of row numbers), and as
+    // soon as a wave holds 64 of them every lane takes one and runs the whole pipeline on it -- the other columns at the row, the
+    // lookups, the aggregates.  The staged forms above do the same work in the tile's row layout, where a wave has four or five lanes
+    // alive per stage and as many loads in flight: three dependent stages deep they were bound by latency at 0.41 of the peak
+    // (profiles/r04/q14_bound.txt).
+    if (STAGED && C.queued) {
+        // (a wave holds fewer than 64 rows when it pushes a tile's -- at most 64 per row slot --, and only then takes them out 64 at a
+        // time: ONE call site for the pipeline below; inlined at every push it was three copies, the lambdas stopped being inlined and
+        // the descriptor went to scratch memory)
+        constexpr int QNEED = kWave - 1 + ROWS * kWave;
+        constexpr int QCAP = QNEED <= 128 ? 128 : QNEED <= 256 ? 256 : QNEED <= 512 ? 512 : 1024;
+        static_assert(QNEED <= QCAP, "the queue holds a tile's rows beside what was left");
+        __shared__ int64_t queue[kMsBlock / kWave][QCAP];
+        const int lane = tid & (kWave - 1), wave = tid / kWave;
+        int head = 0, held = 0;                                    // wave-uniform
+        const int64_t all_tiles = (Cr.n + TILE - 1) / TILE;
+        for (int64_t tile = blockIdx.x;; tile += gridDim.x) {
+            const bool flush = tile >= all_tiles;                  // (block-uniform) the trip after the last tile takes out what is left
+            if (!flush) {
+                int64_t v[NC][ROWS], rowid[ROWS];
+                const int64_t base = tile * TILE + (int64_t)tid * 2;
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) rowid[r] = Cr.row0 + base + (int64_t)(r >> 1) * (BS * 2) + (r & 1);
+                if (tile < ntiles) load_tile<NC, U, VEC, NT>(C, Cr, base, v, C.lazy);
+                else {                                             // the partial last tile: clamped scalar loads
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        if (c < C.ncol && !(((C.derived | C.lazy) >> c) & 1u)) {
+#pragma unroll
+                            for (int r = 0; r < ROWS; r++) { const int64_t i = rowid[r] - Cr.row0; v[c][r] = load_scalar(Cr.ptr[c], C.width(c), i < Cr.n ? i : Cr.n - 1); }
+                        }
+                    }
+                }
+                bool alive[ROWS];
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) alive[r] = rowid[r] - Cr.row0 < Cr.n;
+                constexpr int RW = ROWS;
+                VDL_QUEUE_FILTER
+#ifdef VDL_CENSUS
+                // the lines the queued rows will ask for, counted here where the rows still lie in address order: a lane's two rows are
+                // adjacent, the wave's lanes hold consecutive addresses (stride 2 w), so a lane is the first asker of its 128-byte line
+                // when no lower lane with a row still in lies in the same line (as the staged forms' generated census does)
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    if (c < C.ncol && ((C.lazy >> c) & 1u) && !((C.derived >> c) & 1u)) {
+                        const int w = C.width(c);
+#pragma unroll
+                        for (int u = 0; u < U; u++) {
+                            const bool any = alive[2 * u] | alive[2 * u + 1];
+                            const uint64_t m = __ballot(any);
+                            const uint64_t a = (uint64_t)Cr.ptr[c] + (uint64_t)(rowid[2 * u] - Cr.row0) * (uint64_t)w;
+                            int lo = lane - (int)((a & 127ull) / (uint64_t)(2 * w));
+                            if (lo < 0) lo = 0;
+                            const bool first = any && ((m >> lo) & ((1ull << (lane - lo)) - 1ull)) == 0ull;
+                            const uint64_t f = __ballot(first);
+                            if (lane == 0) census_cnt[c] += (unsigned long long)__popcll(f);
+                        }
+                    }
+                }
+#endif
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) {
+                    const uint64_t m = __ballot(alive[r]);
+                    if (alive[r]) queue[wave][(head + held + __popcll(m & ((1ull << lane) - 1))) & (QCAP - 1)] = rowid[r];
+                    held += __popcll(m);
+                }
+            }
+            while (held >= (flush ? 1 : kWave)) {                  // every lane takes one queued row and runs the whole pipeline on it
+                const int k = held < kWave ? held : kWave;
+                if (lane < k) {
+                    int64_t v1[NC][1], rid[1];
+                    rid[0] = queue[wave][(head + lane) & (QCAP - 1)];
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        v1[c][0] = 0;
+                        if (c < C.ncol && !((C.derived >> c) & 1u)) v1[c][0] = load_scalar(Cr.ptr[c], C.width(c), rid[0] - Cr.row0);
+                    }
+                    process(IntTag<1>{}, v1, rid, 1, IntTag<0>{});
+                }
+                head = (head + k) & (QCAP - 1);
+                held -= k;
+            }
+            if (flush) break;
+        }
+    } else
+#endif
+    {
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int64_t v[NC][ROWS], rowid[ROWS];
         const int64_t base = tile * TILE + (int64_t)tid * 2;
 #pragma unroll
         for (int u = 0; u < U; u++) { rowid[2 * u] = Cr.row0 + base + (int64_t)u * (BS * 2); rowid[2 * u + 1] = rowid[2 * u] + 1; }
         load_tile<NC, U, VEC, NT>(C, Cr, base, v, STAGED ? C.lazy : 0u);
-        process(IntTag<ROWS>{}, v, rowid, (int64_t)1 << 40);
+        process(IntTag<ROWS>{}, v, rowid, (int64_t)1 << 40, IntTag<1>{});
     }
     if (blockIdx.x == gridDim.x - 1 && ntiles * TILE < Cr.n) {
         if (DER) {
@@ -572,7 +661,7 @@ __device__ __forceinline__ void mscan_body(const MsArgs &C, const MsArgs &Cr, co
                     }
                 }
             }
-            process(IntTag<ROWS>{}, v, rowid, Cr.n - base);
+            process(IntTag<ROWS>{}, v, rowid, Cr.n - base, IntTag<1>{});
         } else {
             for (int64_t i = ntiles * TILE + tid; i < Cr.n; i += BS) {      // tail rows, one per lane
                 int64_t v1[NC][1], rid[1];
@@ -580,9 +669,10 @@ __device__ __forceinline__ void mscan_body(const MsArgs &C, const MsArgs &Cr, co
 #pragma unroll
                 for (int c = 0; c < NC; c++)
                     if (c < C.ncol) v1[c][0] = load_scalar(Cr.ptr[c], C.width(c), i);
-                process(IntTag<1>{}, v1, rid, 1);
+                process(IntTag<1>{}, v1, rid, 1, IntTag<1>{});
             }
         }
+    }
     }
     __syncthreads();
     __shared__ int64_t red[kMsBlock / kWave];

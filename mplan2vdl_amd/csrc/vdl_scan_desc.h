@@ -164,6 +164,9 @@ struct MsArgs {
     // the rows that passed every filter on table columns; 15: an aggregate input only, read for the rows that passed everything
     uint64_t stages = 0;
     VDL_SD constexpr int stage(int c) const { return (int)((stages >> (4 * c)) & 15u); }
+    // the QUEUE form of a specialised scan that reads late (round 4): the columns outside `lazy` (the most selective filter column) come with the
+    // tile and are filtered there; the rows still in are queued per wave and everything else is read for 64 of them at a time, every lane busy
+    int queued = 0;
     int64_t n = 0, row0 = 0;
     int64_t rowid_base = 0;                  // what a row-id column subtracts from the global row number: row0 (ids inside this shard) or 0
     const void *ptr[kMaxVCols] = {};

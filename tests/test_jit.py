@@ -56,6 +56,13 @@ def test_specialised_kernels_of_the_tpch_plans_build_without_a_gpu(n, tmp_path, 
     census = p.jit_check()
     assert "(late)" in census and code_bytes(census) != code_bytes(late) and max(code_bytes(census)) < 96 << 10, census
     monkeypatch.delenv("VDL_JIT_CENSUS")
+    # ... and the queue form (one filter column with the tile, the rows still in queued per wave and finished 64 at a time), with its census build
+    monkeypatch.setenv("VDL_JIT_LATE", "3")
+    queue = p.jit_check()
+    assert "(queue)" in queue and max(code_bytes(queue)) < 64 << 10, queue
+    monkeypatch.setenv("VDL_JIT_CENSUS", "1")
+    assert "(queue)" in p.jit_check()
+    monkeypatch.delenv("VDL_JIT_CENSUS")
     monkeypatch.delenv("VDL_JIT_LATE")
     monkeypatch.delenv("VDL_JIT_ASSUME_SELECTIVITY")
     assert ("derived" in note) == (n != 1)                      # the join scans carry looked-up / condition columns
@@ -175,9 +182,10 @@ def test_specialised_tpch_plans_match_the_oracle(tune, scale):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("late", [0, 1, 2])
+@pytest.mark.parametrize("late", [0, 1, 2, 3])
 def test_specialised_random_programs_match_the_oracle(late, monkeypatch):
-    """late: staged reads -- that many filter columns with the tile, the other table columns for the rows still in
+    """late: staged reads -- that many filter columns with the tile, the other table columns for the rows still in; 3 = the queue
+    form: one filter column with the tile, the rows still in queued per wave and finished 64 at a time with every lane busy
     (VDL_JIT_LATE forces what the tuner otherwise decides by timing)."""
     from test_random_conditions import Gen as CondGen
     from test_random_fused import Gen as FusedGen
@@ -202,12 +210,12 @@ def test_specialised_random_programs_match_the_oracle(late, monkeypatch):
             e.close()
             check_against_oracle("specialised_random_" + tag, seed, text, cols, got, want)
             ran += "k_mscan_specialised<" in note
-            lates += ",late" in note
-    assert ran >= 60 and (lates >= 30 if late else lates == 0)
+            lates += (",queue" if late == 3 else ",late") in note
+    assert ran >= 60 and (lates >= (20 if late == 3 else 30) if late else lates == 0), (ran, lates)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("late", [0, 1, 2])
+@pytest.mark.parametrize("late", [0, 1, 2, 3])
 def test_scan_traffic_counts_the_lines_a_staged_scan_asks_for(late, monkeypatch, q6_text):
     """vdl_plan_scan_traffic (bench.py's `roofline.achieved` is built on it): a scan that reads everything moves its algorithmic
     bytes; a staged scan moves the eager columns plus 128 B per line of a late column in which a row was still in -- the census
@@ -235,6 +243,8 @@ def test_scan_traffic_counts_the_lines_a_staged_scan_asks_for(late, monkeypatch,
     a1 = a0 & (disc >= 5) & (disc <= 7)
     a2 = a1 & (q < 2400)
     want = 4 * n + (8 * n if late == 2 else 128 * lines(a0)) + 128 * lines(a1) + 128 * lines(a2)
+    if late == 3:                                                # the queue form: every other column for the rows inside the date range
+        want = 4 * n + 3 * 128 * lines(a0)
     assert moved == want, (moved, want, detail)
     assert want < 28 * n and "late:" in detail
 

@@ -50,6 +50,8 @@ def pin_of(label):
     m = re.match(r"k_mscan_specialised<\d+,(\d+),[^>]*>", label)
     if not m:
         return None
+    if ",queue>" in label:
+        return "u=%s,late=3" % m.group(1)
     late = re.search(r",late(\d?)>", label)
     return "u=%s,late=%s" % (m.group(1), (late.group(1) or "1") if late else "0")
 
