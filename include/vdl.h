@@ -276,11 +276,18 @@ void vdl_comm_free(vdl_ctx *ctx);                       /* also done by vdl_clos
  *   counts -> all-gather of {status, survivors} -> ONE grouped send / receive of the survivors' vectors to every rank (rank after
  *   rank = row order) -> the statements above the front run everywhere on the complete vectors; every rank ends with the full
  *   result.  Tried after the exchange; the row-id conditions of the front count from the table's first row.
- * The last resort, for a plan none of the four serves (TPC-H Q18): the sharded table's columns the plan loads are all-gathered ONCE per
+ * A fifth, the "chain" (TPC-H Q18: a GROUP BY over ALL rows of the sharded table whose groups only feed position sets --
+ *   Scatter(constant, size, a value of the group): the semi-join set of `in (select .. group by .. having ..)` -- and a rest that reads the
+ *   sets and the table a second time): the rows travel to the owners of their key range as on the exchange route and every owner runs the
+ *   GROUP BY on complete groups -> all-gather of {status, positions found, length} + ONE grouped send / receive per set: every rank
+ *   builds the same sets -> the rest runs with the sets given: per-row work on each rank's OWN rows, all-gather of {status, rows} and
+ *   ONE grouped send / receive of the rows that reach the next Partition (rank after rank = row order), the tail on every rank; every
+ *   rank ends with the full result (VDL_NO_CHAIN_ROUTE=1 switches it off).
+ * The last resort, for a plan none of the five serves: the sharded table's columns the plan loads are all-gathered ONCE per
  *   catalog state into plan-owned buffers, and every rank runs the whole query over them -- the query itself does not scale, later
  *   runs move nothing, every rank ends with the full result ("replicate"; VDL_NO_REPLICATE_ROUTE=1 turns it into the refusal with the
  *   reasons).
- * vdl_plan_sharded_route tells which route a plan takes ("fold" | "set" | "exchange" | "front" | "replicate") and whether every rank
+ * vdl_plan_sharded_route tells which route a plan takes ("fold" | "set" | "exchange" | "front" | "chain" | "replicate") and whether every rank
  * ends with the whole answer (replicated = 1) or with its slice (0: concatenate the ranks' outputs in rank order). */
 int  vdl_plan_sharded_route(vdl_ctx *ctx, vdl_plan *plan, const char **route, int *replicated);
 int  vdl_run_sharded(vdl_ctx *ctx, vdl_plan *plan);     /* results through vdl_output as after vdl_run */

@@ -702,6 +702,108 @@ static void sharded_replicate(vdl_ctx *c, vdl_plan *p) {
     if (vdl_run(c, p) != VDL_OK) throw Error(VDL_ERR_DEVICE, c->err);
 }
 
+// ---- the "chain" route (TPC-H Q18; analysis and the reasoning: vdl_exchange.cpp analyse_chain) ----
+// stage 1: the exchange route's own run over the rewritten program with the operands of the position sets for outputs (every rank ends
+// with the packed positions its key range contributes); merge: one all-gather of {status, positions and length per set}, one grouped
+// send / receive per set, every rank builds the same sets; stage 2: the rest with the sets given -- per-row work on each rank's own
+// shard, the rows that reach the next Partition all-gathered (rank after rank = row order), the tail on every rank.  Every rank reaches
+// every collective once per run whatever fails where: a failure travels in the next status exchange.
+static bool chain_route(vdl_plan *p, std::string *why = nullptr) {
+    if (getenv("VDL_NO_CHAIN_ROUTE")) { if (why) *why = "switched off (VDL_NO_CHAIN_ROUTE)"; return false; }
+    std::string w;
+    const bool ok = chain_plan(p, w) != nullptr;
+    if (why) *why = w;
+    return ok;
+}
+
+static void sharded_chain(vdl_ctx *c, vdl_plan *p) {
+    need_device(c);
+    CommState &m = comm_of(c);
+    std::string why;
+    const std::shared_ptr<ChainPlan> cp = chain_plan(p, why);
+    if (!cp) throw Error(VDL_ERR_UNSUPPORTED, "no chain route: " + why);
+    struct Restore {
+        vdl_plan *p; Program saved;
+        ~Restore() { p->prog = std::move(saved); p->chain.stage = 0; p->chain.lists.clear(); p->chain.sets.clear(); p->shard_keep.reset(); }
+    } restore{p, p->prog};
+    const std::vector<int> outputs = p->prog.outputs;
+    p->prog = cp->prog;
+    const size_t nsets = cp->sets.size();
+    // ---- stage 1
+    p->chain.stage = 1;
+    p->prog.outputs = cp->targets;
+    std::sort(p->prog.outputs.begin(), p->prog.outputs.end());
+    p->prog.outputs.erase(std::unique(p->prog.outputs.begin(), p->prog.outputs.end()), p->prog.outputs.end());
+    int rc = VDL_OK;
+    std::string own;
+    try { sharded_exchange(c, p); }
+    catch (const Error &e) { rc = e.code; own = e.what(); }
+    if (rc == VDL_OK && p->chain.lists.size() != nsets) { rc = VDL_ERR_DEVICE; own = "the position sets were not collected"; }
+    p->prog.outputs = outputs;
+    // ---- merge
+    std::vector<int64_t> mine(1 + 2 * nsets, 0);
+    mine[0] = rc;
+    if (rc == VDL_OK) for (size_t k = 0; k < nsets; k++) { mine[1 + 2 * k] = p->chain.lists[k].m; mine[2 + 2 * k] = p->chain.lists[k].len; }
+    std::vector<int64_t> all = gather_words(c, mine);
+    const size_t row = mine.size();
+    for (int r = 0; r < m.world; r++)
+        if (all[(size_t)r * row] != VDL_OK) {
+            if (rc != VDL_OK) throw Error(rc, own);
+            throw Error(VDL_ERR_UNSUPPORTED, "sharded run: the GROUP BY behind the position sets failed on rank " + std::to_string(r) + " (its error is reported there)");
+        }
+    for (size_t k = 0; k < nsets; k++) {
+        std::vector<int64_t> cnt((size_t)m.world);
+        int64_t total = 0, len = 0;
+        for (int r = 0; r < m.world; r++) {
+            cnt[(size_t)r] = all[(size_t)r * row + 1 + 2 * k];
+            total += cnt[(size_t)r];
+            const int64_t l = all[(size_t)r * row + 2 + 2 * k];
+            len = cp->size_replicated[k] ? std::max(len, l) : len + l;
+        }
+        BufP got = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(total, 1));
+        all_gather_rows(c, {(const int64_t *)p->chain.lists[k].list->p}, {(int64_t *)got->p}, cnt, c->stream);
+        chain_build_set(c, p, k, got, total, len);
+        HIP_CHECK(hipStreamSynchronize(c->stream));          // (`got` goes)
+    }
+    p->chain.lists.clear();
+    // ---- stage 2
+    p->chain.stage = 2;
+    if (!cp->second_cut) {
+        // nothing above the sets reads the sharded table: the rest is the same on every rank
+        if (guard(c, [&] { chain_run_everywhere(c, p); }) != VDL_OK) throw Error(VDL_ERR_DEVICE, c->err);
+        return;
+    }
+    int ncols = 0;
+    int64_t n_send = 0;
+    BufP send;
+    rc = guard(c, [&] {
+        if (vdl_exchange_spec(p, p->sharded_table.c_str(), &ncols) != VDL_OK) throw Error(VDL_ERR_UNSUPPORTED, c->err);
+        exchange_local(c, p, 1);                              // "one destination": every row with a key, in row order
+        exchange_route(c, p, nullptr, &n_send);
+        send = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(n_send * ncols, 1));
+        if (vdl_exchange_pack(c, p, send->p) != VDL_OK) throw Error(VDL_ERR_DEVICE, c->err);
+    });
+    own = c->err;
+    all = gather_words(c, {rc, rc == VDL_OK ? n_send : 0});
+    std::vector<int64_t> cnt((size_t)m.world);
+    int64_t total = 0;
+    for (int r = 0; r < m.world; r++) {
+        if (all[(size_t)r * 2] != VDL_OK) {
+            if (rc != VDL_OK) throw Error(rc, own);
+            throw Error(VDL_ERR_UNSUPPORTED, "sharded run: the scan above the position sets failed on rank " + std::to_string(r) + " (its error is reported there)");
+        }
+        cnt[(size_t)r] = all[(size_t)r * 2 + 1];
+        total += cnt[(size_t)r];
+    }
+    BufP recv = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(total * ncols, 1));
+    std::vector<const int64_t *> from;
+    std::vector<int64_t *> to;
+    for (int k = 0; k < ncols; k++) { from.push_back((const int64_t *)send->p + (int64_t)k * n_send); to.push_back((int64_t *)recv->p + (int64_t)k * total); }
+    all_gather_rows(c, from, to, cnt, c->stream);
+    p->shard_keep = recv;
+    if (vdl_exchange_finish(c, p, recv->p, total) != VDL_OK) throw Error(VDL_ERR_DEVICE, c->err);
+}
+
 static bool fold_route(vdl_ctx *c, vdl_plan *p) {
     int64_t nw = 0;
     const int32_t *ops = nullptr;
@@ -796,8 +898,10 @@ int vdl_plan_sharded_route(vdl_ctx *c, vdl_plan *p, const char **route, int *rep
         else {
             const std::string why_not_exchange = c->err;
             const std::string why = front_route_refusal(p);
+            std::string why_not_chain;
             if (why.empty()) name = "front";
-            else if (getenv("VDL_NO_REPLICATE_ROUTE")) { c->err = why_not_exchange + "; no front route either: " + why; return rc; }
+            else if (chain_route(p, &why_not_chain)) { c->err.clear(); name = "chain"; }
+            else if (getenv("VDL_NO_REPLICATE_ROUTE")) { c->err = why_not_exchange + "; no front route either: " + why + "; no chain route: " + why_not_chain; return rc; }
             else {
                 // the last resort: the table's columns gathered once, the whole query on every rank -- the reasons stay readable
                 c->err.clear();
@@ -850,9 +954,10 @@ int vdl_run_sharded(vdl_ctx *c, vdl_plan *p) {
             p->ex_allow_folds = false;
             if (!exchange_ok) {
                 const bool front = front_route_refusal(p).empty();
-                if (front || !getenv("VDL_NO_REPLICATE_ROUTE")) {
+                const bool chain = !front && chain_route(p);
+                if (front || chain || !getenv("VDL_NO_REPLICATE_ROUTE")) {
                     c->err = keep;
-                    if (c->comm->world > 1 || getenv("VDL_FRONT_ROUTE_ALWAYS")) { if (front) sharded_front(c, p); else sharded_replicate(c, p); }      // (the switch: tests send a one-rank communicator through the collectives)
+                    if (c->comm->world > 1 || getenv("VDL_FRONT_ROUTE_ALWAYS")) { if (front) sharded_front(c, p); else if (chain) sharded_chain(c, p); else sharded_replicate(c, p); }      // (the switch: tests send a one-rank communicator through the collectives)
                     else if (vdl_run(c, p) != VDL_OK) throw Error(VDL_ERR_DEVICE, c->err);      // one rank holds the whole table
                     return;
                 }

@@ -215,6 +215,16 @@ struct vdl_ctx {
     ~vdl_ctx() { if (pinned_words) (void)hipHostFree(pinned_words); if (small_stage_words) (void)hipHostFree(small_stage_words); }
 };
 
+// The "chain" route of a sharded run (analysis: vdl_exchange.cpp analyse_chain; the collectives: vdl_comm.cpp sharded_chain).
+struct ChainPlan {
+    Program prog;                          // the program with a group's first-row lookups carried through the fold (rewrite_chain_lookups)
+    std::vector<int> sets;                 // position sets the first GROUP BY feeds: Scatter(constant, size, positions) statements
+    std::vector<int> targets;              // what stage 1 evaluates instead of the outputs: {value, size, positions} of every set
+    std::vector<int64_t> constant;         // the scattered constant of every set
+    std::vector<char> size_replicated;     // the set's length is a replicated vector's (else: the groups', summed over the ranks)
+    bool second_cut = false;               // the rest reads the sharded table again (its rows reach every rank at the next Partition)
+};
+
 struct vdl_plan {
     vdl_ctx *ctx = nullptr;          // only dereferenced inside calls that receive the live context
     int device = -1;                 // copied at parse time: the plan may outlive its context
@@ -283,6 +293,16 @@ struct vdl_plan {
         std::vector<int> folds;
         std::vector<int64_t> fold_n, fold_words, fold_merged;
     } ex;
+    // "chain" route: stage 1 = exchange at the first Partition with the sets' operands as targets (the packed positions of every set are
+    // left in `lists`); stage 2 = the rest of the program with the merged `sets` in place of their statements
+    struct ChainRun {
+        int stage = 0;
+        std::shared_ptr<ChainPlan> plan;
+        std::string plan_table, why;       // the placement `plan` was analysed for; why there is none
+        struct SetList { BufP list; int64_t m = 0, len = 0; };
+        std::vector<SetList> lists;
+        std::map<int, DVec> sets;
+    } chain;
     bool ex_allow_folds = false;           // set by vdl_run_sharded around the exchange calls (callers of the bare calls get no fold merge)
     std::shared_ptr<ShardState> shard;     // vdl_run_sharded: send / receive / merged word buffers
     BufP shard_keep;                       // vdl_run_sharded: received rows while the tail of an exchange plan reads them
@@ -350,6 +370,9 @@ namespace eng {
 // the sharded Partition's local phase in steps (vdl_exchange.cpp): vdl_exchange_begin = local + route(null); vdl_run_sharded puts the
 // ranks' key histograms in between and routes by the cut they give
 void exchange_local(vdl_ctx *c, vdl_plan *p, int world);
+std::shared_ptr<ChainPlan> chain_plan(vdl_plan *p, std::string &why);             // the plan's chain route for p->sharded_table, or null and why not
+void chain_build_set(vdl_ctx *c, vdl_plan *p, size_t k, const BufP &positions, int64_t m, int64_t len);   // p->chain.sets[set k] from everybody's positions
+void chain_run_everywhere(vdl_ctx *c, vdl_plan *p);                               // stage 2 without a second cut: the rest on every rank
 void exchange_histogram(vdl_ctx *c, vdl_plan *p, int64_t *hist_host /* kExBins + 1 */);
 void exchange_route(vdl_ctx *c, vdl_plan *p, const int32_t *owner_host /* kExBins, or null */, int64_t *counts_host);
 

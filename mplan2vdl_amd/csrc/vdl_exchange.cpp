@@ -86,7 +86,12 @@ bool classify_rows(const Program &P, const std::vector<int> &roots, const std::s
 // element-wise operators, constants and Gathers *from* replicated vectors only.
 // allow_folds: the caller merges global fold records across the ranks (vdl_run_sharded); then a global Fold over row-local data
 // of the sharded table may stand beside the Partition and what is above it may read its (merged) result.
-ExchangeSpec analyse_exchange(const Program &P, const std::string &table = std::string(), bool allow_folds = false) {
+enum : char { TR = 0, TG = 1, TI = 2, TS = 3 };     // classes above the cut of analyse_exchange (see there)
+// gather_all (the second cut of the "chain" route, below): the rows that reach the FIRST Partition over the sharded table go to EVERY rank,
+// rank after rank = row order, and the tail runs everywhere on all of them: further Partitions may stand above the cut and the tail
+// need not treat every group by itself.  tail_class: the classes of the statements above the cut (TR / TG / TI / TS, below).
+ExchangeSpec analyse_exchange(const Program &P, const std::string &table = std::string(), bool allow_folds = false, bool gather_all = false,
+                              std::vector<char> *tail_class = nullptr) {
     ExchangeSpec x;
     std::vector<char> needed(P.nodes.size(), 0);
     for (int id : P.outputs) needed[(size_t)id] = 1;
@@ -95,8 +100,18 @@ ExchangeSpec analyse_exchange(const Program &P, const std::string &table = std::
         if (!needed[(size_t)n.id]) continue;
         for (int opnd : {n.a, n.b, n.c}) if (opnd > 0) needed[(size_t)opnd] = 1;
     }
+    std::vector<char> reads_table(P.nodes.size(), 0);
+    for (int id : P.order) {
+        const Node &n = P.at(id);
+        if (n.op == Op::Load) { reads_table[(size_t)id] = !table.empty() && n.column.compare(0, table.size() + 1, table + ".") == 0; continue; }
+        for (int opnd : {n.a, n.b, n.c}) if (opnd > 0 && reads_table[(size_t)opnd]) reads_table[(size_t)id] = 1;
+    }
     for (int id : P.order) {
         if (!needed[(size_t)id] || P.at(id).op != Op::Partition) continue;
+        if (gather_all) {
+            if (!x.part && reads_table[(size_t)id]) x.part = id;
+            continue;
+        }
         if (x.part) { x.why = "more than one Partition"; return x; }
         x.part = id;
     }
@@ -184,13 +199,13 @@ ExchangeSpec analyse_exchange(const Program &P, const std::string &table = std::
     } else {
         x.folds.clear();
     }
+    if (gather_all) { x.folds.clear(); x.ok = true; return x; }
     // What stands ABOVE the scatters runs on every rank over the groups of ITS key range, and the ranks' outputs are concatenated: that is
     // the unsharded answer only if the tail treats every group by itself.  (Round 4: TPC-H Q20 was accepted although its tail feeds a
     // semi-join set over suppliers from the groups -- a supplier whose qualifying groups lie on two ranks came out twice; it went unseen
     // while the tests' keys filled so little of their declared domain that the even cut sent every row to rank 0.)  Classes above the cut:
     // R replicated / scalar, G one slot per received row, I the slots' own ids, S positions of a selection of slots.
     {
-        enum : char { TR = 0, TG = 1, TI = 2, TS = 3 };
         std::vector<char> above(P.nodes.size(), 0), tc(P.nodes.size(), TR);
         std::vector<int> st(P.outputs.begin(), P.outputs.end());
         while (!st.empty()) {
@@ -258,6 +273,7 @@ ExchangeSpec analyse_exchange(const Program &P, const std::string &table = std::
                 out = TR;
             }
         }
+        if (tail_class) *tail_class = tc;
     }
     x.ok = true;
     return x;
@@ -334,13 +350,194 @@ FoldCut analyse_folds(const Program &P, const std::string &table) {
 
 int fold_reduce_kind(Op op) { return op == Op::FoldMin ? 1 : op == Op::FoldMax ? 2 : 0; }       // count merges as a sum
 
+// ------------------------------------------------------------------------------------------------
+// The "chain" route (TPC-H Q18, /root/reference/tests/tpch10noorder/18.sql.mplan): a GROUP BY over ALL rows of the sharded table
+// whose groups only feed POSITION SETS -- Scatter(constant, size, a value of the group): the semi-join set of `o_orderkey in (select
+// l_orderkey .. group by l_orderkey having sum(l_quantity) > 300)`, Vlite.hs:1212-1222 -- and a rest that reads the sets and the table
+// a second time.  Three mechanisms the other routes already have, one after the other:
+//   stage 1  the rows travel to the owners of their key range (the exchange route's cut, analyse_exchange with the sets' operands as
+//            its outputs: the tail up to them must treat every group by itself); every owner runs the GROUP BY on complete groups and
+//            packs the positions its groups put into every set;
+//   merge    the packed positions are all-gathered (a set of constants is the union of its positions, whoever found them) and every
+//            rank builds the same set vectors, as long as the unsharded Scatter would have been;
+//   stage 2  the rest of the program with the sets in place: what it computes per row of the table runs on each rank's OWN rows (the
+//            shard it was given, not the exchanged rows: rank after rank = row order), the rows that reach the next Partition are
+//            all-gathered and the tail runs on every rank (analyse_exchange, gather_all) -- every rank ends with the whole answer.
+// The scan of the table, the GROUP BY over all of it and the second scan scale with the ranks; the tail over the survivors does not.
+// ------------------------------------------------------------------------------------------------
+
+// Gather(X, Gather(FoldChoose(C, Scatter(row ids [of a selection S], .., P)), sel)) -- a column of the group's first row, looked up by row
+// NUMBER for the groups `sel` keeps, which a rank of a sharded run cannot serve -- is Gather(FoldChoose(C, Scatter(X [on S], .., P)), sel):
+// the column travels through the fold like any other value of the group.  (rewrite_program, vdl_fuse.cpp, does the same for the form
+// without `sel`; this one is kept out of unsharded runs, where it would send a whole column through the Partition for the sake of a few
+// groups.)  The new Scatter takes its length from the vector it scatters, so that nothing above the cut hangs off the row ids.
+void rewrite_chain_lookups(Program &P) {
+    auto alias = [&](int id) { return id > 0 ? resolve_alias(P, id) : id; };
+    auto table_of = [](const std::string &column) { const size_t dot = column.find('.'); return dot == std::string::npos ? column : column.substr(0, dot); };
+    auto rowids_of = [&](int id) -> std::string {
+        const Node &r = P.at(alias(id));
+        if (r.op != Op::RangeV || r.imm0 != 0 || r.imm1 != 1) return "";
+        const Node &l = P.at(alias(r.a));
+        return l.op == Op::Load ? table_of(l.column) : "";
+    };
+    const std::vector<int> order = P.order;
+    int next_id = 0;
+    for (int id : order) next_id = std::max(next_id, id);
+    std::vector<int> out;
+    auto add = [&](Node n) {
+        n.id = ++next_id; n.field = "val";
+        if (P.nodes.size() <= (size_t)n.id) P.nodes.resize((size_t)n.id + 64);
+        P.nodes[(size_t)n.id] = n;
+        out.push_back(n.id);
+        return n.id;
+    };
+    for (int id : order) {
+        Node g = P.at(id);
+        if (g.op == Op::Gather && (size_t)next_id + 4 < ((size_t)1 << 24)) {
+            const Node x = P.at(alias(g.a)), g2 = P.at(alias(g.b));
+            if (x.op == Op::Load && x.column.find(".heap") == std::string::npos && g2.op == Op::Gather) {
+                const Node fc = P.at(alias(g2.a));
+                if (fc.op == Op::FoldChoose) {
+                    const Node sc = P.at(alias(fc.b));
+                    const Node szn = sc.op == Op::Scatter ? P.at(alias(sc.b)) : Node();
+                    if (sc.op == Op::Scatter && (alias(sc.b) == alias(sc.a) || (szn.op == Op::RangeV && alias(szn.a) == alias(sc.a)))) {
+                        const Node r = P.at(alias(sc.a));
+                        const std::string t = table_of(x.column);
+                        int through = -2;                                  // -1: no filter; >= 0: the selection S
+                        if (r.op == Op::Gather && rowids_of(r.a) == t) through = r.b;
+                        else if (rowids_of(sc.a) == t) through = -1;
+                        if (through != -2) {
+                            int src = g.a;
+                            if (through >= 0) { Node n1; n1.op = Op::Gather; n1.a = g.a; n1.b = through; n1.line = g.line; src = add(n1); }
+                            Node n2; n2.op = Op::Scatter; n2.a = src; n2.b = src; n2.c = sc.c; n2.line = g.line;
+                            const int scattered = add(n2);
+                            Node n3; n3.op = Op::FoldChoose; n3.a = fc.a; n3.b = scattered; n3.line = g.line;
+                            g.a = add(n3); g.b = g2.b;
+                            P.nodes[(size_t)id] = g;
+                        }
+                    }
+                }
+            }
+        }
+        out.push_back(id);
+    }
+    P.order = out;
+}
+
+struct ChainSpec {
+    bool ok = false;
+    std::string why;
+    ChainPlan plan;
+};
+
+// the program with every set statement standing for a vector all ranks share (stage 2's view)
+Program with_sets_given(const Program &P, const std::vector<int> &sets) {
+    Program B = P;
+    for (int id : sets) {
+        Node n; n.id = id; n.op = Op::Load; n.column = "(position set " + std::to_string(id) + ")"; n.field = P.at(id).field; n.line = P.at(id).line;
+        B.nodes[(size_t)id] = n;
+    }
+    return B;
+}
+
+ChainSpec analyse_chain(const Program &P0, const std::string &table) {
+    ChainSpec ch;
+    if (table.empty()) { ch.why = "no row-sharded table named (vdl_plan_set_sharded_table)"; return ch; }
+    ChainPlan &cp = ch.plan;
+    cp.prog = P0;
+    rewrite_chain_lookups(cp.prog);
+    const Program &P = cp.prog;
+    std::vector<char> needed(P.nodes.size(), 0), reads_table(P.nodes.size(), 0);
+    for (int id : P.outputs) needed[(size_t)id] = 1;
+    for (auto it = P.order.rbegin(); it != P.order.rend(); ++it) {
+        const Node &n = P.at(*it);
+        if (!needed[(size_t)n.id]) continue;
+        for (int opnd : {n.a, n.b, n.c}) if (opnd > 0) needed[(size_t)opnd] = 1;
+    }
+    for (int id : P.order) {
+        const Node &n = P.at(id);
+        if (n.op == Op::Load) { reads_table[(size_t)id] = n.column.compare(0, table.size() + 1, table + ".") == 0; continue; }
+        for (int opnd : {n.a, n.b, n.c}) if (opnd > 0 && reads_table[(size_t)opnd]) reads_table[(size_t)id] = 1;
+    }
+    // raw: depends on the first Partition over the table other than through a position set
+    int first = 0;
+    std::vector<char> raw(P.nodes.size(), 0);
+    for (int id : P.order) {
+        if (!needed[(size_t)id]) continue;
+        const Node &n = P.at(id);
+        if (n.op == Op::Partition && !first && reads_table[(size_t)id]) { first = id; raw[(size_t)id] = 1; continue; }
+        bool r = false;
+        for (int opnd : {n.a, n.b, n.c}) r |= opnd > 0 && raw[(size_t)opnd] != 0;
+        if (!r) continue;
+        if (n.op == Op::Scatter && n.c > 0 && raw[(size_t)n.c] && resolve_alias(P, n.c) != first) {
+            const Node &v = P.at(resolve_alias(P, n.a));
+            if (v.op == Op::RangeV && v.imm1 == 0) {
+                cp.sets.push_back(id);
+                cp.constant.push_back(v.imm0);
+                for (int opnd : {n.a, n.b, n.c}) cp.targets.push_back(opnd);
+                continue;                                      // (what reads the set does not read the groups)
+            }
+        }
+        raw[(size_t)id] = 1;
+    }
+    if (!first) { ch.why = "no Partition over table " + table; return ch; }
+    if (cp.sets.empty()) { ch.why = "the first Partition over table " + table + " (statement " + std::to_string(first) + ") feeds no position set"; return ch; }
+    for (int id : P.outputs)
+        if (raw[(size_t)id]) { ch.why = "output " + std::to_string(id) + " reads the groups of statement " + std::to_string(first) + " other than through a position set"; return ch; }
+    // stage 1: the exchange route's analysis with the sets' operands for outputs
+    {
+        Program A = P;
+        A.outputs = cp.targets;
+        std::sort(A.outputs.begin(), A.outputs.end());
+        A.outputs.erase(std::unique(A.outputs.begin(), A.outputs.end()), A.outputs.end());
+        std::vector<char> tc;
+        const ExchangeSpec x = analyse_exchange(A, table, false, false, &tc);
+        if (!x.ok) { ch.why = "up to its position sets: " + x.why; return ch; }
+        if (x.part != first) { ch.why = "the position sets hang off another Partition than the first over table " + table; return ch; }
+        for (size_t k = 0; k < cp.sets.size(); k++) {
+            const int a = cp.targets[3 * k], b = cp.targets[3 * k + 1], c = cp.targets[3 * k + 2];
+            const std::string at = " (statement " + std::to_string(cp.sets[k]) + ")";
+            if (tc[(size_t)c] != TG) { ch.why = "the positions of a set are not values of the groups" + at; return ch; }
+            if (tc[(size_t)a] != TG && tc[(size_t)a] != TR) { ch.why = "the constant of a set is spread over rank-local slots" + at; return ch; }
+            if (tc[(size_t)b] == TS) { ch.why = "the length of a set is that of a selection of groups" + at; return ch; }
+            cp.size_replicated.push_back(tc[(size_t)b] == TR);
+        }
+    }
+    // stage 2: the rest, the sets given
+    {
+        const Program B = with_sets_given(P, cp.sets);
+        std::vector<char> need2(B.nodes.size(), 0);
+        for (int id : B.outputs) need2[(size_t)id] = 1;
+        bool reads = false;
+        for (auto it = B.order.rbegin(); it != B.order.rend(); ++it) {
+            const Node &n = B.at(*it);
+            if (!need2[(size_t)n.id]) continue;
+            if (n.op == Op::Load && n.column.compare(0, table.size() + 1, table + ".") == 0) reads = true;
+            for (int opnd : {n.a, n.b, n.c}) if (opnd > 0) need2[(size_t)opnd] = 1;
+        }
+        cp.second_cut = reads;
+        if (reads) {
+            const ExchangeSpec x = analyse_exchange(B, table, false, true);
+            if (!x.ok) { ch.why = "above its position sets: " + (x.part ? x.why : "the rest reads table " + table + " without a Partition to gather its rows at"); return ch; }
+        }
+    }
+    ch.ok = true;
+    return ch;
+}
+
+// the cut the exchange calls work at: the plan's own, or -- inside the chain route's second stage -- the next Partition with the sets given
+ExchangeSpec spec_for(const vdl_plan *p, const std::string &table, bool allow_folds) {
+    if (p->chain.stage == 2 && p->chain.plan) return analyse_exchange(with_sets_given(p->prog, p->chain.plan->sets), table, false, true);
+    return analyse_exchange(p->prog, table, allow_folds);
+}
+
 }  // namespace
 
 namespace vdl {
 namespace eng {
 
 size_t exchange_fold_count(const vdl_plan *p, const std::string &table) {
-    ExchangeSpec x = analyse_exchange(p->prog, table, true);
+    ExchangeSpec x = spec_for(p, table, true);
     return x.ok ? x.folds.size() : 0;
 }
 int exchange_fold_kind(const vdl_plan *p, size_t k) { return k < p->ex.folds.size() ? fold_reduce_kind(p->prog.at(p->ex.folds[k]).op) : 0; }
@@ -398,7 +595,7 @@ extern "C" {
 
 int vdl_exchange_spec(const vdl_plan *p, const char *sharded_table, int *n_columns) {
     if (!p) return VDL_ERR_ARG;
-    ExchangeSpec x = analyse_exchange(p->prog, sharded_table ? sharded_table : "", p->ex_allow_folds);
+    ExchangeSpec x = spec_for(p, sharded_table ? sharded_table : "", p->ex_allow_folds);
     if (!x.ok) {
         if (p->ctx) p->ctx->err = "no sharded-Partition structure: " + x.why;
         return VDL_ERR_UNSUPPORTED;
@@ -413,18 +610,68 @@ int vdl_exchange_spec(const vdl_plan *p, const char *sharded_table, int *n_colum
 namespace vdl {
 namespace eng {
 
+std::shared_ptr<ChainPlan> chain_plan(vdl_plan *p, std::string &why) {
+    vdl_plan::ChainRun &cr = p->chain;
+    if (cr.plan_table != p->sharded_table || (!cr.plan && cr.why.empty())) {
+        ChainSpec ch = analyse_chain(p->prog, p->sharded_table);
+        cr.plan_table = p->sharded_table;
+        cr.plan = ch.ok ? std::make_shared<ChainPlan>(std::move(ch.plan)) : nullptr;
+        cr.why = ch.ok ? std::string() : (ch.why.empty() ? std::string("no chain structure") : ch.why);
+    }
+    why = cr.why;
+    return cr.plan;
+}
+
+// stage 1 of the chain route has run the GROUP BY on this rank's key range (the targets are alive in `g`): the positions every set
+// receives from here, packed -- a position counts where the scattered constant AND the position hold a value
+static void chain_collect(GenExec &g, vdl_plan *p) {
+    const ChainPlan &cp = *p->chain.plan;
+    p->chain.lists.clear();
+    for (size_t k = 0; k < cp.sets.size(); k++) {
+        const DVec a = g.densify(g.vec[(size_t)cp.targets[3 * k]]), pos = g.densify(g.vec[(size_t)cp.targets[3 * k + 2]]);
+        if (a.n != pos.n) throw Error(VDL_ERR_SHAPE, "a position set's constant and positions have different lengths (statement " + std::to_string(cp.sets[k]) + ")");
+        vdl_plan::ChainRun::SetList l;
+        l.len = g.vec[(size_t)cp.targets[3 * k + 1]].n;
+        const BufP bits = (a.valid || pos.valid) ? g.and_bitmaps(a.valid, pos.valid, pos.n) : BufP();
+        BufP offsets;
+        l.m = g.popcount(bits, pos.n, &offsets);
+        l.list = g.compact_write(g.src_of(pos), bits, pos.n, offsets, l.m);
+        p->chain.lists.push_back(l);
+    }
+    HIP_CHECK(hipStreamSynchronize(g.s));                  // (the received rows the vectors may point into go with the caller)
+}
+
+// the set as every rank holds it: the constant wherever a position of ANY rank's groups points, `len` slots like the unsharded Scatter's
+void chain_build_set(vdl_ctx *c, vdl_plan *p, size_t k, const BufP &positions, int64_t m, int64_t len) {
+    const ChainPlan &cp = *p->chain.plan;
+    DVec v;
+    v.kind = DVec::RANGE; v.n = len; v.from = cp.constant[k]; v.step = 0;
+    const int64_t words = std::max<int64_t>(GenExec::nwords(len), 1);
+    v.valid = dev_alloc(c, sizeof(uint64_t) * (size_t)words);
+    HIP_CHECK(launch_fill_words((uint64_t *)v.valid->p, 0, words, c->stream));
+    if (m > 0) HIP_CHECK(launch_set_bits((const int64_t *)positions->p, m, (uint64_t *)v.valid->p, c->stream, len));
+    p->chain.sets[cp.sets[k]] = v;
+}
+
+void chain_run_everywhere(vdl_ctx *c, vdl_plan *p) {
+    need_device(c);
+    GenExec g(c, p);
+    g.run_nodes(p->prog.outputs, &p->chain.sets);
+}
+
 // the local phase of a sharded Partition: the statements up to the key and the scattered vectors on this rank's rows (through the fused
 // front when the plan has one), the global folds beside the Partition as mergeable words
 void exchange_local(vdl_ctx *c, vdl_plan *p, int world) {
     need_device(c);
-    ExchangeSpec x = analyse_exchange(p->prog, p->sharded_table, p->ex_allow_folds);
+    ExchangeSpec x = spec_for(p, p->sharded_table, p->ex_allow_folds);
     if (!x.ok) throw Error(VDL_ERR_UNSUPPORTED, "no sharded-Partition structure: " + x.why);
     std::map<int, DVec> front;                          // the fused front of the local phase (ProjPlan), when the plan has one
-    const bool has_front = run_projection(c, p, front);
+    const bool second_stage = p->chain.stage == 2;      // (chain route: the merged sets stand for their statements; the plan's front belongs to stage 1)
+    const bool has_front = !second_stage && run_projection(c, p, front);
     GenExec g(c, p);
     std::vector<int> targets = x.sources;
     targets.insert(targets.end(), x.folds.begin(), x.folds.end());
-    g.run_nodes(targets, has_front ? &front : nullptr);
+    g.run_nodes(targets, second_stage ? &p->chain.sets : has_front ? &front : nullptr);
     vdl_plan::ExState &ex = p->ex;
     ex = vdl_plan::ExState{};
     ex.world = world; ex.nodes = x.sources; ex.pmin = x.pmin; ex.pcount = x.pcount;
@@ -484,7 +731,9 @@ void exchange_route(vdl_ctx *c, vdl_plan *p, const int32_t *owner_host, int64_t 
         HIP_CHECK(hipMemcpyAsync(owner->p, owner_host, sizeof(int32_t) * (size_t)kExBins, hipMemcpyHostToDevice, c->stream));
         HIP_CHECK(hipStreamSynchronize(c->stream));        // (the table is the caller's)
     }
-    HIP_CHECK(launch_ex_dest(g.src_of(key), g.vp(key), ex.n, ex.pmin, ex.pcount, world, (int64_t *)dest->p, (uint64_t *)ex.vdest->p,
+    // (second stage of the chain route: EVERY row with a key travels, to everybody -- the pivots say nothing about who takes part; the
+    // Partition that follows treats keys outside them as it does in an unsharded run)
+    HIP_CHECK(launch_ex_dest(g.src_of(key), g.vp(key), ex.n, ex.pmin, p->chain.stage == 2 ? 0 : ex.pcount, world, (int64_t *)dest->p, (uint64_t *)ex.vdest->p,
                              (int64_t *)counts->p, (int64_t *)counts->p + world, c->stream, owner ? (const int32_t *)owner->p : nullptr));
     if (ex.n > 0) {
         // stable order inside each destination = one 8-bit Partition pass over the destination ranks
@@ -577,8 +826,10 @@ int vdl_exchange_finish(vdl_ctx *c, vdl_plan *p, const void *dev_recv, int64_t n
         }
         ex.src.clear(); ex.vdest.reset(); ex.pos.reset();          // phase-A vectors are no longer needed
         ex.active = false;
+        if (p->chain.stage == 2) over.insert(p->chain.sets.begin(), p->chain.sets.end());
         GenExec g(c, p);
         g.run_nodes(p->prog.outputs, &over);
+        if (p->chain.stage == 1) chain_collect(g, p);
     });
 }
 

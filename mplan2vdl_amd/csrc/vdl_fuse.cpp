@@ -1136,7 +1136,11 @@ void rewrite_program(Program &P) {
                             if (P.nodes.size() <= (size_t)n1.id) P.nodes.resize((size_t)n1.id + 64);
                             P.nodes[(size_t)n1.id] = n1; out.push_back(n1.id); src = n1.id;
                         }
-                        Node n2; n2.id = ++next_id; n2.op = Op::Scatter; n2.a = src; n2.b = sc.b; n2.c = sc.c; n2.field = "val"; n2.line = g.line;
+                        // (the length: the old Scatter's size reference when it is anything but the scattered row ids themselves or a range
+                        // over them -- otherwise the new source, as long, so that nothing above the Partition hangs off the row ids any more)
+                        const Node &szn = P.at(alias(sc.b));
+                        const bool own_length = alias(sc.b) == alias(sc.a) || (szn.op == Op::RangeV && alias(szn.a) == alias(sc.a));
+                        Node n2; n2.id = ++next_id; n2.op = Op::Scatter; n2.a = src; n2.b = own_length ? src : sc.b; n2.c = sc.c; n2.field = "val"; n2.line = g.line;
                         if (P.nodes.size() <= (size_t)n2.id) P.nodes.resize((size_t)n2.id + 64);
                         P.nodes[(size_t)n2.id] = n2; out.push_back(n2.id);
                         g.op = Op::FoldChoose; g.a = fc.a; g.b = n2.id; g.c = -1;

@@ -198,7 +198,7 @@ hipError_t launch_fill_words(uint64_t *p, uint64_t v, int64_t nwords, hipStream_
 hipError_t launch_select_gather(Src src, const uint64_t *vsrc, int64_t nsrc, Src pos, const uint64_t *vpos, const uint64_t *vc, uint64_t *out,
                                 int64_t n, hipStream_t s);
 // bitmap[idx[k]] = 1 for k < m (bitmap pre-zeroed; idx ascending, so neighbours often share a word)
-hipError_t launch_set_bits(const int64_t *idx, int64_t m, uint64_t *bitmap, hipStream_t s);
+hipError_t launch_set_bits(const int64_t *idx, int64_t m, uint64_t *bitmap, hipStream_t s, int64_t nbits = INT64_MAX /* entries outside [0, nbits) set nothing */);
 
 // FoldSelect over general runs (vdl_engine.cpp: fold_select_runs): head flags of the runs of `ctl` (m entries, all valid),
 // then the sort key 2 * run + (entry not selected) and the bitmap of selected entries

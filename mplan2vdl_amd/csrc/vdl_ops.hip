@@ -1006,17 +1006,17 @@ hipError_t launch_select_gather(Src src, const uint64_t *vsrc, int64_t nsrc, Src
     return launch_status();
 }
 
-__global__ __launch_bounds__(256) void k_set_bits(const int64_t *idx, int64_t m, uint64_t *bitmap) {
+__global__ __launch_bounds__(256) void k_set_bits(const int64_t *idx, int64_t m, uint64_t *bitmap, int64_t nbits) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += stride) {
         const int64_t i = idx[k];
-        atomicOr((unsigned long long *)&bitmap[i >> 6], 1ull << (i & 63));
+        if ((uint64_t)i < (uint64_t)nbits) atomicOr((unsigned long long *)&bitmap[i >> 6], 1ull << (i & 63));
     }
 }
-hipError_t launch_set_bits(const int64_t *idx, int64_t m, uint64_t *bitmap, hipStream_t s) {
+hipError_t launch_set_bits(const int64_t *idx, int64_t m, uint64_t *bitmap, hipStream_t s, int64_t nbits) {
     (void)hipGetLastError();
     if (m <= 0) return hipSuccess;
-    k_set_bits<<<grid_for(m, 256, 4), 256, 0, s>>>(idx, m, bitmap);
+    k_set_bits<<<grid_for(m, 256, 4), 256, 0, s>>>(idx, m, bitmap, nbits);
     return launch_status();
 }
 

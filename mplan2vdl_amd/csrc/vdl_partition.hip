@@ -809,7 +809,7 @@ __global__ __launch_bounds__(256) void k_ex_dest(Src key, const uint64_t *vkey, 
         bool ok = i < n && bit(vkey, i);
         bool out_of_range = false;
         int64_t d = 0;
-        if (ok) {
+        if (ok && pcount > 0) {                                   // (pcount <= 0: every key takes part and goes to destination 0 -- the gather of the chain route)
             const int64_t b = (int64_t)((uint64_t)ld(key, i) - (uint64_t)pmin);
             if (b < 0 || b >= pcount) { out_of_range = true; ok = false; }
             else if (owner) d = owner[(int)(((unsigned __int128)(uint64_t)b * (uint64_t)kExBins) / (uint64_t)pcount)];

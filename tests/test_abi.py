@@ -178,26 +178,30 @@ def test_header_is_plain_c_and_a_c_program_links(tmp_path):
 
 def test_every_compiled_plan_has_a_sharded_route():
     """vdl_plan_sharded_route for the 15 TPC-H plans the front end compiles (no GPU needed: the analysis is host code): partial words
-    merged (fold), rows exchanged by key range, a semi-join set merged, the front's survivors gathered -- and for Q18 the last resort: the
-    table's columns gathered once, the whole query on every rank.  Q20's tail feeds a semi-join set over suppliers from the groups: the
+    merged (fold), rows exchanged by key range, a semi-join set merged, the front's survivors gathered -- and for Q18 the chain of three
+    of them (exchange up to its position set, the set's positions gathered, the second scan's survivors gathered), with the last
+    resort behind it when that is switched off: the table's columns gathered once, the whole query on every rank.  Q20's tail feeds a semi-join set over suppliers from the groups: the
     ranks' outputs would not concatenate (a supplier with qualifying groups on two ranks would come out twice), so the exchange
     analysis refuses it and its fused front carries it (round 4)."""
     from mplan2vdl_amd import frontend
     meta = os.path.join(ROOT, "tests", "golden", "tpch10noorder")
     cfg = frontend.load_metadata(meta)
     want = {1: "fold", 3: "exchange", 4: "set", 5: "exchange", 6: "fold", 9: "exchange", 10: "exchange", 11: "exchange", 12: "fold", 14: "fold",
-            15: "front", 16: "front", 18: "replicate", 19: "fold", 20: "front"}
+            15: "front", 16: "front", 18: "chain", 19: "fold", 20: "front"}
     for q, route in want.items():
         text = frontend.compile_plan(open(os.path.join(meta, "%02d.sql.mplan" % q)).read(), cfg)
         e = m.Engine(device=None)
         p = e.parse(text)
         p.set_sharded_table("partsupp" if q in (11, 16) else "lineitem")
         assert p.sharded_route() == (route, route != "exchange"), q
-        if route == "replicate":                            # the last resort can be switched off: then the reasons are the answer
-            os.environ["VDL_NO_REPLICATE_ROUTE"] = "1"
+        if route == "chain":                                # without it the last resort; that can be switched off too: then the reasons are the answer
+            os.environ["VDL_NO_CHAIN_ROUTE"] = "1"
             try:
+                assert p.sharded_route() == ("replicate", True)
+                os.environ["VDL_NO_REPLICATE_ROUTE"] = "1"
                 with pytest.raises(m.VdlError) as err:
                     p.sharded_route()
-                assert "more than one Partition" in str(err.value) and "no fused front" in str(err.value)
+                assert "more than one Partition" in str(err.value) and "no fused front" in str(err.value) and "VDL_NO_CHAIN_ROUTE" in str(err.value)
             finally:
-                del os.environ["VDL_NO_REPLICATE_ROUTE"]
+                del os.environ["VDL_NO_CHAIN_ROUTE"]
+                os.environ.pop("VDL_NO_REPLICATE_ROUTE", None)

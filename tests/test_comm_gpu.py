@@ -216,10 +216,141 @@ def test_a_global_fold_beside_the_partition_is_merged_with_the_counts(world):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_a_plan_no_route_serves_runs_on_the_replicated_table(world):
+@pytest.mark.parametrize("clustered", [True, False])
+def test_a_group_by_over_all_rows_that_feeds_a_position_set_runs_as_a_chain(world, clustered):
+    """TPC-H Q18 (/root/reference/tests/tpch10noorder/18.sql.mplan) groups ALL lineitems by order, keeps the orders of the groups that
+    pass its HAVING as a position set and scans lineitem a second time against that set.  The "chain" route: the rows travel to the
+    owners of their key range (complete groups everywhere, whether the table is clustered by order or not), the positions every owner
+    finds are all-gathered into the same set on every rank, the second scan runs on each rank's OWN rows and its survivors are
+    gathered for the second GROUP BY.  Every rank ends with the whole answer, twice in a row."""
+    cfg = frontend.load_metadata(META)
+    text = frontend.compile_plan(open(os.path.join(META, "18.sql.mplan")).read(), cfg)
+    cols = catalog.synth_columns(META, cfg, text, scale=2e-3, seed=3, clustered=("lineitem.lineitem_orders",) if clustered else ())
+    want = oracle_run(text, cols)
+    assert any(len(list(v.values())[0]) for v in want.values())
+    shards = table_shards(cols, world, "lineitem")
+
+    def work(rank, rv):
+        r0, c = shards[rank]
+        e = engine_with(c)
+        e.comm_init_host(rank, world, *rv.transport(rank))
+        p = e.parse(text)
+        p.set_sharded_table("lineitem")
+        p.set_row_offset(r0)
+        assert p.sharded_route() == ("chain", True)
+        first = p.run_sharded()["results"]
+        second = p.run_sharded()["results"]
+        plain = None
+        if rank == 0:                                            # the plan is what it was: unsharded runs of it are untouched
+            e2 = engine_with(cols)
+            plain = e2.parse(text).run()["results"]
+            e2.close()
+        e.close()
+        return first, second, plain
+
+    got = run_ranks(world, work, timeout=120)
+    assert [g[:2] for g in got] == [(want, want)] * world
+    assert got[0][2] == want
+
+
+def chain_program(nd, threshold, second_scan):
+    """GROUP BY f.k over ALL rows of f, HAVING sum(f.v) > threshold, the keys of the groups that pass as a position set; then the
+    dimension rows in the set (no second scan), or the rows of f whose key is in the set, grouped by f.a (second scan)."""
+    from helpers import prog
+    lines = ["1,Load,f.k", "2,Project,val,Id 1,k", "3,Load,f.v", "4,Project,val,Id 3,v", "5,Load,d.g", "6,Project,val,Id 5,g",
+             "7,RangeC,val,0,%d,1" % nd, "8,Partition,val,Id 2,val,Id 7,val",
+             "9,RangeV,val,0,Id 2,1", "10,Scatter,Id 2,Id 9,val,Id 8,val", "11,RangeV,val,0,Id 4,1", "12,Scatter,Id 4,Id 11,val,Id 8,val",
+             "13,FoldSum,val,Id 10,val,Id 12,val", "14,RangeV,val,%d,Id 13,0" % threshold, "15,Greater,val,Id 13,val,Id 14,val",
+             "16,RangeV,val,0,Id 15,1", "17,FoldSelect,val,Id 16,val,Id 15,val", "18,Gather,Id 10,Id 17,val",      # the keys of the groups that pass
+             "19,RangeV,val,1,Id 18,0", "20,RangeV,val,0,Id 19,1", "21,Scatter,Id 19,Id 20,val,Id 18,val"]          # ones at those positions: the set
+    if not second_scan:
+        lines += ["22,RangeV,val,0,Id 21,1", "23,FoldSelect,val,Id 22,val,Id 21,val", "24,Gather,Id 6,Id 23,val",
+                  "25,Project,g,Id 24,val", "26,MaterializeCompact,Id 25", "27,Project,row,Id 23,val", "28,MaterializeCompact,Id 27"]
+    else:
+        lines += ["22,Load,f.a", "23,Project,val,Id 22,a",
+                  "24,Gather,Id 21,Id 2,val",                                                            # per row of f: is its key in the set?
+                  "25,RangeV,val,0,Id 24,1", "26,FoldSelect,val,Id 25,val,Id 24,val",
+                  "27,Gather,Id 23,Id 26,val", "28,Gather,Id 4,Id 26,val", "29,Gather,Id 6,Id 27,val",         # a, v of the survivors; d.g by a
+                  "30,RangeC,val,0,%d,1" % nd, "31,Partition,val,Id 27,val,Id 30,val",
+                  "32,RangeV,val,0,Id 27,1", "33,Scatter,Id 27,Id 32,val,Id 31,val", "34,Scatter,Id 28,Id 32,val,Id 31,val", "35,Scatter,Id 29,Id 32,val,Id 31,val",
+                  "36,FoldSum,val,Id 33,val,Id 34,val", "37,FoldChoose,val,Id 33,val,Id 35,val", "38,FoldCount,val,Id 33,val,Id 34,val",
+                  "39,Project,total,Id 36,val", "40,MaterializeCompact,Id 39", "41,Project,g,Id 37,val", "42,MaterializeCompact,Id 41",
+                  "43,Project,rows,Id 38,val", "44,MaterializeCompact,Id 43"]
+    return prog(*lines)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("second_scan", [False, True])
+def test_the_chain_route_with_and_without_a_second_scan(world, second_scan):
+    """The chain route on programs written for it: the groups' keys straddle the ranks' row ranges (random order), one rank's groups
+    contribute nothing to the set, and the rest either reads only the replicated table through the set (no second cut: it runs on
+    every rank as it stands) or scans the sharded table again and groups the survivors by another column."""
+    rng = np.random.default_rng(5 + world + 10 * second_scan)
+    n, nd = 12000, 400
+    cols = {"f.k": rng.integers(0, nd, n).astype(np.int64), "f.v": rng.integers(0, 100, n).astype(np.int64), "f.a": rng.integers(0, nd, n).astype(np.int64),
+            "d.g": rng.integers(0, 1000, nd).astype(np.int64)}
+    cols["f.k"][cols["f.k"] < nd // 3] += nd // 3                  # no key in the first third of the domain: the owner of that range finds nothing
+    sums = np.bincount(cols["f.k"], weights=cols["f.v"], minlength=nd)
+    threshold = int(np.sort(sums)[-40])                               # about forty groups pass
+    text = chain_program(nd, threshold, second_scan)
+    want = oracle_run(text, cols)
+    assert all(len(list(v.values())[0]) > 0 for v in want.values())
+    shards = table_shards(cols, world, "f")
+
+    def work(rank, rv):
+        r0, c = shards[rank]
+        e = engine_with(c)
+        e.comm_init_host(rank, world, *rv.transport(rank))
+        p = e.parse(text)
+        p.set_sharded_table("f")
+        p.set_row_offset(r0)
+        assert p.sharded_route() == ("chain", True)
+        res = p.run_sharded()["results"]
+        e.close()
+        return res
+
+    assert run_ranks(world, work, timeout=120) == [want] * world
+
+
+@pytest.mark.parametrize("world", [2])
+def test_a_failure_inside_the_chain_reaches_every_rank(world):
+    """One rank lacks a column the second scan reads: it fails in its local phase of stage 2, says so in the status exchange that precedes
+    the gather of the survivors, and every rank stops with an error instead of waiting in a collective."""
+    rng = np.random.default_rng(77)
+    n, nd = 6000, 200
+    cols = {"f.k": rng.integers(0, nd, n).astype(np.int64), "f.v": rng.integers(0, 100, n).astype(np.int64), "f.a": rng.integers(0, nd, n).astype(np.int64),
+            "d.g": rng.integers(0, 1000, nd).astype(np.int64)}
+    text = chain_program(nd, 2000, True)
+    shards = table_shards(cols, world, "f")
+
+    def work(rank, rv):
+        r0, c = shards[rank]
+        if rank == 1:
+            c = {k: v for k, v in c.items() if k != "f.a"}
+        e = engine_with(c)
+        e.comm_init_host(rank, world, *rv.transport(rank))
+        p = e.parse(text)
+        p.set_sharded_table("f")
+        p.set_row_offset(r0)
+        try:
+            p.run_sharded()
+            return "ran"
+        except m.VdlError as exc:
+            return str(exc)
+        finally:
+            e.close()
+
+    got = run_ranks(world, work, timeout=120)
+    assert "f.a" in got[1] and "rank 1" in got[0], got
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_a_plan_no_route_serves_runs_on_the_replicated_table(world, monkeypatch):
     """TPC-H Q18 groups ALL lineitems by order before it filters anything, feeds a semi-join set from the groups and scans lineitem a
-    second time: no fold, no exchange, no front.  The last resort gathers the lineitem columns it loads once (rank after rank = row
+    second time: no fold, no exchange, no front -- and, with the chain route switched off (VDL_NO_CHAIN_ROUTE), nothing that scales.
+    The last resort gathers the lineitem columns it loads once (rank after rank = row
     order) and runs the whole query on every rank; the second run of the same plan moves nothing."""
+    monkeypatch.setenv("VDL_NO_CHAIN_ROUTE", "1")
     cfg = frontend.load_metadata(META)
     text = frontend.compile_plan(open(os.path.join(META, "18.sql.mplan")).read(), cfg)
     cols = catalog.synth_columns(META, cfg, text, scale=2e-3, seed=3, clustered=("lineitem.lineitem_orders",))
@@ -472,12 +603,15 @@ def test_rccl_communicator_of_one_rank_runs_both_routes(q6_text):
 
 def test_rccl_communicator_of_one_rank_runs_the_set_and_front_routes(monkeypatch):
     """The other two routes through real RCCL with one rank: Q4's all-gather of the semi-join set, and -- with
-    VDL_FRONT_ROUTE_ALWAYS, which keeps a one-rank run on the collectives -- Q16's and Q15's grouped send / receive of the front's vectors."""
+    VDL_FRONT_ROUTE_ALWAYS, which keeps a one-rank run on the collectives -- Q16's and Q15's grouped send / receive of the front's vectors, Q18's chain (its three
+    gathers) and, with that switched off, the last resort."""
     cfg = frontend.load_metadata(META)
     monkeypatch.setenv("VDL_FRONT_ROUTE_ALWAYS", "1")
-    for plan, table, route in ((4, "lineitem", "set"), (16, "partsupp", "front"), (15, "lineitem", "front"), (18, "lineitem", "replicate")):
+    for plan, table, route in ((4, "lineitem", "set"), (16, "partsupp", "front"), (15, "lineitem", "front"), (18, "lineitem", "chain"), (18, "lineitem", "replicate")):
         text = frontend.compile_plan(open(os.path.join(META, "%02d.sql.mplan" % plan)).read(), cfg)
         cols = catalog.synth_columns(META, cfg, text, scale=2e-3, seed=3)
+        if route == "replicate":
+            monkeypatch.setenv("VDL_NO_CHAIN_ROUTE", "1")
         e = engine_with(cols)
         e.comm_init_rccl(0, 1, e.comm_unique_id())
         p = e.parse(text)

@@ -39,7 +39,8 @@ def test_vdlrun_gpus_merges_the_partial_words_over_rccl(query, world):
 @pytest.mark.parametrize("plan,table", [(3, "lineitem"), (14, "lineitem"), (10, "lineitem"), (4, "lineitem"), (11, "partsupp"), (16, "partsupp"), (15, "lineitem"), (18, "lineitem")])
 def test_vdlrun_gpus_exchanges_rows_over_rccl(tmp_path, plan, table, world):
     """Q3 / Q10: the Partition exchange (rows by key range, outputs of the ranks concatenate in rank order); Q14: fold records; Q4: merged
-    semi-join sets; Q11: a global fold beside the Partition; Q16: the front's survivors gathered, the tail on every rank."""
+    semi-join sets; Q11: a global fold beside the Partition; Q16 / Q15: the front's survivors gathered, the tail on every rank; Q18: the chain
+    (exchange up to its position set, the positions gathered, the second scan's survivors gathered)."""
     cfg = frontend.load_metadata(META)
     text = frontend.compile_plan(open(os.path.join(META, "%02d.sql.mplan" % plan)).read(), cfg)
     text = "\n".join(ln.split(";;")[0].rstrip() for ln in text.splitlines()) + "\n"
