@@ -688,7 +688,14 @@ struct GenExec {
 
     // Gather with a sparse side: the filter idiom Gather(x, FoldSelect(..)) producing or narrowing a SPARSE vector,
     // and gathers through sparse positions (FK joins of filtered fact rows).  false = take the general route.
-    bool sparse_gather(const DVec &src, const DVec &pos, DVec &o) {
+    bool sparse_gather(const DVec &src, const DVec &pos0, DVec &o) {
+        DVec pos = pos0;
+        if (pos.kind == DVec::RANGE && pos.from == 0 && pos.step == 1 && pos.n != src.n && pos.valid) {
+            // the slots' own ids on a selection, read out of a vector of ANOTHER length (TPC-H Q18: the orders in its semi-join set -- a
+            // set as long as lineitem -- looked up in the orders table): the selection's slot list is the position vector
+            SelP sel = sel_for(pos.valid, pos.n);
+            if (sel->worth && sel->idx) { pos = make_sparse(sel, sel->idx); pos.ids = true; }
+        }
         const bool identity = pos.kind == DVec::RANGE && pos.from == 0 && pos.step == 1 && pos.n == src.n;
         if (identity) {
             if (!pos.valid) return false;
@@ -1109,6 +1116,11 @@ struct GenExec {
             if (ctl.n != d.n) throw Error(VDL_ERR_SHAPE, "FoldSelect (Id " + std::to_string(n.id) + "): operand lengths differ");
             if (!(ctl.kind == DVec::RANGE && ctl.step != 0)) return fold_select_runs(ctl, d);
             o.kind = DVec::RANGE; o.n = d.n; o.from = 0; o.step = 1;
+            if (d.kind == DVec::RANGE && d.step == 0 && d.from != 0 && (d.valid || ctl.valid)) {
+                // a non-zero constant: selected wherever it (and the control) holds a value -- the members of a set kept as its bitmap
+                o.valid = d.valid && ctl.valid ? and_bitmaps(d.valid, ctl.valid, d.n) : (d.valid ? d.valid : ctl.valid);
+                return o;
+            }
             o.valid = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(d.n), 1));
             HIP_CHECK(launch_select_bitmap(src_of(d), vp(d), vp(ctl), (uint64_t *)o.valid->p, d.n, s));
             note_subset(o.valid, d.valid); note_subset(o.valid, ctl.valid);
@@ -1172,6 +1184,14 @@ struct GenExec {
                 else if (ok && sv.kind == DVec::RANGE && sv.step == 0 && subset(bitmap_of(sp.sel), sv.valid)) { ssrc.kind = SRC_RANGE; ssrc.from = sv.from; ssrc.step = 0; }
                 else if (ok && sv.kind == DVec::RANGE && sv.from == 0 && sv.step == 1 && subset(bitmap_of(sp.sel), sv.valid)) ssrc = idx_src(*sp.sel);   // row ids
                 else ok = false;
+                if (ok && ssrc.kind == SRC_RANGE && ssrc.step == 0 && !sp.perm && !sp.valid) {
+                    // a constant at a few positions (a semi-join set: ones at the keys of the groups that pass): the set is its bitmap
+                    need_positions(vec[(size_t)n.c]);
+                    o.kind = DVec::RANGE; o.n = nout; o.from = ssrc.from; o.step = 0;
+                    o.valid = zero_bitmap(nout);
+                    HIP_CHECK(launch_set_bits((const int64_t *)sp.data->p, sp.sel->m, (uint64_t *)o.valid->p, s, nout));
+                    return o;
+                }
                 if (ok) {
                     const int64_t m = sp.sel->m;
                     if (sp.perm && m <= nout) {

@@ -259,7 +259,7 @@ hipError_t launch_like(Src data, const uint64_t *vdata, int64_t n, Src heap, con
                        int64_t *out, hipStream_t s);
 hipError_t launch_ex_dest(Src key, const uint64_t *vkey, int64_t n, int64_t pmin, int64_t pcount, int world, int64_t *dest,
                           uint64_t *vdest, int64_t *counts /* world, pre-zeroed */, int64_t *oob /* pre-zeroed */, hipStream_t s, const int32_t *owner = nullptr /* kExBins entries: slice of the domain -> rank (the balanced cut of vdl_run_sharded) */);
-constexpr int kExBins = 4096;              // equal slices of the pivots' domain in which a rank counts its keys (hist: kExBins + 1 words, the last = keys outside the pivots; pre-zeroed)
+constexpr int kExBins = 4096;              // at most this many equal, power-of-two-wide slices of the pivots' domain in which a rank counts its keys (hist: kExBins + 1 words, the last = keys outside the pivots; pre-zeroed)
 hipError_t launch_ex_hist(Src key, const uint64_t *vkey, int64_t n, int64_t pmin, int64_t pcount, int64_t *hist, hipStream_t s);
 hipError_t launch_ex_pack(Src src, const uint64_t *vdest, const int64_t *pos, int64_t n, int64_t *out, hipStream_t s);
 hipError_t launch_ex_mask(const ExValid &v, const uint64_t *vdest, const int64_t *pos, int64_t n, int64_t *out, hipStream_t s);

@@ -773,16 +773,35 @@ int partition_passes(int64_t pcount) {
 //                 cut the domain where the DATA is, so that every rank receives about as many rows (`owner`: slice -> rank).  With the
 //                 declared domain cut evenly, TPC-H's order keys -- which reach 0.56 of their power-of-two domain -- left the last three
 //                 of eight ranks without a row.
-__global__ __launch_bounds__(256) void k_ex_hist(Src key, const uint64_t *vkey, int64_t n, int64_t pmin, int64_t pcount, unsigned long long *hist /* kExBins + 1 */) {
+// slice of the pivots' domain a key offset b in [0, pcount) falls into: slices are a power of two wide -- the narrowest that leaves at most
+// kExBins of them (so between kExBins / 2 + 1 and kExBins are in use) --, which makes the slice a shift instead of a 128-bit division per row
+__host__ __device__ inline int ex_slice_shift(int64_t pcount) {
+    int sh = 0;
+    while (sh < 62 && ((pcount - 1) >> sh) >= kExBins) sh++;
+    return sh;
+}
+__global__ __launch_bounds__(256) void k_ex_hist(Src key, const uint64_t *vkey, int64_t n, int64_t pmin, int64_t pcount, int shift, unsigned long long *hist /* kExBins + 1 */) {
     __shared__ unsigned int cnt[kExBins + 1];
     for (int i = threadIdx.x; i <= kExBins; i += blockDim.x) cnt[i] = 0;
     __syncthreads();
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        if (!bit(vkey, i)) continue;
-        const int64_t b = (int64_t)((uint64_t)ld(key, i) - (uint64_t)pmin);
-        if (b < 0 || b >= pcount) atomicAdd(&cnt[kExBins], 1u);
-        else atomicAdd(&cnt[(int)(((unsigned __int128)(uint64_t)b * (uint64_t)kExBins) / (uint64_t)pcount)], 1u);
+    const int64_t nw = (n + 63) >> 6;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave);
+    for (int64_t w = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; w < nw; w += wstride) {
+        const int64_t i = (w << 6) + lane;
+        const bool ok = i < n && bit(vkey, i);
+        int slot = kExBins;
+        if (ok) {
+            const int64_t b = (int64_t)((uint64_t)ld(key, i) - (uint64_t)pmin);
+            if (b >= 0 && b < pcount) slot = (int)(b >> shift);
+        }
+        // a table clustered by the key puts a whole wave into one slice (64 LDS atomics on one address, one after the other): count once then
+        const uint64_t live = __ballot(ok);
+        if (!live) continue;
+        const int first = __shfl(slot, __ffsll((long long)live) - 1, kWave);
+        const uint64_t same = __ballot(ok && slot == first);
+        if (same == live) { if (lane == 0) atomicAdd(&cnt[first], (unsigned)__popcll(live)); }
+        else if (ok) atomicAdd(&cnt[slot], 1u);
     }
     __syncthreads();
     for (int i = threadIdx.x; i <= kExBins; i += blockDim.x) { const unsigned c = cnt[i]; if (c) atomicAdd(&hist[i], (unsigned long long)c); }
@@ -791,13 +810,13 @@ hipError_t launch_ex_hist(Src key, const uint64_t *vkey, int64_t n, int64_t pmin
     (void)hipGetLastError();
     if (n <= 0) return hipSuccess;
     int grid = grid_for(n, 256, 16);
-    if (grid > 1024) grid = 1024;
-    k_ex_hist<<<grid, 256, 0, s>>>(key, vkey, n, pmin, pcount, (unsigned long long *)hist);
+    if (grid > 2048) grid = 2048;
+    k_ex_hist<<<grid, 256, 0, s>>>(key, vkey, n, pmin, pcount, ex_slice_shift(pcount), (unsigned long long *)hist);
     return launch_status();
 }
 
 __global__ __launch_bounds__(256) void k_ex_dest(Src key, const uint64_t *vkey, int64_t n, int64_t pmin, int64_t pcount, int world,
-                                                 int64_t *dest, uint64_t *vdest, int64_t *counts, int64_t *oob, const int32_t *owner /* kExBins entries, or null */) {
+                                                 int64_t *dest, uint64_t *vdest, int64_t *counts, int64_t *oob, const int32_t *owner /* kExBins entries, or null */, int shift) {
     __shared__ unsigned long long cnt[kMaxExWorld + 1];       // per-block row counts per destination (+ out-of-range keys)
     for (int i = threadIdx.x; i <= kMaxExWorld; i += blockDim.x) cnt[i] = 0;
     __syncthreads();
@@ -812,7 +831,7 @@ __global__ __launch_bounds__(256) void k_ex_dest(Src key, const uint64_t *vkey, 
         if (ok && pcount > 0) {                                   // (pcount <= 0: every key takes part and goes to destination 0 -- the gather of the chain route)
             const int64_t b = (int64_t)((uint64_t)ld(key, i) - (uint64_t)pmin);
             if (b < 0 || b >= pcount) { out_of_range = true; ok = false; }
-            else if (owner) d = owner[(int)(((unsigned __int128)(uint64_t)b * (uint64_t)kExBins) / (uint64_t)pcount)];
+            else if (owner) d = owner[(int)(b >> shift)];
             else d = (int64_t)(((unsigned __int128)(uint64_t)b * (uint64_t)world) / (uint64_t)pcount);
         }
         if (i < n) dest[i] = d;
@@ -840,7 +859,7 @@ hipError_t launch_ex_dest(Src key, const uint64_t *vkey, int64_t n, int64_t pmin
                           uint64_t *vdest, int64_t *counts, int64_t *oob, hipStream_t s, const int32_t *owner) {
     (void)hipGetLastError();
     if (n <= 0) return hipSuccess;
-    k_ex_dest<<<grid_for(n, 256, 4), 256, 0, s>>>(key, vkey, n, pmin, pcount, world, dest, vdest, counts, oob, owner);
+    k_ex_dest<<<grid_for(n, 256, 4), 256, 0, s>>>(key, vkey, n, pmin, pcount, world, dest, vdest, counts, oob, owner, ex_slice_shift(pcount));
     return launch_status();
 }
 
