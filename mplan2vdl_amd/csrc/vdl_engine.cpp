@@ -9,15 +9,26 @@
 
 namespace {
 
-// the descriptor `d` on the device under `role` (vdl_plan::desc_slots): uploaded when it differs from the bytes already there
+// the descriptor `d` on the device under `role` (vdl_plan::desc_slots): uploaded when none of the role's copies already holds these
+// bytes.  A role keeps up to three copies, the least recently used one is overwritten: the fused front's take descriptor names the
+// output buffers, which alternate between two sets of addresses from run to run (the last run's results are still the plan's when
+// the next run allocates), and with one copy per role every query paid a 5 us upload in the stream.
 static const MScanDesc *desc_on_device(vdl_ctx *c, vdl_plan *p, const std::string &role, const MScanDesc &d) {
-    vdl_plan::DescSlot &sl = p->desc_slots[role];
-    if (!sl.dev) sl.dev = dev_alloc(c, sizeof(MScanDesc));
-    if (sl.shadow.size() != sizeof(MScanDesc) || std::memcmp(sl.shadow.data(), &d, sizeof(MScanDesc)) != 0) {
-        // the shadow is the SOURCE of the copy: it stays put until the next upload, the caller's `d` may be a local
-        sl.shadow.assign((const unsigned char *)&d, (const unsigned char *)&d + sizeof(MScanDesc));
-        HIP_CHECK(hipMemcpyAsync(sl.dev->p, sl.shadow.data(), sizeof(MScanDesc), hipMemcpyHostToDevice, c->stream));
+    constexpr int kCopies = 3;
+    vdl_plan::DescSlot *hit = nullptr, *oldest = nullptr;
+    for (int k = 0; k < kCopies; k++) {
+        vdl_plan::DescSlot &sl = p->desc_slots[role + "#" + std::to_string(k)];
+        if (sl.shadow.size() == sizeof(MScanDesc) && std::memcmp(sl.shadow.data(), &d, sizeof(MScanDesc)) == 0) { hit = &sl; break; }
+        if (!oldest || sl.used < oldest->used) oldest = &sl;
     }
+    uint64_t &clock = p->desc_clock;
+    if (hit) { hit->used = ++clock; return (const MScanDesc *)hit->dev->p; }
+    vdl_plan::DescSlot &sl = *oldest;
+    if (!sl.dev) sl.dev = dev_alloc(c, sizeof(MScanDesc));
+    // the shadow is the SOURCE of the copy: it stays put until the next upload, the caller's `d` may be a local
+    sl.shadow.assign((const unsigned char *)&d, (const unsigned char *)&d + sizeof(MScanDesc));
+    sl.used = ++clock;
+    HIP_CHECK(hipMemcpyAsync(sl.dev->p, sl.shadow.data(), sizeof(MScanDesc), hipMemcpyHostToDevice, c->stream));
     return (const MScanDesc *)sl.dev->p;
 }
 
@@ -1176,6 +1187,7 @@ void vdl_close(vdl_ctx *c) {
         (void)hipDeviceSynchronize();
         c->comm.reset();
         c->cols.clear();
+        c->sorted_state.reset();
         c->pool->trim();
         c->pool->closed = true;
         if (c->own_stream) (void)hipStreamDestroy(c->own_stream);

@@ -196,6 +196,7 @@ struct vdl_ctx {
         return words <= kPinnedWords - kFlagWords ? pinned_words : nullptr;
     }
     int64_t *flag_words() { return pinned(1) ? pinned_words + (kPinnedWords - kFlagWords) : nullptr; }
+    BufP sorted_state;                 // four device words the fused sortedness pass keeps between its launches (k_sorted_heads_counted)
     int64_t post_seq = 0;
     // Round trips without hipStreamSynchronize: a one-block kernel behind whatever is queued posts words and a sequence number into
     // pinned memory with system-scope stores, the host polls the number (and the stream's state now and then, so that a failed
@@ -315,8 +316,9 @@ struct vdl_plan {
     // scan descriptors on the device, by role ("scan3", "dim0", "select", "take"): a plan-owned buffer and the bytes it holds -- the
     // descriptor of a run is uploaded only when it differs from what is there (pool buffers come back at the same addresses run
     // after run, so it rarely does: each upload was a 5 us staged copy on the stream plus the host's part of it)
-    struct DescSlot { BufP dev; std::vector<unsigned char> shadow; };
+    struct DescSlot { BufP dev; std::vector<unsigned char> shadow; uint64_t used = 0; };
     std::map<std::string, DescSlot> desc_slots;
+    uint64_t desc_clock = 0;
     double front_usec = 0;
     int64_t front_m_seen = -1;               // survivors of the front's last run: the next run launches its take pass with room for about as many
     bool bound = false;

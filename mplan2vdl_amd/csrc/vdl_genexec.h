@@ -861,11 +861,25 @@ struct GenExec {
             BufP counts = dev_alloc(c, sizeof(int64_t) * (size_t)(nb + 4));                 // tile counts, their total, then {descends, max, min}
             int64_t *flag = (int64_t *)counts->p + nb + 1;
             BufP heads = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(o.n), 1));
-            HIP_CHECK(launch_sorted_heads(src_of(data), o.n, (uint64_t *)heads->p, flag, s));     // (sets the two flag words itself)
-            HIP_CHECK(launch_compact_count((const uint64_t *)heads->p, o.n, (int64_t *)counts->p, s));
-            HIP_CHECK(launch_compact_scan((int64_t *)counts->p, nb, s));
             int64_t back[4] = {0, 0, 0, 0};
-            c->fetch_to_host((int64_t *)counts->p + nb, 4, back, s);      // (posted into pinned memory and polled: no stream synchronise)
+            int64_t *pin = c->pinned(4), *pflag = c->flag_words();
+            const Src ds = src_of(data);
+            if (pin && pflag && compact_tile() == 4096 && sorted_heads_counted_serves(ds, o.n)) {
+                // one launch: heads, their counts per tile, the scan, the verdict posted into pinned memory (polled: no stream synchronise)
+                if (!c->sorted_state) {
+                    c->sorted_state = dev_alloc(c, 4 * sizeof(int64_t));
+                    HIP_CHECK(launch_sorted_state_init((int64_t *)c->sorted_state->p, s));
+                }
+                const int64_t seq = ++c->post_seq;
+                HIP_CHECK(launch_sorted_heads_counted((const int64_t *)ds.p, o.n, (uint64_t *)heads->p, (int64_t *)counts->p, (int64_t *)c->sorted_state->p, pin, pflag, seq, s));
+                while (*(volatile int64_t *)pflag != seq) c->wait_flag(pflag, *(volatile int64_t *)pflag, s);
+                std::memcpy(back, pin, sizeof back);
+            } else {
+                HIP_CHECK(launch_sorted_heads(ds, o.n, (uint64_t *)heads->p, flag, s));     // (sets the two flag words itself)
+                HIP_CHECK(launch_compact_count((const uint64_t *)heads->p, o.n, (int64_t *)counts->p, s));
+                HIP_CHECK(launch_compact_scan((int64_t *)counts->p, nb, s));
+                c->fetch_to_host((int64_t *)counts->p + nb, 4, back, s);      // (posted into pinned memory and polled: no stream synchronise)
+            }
             const int64_t nheads = back[0], seen[2] = {back[1], back[2]};
             // every value inside the pivots: bucket = value - pmin exactly, so the sorted buckets ARE the sorted values
             values_inside = back[3] >= pmin && (uint64_t)back[2] - (uint64_t)pmin <= (uint64_t)pcount && back[2] >= back[3];

@@ -258,7 +258,8 @@ hipError_t launch_project_front(const MScanCols &scols, const MScanDesc *dev_sde
     (void)hipGetLastError();
     if (scols.n <= 0) return hipSuccess;
     if (project_tiles(scols.n) >= ((int64_t)1 << (kFrontFanBits * kFrontLevels))) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(look, 0, (size_t)project_look_bytes(scols.n), s);
+    // (one kernel: the runtime's memset of a size like this one came as two fill kernels of 5 us each)
+    hipError_t e = launch_fill_words((uint64_t *)look, 0, project_look_bytes(scols.n) / (int64_t)sizeof(uint64_t), s);
     if (e != hipSuccess) return e;
     FrontLook lk;
     lk.ticket = (unsigned int *)look; lk.nodes = (unsigned long long *)((char *)look + 64); lk.total = total_dev; lk.total_host = total_host;

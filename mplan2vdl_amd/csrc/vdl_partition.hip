@@ -663,6 +663,154 @@ __global__ __launch_bounds__(256) void k_sorted_heads_dense(const int64_t *__res
         if (lo < *(volatile int64_t *)&flag[2]) atomicMin((long long *)&flag[2], (long long)lo);
     }
 }
+// The sortedness pass, the heads' tile counts, their scan and the report to the host in ONE launch (round 4: the five launches it replaces
+// -- init, heads, count, scan, post -- were 40 us of a 490 us Q3 at SF10, most of it the gaps between them).  A wave owns whole compaction
+// tiles (4096 entries = 16 groups of 256, two groups in flight) and STORES its tiles' head counts, so nothing has to be zeroed first; the
+// block that finishes last (a counter in `state`, which lives with the context and is left as it was found: {0, INT64_MIN, INT64_MAX, 0})
+// scans the counts in place, appends {total, descends, largest, smallest} and posts those four words and the sequence number into pinned
+// host memory with system-scope stores (vdl_ctx::wait_flag polls it).  Counts and flags cross the blocks as agent-scope atomics: the XCDs'
+// L2s do not see one another's plain stores inside a kernel.
+constexpr int kHeadTileGroups = 16;         // 256-entry groups per compaction tile (compact_tile() = 4096, vdl_ops.hip)
+__global__ __launch_bounds__(256) void k_sorted_heads_counted(const int64_t *__restrict__ d, int64_t n, uint64_t *__restrict__ heads, int64_t *counts, int64_t nb,
+                                                              int64_t *state, int64_t *pin, int64_t *pflag, int64_t seq) {
+    typedef long long i64x2 __attribute__((ext_vector_type(2)));
+    constexpr int R = 2;
+    __shared__ int64_t wmax[256 / kWave], wmin[256 / kWave];
+    __shared__ int wbad[256 / kWave];
+    __shared__ int last_block;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int64_t nq = (n + 255) >> 8;
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / kWave);
+    bool bad = false;
+    int64_t mx = INT64_MIN, mn = INT64_MAX;
+    for (int64_t t = (int64_t)blockIdx.x * (blockDim.x / kWave) + wave; t < nb; t += nwaves) {
+        int found = 0;
+        for (int g = 0; g < kHeadTileGroups; g += R) {
+            const int64_t q0 = t * kHeadTileGroups + g;
+            if (q0 >= nq) break;                                          // wave-uniform
+            int64_t v[R][4], left[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int64_t q = q0 + r, i0 = (q << 8) + 4 * lane;
+                if (i0 + 4 <= n) {
+                    const i64x2 a = *(const i64x2 *)(d + i0), b = *(const i64x2 *)(d + i0 + 2);
+                    v[r][0] = a.x; v[r][1] = a.y; v[r][2] = b.x; v[r][3] = b.y;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v[r][k] = i0 + k < n ? d[i0 + k] : 0;
+                }
+                left[r] = (lane == 0 && q > 0 && q < nq) ? d[(q << 8) - 1] : 0;
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int64_t q = q0 + r, i0 = (q << 8) + 4 * lane;
+                if (q >= nq) break;                                       // wave-uniform
+                const int64_t up = __shfl_up(v[r][3], 1, kWave);
+                int64_t prev = lane == 0 ? left[r] : up;
+                unsigned nib = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const bool in = i0 + k < n;
+                    const int64_t x = v[r][k];
+                    const bool first = i0 + k == 0;
+                    if (in) {
+                        bad |= !first && x < prev;
+                        mx = x > mx ? x : mx;
+                        mn = x < mn ? x : mn;
+                        if (first || x != prev) nib |= 1u << k;
+                    }
+                    prev = x;
+                }
+                found += __popc(nib);
+                uint64_t m = (uint64_t)nib << (4 * (lane & 15));
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) m |= __shfl_xor(m, off, kWave);
+                const int64_t w = (q << 2) + (lane >> 4);
+                if ((lane & 15) == 0 && w < ((n + 63) >> 6)) heads[w] = m;
+            }
+        }
+        const int64_t total = wave_reduce((int64_t)found, R_SUM);
+        if (lane == 0) __hip_atomic_store(&counts[t], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const bool anybad = __ballot(bad) != 0;
+    mx = wave_reduce(mx, R_MAX);
+    mn = wave_reduce(mn, R_MIN);
+    if (lane == 0) { wmax[wave] = mx; wmin[wave] = mn; wbad[wave] = anybad ? 1 : 0; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t m = wmax[0], lo = wmin[0];
+        int b = wbad[0];
+        for (int w = 1; w < 256 / kWave; w++) { m = wmax[w] > m ? wmax[w] : m; lo = wmin[w] < lo ? wmin[w] : lo; b |= wbad[w]; }
+        if (b) __hip_atomic_store(&state[0], (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (m != INT64_MIN) atomicMax((long long *)&state[1], (long long)m);
+        if (lo != INT64_MAX) atomicMin((long long *)&state[2], (long long)lo);
+        __threadfence();                                                  // this block's counts, heads and flags before its arrival
+        const int64_t before = __hip_atomic_fetch_add(&state[3], (int64_t)1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last_block = before == (int64_t)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last_block) return;
+    // ---- the last block: exclusive scan of the tile counts in place, total behind them
+    constexpr int K = 8;
+    __shared__ int64_t wsum[256 / kWave];
+    __shared__ int64_t carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nb; base += 256 * K) {
+        const int64_t i0 = base + (int64_t)tid * K;
+        int64_t x[K], sum = 0;
+#pragma unroll
+        for (int k = 0; k < K; k++) { x[k] = i0 + k < nb ? __hip_atomic_load(&counts[i0 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0; sum += x[k]; }
+        int64_t incl = sum;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const int64_t y = __shfl_up(incl, off, kWave);
+            if (lane >= off) incl += y;
+        }
+        if (lane == kWave - 1) wsum[wave] = incl;
+        __syncthreads();
+        int64_t wprefix = 0;
+        for (int w = 0; w < wave; w++) wprefix += wsum[w];
+        int64_t run = carry + wprefix + incl - sum;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; k++) { if (i0 + k < nb) counts[i0 + k] = run; run += x[k]; }
+        if (tid == 255) carry = run;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int64_t out[4] = {carry, __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(&state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                __hip_atomic_load(&state[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
+        for (int k = 0; k < 4; k++) { counts[nb + k] = out[k]; if (pin) __hip_atomic_store(pin + k, out[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+        // the state as the next launch wants to find it
+        __hip_atomic_store(&state[0], (int64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&state[1], INT64_MIN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&state[2], INT64_MAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&state[3], (int64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (pflag) {
+            __threadfence_system();
+            __hip_atomic_store(pflag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+__global__ void k_sorted_state_init(int64_t *state) { state[0] = 0; state[1] = INT64_MIN; state[2] = INT64_MAX; state[3] = 0; }
+hipError_t launch_sorted_state_init(int64_t *state, hipStream_t s) {
+    (void)hipGetLastError();
+    k_sorted_state_init<<<1, 1, 0, s>>>(state);
+    return launch_status();
+}
+bool sorted_heads_counted_serves(Src d, int64_t n) { return n > 0 && d.kind == SRC_I64 && ((uintptr_t)d.p & 15u) == 0 && !getenv("VDL_NO_DENSE_HEADS"); }
+hipError_t launch_sorted_heads_counted(const int64_t *d, int64_t n, uint64_t *heads, int64_t *counts, int64_t *state, int64_t *pinned_dst, int64_t *pinned_flag,
+                                       int64_t seq, hipStream_t s) {
+    (void)hipGetLastError();
+    const int64_t nb = (n + compact_tile() - 1) / compact_tile();
+    int64_t grid = (nb + 3) / 4;                                          // one tile per wave
+    if (grid > 2048) grid = 2048;
+    k_sorted_heads_counted<<<(int)grid, 256, 0, s>>>(d, n, heads, counts, nb, state, pinned_dst, pinned_flag, seq);
+    return launch_status();
+}
+
 hipError_t launch_sorted_heads(Src d, int64_t n, uint64_t *heads, int64_t *flag, hipStream_t s) {
     (void)hipGetLastError();
     k_sorted_init<<<1, 1, 0, s>>>(flag);
