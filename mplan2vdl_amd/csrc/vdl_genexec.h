@@ -858,7 +858,7 @@ struct GenExec {
             // (the same pass leaves the run heads: if the data is in order the folds over it need no head pass and no count of
             // their own -- and their number comes back with the verdict, in this one round trip through pinned memory)
             const int64_t nb = (o.n + compact_tile() - 1) / compact_tile();
-            BufP counts = dev_alloc(c, sizeof(int64_t) * (size_t)(nb + 4));                 // tile counts, their total, then {descends, max, min}
+            BufP counts = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(nb + 4, sorted_heads_counts_words(o.n)));   // tile counts, their total, then {descends, max, min} (and the fused pass's verdict per block)
             int64_t *flag = (int64_t *)counts->p + nb + 1;
             BufP heads = dev_alloc(c, sizeof(uint64_t) * (size_t)std::max<int64_t>(nwords(o.n), 1));
             int64_t back[4] = {0, 0, 0, 0};
@@ -867,7 +867,7 @@ struct GenExec {
             if (pin && pflag && compact_tile() == 4096 && sorted_heads_counted_serves(ds, o.n)) {
                 // one launch: heads, their counts per tile, the scan, the verdict posted into pinned memory (polled: no stream synchronise)
                 if (!c->sorted_state) {
-                    c->sorted_state = dev_alloc(c, 4 * sizeof(int64_t));
+                    c->sorted_state = dev_alloc(c, (size_t)sorted_heads_state_words() * sizeof(int64_t));
                     HIP_CHECK(launch_sorted_state_init((int64_t *)c->sorted_state->p, s));
                 }
                 const int64_t seq = ++c->post_seq;

@@ -220,11 +220,13 @@ hipError_t launch_sorted_check(Src d, int64_t n, int64_t *flag, hipStream_t s);
 // vector, unmoved).  flag[0] / flag[1] as above (pre-set to 0 / INT64_MIN).
 hipError_t launch_sorted_heads(Src d, int64_t n, uint64_t *heads /* (n + 63) / 64 words */, int64_t *flag /* 3 words: descends, largest, smallest */, hipStream_t s);
 // ... with the heads counted per compaction tile, the counts scanned in place (counts[nb] = total, then {descends, largest, smallest}) and
-// those four words posted into pinned host memory behind `seq` -- one launch.  `state`: four words owned by the caller between launches,
+// those four words posted into pinned host memory behind `seq` -- one launch.  `state`: words owned by the caller between launches,
 // once prepared by launch_sorted_state_init.  Serves int64 vectors at 16-byte aligned addresses (sorted_heads_counted_serves).
 bool sorted_heads_counted_serves(Src d, int64_t n);
-hipError_t launch_sorted_state_init(int64_t *state /* 4 words */, hipStream_t s);
-hipError_t launch_sorted_heads_counted(const int64_t *d, int64_t n, uint64_t *heads, int64_t *counts /* nb + 4 */, int64_t *state, int64_t *pinned_dst /* 4 words */,
+int64_t sorted_heads_state_words();
+int64_t sorted_heads_counts_words(int64_t n);
+hipError_t launch_sorted_state_init(int64_t *state /* sorted_heads_state_words() */, hipStream_t s);
+hipError_t launch_sorted_heads_counted(const int64_t *d, int64_t n, uint64_t *heads, int64_t *counts /* sorted_heads_counts_words(n) */, int64_t *state, int64_t *pinned_dst /* 4 words */,
                                        int64_t *pinned_flag, int64_t seq, hipStream_t s);
 // Every fold of one GROUP BY in one launch, results PACKED (one per run, in run order): fold j reduces data[j] over the runs whose
 // heads are given (m entries, all holding a value; entry 0 is a head) and writes out[j][g] for the g-th run.  offsets = exclusive

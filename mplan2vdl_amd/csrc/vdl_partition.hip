@@ -664,12 +664,14 @@ __global__ __launch_bounds__(256) void k_sorted_heads_dense(const int64_t *__res
     }
 }
 // The sortedness pass, the heads' tile counts, their scan and the report to the host in ONE launch (round 4: the five launches it replaces
-// -- init, heads, count, scan, post -- were 40 us of a 490 us Q3 at SF10, most of it the gaps between them).  A wave owns whole compaction
-// tiles (4096 entries = 16 groups of 256, two groups in flight) and STORES its tiles' head counts, so nothing has to be zeroed first; the
+// -- init, heads, count, scan, post -- were 40 us of a 490 us Q3 at SF10, most of it the gaps between them).  A block owns whole compaction
+// tiles (4096 entries = 16 groups of 256, two per wave in flight) and STORES its tiles' head counts, so nothing has to be zeroed first; the
 // block that finishes last (a counter in `state`, which lives with the context and is left as it was found: {0, INT64_MIN, INT64_MAX, 0})
 // scans the counts in place, appends {total, descends, largest, smallest} and posts those four words and the sequence number into pinned
 // host memory with system-scope stores (vdl_ctx::wait_flag polls it).  Counts and flags cross the blocks as agent-scope atomics: the XCDs'
 // L2s do not see one another's plain stores inside a kernel.
+constexpr int kHeadMaxGrid = 2048;
+constexpr int kHeadArrivals = 64;          // arrival counters of k_sorted_heads_counted (+ the one their last arrivals meet on): kHeadStateWords words of state
 constexpr int kHeadTileGroups = 16;         // 256-entry groups per compaction tile (compact_tile() = 4096, vdl_ops.hip)
 __global__ __launch_bounds__(256) void k_sorted_heads_counted(const int64_t *__restrict__ d, int64_t n, uint64_t *__restrict__ heads, int64_t *counts, int64_t nb,
                                                               int64_t *state, int64_t *pin, int64_t *pflag, int64_t seq) {
@@ -678,16 +680,19 @@ __global__ __launch_bounds__(256) void k_sorted_heads_counted(const int64_t *__r
     __shared__ int64_t wmax[256 / kWave], wmin[256 / kWave];
     __shared__ int wbad[256 / kWave];
     __shared__ int last_block;
+    __shared__ int64_t wcount[256 / kWave];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const int64_t nq = (n + 255) >> 8;
-    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / kWave);
     bool bad = false;
     int64_t mx = INT64_MIN, mn = INT64_MAX;
-    for (int64_t t = (int64_t)blockIdx.x * (blockDim.x / kWave) + wave; t < nb; t += nwaves) {
+    // a BLOCK owns a compaction tile (its four waves take two neighbouring groups each, twice), blocks take neighbouring tiles: what is in
+    // flight at any moment is one contiguous stretch of the vector.  (A wave per tile -- 2 000 streams 32 KB apart -- ran at a third of
+    // the rate: 112-184 us for 260 MB.)
+    for (int64_t t = blockIdx.x; t < nb; t += gridDim.x) {
         int found = 0;
-        for (int g = 0; g < kHeadTileGroups; g += R) {
-            const int64_t q0 = t * kHeadTileGroups + g;
-            if (q0 >= nq) break;                                          // wave-uniform
+        for (int gi = 0; gi < kHeadTileGroups; gi += R * (256 / kWave)) {
+            const int64_t q0 = t * kHeadTileGroups + gi + wave * R;
+            if (q0 >= nq) continue;                                       // wave-uniform
             int64_t v[R][4], left[R];
 #pragma unroll
             for (int r = 0; r < R; r++) {
@@ -730,8 +735,20 @@ __global__ __launch_bounds__(256) void k_sorted_heads_counted(const int64_t *__r
             }
         }
         const int64_t total = wave_reduce((int64_t)found, R_SUM);
-        if (lane == 0) __hip_atomic_store(&counts[t], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) wcount[wave] = total;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int64_t sum = 0;
+            for (int w = 0; w < 256 / kWave; w++) sum += wcount[w];
+            __hip_atomic_store(&counts[t], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
     }
+    // What crosses the blocks -- the tile counts, the flags, the arrival counter -- are agent-scope atomics, which are performed where every
+    // XCD sees them; a wave waits for ITS stores to be acknowledged (a workgroup-scope release is that wait and nothing else) before the block
+    // announces its arrival.  An agent-scope release fence instead writes back the XCD's whole L2 (buffer_wbl2) once per block: 2 000 blocks
+    // at 32 M entries spent 240 us in a pass that moves 260 MB.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     const bool anybad = __ballot(bad) != 0;
     mx = wave_reduce(mx, R_MAX);
     mn = wave_reduce(mn, R_MIN);
@@ -741,15 +758,45 @@ __global__ __launch_bounds__(256) void k_sorted_heads_counted(const int64_t *__r
         int64_t m = wmax[0], lo = wmin[0];
         int b = wbad[0];
         for (int w = 1; w < 256 / kWave; w++) { m = wmax[w] > m ? wmax[w] : m; lo = wmin[w] < lo ? wmin[w] : lo; b |= wbad[w]; }
-        if (b) __hip_atomic_store(&state[0], (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (m != INT64_MIN) atomicMax((long long *)&state[1], (long long)m);
-        if (lo != INT64_MAX) atomicMin((long long *)&state[2], (long long)lo);
-        __threadfence();                                                  // this block's counts, heads and flags before its arrival
-        const int64_t before = __hip_atomic_fetch_add(&state[3], (int64_t)1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        last_block = before == (int64_t)gridDim.x - 1;
+        // this block's verdict in its own three words behind the counts; its arrival on one of kHeadArrivals counters, the last of each on
+        // the top one.  (One counter and one pair of atomic max / min words for everybody: same-address atomics are carried out one after
+        // the other where all XCDs meet, 50-70 ns each -- 4 096 blocks spent 290 us on a pass that moves 260 MB.)
+        int64_t *rec = counts + nb + 4 + 3 * (int64_t)blockIdx.x;
+        __hip_atomic_store(&rec[0], (int64_t)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&rec[1], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&rec[2], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");           // this block's counts and verdict have arrived before it says so
+        const int64_t groups = (int64_t)gridDim.x < kHeadArrivals ? (int64_t)gridDim.x : kHeadArrivals;
+        const int64_t mine = blockIdx.x % kHeadArrivals, members = ((int64_t)gridDim.x - mine + kHeadArrivals - 1) / kHeadArrivals;
+        int last = 0;
+        if (__hip_atomic_fetch_add(&state[mine], (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+            __hip_atomic_store(&state[mine], (int64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);           // as the next launch wants to find it
+            if (__hip_atomic_fetch_add(&state[kHeadArrivals], (int64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1) {
+                __hip_atomic_store(&state[kHeadArrivals], (int64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = 1;
+            }
+        }
+        last_block = last;
     }
     __syncthreads();
     if (!last_block) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // ---- the last block: everybody's verdicts
+    {
+        int64_t m = INT64_MIN, lo = INT64_MAX;
+        bool b = false;
+        for (int64_t k = threadIdx.x; k < (int64_t)gridDim.x; k += 256) {
+            const int64_t *rec = counts + nb + 4 + 3 * k;
+            b |= __hip_atomic_load(&rec[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            const int64_t x = __hip_atomic_load(&rec[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), y = __hip_atomic_load(&rec[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            m = x > m ? x : m; lo = y < lo ? y : lo;
+        }
+        const bool anyb = __ballot(b) != 0;
+        m = wave_reduce(m, R_MAX); lo = wave_reduce(lo, R_MIN);
+        __syncthreads();                                                  // (wmax / wmin / wbad are read above by thread 0 only, before the barrier)
+        if (lane == 0) { wmax[wave] = m; wmin[wave] = lo; wbad[wave] = anyb ? 1 : 0; }
+        __syncthreads();
+    }
     // ---- the last block: exclusive scan of the tile counts in place, total behind them
     constexpr int K = 8;
     __shared__ int64_t wsum[256 / kWave];
@@ -780,33 +827,35 @@ __global__ __launch_bounds__(256) void k_sorted_heads_counted(const int64_t *__r
         __syncthreads();
     }
     if (tid == 0) {
-        const int64_t out[4] = {carry, __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(&state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                __hip_atomic_load(&state[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
+        int64_t m = wmax[0], lo = wmin[0];
+        int b = wbad[0];
+        for (int w = 1; w < 256 / kWave; w++) { m = wmax[w] > m ? wmax[w] : m; lo = wmin[w] < lo ? wmin[w] : lo; b |= wbad[w]; }
+        const int64_t out[4] = {carry, (int64_t)b, m, lo};
         for (int k = 0; k < 4; k++) { counts[nb + k] = out[k]; if (pin) __hip_atomic_store(pin + k, out[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-        // the state as the next launch wants to find it
-        __hip_atomic_store(&state[0], (int64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&state[1], INT64_MIN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&state[2], INT64_MAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&state[3], (int64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (pflag) {
             __threadfence_system();
             __hip_atomic_store(pflag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
-__global__ void k_sorted_state_init(int64_t *state) { state[0] = 0; state[1] = INT64_MIN; state[2] = INT64_MAX; state[3] = 0; }
+__global__ void k_sorted_state_init(int64_t *state) { if (threadIdx.x <= kHeadArrivals) state[threadIdx.x] = 0; }
 hipError_t launch_sorted_state_init(int64_t *state, hipStream_t s) {
     (void)hipGetLastError();
-    k_sorted_state_init<<<1, 1, 0, s>>>(state);
+    k_sorted_state_init<<<1, 128, 0, s>>>(state);
     return launch_status();
+}
+int64_t sorted_heads_state_words() { return kHeadArrivals + 1; }
+int64_t sorted_heads_counts_words(int64_t n) {                            // tile counts, {total, descends, largest, smallest}, a verdict per block
+    const int64_t nb = (n + compact_tile() - 1) / compact_tile();
+    return nb + 4 + 3 * std::min<int64_t>(std::max<int64_t>(nb, 1), kHeadMaxGrid);
 }
 bool sorted_heads_counted_serves(Src d, int64_t n) { return n > 0 && d.kind == SRC_I64 && ((uintptr_t)d.p & 15u) == 0 && !getenv("VDL_NO_DENSE_HEADS"); }
 hipError_t launch_sorted_heads_counted(const int64_t *d, int64_t n, uint64_t *heads, int64_t *counts, int64_t *state, int64_t *pinned_dst, int64_t *pinned_flag,
                                        int64_t seq, hipStream_t s) {
     (void)hipGetLastError();
     const int64_t nb = (n + compact_tile() - 1) / compact_tile();
-    int64_t grid = (nb + 3) / 4;                                          // one tile per wave
-    if (grid > 2048) grid = 2048;
+    int64_t grid = nb;                                                    // a tile per block and trip
+    if (grid > kHeadMaxGrid) grid = kHeadMaxGrid;
     k_sorted_heads_counted<<<(int)grid, 256, 0, s>>>(d, n, heads, counts, nb, state, pinned_dst, pinned_flag, seq);
     return launch_status();
 }
