@@ -509,7 +509,11 @@ template <bool FIRST, bool PACKED, int MODE, class ST>
 __global__ __launch_bounds__(kPartBlock, VDL_PART_EU) void k_part_pass(PartIn in, uint64_t *keys_out, int64_t *slots_out, int64_t *pos_out) {
     __shared__ PartLds<MODE, ST> L;
     const int tid = threadIdx.x;
+#ifdef VDL_PART_NOTICKET                                        // (ablation, tools/ubench/part_sweep.sh: tiles by block number -- no guarantee that earlier tiles run)
+    if (tid == 0) L.tile = blockIdx.x;
+#else
     if (tid == 0) L.tile = atomicAdd(in.ticket, 1u);
+#endif
 #pragma unroll
     for (int k = 0; k < kPartWaves * kRadix / kPartBlock; k++) { (&L.whist[0][0])[k * kPartBlock + tid] = 0; L.stage[k * kPartBlock + tid] = 0; }
     if (tid < kRadix) { L.chist[tid] = 0; L.before[tid] = 0; }

@@ -8,7 +8,7 @@
 #include "../../mplan2vdl_amd/csrc/vdl_partition.hip"
 #include <cstdio>
 #include <vector>
-namespace vdl { hipError_t launch_compact_scan(int64_t *, int64_t, hipStream_t, int64_t *) { return hipErrorNotSupported; } }   // (launch_prefix_sum's helper lives in vdl_ops.hip; not used here)
+namespace vdl { hipError_t launch_compact_scan(int64_t *, int64_t, hipStream_t, int64_t *) { return hipErrorNotSupported; } int64_t compact_tile() { return 4096; } }   // (launch_prefix_sum's helper lives in vdl_ops.hip; not used here)
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 __device__ __forceinline__ uint64_t mix(uint64_t x) { x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31); }
 __global__ void k_make(int64_t *k, int64_t n) {

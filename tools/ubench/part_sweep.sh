@@ -3,7 +3,7 @@
 #   tools/ubench/part_sweep.sh build    |    tools/ubench/part_sweep.sh run <tag>
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 B=$ROOT/tools/ubench/part_bench_bin
-VARIANTS=("512 16 4 -DVDL_PART_TIMING=2" "512 16 4")
+VARIANTS=("512 16 4" "512 16 4 -DVDL_PART_NOTICKET")
 if [ "$1" = build ]; then
     mkdir -p $B; rm -f $B/*
     i=0
