@@ -322,22 +322,36 @@ hipError_t launch_fill_words(uint64_t *p, uint64_t v, int64_t nw, hipStream_t s)
 // row ids themselves (a virtual range), so only the validity bitmap is produced: one 64-bit
 // ballot per wave = one bitmap word.
 __global__ __launch_bounds__(256) void k_select_bitmap(Src d, const uint64_t *vd, const uint64_t *vc, uint64_t *out, int64_t n) {
+    constexpr int U = 8;                                        // bitmap words per wave and trip: 4 KB of int64 data in flight per wave (one word
+                                                                // per trip left a cold stream at 3.7 TB/s: 130 us for 60 M rows)
     const int64_t nw = (n + 63) >> 6;
     const int lane = threadIdx.x & (kWave - 1);
-    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave);
-    for (int64_t w = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; w < nw; w += wstride) {
-        const int64_t i = (w << 6) + lane;
-        bool nz = (i < n) && (ld(d, i) != 0);
-        uint64_t m = __ballot(nz);
-        if (vd) m &= vd[w];
-        if (vc) m &= vc[w];
-        if (lane == 0) out[w] = m;
-    }
+    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave) * U;
+    by_kind(d.kind, [&](auto kd) {
+        for (int64_t w0 = wave_index() * U; w0 < nw; w0 += wstride) {
+            int64_t x[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int64_t i = ((w0 + u) << 6) + lane;
+                x[u] = ldk<decltype(kd)::value>(d, i < n ? i : n - 1);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int64_t w = w0 + u;
+                if (w >= nw) break;                             // wave-uniform
+                const int64_t i = (w << 6) + lane;
+                uint64_t m = __ballot(i < n && x[u] != 0);
+                if (vd) m &= vd[w];
+                if (vc) m &= vc[w];
+                if (lane == 0) out[w] = m;
+            }
+        }
+    });
 }
 hipError_t launch_select_bitmap(Src d, const uint64_t *vd, const uint64_t *vc, uint64_t *out, int64_t n, hipStream_t s) {
     (void)hipGetLastError();   // see launch_status()
     if (n <= 0) return hipSuccess;
-    k_select_bitmap<<<grid_for(n, 256, 4), 256, 0, s>>>(d, vd, vc, out, n);
+    k_select_bitmap<<<grid_for(n, 256, 8), 256, 0, s>>>(d, vd, vc, out, n);
     return launch_status();
 }
 
