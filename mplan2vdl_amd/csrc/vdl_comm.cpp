@@ -314,7 +314,7 @@ static void sharded_exchange(vdl_ctx *c, vdl_plan *p) {
     // whom out of the gathered histograms.  (With the DECLARED domain cut evenly the last three of eight ranks received nothing for
     // TPC-H Q3: the order keys in use reach 0.56 of their power-of-two domain.)  Owners stay contiguous key ranges in rank order, so the
     // ranks' outputs still concatenate to the unsharded result.
-    const size_t row = 1 + (size_t)kExBins + 1 + n_fold_words;          // {status, histogram, keys outside the pivots, fold words}
+    const size_t row = 1 + (size_t)kExBins + 1 + n_fold_words + 1;      // {status, histogram, keys outside the pivots, fold words, holes}
     std::vector<int64_t> mine(row, 0);
     std::string local_error;
     int rc = guard(c, [&] {
@@ -328,12 +328,20 @@ static void sharded_exchange(vdl_ctx *c, vdl_plan *p) {
     if (rc != VDL_OK) { local_error = c->err; mine.assign(row, 0); }
     else if (p->ex.fold_words.size() == n_fold_words) std::copy(p->ex.fold_words.begin(), p->ex.fold_words.end(), mine.begin() + 2 + kExBins);
     mine[0] = rc;
+    // (does any travelling vector of this rank have empty slots of its own?  If nobody's has, the mask column that carries the vectors'
+    // validity is neither written nor sent nor read: one column in four of TPC-H Q18's exchange)
+    mine[row - 1] = rc == VDL_OK && exchange_has_holes(p) ? 1 : 0;
     const std::vector<int64_t> all = gather_words(c, mine);
-    for (int r = 0; r < m.world; r++)
+    bool holes = false;
+    for (int r = 0; r < m.world; r++) {
         if (all[(size_t)r * row] != VDL_OK) {
             if (rc != VDL_OK) throw Error(rc, local_error);
             throw Error(VDL_ERR_UNSUPPORTED, "sharded Partition exchange failed on rank " + std::to_string(r));
         }
+        holes |= all[(size_t)r * row + row - 1] != 0;
+    }
+    p->ex.skip_mask = !holes;
+    const int sent_cols = holes ? ncols : ncols - 1;
     if (n_fold_words) {
         // merge: value by the fold's reduction, first row by MIN, count by SUM (vdl_exchange.cpp: k_fold_words / k_fold_record)
         std::vector<int64_t> merged(n_fold_words);
@@ -376,7 +384,7 @@ static void sharded_exchange(vdl_ctx *c, vdl_plan *p) {
     BufP recv = send;
     if (m.world > 1) {
         recv = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(n_recv * ncols, 1));
-        all_to_all_columns(c, (const int64_t *)send->p, n_send, scnt, (int64_t *)recv->p, n_recv, rcnt, ncols, c->stream);
+        all_to_all_columns(c, (const int64_t *)send->p, n_send, scnt, (int64_t *)recv->p, n_recv, rcnt, sent_cols, c->stream);
     }
     p->shard_keep = recv;                                     // the tail reads the received columns in place
     if (vdl_exchange_finish(c, p, recv->p, n_recv) != VDL_OK) throw Error(VDL_ERR_DEVICE, c->err);

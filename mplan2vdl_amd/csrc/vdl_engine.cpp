@@ -1164,7 +1164,7 @@ void vdl_ctx::wait_here(hipStream_t s) {
     if (!flag) { HIP_CHECK(hipStreamSynchronize(s)); return; }
     const int64_t seq = ++post_seq;
     HIP_CHECK(launch_post_words(nullptr, 0, nullptr, flag, seq, s));
-    while (*(volatile int64_t *)flag != seq) wait_flag(flag, *(volatile int64_t *)flag, s);
+    wait_seq(flag, seq, s);
 }
 void vdl_ctx::fetch_to_host(const void *dev, size_t k, int64_t *out, hipStream_t s) {
     if (k == 0) return;
@@ -1176,7 +1176,7 @@ void vdl_ctx::fetch_to_host(const void *dev, size_t k, int64_t *out, hipStream_t
     }
     const int64_t seq = ++post_seq;
     HIP_CHECK(launch_post_words((const int64_t *)dev, (int64_t)k, pin, flag, seq, s));
-    while (*(volatile int64_t *)flag != seq) wait_flag(flag, *(volatile int64_t *)flag, s);
+    wait_seq(flag, seq, s);
     std::memcpy(out, pin, sizeof(int64_t) * k);
 }
 

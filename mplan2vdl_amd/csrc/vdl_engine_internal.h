@@ -202,6 +202,17 @@ struct vdl_ctx {
     // pinned memory with system-scope stores, the host polls the number (and the stream's state now and then, so that a failed
     // launch ends the wait).  wait_here: "everything queued on s so far is done".
     void wait_flag(int64_t *word, int64_t until_not, hipStream_t s);          // until *word != until_not
+    // until *word == seq.  (The word is read ONCE per turn: "while (*w != seq) wait_flag(w, *w, s)" read it twice, and a post that landed
+    // between the two reads left wait_flag waiting for the word to move away from `seq` -- until its idle-stream check, a few
+    // milliseconds later, declared the kernel lost: one spurious "did not report" in some thousands of round trips.)
+    void wait_seq(int64_t *word, int64_t seq, hipStream_t s) {
+        for (;;) {
+            const int64_t seen = *(volatile int64_t *)word;
+            if (seen == seq) break;
+            wait_flag(word, seen, s);
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
     void wait_here(hipStream_t s);
     // `k` int64 words from the device to `out`, waited for on `s`: through the pinned words when they fit -- no copy of this library
     // has pageable host memory for its destination unless it is larger than that (result vectors, traces)
@@ -286,7 +297,9 @@ struct vdl_plan {
         int world = 0;
         int64_t n = 0, n_send = 0;
         std::vector<DVec> src;             // [0] = key, then the other scattered vectors
-        BufP vdest, pos;
+        BufP tileoff, owner, routecnt;     // where the rows of every destination begin, tile by tile; the slice -> rank table (device); launch_ex_route's counts
+        ExRoute route;                     // how a row's destination is found (exchange_route; the key lives in src[0])
+        bool skip_mask = false;            // vdl_run_sharded: no rank's vectors have holes, so the mask column is neither written nor sent nor read
         std::vector<int> nodes;
         int64_t pmin = 0, pcount = 0;
         // global folds over the sharded table that the tail reads beside the Partition (Q11: HAVING sum(..) > (select sum(..) * k)):
@@ -372,6 +385,7 @@ namespace eng {
 // the sharded Partition's local phase in steps (vdl_exchange.cpp): vdl_exchange_begin = local + route(null); vdl_run_sharded puts the
 // ranks' key histograms in between and routes by the cut they give
 void exchange_local(vdl_ctx *c, vdl_plan *p, int world);
+bool exchange_has_holes(const vdl_plan *p);                                        // after exchange_local: some travelling vector but the key has empty slots of its own
 std::shared_ptr<ChainPlan> chain_plan(vdl_plan *p, std::string &why);             // the plan's chain route for p->sharded_table, or null and why not
 void chain_build_set(vdl_ctx *c, vdl_plan *p, size_t k, const BufP &positions, int64_t m, int64_t len);   // p->chain.sets[set k] from everybody's positions
 void chain_run_everywhere(vdl_ctx *c, vdl_plan *p);                               // stage 2 without a second cut: the rest on every rank

@@ -702,6 +702,11 @@ void exchange_local(vdl_ctx *c, vdl_plan *p, int world) {
         if (v.n != ex.n) throw Error(VDL_ERR_SHAPE, "vectors scattered by one Partition have different lengths");
 }
 
+bool exchange_has_holes(const vdl_plan *p) {
+    for (size_t k = 1; k < p->ex.src.size(); k++) if (p->ex.src[k].valid) return true;
+    return false;
+}
+
 // how this rank's keys spread over kExBins equal slices of the pivots' domain (hist[kExBins] = keys outside the pivots)
 void exchange_histogram(vdl_ctx *c, vdl_plan *p, int64_t *hist_host) {
     vdl_plan::ExState &ex = p->ex;
@@ -719,30 +724,27 @@ void exchange_route(vdl_ctx *c, vdl_plan *p, const int32_t *owner_host, int64_t 
     const int world = ex.world;
     GenExec g(c, p);
     const DVec &key = ex.src[0];
-    const size_t nw = (size_t)std::max<int64_t>(GenExec::nwords(ex.n), 1);
-    BufP dest = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(ex.n, 1));
-    ex.vdest = dev_alloc(c, sizeof(uint64_t) * nw);
-    ex.pos = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>(ex.n, 1));
-    BufP counts = dev_alloc(c, sizeof(int64_t) * (size_t)(world + 1));
-    HIP_CHECK(hipMemsetAsync(counts->p, 0, sizeof(int64_t) * (size_t)(world + 1), c->stream));
-    BufP owner;
+    BufP counts = dev_alloc(c, sizeof(int64_t) * (size_t)(2 * world + 1));
+    HIP_CHECK(hipMemsetAsync(counts->p, 0, sizeof(int64_t) * (size_t)(2 * world + 1), c->stream));
+    ex.routecnt = counts;
+    ex.owner.reset();
     if (owner_host) {
-        owner = dev_alloc(c, sizeof(int32_t) * (size_t)kExBins);
-        HIP_CHECK(hipMemcpyAsync(owner->p, owner_host, sizeof(int32_t) * (size_t)kExBins, hipMemcpyHostToDevice, c->stream));
+        ex.owner = dev_alloc(c, sizeof(int32_t) * (size_t)kExBins);
+        HIP_CHECK(hipMemcpyAsync(ex.owner->p, owner_host, sizeof(int32_t) * (size_t)kExBins, hipMemcpyHostToDevice, c->stream));
         HIP_CHECK(hipStreamSynchronize(c->stream));        // (the table is the caller's)
     }
+    ExRoute &R = ex.route;
+    R = ExRoute{};
+    R.key = g.src_of(key); R.vkey = g.vp(key); R.n = ex.n; R.pmin = ex.pmin;
     // (second stage of the chain route: EVERY row with a key travels, to everybody -- the pivots say nothing about who takes part; the
     // Partition that follows treats keys outside them as it does in an unsharded run)
-    HIP_CHECK(launch_ex_dest(g.src_of(key), g.vp(key), ex.n, ex.pmin, p->chain.stage == 2 ? 0 : ex.pcount, world, (int64_t *)dest->p, (uint64_t *)ex.vdest->p,
-                             (int64_t *)counts->p, (int64_t *)counts->p + world, c->stream, owner ? (const int32_t *)owner->p : nullptr));
-    if (ex.n > 0) {
-        // stable order inside each destination = one 8-bit Partition pass over the destination ranks
-        BufP scr = dev_alloc(c, partition_scratch_bytes(ex.n, world));
-        BufP nvalid = dev_alloc(c, sizeof(int64_t));
-        Src d; d.p = dest->p; d.kind = SRC_I64;
-        HIP_CHECK(launch_partition(d, (const uint64_t *)ex.vdest->p, ex.n, 0, world, scr->p, nullptr, nullptr,
-                                   nullptr, nullptr, (int64_t *)nvalid->p, (int64_t *)ex.pos->p, c->stream));
-    }
+    R.pcount = p->chain.stage == 2 ? 0 : ex.pcount;
+    R.world = world; R.shift = ex_route_shift(R.pcount);
+    R.owner = ex.owner ? (const int32_t *)ex.owner->p : nullptr;
+    // rows per destination and tile, scanned: a row's place in the send buffer is its destination's offset at its tile + its rank among
+    // the tile's rows for that destination, which the pack computes again from the key (no destination vector, no positions)
+    ex.tileoff = dev_alloc(c, sizeof(int64_t) * (size_t)std::max<int64_t>((int64_t)world * ex_route_tiles(ex.n), 1));
+    HIP_CHECK(launch_ex_route(R, (int64_t *)ex.tileoff->p, (int64_t *)counts->p, c->stream));
     std::vector<int64_t> h((size_t)world + 1);
     c->fetch_to_host(counts->p, (size_t)(world + 1), h.data(), c->stream);
     if (h[(size_t)world] > 0)
@@ -775,12 +777,18 @@ int vdl_exchange_pack(vdl_ctx *c, vdl_plan *p, void *dev_send) {
         if (!dev_send) throw Error(VDL_ERR_ARG, "vdl_exchange_pack: null send buffer");
         GenExec g(c, p);
         int64_t *out = (int64_t *)dev_send;
-        ExValid ev;
-        for (size_t k = 0; k < ex.src.size(); k++) {
-            HIP_CHECK(launch_ex_pack(g.src_of(ex.src[k]), (const uint64_t *)ex.vdest->p, (const int64_t *)ex.pos->p, ex.n, out + (int64_t)k * ex.n_send, c->stream));
-            if (k > 0) ev.valid[ev.n++] = g.vp(ex.src[k]);
+        // every column and the mask of the vectors' validity in one pass over the rows (kExPackCols columns per launch)
+        const int ncols = (int)ex.src.size();
+        for (int k0 = 0; k0 < ncols; k0 += kExPackCols) {
+            ExCols cols;
+            cols.first = k0; cols.ncol = std::min(kExPackCols, ncols - k0);
+            for (int k = 0; k < cols.ncol; k++) cols.src[k] = g.src_of(ex.src[(size_t)(k0 + k)]);
+            if (k0 + kExPackCols >= ncols && !ex.skip_mask) {
+                cols.mask_at = ncols;
+                for (int k = 1; k < ncols; k++) cols.valid[cols.nvalid++] = g.vp(ex.src[(size_t)k]);
+            }
+            HIP_CHECK(launch_ex_pack_all(ex.route, cols, (const int64_t *)ex.tileoff->p, (const int64_t *)ex.routecnt->p, ex.n_send, out, c->stream));
         }
-        HIP_CHECK(launch_ex_mask(ev, (const uint64_t *)ex.vdest->p, (const int64_t *)ex.pos->p, ex.n, out + (int64_t)ex.src.size() * ex.n_send, c->stream));
         HIP_CHECK(hipStreamSynchronize(c->stream));      // the buffer goes to the caller's collective, possibly on another stream
     });
 }
@@ -795,7 +803,7 @@ int vdl_exchange_finish(vdl_ctx *c, vdl_plan *p, const void *dev_recv, int64_t n
         const size_t m = ex.src.size();
         std::map<int, DVec> over;
         // usually every travelling row holds a value in every vector (mask word = all ones): no bitmaps needed then
-        bool all_valid = n_recv == 0 || m <= 1;
+        bool all_valid = n_recv == 0 || m <= 1 || ex.skip_mask;
         if (!all_valid) {
             BufP scratch = dev_alloc(c, sizeof(int64_t) * 3 * (size_t)fold_scratch_blocks());
             BufP r = dev_alloc(c, 3 * sizeof(int64_t));
@@ -824,7 +832,7 @@ int vdl_exchange_finish(vdl_ctx *c, vdl_plan *p, const void *dev_recv, int64_t n
             HIP_CHECK(hipStreamSynchronize(c->stream));            // (`w` and the host words may go)
             over[ex.folds[k]] = v;
         }
-        ex.src.clear(); ex.vdest.reset(); ex.pos.reset();          // phase-A vectors are no longer needed
+        ex.src.clear(); ex.tileoff.reset(); ex.owner.reset(); ex.routecnt.reset();      // phase-A vectors are no longer needed
         ex.active = false;
         if (p->chain.stage == 2) over.insert(p->chain.sets.begin(), p->chain.sets.end());
         GenExec g(c, p);

@@ -872,7 +872,7 @@ struct GenExec {
                 }
                 const int64_t seq = ++c->post_seq;
                 HIP_CHECK(launch_sorted_heads_counted((const int64_t *)ds.p, o.n, (uint64_t *)heads->p, (int64_t *)counts->p, (int64_t *)c->sorted_state->p, pin, pflag, seq, s));
-                while (*(volatile int64_t *)pflag != seq) c->wait_flag(pflag, *(volatile int64_t *)pflag, s);
+                c->wait_seq(pflag, seq, s);
                 std::memcpy(back, pin, sizeof back);
             } else {
                 HIP_CHECK(launch_sorted_heads(ds, o.n, (uint64_t *)heads->p, flag, s));     // (sets the two flag words itself)

@@ -266,12 +266,26 @@ hipError_t launch_cross(int64_t n, int64_t k, int inner, int64_t *out, hipStream
 struct LikePattern { unsigned char p[256]; int len; };
 hipError_t launch_like(Src data, const uint64_t *vdata, int64_t n, Src heap, const uint64_t *vheap, int64_t heap_n, const LikePattern &pat,
                        int64_t *out, hipStream_t s);
-hipError_t launch_ex_dest(Src key, const uint64_t *vkey, int64_t n, int64_t pmin, int64_t pcount, int world, int64_t *dest,
-                          uint64_t *vdest, int64_t *counts /* world, pre-zeroed */, int64_t *oob /* pre-zeroed */, hipStream_t s, const int32_t *owner = nullptr /* kExBins entries: slice of the domain -> rank (the balanced cut of vdl_run_sharded) */);
 constexpr int kExBins = 4096;              // at most this many equal, power-of-two-wide slices of the pivots' domain in which a rank counts its keys (hist: kExBins + 1 words, the last = keys outside the pivots; pre-zeroed)
 hipError_t launch_ex_hist(Src key, const uint64_t *vkey, int64_t n, int64_t pmin, int64_t pcount, int64_t *hist, hipStream_t s);
-hipError_t launch_ex_pack(Src src, const uint64_t *vdest, const int64_t *pos, int64_t n, int64_t *out, hipStream_t s);
-hipError_t launch_ex_mask(const ExValid &v, const uint64_t *vdest, const int64_t *pos, int64_t n, int64_t *out, hipStream_t s);
+// Routing of a sharded Partition's rows (vdl_partition.hip "routing"): where every row goes, the rows per destination, and the packed send buffer.
+struct ExRoute {
+    Src key; const uint64_t *vkey = nullptr;
+    int64_t n = 0, pmin = 0, pcount = 0;                    // pcount <= 0: every row with a key takes part and goes to destination 0
+    int world = 1, shift = 0;                               // shift = ex_route_shift(pcount): the width of a slice of the domain
+    const int32_t *owner = nullptr;                         // slice of the domain -> rank (kExBins entries; the balanced cut of vdl_run_sharded), or null: the domain cut evenly
+};
+constexpr int kExPackCols = 8;             // columns one launch of the pack writes
+struct ExCols {
+    int ncol = 0, first = 0;               // columns first .. first + ncol - 1 of the send buffer
+    Src src[kExPackCols];
+    int mask_at = -1, nvalid = 0;          // mask_at >= 0: this launch also writes the mask column there: bit v = valid[v] holds a value in the row
+    const uint64_t *valid[kMaxExSources] = {};
+};
+int64_t ex_route_tiles(int64_t n);
+int ex_route_shift(int64_t pcount);
+hipError_t launch_ex_route(const ExRoute &R, int64_t *tileoff /* world x ex_route_tiles(n) */, int64_t *counts /* 2 world + 1, pre-zeroed: rows per destination, keys outside the pivots, where each destination's rows begin */, hipStream_t s);
+hipError_t launch_ex_pack_all(const ExRoute &R, const ExCols &C, const int64_t *tileoff, const int64_t *counts /* as launch_ex_route left them */, int64_t n_send, int64_t *out, hipStream_t s);
 hipError_t launch_ex_unmask(const int64_t *mask, int64_t n, int j, uint64_t *valid, hipStream_t s);
 
 }  // namespace vdl

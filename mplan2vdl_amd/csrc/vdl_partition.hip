@@ -964,10 +964,9 @@ int partition_passes(int64_t pcount) {
 // xGMI).  Each rank sends every row of the partition key and of the vectors scattered by it to the
 // rank that owns the row's key range; afterwards Partition / Scatter / Fold run locally on the
 // received rows and the outputs of the ranks concatenate in rank order (keys ascend across ranks).
-//   k_ex_dest   : destination rank of each row = (key - pmin) * world / pcount, EPS for rows that do
-//                 not take part; per-destination row counts by 64-bit atomics (world <= 256)
-//   (stable order inside each destination: launch_partition over the destination vector)
-//   k_ex_pack   : scatter a column into send order; k_ex_mask: validity word of the source vectors
+//   destination rank of a row = (key - pmin) * world / pcount, or the balanced cut's slice -> rank table; rows without a key do not
+//   take part; the order inside each destination is the rows' own (stable)
+//   k_ex_count / k_ex_offsets / k_ex_bases / k_ex_pack_all : "routing" below
 //   k_ex_unmask : received validity words -> one bitmap per source vector
 // ------------------------------------------------------------------------------------------
 //   k_ex_hist   : (round 4) how the keys spread over kExBins equal slices of the pivots' domain: the ranks all-gather these histograms and
@@ -981,28 +980,39 @@ __host__ __device__ inline int ex_slice_shift(int64_t pcount) {
     while (sh < 62 && ((pcount - 1) >> sh) >= kExBins) sh++;
     return sh;
 }
-__global__ __launch_bounds__(256) void k_ex_hist(Src key, const uint64_t *vkey, int64_t n, int64_t pmin, int64_t pcount, int shift, unsigned long long *hist /* kExBins + 1 */) {
+__global__ __launch_bounds__(256) void k_ex_hist(Src key_src, const uint64_t *vkey, int64_t n, int64_t pmin, int64_t pcount, int shift, unsigned long long *hist /* kExBins + 1 */) {
     __shared__ unsigned int cnt[kExBins + 1];
     for (int i = threadIdx.x; i <= kExBins; i += blockDim.x) cnt[i] = 0;
     __syncthreads();
     const int64_t nw = (n + 63) >> 6;
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave);
-    for (int64_t w = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; w < nw; w += wstride) {
-        const int64_t i = (w << 6) + lane;
-        const bool ok = i < n && bit(vkey, i);
-        int slot = kExBins;
-        if (ok) {
-            const int64_t b = (int64_t)((uint64_t)ld(key, i) - (uint64_t)pmin);
-            if (b >= 0 && b < pcount) slot = (int)(b >> shift);
+    constexpr int U = 4;                                        // bitmap words per wave and trip (their loads in flight together)
+    for (int64_t w0 = ((int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave) * U; w0 < nw; w0 += wstride * U) {
+        int64_t key[U];
+        bool okv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t i = ((w0 + u) << 6) + lane;
+            okv[u] = i < n && bit(vkey, i);
+            key[u] = ld(key_src, okv[u] ? i : 0);
         }
-        // a table clustered by the key puts a whole wave into one slice (64 LDS atomics on one address, one after the other): count once then
-        const uint64_t live = __ballot(ok);
-        if (!live) continue;
-        const int first = __shfl(slot, __ffsll((long long)live) - 1, kWave);
-        const uint64_t same = __ballot(ok && slot == first);
-        if (same == live) { if (lane == 0) atomicAdd(&cnt[first], (unsigned)__popcll(live)); }
-        else if (ok) atomicAdd(&cnt[slot], 1u);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const bool ok = okv[u];
+            int slot = kExBins;
+            if (ok) {
+                const int64_t b = (int64_t)((uint64_t)key[u] - (uint64_t)pmin);
+                if (b >= 0 && b < pcount) slot = (int)(b >> shift);
+            }
+            // a table clustered by the key puts a whole wave into one slice (64 LDS atomics on one address, one after the other): count once then
+            const uint64_t live = __ballot(ok);
+            if (!live) continue;
+            const int first = __shfl(slot, __ffsll((long long)live) - 1, kWave);
+            const uint64_t same = __ballot(ok && slot == first);
+            if (same == live) { if (lane == 0) atomicAdd(&cnt[first], (unsigned)__popcll(live)); }
+            else if (ok) atomicAdd(&cnt[slot], 1u);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i <= kExBins; i += blockDim.x) { const unsigned c = cnt[i]; if (c) atomicAdd(&hist[i], (unsigned long long)c); }
@@ -1016,80 +1026,198 @@ hipError_t launch_ex_hist(Src key, const uint64_t *vkey, int64_t n, int64_t pmin
     return launch_status();
 }
 
-__global__ __launch_bounds__(256) void k_ex_dest(Src key, const uint64_t *vkey, int64_t n, int64_t pmin, int64_t pcount, int world,
-                                                 int64_t *dest, uint64_t *vdest, int64_t *counts, int64_t *oob, const int32_t *owner /* kExBins entries, or null */, int shift) {
-    __shared__ unsigned long long cnt[kMaxExWorld + 1];       // per-block row counts per destination (+ out-of-range keys)
+// ---- routing (round 4, second form): no destination vector, no positions, no sort ----------------------------------------------
+// A row's place in the send buffer = rows of its destination in earlier tiles + earlier rows of its destination in its own tile.
+//   k_ex_count    : a block per tile of kExTile rows: the rows per destination of the tile (tilecnt[destination][tile]) and of the rank
+//   k_ex_offsets  : a block per destination: its tile counts scanned in place, the rows of the destinations before it added
+//   k_ex_pack_all : a block per tile again: the rows' destinations once more (a shift and a table lookup), their rank inside the tile
+//                   (per wave by matching ballots, across the tile's 64 wave-slices by a small table in LDS), and every column --
+//                   and the mask word of the vectors' validity -- written to its place.
+// The first form wrote a destination per row, ran one pass of the radix Partition over it for the stable positions, and packed column
+// by column through them: 2.0 ms per 60 M rows of three columns (TPC-H Q18's GROUP BY over all of lineitem, profiles/r04/q18_chain.txt),
+// more than the query it served.
+int64_t ex_route_tiles(int64_t n);
+constexpr int kExRows = 16, kExTile = 256 * kExRows;       // a thread's rows of a tile: row = tile * kExTile + j * 256 + tid
+// (the keys of a thread's rows are loaded first, all of them in flight at once; what follows -- ballots, LDS -- waits for them once)
+__device__ __forceinline__ void ex_load_keys(const ExRoute &R, int64_t tile, int tid, int64_t (&key)[kExRows], unsigned &present) {
+    present = 0;
+#pragma unroll
+    for (int j = 0; j < kExRows; j++) {
+        const int64_t i = tile * kExTile + (int64_t)j * 256 + tid;
+        const bool ok = i < R.n && bit(R.vkey, i);
+        key[j] = R.pcount > 0 ? ld(R.key, ok ? i : 0) : 0;
+        if (ok) present |= 1u << j;
+    }
+}
+__device__ __forceinline__ int ex_destination(const ExRoute &R, int64_t key, bool &ok, bool &outside) {
+    outside = false;
+    if (!ok || R.pcount <= 0) return 0;
+    const int64_t b = (int64_t)((uint64_t)key - (uint64_t)R.pmin);
+    if (b < 0 || b >= R.pcount) { ok = false; outside = true; return 0; }
+    return R.owner ? R.owner[(int)(b >> R.shift)] : (int)(((unsigned __int128)(uint64_t)b * (uint64_t)R.world) / (uint64_t)R.pcount);
+}
+__global__ __launch_bounds__(256) void k_ex_count(ExRoute R, int64_t ntiles, int64_t *tilecnt, unsigned long long *counts /* world, then keys outside the pivots */) {
+    __shared__ unsigned int cnt[kMaxExWorld + 1];
     for (int i = threadIdx.x; i <= kMaxExWorld; i += blockDim.x) cnt[i] = 0;
     __syncthreads();
-    const int64_t nw = (n + 63) >> 6;
     const int lane = threadIdx.x & (kWave - 1);
-    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x / kWave);
-    for (int64_t w = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; w < nw; w += wstride) {
-        const int64_t i = (w << 6) + lane;
-        bool ok = i < n && bit(vkey, i);
-        bool out_of_range = false;
-        int64_t d = 0;
-        if (ok && pcount > 0) {                                   // (pcount <= 0: every key takes part and goes to destination 0 -- the gather of the chain route)
-            const int64_t b = (int64_t)((uint64_t)ld(key, i) - (uint64_t)pmin);
-            if (b < 0 || b >= pcount) { out_of_range = true; ok = false; }
-            else if (owner) d = owner[(int)(b >> shift)];
-            else d = (int64_t)(((unsigned __int128)(uint64_t)b * (uint64_t)world) / (uint64_t)pcount);
-        }
-        if (i < n) dest[i] = d;
-        const uint64_t m = __ballot(ok);
-        if (lane == 0) vdest[w] = m;
-        const uint64_t bad = __ballot(out_of_range);
-        if (bad && lane == 0) atomicAdd(&cnt[kMaxExWorld], (unsigned long long)__popcll(bad));
-        // one LDS atomic per (wave, destination present in the wave)
-        uint64_t todo = m;
+    const int64_t tile = blockIdx.x;
+    int64_t key[kExRows];
+    unsigned present;
+    ex_load_keys(R, tile, threadIdx.x, key, present);
+#pragma unroll
+    for (int j = 0; j < kExRows; j++) {
+        if (tile * kExTile + (int64_t)j * 256 >= R.n) break;          // block-uniform
+        bool ok = (present >> j) & 1u, outside;
+        const int d = ex_destination(R, key[j], ok, outside);
+        const uint64_t bad = __ballot(outside);
+        if (bad && lane == 0) atomicAdd(&cnt[kMaxExWorld], (unsigned)__popcll(bad));
+        uint64_t todo = __ballot(ok);                                   // one LDS atomic per (wave, destination present in the wave)
         while (todo) {
             const int leader = __ffsll((long long)todo) - 1;
-            const int64_t dl = __shfl(d, leader, kWave);
+            const int dl = __shfl(d, leader, kWave);
             const uint64_t same = __ballot(ok && d == dl) & todo;
-            if (lane == leader) atomicAdd(&cnt[dl], (unsigned long long)__popcll(same));
+            if (lane == leader) atomicAdd(&cnt[dl], (unsigned)__popcll(same));
             todo &= ~same;
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i <= kMaxExWorld; i += blockDim.x) {
-        const unsigned long long c = cnt[i];
-        if (c) atomicAdd((unsigned long long *)(i == kMaxExWorld ? oob : &counts[i]), c);
+    for (int d = threadIdx.x; d <= kMaxExWorld; d += blockDim.x) {
+        const unsigned c = cnt[d];
+        if (d < R.world) tilecnt[(int64_t)d * ntiles + tile] = c;
+        // (the rows per destination are what k_ex_offsets' scan ends with: one atomic per block and destination on `world` words was 15 000
+        // same-address atomics for 60 M rows -- a third of this kernel's time)
+        if (c && d == kMaxExWorld) atomicAdd(&counts[R.world], (unsigned long long)c);
     }
 }
-hipError_t launch_ex_dest(Src key, const uint64_t *vkey, int64_t n, int64_t pmin, int64_t pcount, int world, int64_t *dest,
-                          uint64_t *vdest, int64_t *counts, int64_t *oob, hipStream_t s, const int32_t *owner) {
-    (void)hipGetLastError();
-    if (n <= 0) return hipSuccess;
-    k_ex_dest<<<grid_for(n, 256, 4), 256, 0, s>>>(key, vkey, n, pmin, pcount, world, dest, vdest, counts, oob, owner, ex_slice_shift(pcount));
-    return launch_status();
+__global__ __launch_bounds__(1024) void k_ex_offsets(int64_t *tilecnt, int64_t ntiles, unsigned long long *counts) {
+    constexpr int K = 8;
+    __shared__ int64_t wsum[1024 / kWave];
+    __shared__ int64_t carry;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    int64_t *c = tilecnt + (int64_t)blockIdx.x * ntiles;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < ntiles; base += 1024 * K) {
+        const int64_t i0 = base + (int64_t)tid * K;
+        int64_t x[K], sum = 0;
+#pragma unroll
+        for (int k = 0; k < K; k++) { x[k] = i0 + k < ntiles ? c[i0 + k] : 0; sum += x[k]; }
+        int64_t incl = sum;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const int64_t y = __shfl_up(incl, off, kWave);
+            if (lane >= off) incl += y;
+        }
+        if (lane == kWave - 1) wsum[wave] = incl;
+        __syncthreads();
+        int64_t wprefix = 0;
+        for (int w = 0; w < wave; w++) wprefix += wsum[w];
+        int64_t run = carry + wprefix + incl - sum;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; k++) { if (i0 + k < ntiles) c[i0 + k] = run; run += x[k]; }
+        if (tid == 1023) carry = run;
+        __syncthreads();
+    }
+    if (tid == 0) counts[blockIdx.x] = (unsigned long long)carry;          // the rows this destination receives from here
 }
-
-__global__ __launch_bounds__(256) void k_ex_pack(Src src, const uint64_t *vdest, const int64_t *pos, int64_t n, int64_t *out) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        if (bit(vdest, i)) out[pos[i]] = ld(src, i);
-}
-hipError_t launch_ex_pack(Src src, const uint64_t *vdest, const int64_t *pos, int64_t n, int64_t *out, hipStream_t s) {
-    (void)hipGetLastError();
-    if (n <= 0) return hipSuccess;
-    k_ex_pack<<<grid_for(n, 256, 4), 256, 0, s>>>(src, vdest, pos, n, out);
-    return launch_status();
-}
-
-// mask word per row: bit j = source vector j holds a value in that row (j < 63)
-__global__ __launch_bounds__(256) void k_ex_mask(ExValid v, const uint64_t *vdest, const int64_t *pos, int64_t n, int64_t *out) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        if (!bit(vdest, i)) continue;
-        uint64_t m = 0;
-        for (int j = 0; j < v.n; j++) m |= (uint64_t)bit(v.valid[j], i) << j;
-        out[pos[i]] = (int64_t)m;
+// counts[world + 1 + d] = rows of the destinations before d: where d's rows begin in the send buffer
+__global__ void k_ex_bases(unsigned long long *counts, int world) {
+    if (threadIdx.x == 0) {
+        unsigned long long before = 0;
+        for (int d = 0; d < world; d++) { counts[world + 1 + d] = before; before += counts[d]; }
     }
 }
-hipError_t launch_ex_mask(const ExValid &v, const uint64_t *vdest, const int64_t *pos, int64_t n, int64_t *out, hipStream_t s) {
+hipError_t launch_ex_route(const ExRoute &R, int64_t *tileoff, int64_t *counts, hipStream_t s) {
     (void)hipGetLastError();
-    if (n <= 0) return hipSuccess;
-    k_ex_mask<<<grid_for(n, 256, 4), 256, 0, s>>>(v, vdest, pos, n, out);
+    if (R.n <= 0) return hipSuccess;
+    if (R.world < 1 || R.world > kMaxExWorld) return hipErrorInvalidValue;
+    const int64_t ntiles = ex_route_tiles(R.n);
+    k_ex_count<<<(unsigned)ntiles, 256, 0, s>>>(R, ntiles, tileoff, (unsigned long long *)counts);
+    hipError_t e = launch_status();
+    if (e != hipSuccess) return e;
+    k_ex_offsets<<<R.world, 1024, 0, s>>>(tileoff, ntiles, (unsigned long long *)counts);
+    e = launch_status();
+    if (e != hipSuccess) return e;
+    k_ex_bases<<<1, 64, 0, s>>>((unsigned long long *)counts, R.world);
+    return launch_status();
+}
+int64_t ex_route_tiles(int64_t n) { return (n + kExTile - 1) / kExTile; }
+int ex_route_shift(int64_t pcount) { return ex_slice_shift(pcount); }
+
+__global__ __launch_bounds__(256) void k_ex_pack_all(ExRoute R, ExCols C, const int64_t *tileoff, const int64_t *bases, int64_t ntiles, int64_t n_send, int64_t *out) {
+    constexpr int NW = 256 / kWave, CELLS = kExRows * NW;
+    __shared__ unsigned short cell[CELLS][kMaxExWorld];     // rows of destination d in wave-slice c of the tile; then: in the slices before c
+    __shared__ int64_t base[kMaxExWorld];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const int64_t tile = blockIdx.x;
+    for (int i = tid; i < CELLS * R.world; i += 256) cell[i / R.world][i % R.world] = 0;
+    __syncthreads();
+    int dest[kExRows], rank[kExRows];
+    unsigned okbits = 0;
+    const uint64_t below = (1ull << lane) - 1;
+    {
+        int64_t key[kExRows];
+        unsigned present;
+        ex_load_keys(R, tile, tid, key, present);
+#pragma unroll
+        for (int j = 0; j < kExRows; j++) {
+            bool ok = (present >> j) & 1u, outside;
+            dest[j] = ex_destination(R, key[j], ok, outside);
+            if (ok) okbits |= 1u << j;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kExRows; j++) {
+        const bool ok = (okbits >> j) & 1u;
+        const int d = dest[j];
+        rank[j] = 0;
+        uint64_t todo = __ballot(ok);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int dl = __shfl(d, leader, kWave);
+            const uint64_t same = __ballot(ok && d == dl) & todo;
+            if (ok && d == dl) rank[j] = __popcll(same & below);
+            if (lane == leader) cell[j * NW + wave][dl] = (unsigned short)__popcll(same);
+            todo &= ~same;
+        }
+    }
+    __syncthreads();
+    for (int d = tid; d < R.world; d += 256) {
+        unsigned pre = 0;
+        for (int c = 0; c < CELLS; c++) { const unsigned t = cell[c][d]; cell[c][d] = (unsigned short)pre; pre += t; }
+        base[d] = bases[d] + tileoff[(int64_t)d * ntiles + tile];
+    }
+    __syncthreads();
+    int64_t where[kExRows];
+#pragma unroll
+    for (int j = 0; j < kExRows; j++) where[j] = base[dest[j]] + cell[j * NW + wave][dest[j]] + rank[j];
+    for (int k = 0; k < C.ncol; k++) {
+        const Src src = C.src[k];
+        int64_t *o = out + (int64_t)(C.first + k) * n_send;
+#pragma unroll
+        for (int j = 0; j < kExRows; j++)
+            if ((okbits >> j) & 1u) o[where[j]] = ld(src, tile * kExTile + (int64_t)j * 256 + tid);
+    }
+    if (C.mask_at >= 0) {
+        int64_t *o = out + (int64_t)C.mask_at * n_send;
+#pragma unroll
+        for (int j = 0; j < kExRows; j++) {
+            if (!((okbits >> j) & 1u)) continue;
+            const int64_t i = tile * kExTile + (int64_t)j * 256 + tid;
+            uint64_t m = 0;
+            for (int v = 0; v < C.nvalid; v++) m |= (uint64_t)bit(C.valid[v], i) << v;
+            o[where[j]] = (int64_t)m;
+        }
+    }
+}
+hipError_t launch_ex_pack_all(const ExRoute &R, const ExCols &C, const int64_t *tileoff, const int64_t *counts, int64_t n_send, int64_t *out, hipStream_t s) {
+    (void)hipGetLastError();
+    if (R.n <= 0 || n_send <= 0) return hipSuccess;
+    if (R.world < 1 || R.world > kMaxExWorld || C.ncol < 0 || C.ncol > kExPackCols) return hipErrorInvalidValue;
+    const int64_t ntiles = ex_route_tiles(R.n);
+    k_ex_pack_all<<<(unsigned)ntiles, 256, 0, s>>>(R, C, tileoff, counts + R.world + 1, ntiles, n_send, out);
     return launch_status();
 }
 

@@ -659,6 +659,37 @@ def test_q3_sharded_partition_exchange_matches_oracle(world, n_orders):
         assert all(sum(c) > 0 for c in counts)
 
 
+@pytest.mark.parametrize("world,n", [(19, 50003), (47, 9000), (3, 4096), (2, 4097)])
+def test_exchange_routes_rows_in_row_order_whatever_the_key_order(world, n):
+    """The routing of a sharded Partition (k_ex_count / k_ex_offsets / k_ex_pack_all): keys in RANDOM order (every wave holds many
+    destinations), more ranks than a wave has... patience for, rows that do not take part (a filter), a carried vector with holes of
+    its own (the mask column), a row count that ends inside a tile -- and folds that depend on the order the rows arrive in
+    (FoldChoose = the first value in ROW order): the ranks' outputs concatenated are the unsharded answer."""
+    from helpers import prog
+    rng = np.random.default_rng(world * 1000 + n)
+    nd = 700
+    cols = {"f.k": rng.integers(0, nd, n).astype(np.int64), "f.v": rng.integers(0, 100, n).astype(np.int64), "f.w": rng.integers(0, 100, n).astype(np.int64)}
+    text = prog("1,Load,f.k", "2,Project,val,Id 1,k", "3,Load,f.v", "4,Project,val,Id 3,v", "5,Load,f.w", "6,Project,val,Id 5,w",
+                "7,RangeV,val,10,Id 4,0", "8,Greater,val,Id 4,val,Id 7,val", "9,RangeV,val,0,Id 8,1", "10,FoldSelect,val,Id 9,val,Id 8,val",      # v > 10
+                "11,Gather,Id 2,Id 10,val", "12,Gather,Id 4,Id 10,val", "13,Gather,Id 6,Id 10,val",
+                "14,RangeV,val,50,Id 13,0", "15,Greater,val,Id 13,val,Id 14,val", "16,RangeV,val,0,Id 15,1", "17,FoldSelect,val,Id 16,val,Id 15,val",  # ... and w > 50
+                "18,Gather,Id 13,Id 17,val",                                                                                                  # w where both hold: holes of its own
+                "19,RangeC,val,0,%d,1" % nd, "20,Partition,val,Id 11,val,Id 19,val", "21,RangeV,val,0,Id 11,1",
+                "22,Scatter,Id 11,Id 21,val,Id 20,val", "23,Scatter,Id 12,Id 21,val,Id 20,val", "24,Scatter,Id 18,Id 21,val,Id 20,val",
+                "25,FoldSum,val,Id 22,val,Id 23,val", "26,FoldChoose,val,Id 22,val,Id 23,val", "27,FoldCount,val,Id 22,val,Id 24,val", "28,FoldChoose,val,Id 22,val,Id 24,val",
+                "29,Project,sum,Id 25,val", "30,MaterializeCompact,Id 29", "31,Project,first,Id 26,val", "32,MaterializeCompact,Id 31",
+                "33,Project,holes,Id 27,val", "34,MaterializeCompact,Id 33", "35,Project,firstw,Id 28,val", "36,MaterializeCompact,Id 35")
+    want = oracle_run(text, cols)
+    assert all(len(list(v.values())[0]) > 0 for v in want.values())
+    from mplan2vdl_amd import shard_rows
+    shards = []
+    for r in range(world):
+        r0, r1 = shard_rows(n, r, world)
+        shards.append({k: v[r0:r1] for k, v in cols.items()})
+    got, counts = _emulated_exchange(text, shards, "f")
+    assert got == want
+
+
 @pytest.mark.parametrize("plan_no", [3, 5, 9, 10, 12])
 @pytest.mark.parametrize("world", [2, 3])
 def test_tpch_plans_with_a_sharded_route_match_the_oracle(plan_no, world):
