@@ -12,6 +12,8 @@ keep = datagen.register_q3_columns(e, n_orders, (r0, r1), device="cuda:0", copar
 meta = "/root/repo/tests/golden/tpch10noorder"
 text = frontend.compile_plan(open(meta + "/03.sql.mplan").read(), catalog.tpch_scaled_config(frontend.load_metadata(meta), 10))
 plan = e.parse(text)
+if os.environ.get("Q3_JIT", "1") == "1":
+    plan.set_jit(True)          # (the front specialised, as bench.py runs it)
 if os.environ.get("Q3_DEVICE_OUTPUTS"):
     plan.set_device_outputs(True)
 ncols = plan.exchange_columns("lineitem")
