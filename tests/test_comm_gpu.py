@@ -312,6 +312,38 @@ def test_the_chain_route_with_and_without_a_second_scan(world, second_scan):
     assert run_ranks(world, work, timeout=120) == [want] * world
 
 
+@pytest.mark.parametrize("case", ["empty set", "rank without rows", "one key"])
+def test_the_chain_route_at_its_edges(case):
+    """No group passes the HAVING (an empty set: nothing to gather, nothing survives the second scan); more ranks than rows (ranks whose
+    shard is empty take part in every collective); every row carries the same key (one owner gets everything, the others nothing)."""
+    rng = np.random.default_rng(len(case))
+    world = 3
+    n, nd = (2, 50) if case == "rank without rows" else (5000, 120)
+    cols = {"f.k": rng.integers(0, nd, n).astype(np.int64), "f.v": rng.integers(1, 100, n).astype(np.int64), "f.a": rng.integers(0, nd, n).astype(np.int64),
+            "d.g": rng.integers(0, 1000, nd).astype(np.int64)}
+    if case == "one key":
+        cols["f.k"][:] = 77
+    threshold = 10 ** 9 if case == "empty set" else 0
+    for second_scan in (False, True):
+        text = chain_program(nd, threshold, second_scan)
+        want = oracle_run(text, cols)
+        shards = table_shards(cols, world, "f")
+
+        def work(rank, rv):
+            r0, c = shards[rank]
+            e = engine_with(c)
+            e.comm_init_host(rank, world, *rv.transport(rank))
+            p = e.parse(text)
+            p.set_sharded_table("f")
+            p.set_row_offset(r0)
+            assert p.sharded_route() == ("chain", True)
+            res = p.run_sharded()["results"]
+            e.close()
+            return res
+
+        assert run_ranks(world, work, timeout=120) == [want] * world, (case, second_scan)
+
+
 @pytest.mark.parametrize("world", [2])
 def test_a_failure_inside_the_chain_reaches_every_rank(world):
     """One rank lacks a column the second scan reads: it fails in its local phase of stage 2, says so in the status exchange that precedes
