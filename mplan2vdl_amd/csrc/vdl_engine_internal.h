@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "vdl.h"
+#include "vdl_exchange_analysis.h"
 #include "vdl_fuse.h"
 #include "vdl_ir.h"
 #include "vdl_jit.h"
@@ -225,16 +226,6 @@ struct vdl_ctx {
         return small_stage_words;
     }
     ~vdl_ctx() { if (pinned_words) (void)hipHostFree(pinned_words); if (small_stage_words) (void)hipHostFree(small_stage_words); }
-};
-
-// The "chain" route of a sharded run (analysis: vdl_exchange.cpp analyse_chain; the collectives: vdl_comm.cpp sharded_chain).
-struct ChainPlan {
-    Program prog;                          // the program with a group's first-row lookups carried through the fold (rewrite_chain_lookups)
-    std::vector<int> sets;                 // position sets the first GROUP BY feeds: Scatter(constant, size, positions) statements
-    std::vector<int> targets;              // what stage 1 evaluates instead of the outputs: {value, size, positions} of every set
-    std::vector<int64_t> constant;         // the scattered constant of every set
-    std::vector<char> size_replicated;     // the set's length is a replicated vector's (else: the groups', summed over the ranks)
-    bool second_cut = false;               // the rest reads the sharded table again (its rows reach every rank at the next Partition)
 };
 
 struct vdl_plan {

@@ -1119,12 +1119,14 @@ void rewrite_program(Program &P) {
         Node g = P.at(id);
         bool done = false;
         if (g.op == Op::Gather) {
-            const Node &x = P.at(alias(g.a));
-            const Node &fc = P.at(alias(g.b));
+            // (copies, not references: the new statements below grow P.nodes, and what pointed into it would dangle -- found by
+            // AddressSanitizer once tools/sanitize ran this function, round 4)
+            const Node x = P.at(alias(g.a));
+            const Node fc = P.at(alias(g.b));
             if (x.op == Op::Load && x.column.find(".heap") == std::string::npos && fc.op == Op::FoldChoose) {
-                const Node &sc = P.at(alias(fc.b));
+                const Node sc = P.at(alias(fc.b));
                 if (sc.op == Op::Scatter) {
-                    const Node &r = P.at(alias(sc.a));
+                    const Node r = P.at(alias(sc.a));
                     const std::string t = table_of(x.column);
                     int through = -2;                                  // -1: no filter; >= 0: the selection S
                     if (r.op == Op::Gather && rowids_of(r.a) == t) through = r.b;
@@ -1138,7 +1140,7 @@ void rewrite_program(Program &P) {
                         }
                         // (the length: the old Scatter's size reference when it is anything but the scattered row ids themselves or a range
                         // over them -- otherwise the new source, as long, so that nothing above the Partition hangs off the row ids any more)
-                        const Node &szn = P.at(alias(sc.b));
+                        const Node szn = P.at(alias(sc.b));
                         const bool own_length = alias(sc.b) == alias(sc.a) || (szn.op == Op::RangeV && alias(szn.a) == alias(sc.a));
                         Node n2; n2.id = ++next_id; n2.op = Op::Scatter; n2.a = src; n2.b = own_length ? src : sc.b; n2.c = sc.c; n2.field = "val"; n2.line = g.line;
                         if (P.nodes.size() <= (size_t)n2.id) P.nodes.resize((size_t)n2.id + 64);

@@ -6,13 +6,35 @@
 #include <iterator>
 #include <string>
 
+#include <set>
+
 #include "vdl.h"
+#include "vdl_exchange_analysis.h"
 #include "vdl_fuse.h"
 #include "vdl_ir.h"
+
+static long routes_found = 0;
+// the sharded routes' analyses (which vectors travel, why a program does or does not qualify) for every table the program loads
+static void analyse_routes(const vdl::Program &p) {
+    std::set<std::string> tables;
+    for (int id : p.order) {
+        const vdl::Node &n = p.at(id);
+        if (n.op == vdl::Op::Load) { const size_t dot = n.column.find('.'); if (dot != std::string::npos) tables.insert(n.column.substr(0, dot)); }
+    }
+    tables.insert("");
+    for (const std::string &t : tables) {
+        routes_found += vdl::exan::analyse_exchange(p, t, true).ok;
+        routes_found += vdl::exan::analyse_exchange(p, t, false, true).ok;
+        routes_found += vdl::exan::analyse_folds(p, t).ok;
+        routes_found += vdl::exan::analyse_chain(p, t).ok;
+    }
+}
 
 static int try_one(const std::string &text) {
     try {
         vdl::Program p = vdl::parse_program(text.data(), text.size());
+        vdl::rewrite_program(p);
+        analyse_routes(p);
         vdl::FusedPlan f = vdl::fuse_program(p);
         return (int)vdl::describe_fused(f).size() > 0 ? 0 : 1;
     } catch (const vdl::Error &e) {
@@ -34,6 +56,6 @@ int main(int argc, char **argv) {
             (try_one(m) == 0 ? ok : rejected)++;
         }
     }
-    std::printf("sanitize: %d programs planned, %d rejected with an error code, no sanitizer report\n", ok, rejected);
+    std::printf("sanitize: %d programs planned, %d rejected with an error code, %ld sharded routes found, no sanitizer report\n", ok, rejected, routes_found);
     return 0;
 }
