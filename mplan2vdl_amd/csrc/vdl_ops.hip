@@ -760,10 +760,20 @@ __device__ __forceinline__ void atomic_combine(int rk, int64_t *addr, int64_t v)
 // NF = folds handled per trip (their loads are issued together).  vec16 bit f: fold f's data is int64 at a 16-byte aligned
 // address -- four 16-byte loads per lane instead of eight scalar ones.
 constexpr int kGroupK = 8, kGroupSplit = 2;
+// The results of the runs that END inside a wave -- all but the wave's last one -- are staged in LDS at their group's place and stored by
+// consecutive lanes (round 4): a lane storing its own groups put 64 isolated 8-byte writes into every store instruction, nine of them per
+// fold and 512 entries, and the stores were 290 of the kernel's 506 us for Q3's 32 M survivors at SF100 (an ablation build without them:
+// 216 us; -DVDL_GF_ABLATE=1 still builds it).
+#if defined(VDL_GF_ABLATE) && VDL_GF_ABLATE == 1
+#define GF_STORE(g, v) do { if ((g) == -12345) stage[wave][0] = (v); } while (0)
+#else
+#define GF_STORE(g, v) do { stage[wave][(g) - Bw] = (v); } while (0)
+#endif
 template <int NF>
 __global__ __launch_bounds__(256) void k_group_fold(GroupFoldArgs a, unsigned vec16, const uint64_t *heads, int64_t m, const int64_t *offsets) {
     __shared__ int wprefix[kCompactWords];
     __shared__ uint64_t wmask[kCompactWords];
+    __shared__ int64_t stage[256 / kWave][kWave * kGroupK];               // per wave: the results of its groups, by group
     constexpr int K = kGroupK, NW = 256 / kWave, WW = kWave * K / 64;          // WW = head words per wave (8)
     static_assert(kCompactWords == kGroupSplit * NW * WW, "a block's waves cover its share of the tile");
     const int64_t nw = (m + 63) >> 6;
@@ -792,6 +802,8 @@ __global__ __launch_bounds__(256) void k_group_fold(GroupFoldArgs a, unsigned ve
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) { const int y = __shfl_up(incl, off, kWave); if (lane >= off) incl += y; }
     const int64_t B = offsets[tile] + wprefix[wfirst] + (incl - c);           // run heads strictly before my first entry
+    const int64_t Bw = offsets[tile] + wprefix[wfirst];                       // ... before the wave's: its first group's number
+    const int ngw = __shfl(incl, kWave - 1, kWave);                           // run heads inside the wave
     const uint64_t headlanes = __ballot(c != 0);
     const uint64_t below = (1ull << lane) - 1;
     // lanes whose open end my chunk continues: a segment of lanes starts behind every lane that holds a head
@@ -831,7 +843,10 @@ __global__ __launch_bounds__(256) void k_group_fold(GroupFoldArgs a, unsigned ve
                 int64_t g = B - 1;
 #pragma unroll
                 for (int j = 0; j < K; j++)
-                    if ((hb >> j) & 1u) { g++; out[g] = x[f][j]; }
+                    if ((hb >> j) & 1u) { g++; GF_STORE(g, x[f][j]); }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                for (int k = lane; k < ngw; k += kWave) out[Bw + k] = stage[wave][k];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();      // (the area is the next fold's)
                 continue;
             }
             const int rk = kind == 1 ? R_MIN : kind == 2 ? R_MAX : R_SUM;
@@ -842,7 +857,7 @@ __global__ __launch_bounds__(256) void k_group_fold(GroupFoldArgs a, unsigned ve
 #pragma unroll
                 for (int j = 0; j < K; j++) {
                     if ((hb >> j) & 1u) {                      // (a head is always inside the vector)
-                        if (started) out[g] = acc; else pre = acc;          // a run that began and ended in my chunk: stored at once
+                        if (started) GF_STORE(g, acc); else pre = acc;          // a run that began and ended in my chunk: stored at once
                         g++; acc = x[f][j]; started = true;
                     } else if (j < nv) {
                         acc = r_combine(R, acc, x[f][j]);
@@ -858,13 +873,17 @@ __global__ __launch_bounds__(256) void k_group_fold(GroupFoldArgs a, unsigned ve
                 // S of a lane with a head (or of lane 63) = everything between the previous head lane and this lane's first head
                 const int64_t cont = __shfl(S, fetch_from, kWave);
                 if (c != 0) {
-                    if (next_head >= 0) out[g] = r_combine(R, tail, cont);                                  // the run ends inside the wave
+                    if (next_head >= 0) GF_STORE(g, r_combine(R, tail, cont));                                  // the run ends inside the wave
                     else atomic_combine(R, &out[g], lane == kWave - 1 ? tail : r_combine(R, tail, cont));    // it may go on in the next wave
                     if (first_head_lane && B > 0) atomic_combine(R, &out[B - 1], S);                         // ... and this one came from an earlier wave
                 } else if (headlanes == 0 && lane == kWave - 1 && B > 0) {
                     atomic_combine(R, &out[B - 1], S);                                                       // a wave inside one long run
                 }
             });
+            // every group but the wave's last one has ended inside the wave and lies in the staging area: consecutive lanes store them
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+            for (int k = lane; k < ngw - 1; k += kWave) out[Bw + k] = stage[wave][k];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
         }
     }
 }
