@@ -42,7 +42,10 @@ hipError_t launch_binary(int op, Src a, Src b, int64_t *out, int64_t n, hipStrea
 // Fused element-wise expression tree.  The postfix program is wave-uniform, so the operand stack lives in
 // registers with compile-time indices: every instruction switches (scalar branches) on the stack height it runs
 // at and on its operator.  Each lane evaluates kExprRows rows at once to amortise the scalar work.
-constexpr int kExprRows = 4;
+#ifndef VDL_EXPR_ROWS
+#define VDL_EXPR_ROWS 4
+#endif
+constexpr int kExprRows = VDL_EXPR_ROWS;
 // (the leaf's representation is resolved once per push and its loads are unconditional -- rows past n read slot 0 and are
 // never stored -- so the four loads of a push go out together)
 #define VDL_EX_PUSH(K) case K: by_kind(lf.kind, [&](auto kk) { _Pragma("unroll") for (int r = 0; r < kExprRows; r++) st[K][r] = ldk<decltype(kk)::value>(lf, row[r] < n ? row[r] : 0); }); break;
