@@ -42,34 +42,36 @@ hipError_t launch_binary(int op, Src a, Src b, int64_t *out, int64_t n, hipStrea
 // Fused element-wise expression tree.  The postfix program is wave-uniform, so the operand stack lives in
 // registers with compile-time indices: every instruction switches (scalar branches) on the stack height it runs
 // at and on its operator.  Each lane evaluates kExprRows rows at once to amortise the scalar work.
-#ifndef VDL_EXPR_ROWS
-#define VDL_EXPR_ROWS 4
-#endif
-constexpr int kExprRows = VDL_EXPR_ROWS;
+// The stack is D x R registers whether or not the program fills it, and the registers decide how many waves a SIMD holds: a program of
+// stack depth 2 -- TPC-H Q18's group key (l_orderkey - 1) & mask, one stored leaf -- ran in the depth-8 kernel with FOUR loads per lane
+// in flight and three waves per SIMD: 2.7 TB/s (700 us for 120 M rows).  Three shapes now, chosen by the program's depth:
+// 2 x 8 rows, 4 x 4 rows, 8 x 4 rows.
 // (the leaf's representation is resolved once per push and its loads are unconditional -- rows past n read slot 0 and are
-// never stored -- so the four loads of a push go out together)
-#define VDL_EX_PUSH(K) case K: by_kind(lf.kind, [&](auto kk) { _Pragma("unroll") for (int r = 0; r < kExprRows; r++) st[K][r] = ldk<decltype(kk)::value>(lf, row[r] < n ? row[r] : 0); }); break;
+// never stored -- so the loads of a push go out together)
+#define VDL_EX_PUSH(K) case K: if constexpr (K < D) by_kind(lf.kind, [&](auto kk) { _Pragma("unroll") for (int r = 0; r < R; r++) st[K][r] = ldk<decltype(kk)::value>(lf, row[r] < n ? row[r] : 0); }); break;
 // a (x) b for the lane's rows; the operator switch is wave-uniform and sits outside the row loop
-#define VDL_EX_OP(OP) case OP: _Pragma("unroll") for (int r = 0; r < kExprRows; r++) a[r] = apply_bin(OP, a[r], b[r]); break;
-__device__ __forceinline__ void expr_rows(int op, int64_t (&a)[kExprRows], const int64_t (&b)[kExprRows]) {
+#define VDL_EX_OP(OP) case OP: _Pragma("unroll") for (int r = 0; r < R; r++) a[r] = apply_bin(OP, a[r], b[r]); break;
+template <int R>
+__device__ __forceinline__ void expr_rows(int op, int64_t (&a)[R], const int64_t (&b)[R]) {
     switch (op) {
         VDL_EX_OP(B_LAND) VDL_EX_OP(B_LOR) VDL_EX_OP(B_BAND) VDL_EX_OP(B_BOR) VDL_EX_OP(B_SHIFT) VDL_EX_OP(B_EQ)
         VDL_EX_OP(B_ADD) VDL_EX_OP(B_SUB) VDL_EX_OP(B_GT) VDL_EX_OP(B_MUL)
-        case X_GE: _Pragma("unroll") for (int r = 0; r < kExprRows; r++) a[r] = a[r] >= b[r]; break;
-        case X_NE: _Pragma("unroll") for (int r = 0; r < kExprRows; r++) a[r] = a[r] != b[r]; break;
+        case X_GE: _Pragma("unroll") for (int r = 0; r < R; r++) a[r] = a[r] >= b[r]; break;
+        case X_NE: _Pragma("unroll") for (int r = 0; r < R; r++) a[r] = a[r] != b[r]; break;
         // Divide / Modulo are kept out of fused trees (vdl_engine.cpp expr_binary): the 64-bit division routine inlined
         // at every stack height tripled the size of the kernel
     }
 }
 #undef VDL_EX_OP
-#define VDL_EX_BIN(K) case K: expr_rows(op, st[K - 2], st[K - 1]); break;
+#define VDL_EX_BIN(K) case K: if constexpr (K <= D) expr_rows<R>(op, st[K - 2], st[K - 1]); break;
+template <int D, int R>
 __global__ __launch_bounds__(256) void k_expr(const ExprProg P, int64_t *__restrict__ out, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; base < n; base += kExprRows * stride) {
-        int64_t row[kExprRows];
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; base < n; base += R * stride) {
+        int64_t row[R];
 #pragma unroll
-        for (int r = 0; r < kExprRows; r++) row[r] = base + r * stride;
-        int64_t st[kExprDepth][kExprRows];
+        for (int r = 0; r < R; r++) row[r] = base + r * stride;
+        int64_t st[D][R];
         int sp = 0;
         for (int k = 0; k < P.n_instr; k++) {
             const int code = P.code[k];                 // wave-uniform
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256) void k_expr(const ExprProg P, int64_t *__restr
             }
         }
 #pragma unroll
-        for (int r = 0; r < kExprRows; r++) if (row[r] < n) out[row[r]] = st[0][r];
+        for (int r = 0; r < R; r++) if (row[r] < n) out[row[r]] = st[0][r];
     }
 }
 #undef VDL_EX_PUSH
@@ -92,7 +94,12 @@ __global__ __launch_bounds__(256) void k_expr(const ExprProg P, int64_t *__restr
 hipError_t launch_expr(const ExprProg &prog, int64_t *out, int64_t n, hipStream_t s) {
     (void)hipGetLastError();
     if (n <= 0) return hipSuccess;
-    k_expr<<<grid_for(n, 256, kExprRows), 256, 0, s>>>(prog, out, n);
+    int depth = 0, sp = 0;                                      // the stack height the program reaches
+    for (int k = 0; k < prog.n_instr; k++) { sp += prog.code[k] < 0 ? 1 : -1; depth = sp > depth ? sp : depth; }
+    if (depth > kExprDepth || sp != 1) return hipErrorInvalidValue;
+    if (depth <= 2) k_expr<2, 8><<<grid_for(n, 256, 8), 256, 0, s>>>(prog, out, n);
+    else if (depth <= 4) k_expr<4, 4><<<grid_for(n, 256, 4), 256, 0, s>>>(prog, out, n);
+    else k_expr<kExprDepth, 4><<<grid_for(n, 256, 4), 256, 0, s>>>(prog, out, n);
     return launch_status();
 }
 
