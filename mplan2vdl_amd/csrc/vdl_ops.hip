@@ -559,14 +559,15 @@ __global__ void k_onehot_dense(const int64_t *oh, int64_t *out, uint64_t *valid,
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t slot = oh[2] > 0 ? oh[1] : -1;
     const int64_t nw = (n + 63) >> 6;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (i == slot) ? oh[0] : 0;
+    if (out)                                                   // (null: only the validity is wanted -- RangeV over a scalar record)
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (i == slot) ? oh[0] : 0;
     for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nw; w += stride)
         valid[w] = (slot >= 0 && (slot >> 6) == w) ? (1ull << (slot & 63)) : 0ull;
 }
 hipError_t launch_onehot_dense(const int64_t *oh, int64_t *out, uint64_t *valid, int64_t n, hipStream_t s) {
     (void)hipGetLastError();   // see launch_status()
     if (n <= 0) return hipSuccess;
-    k_onehot_dense<<<grid_for(n, 256, 4), 256, 0, s>>>(oh, out, valid, n);
+    k_onehot_dense<<<grid_for(out ? n : (n + 63) / 64, 256, 4), 256, 0, s>>>(oh, out, valid, n);
     return launch_status();
 }
 
