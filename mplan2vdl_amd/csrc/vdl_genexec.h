@@ -1144,6 +1144,21 @@ struct GenExec {
             return o;
         }
         case Op::Gather: {
+            {
+                // a scalar read back at position 0 for every slot of another vector -- how the compiler compares a column with the result of
+                // an ungrouped aggregate (Gather(result, zeros_ other), Vlite.hs:693-712; TPC-H Q15's `total = (select max(total) ..)`, Q11's
+                // HAVING threshold): the scalar as a constant on the other vector's validity.  One round trip for the record instead of a
+                // gather over every slot and everything behind it going dense (Q15 at SF10: 62_Gather 248 + 65_FoldSelect 239 us).
+                const DVec &sv = V(n.a), &pv = V(n.b);
+                if ((sv.kind == DVec::ONEHOT || sv.kind == DVec::OHCONST) && pv.kind == DVec::RANGE && pv.step == 0 && pv.from == 0 && sv.data && !getenv("VDL_NO_SCALAR_BROADCAST")) {
+                    int64_t rec[3] = {0, 0, 0};
+                    fetch_words(sv.data->p, 3, rec);
+                    o.kind = DVec::RANGE; o.n = pv.n; o.step = 0;
+                    if (rec[2] > 0 && rec[1] == 0 && sv.n > 0) { o.from = sv.kind == DVec::OHCONST ? sv.from : rec[0]; o.valid = pv.valid; }
+                    else { o.from = 0; o.valid = zero_bitmap(pv.n); }          // nothing at slot 0: every slot is empty
+                    return o;
+                }
+            }
             if (sparse_on) {
                 DVec fast;
                 if (sparse_gather(V(n.a), V(n.b), fast)) return fast;
