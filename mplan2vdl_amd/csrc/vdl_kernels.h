@@ -259,7 +259,6 @@ hipError_t launch_fold_segmented(int kind, Src ctl, const uint64_t *vc, Src d, c
 // ---- row exchange for sharded Partition (see vdl_partition.hip) ------------------------------------
 constexpr int kMaxExSources = 62;
 constexpr int kMaxExWorld = 128;          // ranks in one exchange (vdl_exchange_begin)
-struct ExValid { int n = 0; const uint64_t *valid[kMaxExSources] = {}; };
 // CrossProductOuter / Inner (Vdl.hs:412-416; Vlite.hs:278-289): positions i / k and i % k over n = m * k slots
 hipError_t launch_cross(int64_t n, int64_t k, int inner, int64_t *out, hipStream_t s);
 // Like (Vdl.hs:444-447): out[i] = string at byte offset data[i] of `heap` matches the SQL LIKE pattern
