@@ -9,11 +9,12 @@ from mplan2vdl_amd import catalog, frontend
 from helpers import oracle_run
 META = os.path.join(ROOT, "tests", "golden", "tpch10noorder")
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.3
-plans = [int(x) for x in sys.argv[2:]] or [1, 4, 6, 12, 14, 19]
+plans = [int(x) for x in sys.argv[2:]] or [1, 3, 4, 5, 6, 9, 10, 11, 12, 14, 15, 16, 18, 19, 20]
+clustered = ("lineitem.lineitem_orders",) if os.environ.get("RUN_PLANS_CLUSTERED", "1") == "1" else ()
 cfg = frontend.load_metadata(META)
 for n in plans:
     text = frontend.compile_plan(open(os.path.join(META, "%02d.sql.mplan" % n)).read(), cfg)
-    cols = catalog.synth_columns(META, cfg, text, scale=scale)
+    cols = catalog.synth_columns(META, cfg, text, scale=scale, clustered=clustered)
     e = m.Engine(0)
     for k, v in cols.items():
         e.upload(k, v)
@@ -24,6 +25,12 @@ for n in plans:
     for _ in range(6):
         out = p.run()
     ok = out["results"] == oracle_run(text, cols) if os.environ.get("JIT_PLANS_ORACLE", "1") == "1" else None
-    t = {k.replace("timeInMicrosecondsFor", ""): v for k, v in out["timings"].items() if "Scan" in k}
-    print("Q%02d %s oracle %s\n    %s" % (n, t, ok, p.jit_note()[:900]))
+    t = {k.replace("timeInMicrosecondsFor", "")[:70]: round(v) for k, v in out["timings"].items() if "Scan" in k or "Front" in k}
+    total = sum(out["timings"].values()) / 1e3
+    t0 = time.perf_counter()
+    p.set_profiling(False)
+    for _ in range(5):
+        p.run()
+    wall = (time.perf_counter() - t0) / 5 * 1e3
+    print("Q%02d fused=%d  %.2f ms of kernels / statements, %.2f ms wall (results to the host)  matches the oracle: %s\n    %s\n    %s" % (n, p.is_fused, total, wall, ok, t, p.jit_note()[:700]), flush=True)
     e.close()
