@@ -670,12 +670,13 @@ __global__ __launch_bounds__(256) void k_sorted_heads_dense(const int64_t *__res
 // The sortedness pass, the heads' tile counts, their scan and the report to the host in ONE launch (round 4: the five launches it replaces
 // -- init, heads, count, scan, post -- were 40 us of a 490 us Q3 at SF10, most of it the gaps between them).  A block owns whole compaction
 // tiles (4096 entries = 16 groups of 256, two per wave in flight) and STORES its tiles' head counts, so nothing has to be zeroed first; the
-// block that finishes last (a counter in `state`, which lives with the context and is left as it was found: {0, INT64_MIN, INT64_MAX, 0})
-// scans the counts in place, appends {total, descends, largest, smallest} and posts those four words and the sequence number into pinned
-// host memory with system-scope stores (vdl_ctx::wait_flag polls it).  Counts and flags cross the blocks as agent-scope atomics: the XCDs'
-// L2s do not see one another's plain stores inside a kernel.
+// block that finishes last (two levels of arrival counters in `state`, which lives with the context and is left all zero as it was found)
+// gathers the blocks' verdicts -- {descends, largest, smallest}, three words per block behind the counts --, scans the counts in place,
+// appends {total, descends, largest, smallest} and posts those four words and the sequence number into pinned host memory with
+// system-scope stores (vdl_ctx::wait_seq polls it).  Counts, verdicts and arrivals cross the blocks as agent-scope atomics: the XCDs' L2s
+// do not see one another's plain stores inside a kernel.
 constexpr int kHeadMaxGrid = 2048;
-constexpr int kHeadArrivals = 64;          // arrival counters of k_sorted_heads_counted (+ the one their last arrivals meet on): kHeadStateWords words of state
+constexpr int kHeadArrivals = 64;          // arrival counters of k_sorted_heads_counted (+ the one their last arrivals meet on): sorted_heads_state_words() words of state
 constexpr int kHeadTileGroups = 16;         // 256-entry groups per compaction tile (compact_tile() = 4096, vdl_ops.hip)
 __global__ __launch_bounds__(256) void k_sorted_heads_counted(const int64_t *__restrict__ d, int64_t n, uint64_t *__restrict__ heads, int64_t *counts, int64_t nb,
                                                               int64_t *state, int64_t *pin, int64_t *pflag, int64_t seq) {
