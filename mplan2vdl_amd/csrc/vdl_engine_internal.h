@@ -190,7 +190,7 @@ struct vdl_ctx {
     // a few words of PINNED host memory for the round trips of the executors (survivor counts, sortedness verdicts): a copy
     // into pageable memory is staged by the runtime and cost 20-30 us of idle GPU each (Q3 at SF10: three of them per query)
     int64_t *pinned_words = nullptr;
-    static constexpr int kPinnedWords = 1 << 15;       // 256 KiB: also the per-rank count tables of the sharded routes (128 ranks x 130 words)
+    static constexpr int kPinnedWords = 1 << 17;       // 1 MiB: also the tables the sharded routes gather (the exchange's: ranks x (4096-slice histogram + a few words) -- eight ranks' did not fit the 256 KiB of round 3 by 32 words and took the staged copy)
     static constexpr int kFlagWords = 8;                // the last words: [0] the flag a posting kernel raises, [1] the fused front's survivor count
     int64_t *pinned(int64_t words) {
         if (!pinned_words && hipHostMalloc((void **)&pinned_words, sizeof(int64_t) * kPinnedWords, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); pinned_words = nullptr; }
